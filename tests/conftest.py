@@ -1,0 +1,27 @@
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import json
+
+    return json.loads((ROOT / "tests" / "golden" / "snapshots_ristretto.json").read_text())
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as o
+
+    o.lib()
+    return o
