@@ -1,0 +1,347 @@
+"""elastic_elgamal_amd -- MI355X (gfx950) batch verifier for slowli/elastic-elgamal ballots.
+
+Python host-side mirror of the reference interface for the ballot-verification hot path, bound with
+ctypes to the C ABI of ``libeg_hip.so`` (``include/eg_hip.h``).  Names follow the reference:
+
+* :class:`Ristretto`              -- the ``Group`` backend (src/group/ristretto.rs), batched
+* :class:`ChoiceParams`           -- ``ChoiceParams::single / ::multi`` (src/app/choice.rs:132-196) with
+  ``verify_batch`` = ``EncryptedChoice::verify`` for every ballot (choice.rs:358-380) + the homomorphic tally
+  of examples/voting.rs:199-203
+* :class:`QuadraticVotingParams`  -- ``QuadraticVotingParams::new`` (src/app/quadratic_voting.rs:63-76) with
+  ``verify_batch`` = ``QuadraticVotingBallot::verify`` (quadratic_voting.rs:291-329)
+
+There is NO CPU path in this package: if the HIP library is missing or no gfx950 device is usable, importing
+works but creating a :class:`Context` raises.  (The CPU oracle lives under ``oracle/`` and is test-only.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+__all__ = [
+    "Context", "Ristretto", "ChoiceParams", "QuadraticVotingParams", "EgError", "library_path", "build",
+    "STATUS_NAMES", "status_kind", "status_detail",
+]
+
+_PKG = Path(__file__).resolve().parent
+_LIB = _PKG / "libeg_hip.so"
+
+OK, BAD_SCALAR, BAD_POINT, OPTIONS_LEN, SUM_CHALLENGE, RANGE_LEN, RANGE_CHALLENGE = range(7)
+QV_VARIANT_LEN, QV_VARIANT_CHALLENGE, QV_CREDIT_RANGE_LEN, QV_CREDIT_RANGE_CHALLENGE = 7, 8, 9, 10
+QV_CREDIT_EQUIV_LEN, QV_CREDIT_EQUIV_CHALLENGE = 11, 12
+STATUS_NAMES = {
+    0: "Ok", 1: "BadScalar", 2: "BadPoint", 3: "OptionsLenMismatch", 4: "Sum(ChallengeMismatch)",
+    5: "Range(LenMismatch)", 6: "Range(ChallengeMismatch)", 7: "Variant(LenMismatch)", 8: "Variant(ChallengeMismatch)",
+    9: "CreditRange(LenMismatch)", 10: "CreditRange(ChallengeMismatch)", 11: "CreditEquivalence(LenMismatch)",
+    12: "CreditEquivalence(ChallengeMismatch)",
+}
+TALLY_POINT_BYTES = 160
+
+
+def status_kind(s: int) -> int:
+    return s & 0xFF
+
+
+def status_detail(s: int) -> int:
+    return s >> 8
+
+
+class EgError(RuntimeError):
+    pass
+
+
+def library_path() -> Path:
+    return _LIB
+
+
+def build(verbose: bool = False) -> Path:
+    """Compile csrc/eg_hip.hip for gfx950 with hipcc into the in-tree libeg_hip.so (no GPU needed)."""
+    import subprocess
+
+    src = _PKG / "csrc" / "eg_hip.hip"
+    deps = list((_PKG / "csrc").glob("*")) + [_PKG.parent / "include" / "eg_hip.h"]
+    if _LIB.exists() and all(d.stat().st_mtime <= _LIB.stat().st_mtime for d in deps):
+        return _LIB
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", str(_LIB), str(src)]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return _LIB
+
+
+_lib = None
+
+
+def _load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not _LIB.exists():
+        raise EgError(
+            f"{_LIB} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback."
+        )
+    lib = C.CDLL(str(_LIB))
+    vp, cp, sz = C.c_void_p, C.c_char_p, C.c_size_t
+    sig = {
+        "eg_init": (C.c_int, [C.c_int, C.POINTER(vp)]),
+        "eg_destroy": (None, [vp]),
+        "eg_last_error": (cp, []),
+        "eg_device_name": (C.c_int, [vp, cp, sz]),
+        "eg_synchronize": (C.c_int, [vp]),
+        "eg_scalar_from_wide_batch": (C.c_int, [vp, sz, cp, cp]),
+        "eg_scalar_is_canonical_batch": (C.c_int, [vp, sz, cp, cp]),
+        "eg_scalar_muladd_batch": (C.c_int, [vp, sz, cp, cp, cp, cp]),
+        "eg_scalar_neg_batch": (C.c_int, [vp, sz, cp, cp]),
+        "eg_point_roundtrip_batch": (C.c_int, [vp, sz, cp, cp, cp]),
+        "eg_point_add_batch": (C.c_int, [vp, sz, cp, cp, C.c_int, cp, cp]),
+        "eg_mul_generator_batch": (C.c_int, [vp, sz, cp, cp]),
+        "eg_vartime_double_mul_generator_batch": (C.c_int, [vp, sz, cp, cp, cp, cp, cp]),
+        "eg_vartime_multi_mul_batch": (C.c_int, [vp, sz, sz, cp, cp, cp, cp]),
+        "eg_choice_params_create": (C.c_int, [vp, cp, C.c_int, C.c_int, C.POINTER(vp)]),
+        "eg_choice_params_destroy": (None, [vp]),
+        "eg_choice_ballot_size": (sz, [C.c_int, C.c_int]),
+        "eg_verify_choice_batch": (C.c_int, [vp, sz, vp, vp, vp]),
+        "eg_verify_choice_batch_device": (C.c_int, [vp, sz, vp, vp, vp]),
+        "eg_choice_tally_reset": (C.c_int, [vp]),
+        "eg_choice_tally_device_ptr": (C.c_int, [vp, C.POINTER(vp), C.POINTER(sz)]),
+        "eg_choice_tally_merge_device": (C.c_int, [vp, vp, C.c_int, vp]),
+        "eg_choice_tally_encode": (C.c_int, [vp, cp]),
+        "eg_qv_params_create": (C.c_int, [vp, cp, C.c_int, C.c_uint64, C.POINTER(vp)]),
+        "eg_qv_params_destroy": (None, [vp]),
+        "eg_qv_ballot_size": (sz, [vp]),
+        "eg_verify_qv_batch": (C.c_int, [vp, sz, vp, vp, vp]),
+        "eg_verify_qv_batch_device": (C.c_int, [vp, sz, vp, vp, vp]),
+        "eg_qv_tally_reset": (C.c_int, [vp]),
+        "eg_qv_tally_device_ptr": (C.c_int, [vp, C.POINTER(vp), C.POINTER(sz)]),
+        "eg_qv_tally_merge_device": (C.c_int, [vp, vp, C.c_int, vp]),
+        "eg_qv_tally_encode": (C.c_int, [vp, cp]),
+        "eg_choice_encrypt_batch_device": (C.c_int, [vp, C.c_uint64, sz, sz, C.c_int, vp, vp]),
+        "eg_qv_encrypt_batch_device": (C.c_int, [vp, C.c_uint64, sz, sz, vp, vp]),
+        "eg_profile_enable": (C.c_int, [vp, C.c_int]),
+        "eg_profile_read": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # raises AttributeError if the ABI is incomplete
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    """Names declared in include/eg_hip.h that the library must export (used by the CPU-side ABI test)."""
+    import re
+
+    hdr = (_PKG.parent / "include" / "eg_hip.h").read_text()
+    return sorted(set(re.findall(r"\b(eg_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        raise EgError(f"libeg_hip error {rc}: {_load().eg_last_error().decode()}")
+
+
+class Context:
+    """One GPU context per process (eg_init).  No reference analogue: the backend there is a ZST."""
+
+    def __init__(self, device: int = 0):
+        lib = _load()
+        self._h = C.c_void_p()
+        _check(lib.eg_init(device, C.byref(self._h)))
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _load().eg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def name(self) -> str:
+        b = C.create_string_buffer(256)
+        _check(_load().eg_device_name(self._h, b, 256))
+        return b.value.decode()
+
+    def synchronize(self):
+        _check(_load().eg_synchronize(self._h))
+
+    def profile_enable(self, on: bool = True):
+        _check(_load().eg_profile_enable(self._h, int(on)))
+
+    def profile_read(self):
+        """(dominant-kernel ms total, launches, whole-verify ms total) since the last read; HIP events."""
+        a, n, b = C.c_double(), C.c_uint64(), C.c_double()
+        _check(_load().eg_profile_read(self._h, C.byref(a), C.byref(n), C.byref(b)))
+        return a.value, n.value, b.value
+
+
+class Ristretto:
+    """Batched ``Group`` backend for Ristretto255 (src/group/ristretto.rs).  All arguments are concatenated
+    32-byte encodings (64-byte for wide scalars); every method runs one GPU lane per problem."""
+
+    SCALAR_SIZE = 32
+    ELEMENT_SIZE = 32
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+
+    def scalar_from_random_bytes(self, wide: bytes) -> bytes:  # ristretto.rs:34-38
+        n = len(wide) // 64
+        out = C.create_string_buffer(32 * n)
+        _check(_load().eg_scalar_from_wide_batch(self.ctx._h, n, wide, out))
+        return out.raw
+
+    def deserialize_scalar_ok(self, scalars: bytes) -> bytes:  # ristretto.rs:59-62
+        n = len(scalars) // 32
+        ok = C.create_string_buffer(n)
+        _check(_load().eg_scalar_is_canonical_batch(self.ctx._h, n, scalars, ok))
+        return ok.raw
+
+    def scalar_muladd(self, a: bytes, b: bytes, c: bytes) -> bytes:
+        n = len(a) // 32
+        out = C.create_string_buffer(32 * n)
+        _check(_load().eg_scalar_muladd_batch(self.ctx._h, n, a, b, c, out))
+        return out.raw
+
+    def scalar_neg(self, a: bytes) -> bytes:
+        n = len(a) // 32
+        out = C.create_string_buffer(32 * n)
+        _check(_load().eg_scalar_neg_batch(self.ctx._h, n, a, out))
+        return out.raw
+
+    def element_roundtrip(self, elements: bytes):
+        """deserialize_element + serialize_element (ristretto.rs:88-95): (re-encodings, ok flags)."""
+        n = len(elements) // 32
+        out, ok = C.create_string_buffer(32 * n), C.create_string_buffer(n)
+        _check(_load().eg_point_roundtrip_batch(self.ctx._h, n, elements, out, ok))
+        return out.raw, ok.raw
+
+    def element_add(self, a: bytes, b: bytes, subtract: bool = False):
+        n = len(a) // 32
+        out, ok = C.create_string_buffer(32 * n), C.create_string_buffer(n)
+        _check(_load().eg_point_add_batch(self.ctx._h, n, a, b, int(subtract), out, ok))
+        return out.raw, ok.raw
+
+    def mul_generator(self, k: bytes) -> bytes:  # ristretto.rs:105-121
+        n = len(k) // 32
+        out = C.create_string_buffer(32 * n)
+        _check(_load().eg_mul_generator_batch(self.ctx._h, n, k, out))
+        return out.raw
+
+    def vartime_double_mul_generator(self, k: bytes, p: bytes, r: bytes):  # ristretto.rs:131-137
+        n = len(k) // 32
+        out, ok = C.create_string_buffer(32 * n), C.create_string_buffer(n)
+        _check(_load().eg_vartime_double_mul_generator_batch(self.ctx._h, n, k, p, r, out, ok))
+        return out.raw, ok.raw
+
+    def vartime_multi_mul(self, terms: int, scalars: bytes, points: bytes):  # ristretto.rs:139-145
+        n = len(scalars) // (32 * terms) if terms else 0
+        out, ok = C.create_string_buffer(32 * max(n, 1)), C.create_string_buffer(max(n, 1))
+        _check(_load().eg_vartime_multi_mul_batch(self.ctx._h, n, terms, scalars, points, out, ok))
+        return out.raw[: 32 * n], ok.raw[:n]
+
+
+class _BatchParams:
+    _prefix = ""
+
+    def _fn(self, name):
+        return getattr(_load(), f"eg_{self._prefix}_{name}")
+
+    def verify_batch(self, ballots: bytes, with_tally: bool = True):
+        """verify() for every packed ballot; returns (status words, tally bytes or None).
+        The tally is the component-wise sum of the ciphertexts of accepted ballots, n_options x (R || B)."""
+        n = len(ballots) // self.ballot_size
+        if n * self.ballot_size != len(ballots):
+            raise ValueError("ballots is not a whole number of packed ballots")
+        st = (C.c_uint32 * max(n, 1))()
+        tally = C.create_string_buffer(64 * self.n_options) if with_tally else None
+        buf = (C.c_char * max(len(ballots), 1)).from_buffer_copy(ballots or b"\0")
+        fn = getattr(_load(), f"eg_verify_{self._prefix}_batch")
+        _check(fn(self._h, n, buf, st, tally))
+        return list(st[:n]), (tally.raw if with_tally else None)
+
+    def verify_batch_device(self, n: int, d_ballots: int, d_status: int, stream: int = 0):
+        """Asynchronous device-pointer variant (torch tensors' data_ptr()); tally accumulates on the device."""
+        fn = getattr(_load(), f"eg_verify_{self._prefix}_batch_device")
+        _check(fn(self._h, n, d_ballots, d_status, stream))
+
+    def tally_reset(self):
+        _check(self._fn("tally_reset")(self._h))
+
+    def tally_device_ptr(self):
+        p, nb = C.c_void_p(), C.c_size_t()
+        _check(self._fn("tally_device_ptr")(self._h, C.byref(p), C.byref(nb)))
+        return p.value, nb.value
+
+    def tally_merge_device(self, d_gathered: int, n_ranks: int, stream: int = 0):
+        _check(self._fn("tally_merge_device")(self._h, d_gathered, n_ranks, stream))
+
+    def tally_encode(self) -> bytes:
+        out = C.create_string_buffer(64 * self.n_options)
+        _check(self._fn("tally_encode")(self._h, out))
+        return out.raw
+
+
+class ChoiceParams(_BatchParams):
+    """``ChoiceParams::single(pk, n)`` / ``::multi(pk, n)`` (choice.rs:160-196)."""
+
+    _prefix = "choice"
+
+    def __init__(self, ctx: Context, public_key: bytes, options_count: int, single: bool = True):
+        self.ctx, self.public_key, self.n_options, self.single = ctx, public_key, options_count, single
+        self._h = C.c_void_p()
+        _check(_load().eg_choice_params_create(ctx._h, public_key, options_count, int(single), C.byref(self._h)))
+        self.ballot_size = _load().eg_choice_ballot_size(options_count, int(single))
+
+    @classmethod
+    def single_choice(cls, ctx, public_key, options_count):
+        return cls(ctx, public_key, options_count, True)
+
+    @classmethod
+    def multi_choice(cls, ctx, public_key, options_count):
+        return cls(ctx, public_key, options_count, False)
+
+    def encrypt_batch_device(self, base_seed: int, first: int, n: int, d_out: int, n_selected: int = 0, stream: int = 0):
+        """EncryptedChoice::new for n synthetic voters, written packed to device memory."""
+        _check(_load().eg_choice_encrypt_batch_device(self._h, base_seed, first, n, n_selected, d_out, stream))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _load().eg_choice_params_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class QuadraticVotingParams(_BatchParams):
+    """``QuadraticVotingParams::new(pk, options, credits)`` (quadratic_voting.rs:63-76)."""
+
+    _prefix = "qv"
+
+    def __init__(self, ctx: Context, public_key: bytes, options_count: int, credits: int):
+        self.ctx, self.public_key, self.n_options, self.credits = ctx, public_key, options_count, credits
+        self._h = C.c_void_p()
+        _check(_load().eg_qv_params_create(ctx._h, public_key, options_count, credits, C.byref(self._h)))
+        self.ballot_size = _load().eg_qv_ballot_size(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _load().eg_qv_params_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

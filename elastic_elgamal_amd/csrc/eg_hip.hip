@@ -1,0 +1,630 @@
+// eg_hip.hip -- host side of libeg_hip.so: context, the plan-driven verification engine and the C ABI
+// declared in include/eg_hip.h.  One process drives one GPU (one rank per GPU under torch.distributed);
+// everything is launched on a single HIP stream, per chunk of ballots:
+//   decode -> canonical checks -> derived points -> [ group equations -> transcript hashing ] x stages
+//   -> status -> tally
+// There is no CPU fallback: every numeric result comes out of the kernels in kernels.cuh.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/eg_hip.h"
+#include "host_plan.hpp"
+#include "kernels.cuh"
+#include "prover_kernels.cuh"
+
+using namespace eg;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPCHK(x)                                                                                   \
+  do {                                                                                              \
+    hipError_t e_ = (x);                                                                            \
+    if (e_ != hipSuccess)                                                                           \
+      return fail(EG_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_) + " (" + __FILE__ + ":" + std::to_string(__LINE__) + ")"); \
+  } while (0)
+
+struct ProfSpan { hipEvent_t a, b; bool msm; };
+
+struct eg_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int cus = 0;
+  std::string name;
+  uint4* tabG = nullptr;     // fixed-base table of the generator
+  u32* gen_words = nullptr;  // generator as 40 limbs
+  int msm_blocks = 0;        // persistent grid of k_msm_jobs
+  uint4* ws = nullptr;       // variable-base table workspace (msm_blocks * 80 * NT uint4)
+  bool prof = false;
+  std::vector<ProfSpan> spans;
+  std::vector<hipEvent_t> event_pool;
+  double msm_ms = 0, all_ms = 0;
+  uint64_t msm_launches = 0;
+};
+
+static int prof_begin(eg_ctx* c, hipStream_t s, bool msm, size_t* idx) {
+  if (!c->prof) return EG_OK;
+  hipEvent_t a, b;
+  for (hipEvent_t* e : {&a, &b}) {
+    if (!c->event_pool.empty()) { *e = c->event_pool.back(); c->event_pool.pop_back(); }
+    else HIPCHK(hipEventCreate(e));
+  }
+  HIPCHK(hipEventRecord(a, s));
+  *idx = c->spans.size();
+  c->spans.push_back({a, b, msm});
+  return EG_OK;
+}
+static int prof_end(eg_ctx* c, hipStream_t s, size_t idx) {
+  if (!c->prof) return EG_OK;
+  HIPCHK(hipEventRecord(c->spans[idx].b, s));
+  return EG_OK;
+}
+
+template <class T>
+static int upload(T** dptr, const std::vector<T>& v, hipStream_t s) {
+  *dptr = nullptr;
+  const size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+  HIPCHK(hipMalloc((void**)dptr, bytes));
+  if (!v.empty()) HIPCHK(hipMemcpyAsync(*dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
+  return EG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+struct StageDev { int job_first, job_count, inst_first, inst_count; };
+struct LevelDev { int first, count; };
+
+struct Engine {
+  eg_ctx* ctx = nullptr;
+  eghost::Plan plan;
+  int n_options = 0;
+  // device plan
+  egplan::WireItem *d_pt_items = nullptr, *d_sc_items = nullptr;
+  egplan::DeriveClass* d_dclasses = nullptr;
+  egplan::DeriveTerm* d_dterms = nullptr;
+  egplan::JobClass* d_jobs = nullptr;
+  egplan::VarTerm* d_vterms = nullptr;
+  egplan::HashInst* d_insts = nullptr;
+  egplan::HashOp* d_ops = nullptr;
+  egplan::StatusRule* d_rules = nullptr;
+  u32* d_tally_slots = nullptr;
+  unsigned char* d_blob = nullptr;
+  uint4 *d_tabK = nullptr, *d_cpts = nullptr;
+  u32* d_prefixes = nullptr;
+  u32* d_key_words = nullptr;   // [0..40) generator, [40..80) key
+  std::vector<StageDev> stages;
+  std::vector<LevelDev> levels;
+  int prefix_inst_first = 0, prefix_inst_count = 0;
+  // chunk workspace
+  u32 cap = 0;
+  uint4 *pts = nullptr, *cmp = nullptr, *chal = nullptr;
+  u32 *states = nullptr, *flags = nullptr, *bad_item = nullptr;
+  u32* partial = nullptr;
+  int tally_blocks = 64;
+  u32* tally = nullptr;        // [2n][40] running tally (extended points)
+  // staging for the host-pointer API
+  unsigned char* d_wire = nullptr;
+  u32* d_status = nullptr;
+  size_t staging_ballots = 0;
+};
+
+static void engine_free(Engine* e) {
+  if (!e) return;
+  void* ptrs[] = {e->d_pt_items, e->d_sc_items, e->d_dclasses, e->d_dterms, e->d_jobs, e->d_vterms, e->d_insts, e->d_ops,
+                  e->d_rules, e->d_tally_slots, e->d_blob, e->d_tabK, e->d_cpts, e->d_prefixes, e->d_key_words, e->pts, e->cmp,
+                  e->chal, e->states, e->flags, e->bad_item, e->partial, e->tally, e->d_wire, e->d_status};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  delete e;
+}
+
+static EngineBufs make_bufs(const Engine* e, const void* d_ballots, u32 n, void* d_status) {
+  EngineBufs B;
+  B.wire = reinterpret_cast<const u32*>(d_ballots);
+  B.stride_words = (u32)(e->plan.stride / 4);
+  B.n = n;
+  B.cap = e->cap;
+  B.pts = e->pts; B.cmp = e->cmp; B.chal = e->chal; B.states = e->states; B.flags = e->flags; B.bad_item = e->bad_item;
+  B.status = reinterpret_cast<u32*>(d_status);
+  B.tabG = e->ctx->tabG; B.tabK = e->d_tabK; B.cpts = e->d_cpts; B.prefixes = e->d_prefixes; B.blob = e->d_blob;
+  B.ws = e->ctx->ws;
+  return B;
+}
+
+static int grid_for(size_t lanes, int cap_blocks) {
+  size_t blocks = (lanes + NT - 1) / NT;
+  if (blocks < 1) blocks = 1;
+  if ((size_t)cap_blocks < blocks) blocks = (size_t)cap_blocks;
+  return (int)blocks;
+}
+
+// build device state for a plan + election key
+static int engine_create(eg_ctx* ctx, eghost::Plan&& plan, const uint8_t pk[32], int n_options, Engine** out) {
+  std::unique_ptr<Engine, void (*)(Engine*)> e(new Engine(), engine_free);
+  e->ctx = ctx;
+  e->plan = std::move(plan);
+  e->n_options = n_options;
+  eghost::Plan& P = e->plan;
+  hipStream_t s = ctx->stream;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (P.pk_off >= 0) memcpy(P.blob.data() + P.pk_off, pk, 32);
+
+  // flatten stages / levels / programs
+  std::vector<egplan::JobClass> jobs;
+  std::vector<egplan::HashInst> insts;
+  std::vector<egplan::HashOp> ops;
+  for (auto& st : P.stages) {
+    StageDev sd;
+    sd.job_first = (int)jobs.size(); sd.job_count = (int)st.jobs.size();
+    jobs.insert(jobs.end(), st.jobs.begin(), st.jobs.end());
+    sd.inst_first = (int)insts.size(); sd.inst_count = (int)st.insts.size();
+    for (auto& prog : st.insts) {
+      insts.push_back({(uint32_t)ops.size(), (uint32_t)prog.size()});
+      ops.insert(ops.end(), prog.begin(), prog.end());
+    }
+    e->stages.push_back(sd);
+  }
+  e->prefix_inst_first = (int)insts.size();
+  e->prefix_inst_count = (int)P.prefix_programs.size();
+  for (auto& prog : P.prefix_programs) {
+    insts.push_back({(uint32_t)ops.size(), (uint32_t)prog.size()});
+    ops.insert(ops.end(), prog.begin(), prog.end());
+  }
+  std::vector<egplan::DeriveClass> dclasses;
+  for (auto& lvl : P.derive_levels) {
+    e->levels.push_back({(int)dclasses.size(), (int)lvl.size()});
+    dclasses.insert(dclasses.end(), lvl.begin(), lvl.end());
+  }
+  int rc;
+  if ((rc = upload(&e->d_pt_items, P.pt_items, s))) return rc;
+  if ((rc = upload(&e->d_sc_items, P.sc_items, s))) return rc;
+  if ((rc = upload(&e->d_dclasses, dclasses, s))) return rc;
+  if ((rc = upload(&e->d_dterms, P.dterms, s))) return rc;
+  if ((rc = upload(&e->d_jobs, jobs, s))) return rc;
+  if ((rc = upload(&e->d_vterms, P.vterms, s))) return rc;
+  if ((rc = upload(&e->d_insts, insts, s))) return rc;
+  if ((rc = upload(&e->d_ops, ops, s))) return rc;
+  if ((rc = upload(&e->d_rules, P.rules, s))) return rc;
+  if ((rc = upload(&e->d_tally_slots, P.tally_slots, s))) return rc;
+  if ((rc = upload(&e->d_blob, P.blob, s))) return rc;
+
+  // election key: decode, reject invalid / identity (keys/mod.rs:161-176), fixed-base table
+  u32* d_pk = nullptr;
+  u32* d_flags = nullptr;
+  HIPCHK(hipMalloc((void**)&d_pk, 32));
+  HIPCHK(hipMalloc((void**)&d_flags, 8));
+  HIPCHK(hipMalloc((void**)&e->d_key_words, 80 * sizeof(u32)));
+  HIPCHK(hipMemcpyAsync(d_pk, pk, 32, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_setup_points, dim3(1), dim3(64), 0, s, d_pk, e->d_key_words, d_flags);
+  u32 hflags[2] = {0, 0};
+  HIPCHK(hipMemcpyAsync(hflags, d_flags, 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  (void)hipFree(d_pk); (void)hipFree(d_flags);
+  if (!hflags[0]) return fail(EG_ERR_BAD_PUBLIC_KEY, "public key is not a valid ristretto255 encoding");
+  if (hflags[1]) return fail(EG_ERR_BAD_PUBLIC_KEY, "public key is the identity");
+  HIPCHK(hipMalloc((void**)&e->d_tabK, 64 * 8 * 8 * sizeof(uint4)));
+  hipLaunchKernelGGL(k_build_fixed_table, dim3(2), dim3(NT), 0, s, e->d_key_words + 40, e->d_tabK);
+
+  // election-constant points [m]G
+  {
+    u64* d_m = nullptr;
+    std::vector<uint64_t> mults = P.const_mults;
+    if (mults.empty()) mults.push_back(0);
+    HIPCHK(hipMalloc((void**)&d_m, mults.size() * 8));
+    HIPCHK(hipMemcpyAsync(d_m, mults.data(), mults.size() * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMalloc((void**)&e->d_cpts, mults.size() * 10 * sizeof(uint4)));
+    hipLaunchKernelGGL(k_const_points, dim3((unsigned)((mults.size() + NT - 1) / NT)), dim3(NT), 0, s, d_m, (int)mults.size(),
+                       ctx->tabG, e->d_cpts);
+    HIPCHK(hipStreamSynchronize(s));
+    (void)hipFree(d_m);
+  }
+
+  // chunk workspace
+  const char* env = getenv("EG_CHUNK");
+  e->cap = env ? (u32)strtoul(env, nullptr, 10) : 131072u;
+  if (e->cap < NT) e->cap = NT;
+  e->cap = (e->cap + NT - 1) / NT * NT;
+  const size_t cap = e->cap;
+  HIPCHK(hipMalloc((void**)&e->pts, (size_t)std::max(P.n_pt_slots, 1) * 10 * cap * sizeof(uint4)));
+  HIPCHK(hipMalloc((void**)&e->cmp, (size_t)std::max(P.n_cmp_slots, 1) * 2 * cap * sizeof(uint4)));
+  HIPCHK(hipMalloc((void**)&e->chal, (size_t)std::max(P.n_chal_slots, 1) * 2 * cap * sizeof(uint4)));
+  HIPCHK(hipMalloc((void**)&e->states, (size_t)std::max(P.n_state_slots, 1) * 52 * cap * sizeof(u32)));
+  HIPCHK(hipMalloc((void**)&e->flags, (size_t)std::max(P.n_flag_slots, 1) * cap * sizeof(u32)));
+  HIPCHK(hipMalloc((void**)&e->bad_item, cap * sizeof(u32)));
+  HIPCHK(hipMalloc((void**)&e->partial, (size_t)P.tally_slots.size() * e->tally_blocks * 40 * sizeof(u32)));
+  HIPCHK(hipMalloc((void**)&e->tally, (size_t)P.tally_slots.size() * 40 * sizeof(u32)));
+  HIPCHK(hipMalloc((void**)&e->d_prefixes, (size_t)std::max(P.n_prefixes, 1) * 52 * sizeof(u32)));
+  hipLaunchKernelGGL(k_tally_init, dim3(1), dim3(NT), 0, s, e->tally, (int)P.tally_slots.size());
+
+  // hoisted transcript prefixes: run the prefix programs once (a single lane each)
+  if (e->prefix_inst_count) {
+    EngineBufs B = make_bufs(e.get(), nullptr, 1, nullptr);
+    hipLaunchKernelGGL(k_hash, dim3(grid_for(e->prefix_inst_count, 1 << 20)), dim3(NT), 0, s, B, e->d_insts, e->d_ops,
+                       e->prefix_inst_first, e->prefix_inst_count);
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipGetLastError());
+  *out = e.release();
+  return EG_OK;
+}
+
+// verify n ballots (device pointers), accumulating accepted ciphertexts into the running tally
+static int engine_verify_device(Engine* e, size_t n, const void* d_ballots, void* d_status, hipStream_t s) {
+  eg_ctx* ctx = e->ctx;
+  if (!s) s = ctx->stream;
+  const eghost::Plan& P = e->plan;
+  size_t all_idx = 0;
+  int rc;
+  if ((rc = prof_begin(ctx, s, false, &all_idx))) return rc;
+  for (size_t off = 0; off < n; off += e->cap) {
+    const u32 cn = (u32)std::min<size_t>(e->cap, n - off);
+    EngineBufs B = make_bufs(e, reinterpret_cast<const unsigned char*>(d_ballots) + off * P.stride, cn,
+                             reinterpret_cast<u32*>(d_status) + off);
+    const int wide = ctx->cus * 8;
+    HIPCHK(hipMemsetAsync(e->bad_item, 0xff, (size_t)cn * sizeof(u32), s));
+    hipLaunchKernelGGL(k_decode_points, dim3(grid_for((size_t)P.pt_items.size() * cn, wide)), dim3(NT), 0, s, B, e->d_pt_items,
+                       (int)P.pt_items.size());
+    hipLaunchKernelGGL(k_check_scalars, dim3(grid_for((size_t)P.sc_items.size() * cn, wide)), dim3(NT), 0, s, B, e->d_sc_items,
+                       (int)P.sc_items.size());
+    for (auto& lv : e->levels)
+      if (lv.count)
+        hipLaunchKernelGGL(k_derive_points, dim3(grid_for((size_t)lv.count * cn, wide)), dim3(NT), 0, s, B, e->d_dclasses,
+                           e->d_dterms, lv.first, lv.count);
+    for (auto& st : e->stages) {
+      if (st.job_count) {
+        size_t pi = 0;
+        if ((rc = prof_begin(ctx, s, true, &pi))) return rc;
+        hipLaunchKernelGGL(k_msm_jobs, dim3(grid_for((size_t)st.job_count * cn, ctx->msm_blocks)), dim3(NT), 0, s, B, e->d_jobs,
+                           e->d_vterms, st.job_first, st.job_count);
+        if ((rc = prof_end(ctx, s, pi))) return rc;
+      }
+      if (st.inst_count)
+        hipLaunchKernelGGL(k_hash, dim3(grid_for((size_t)st.inst_count * cn, 1 << 30)), dim3(NT), 0, s, B, e->d_insts, e->d_ops,
+                           st.inst_first, st.inst_count);
+    }
+    hipLaunchKernelGGL(k_status, dim3((cn + NT - 1) / NT), dim3(NT), 0, s, B, e->d_rules, (int)P.rules.size());
+    const int G = std::min<int>(e->tally_blocks, (int)((cn + NT - 1) / NT));
+    hipLaunchKernelGGL(k_tally_partial, dim3(G, (unsigned)P.tally_slots.size()), dim3(NT), 0, s, B, e->d_tally_slots, e->partial);
+    hipLaunchKernelGGL(k_tally_final, dim3((unsigned)P.tally_slots.size()), dim3(NT), 0, s, e->partial, G, e->tally);
+  }
+  if ((rc = prof_end(ctx, s, all_idx))) return rc;
+  HIPCHK(hipGetLastError());
+  return EG_OK;
+}
+
+static int engine_tally_encode(Engine* e, uint8_t* out) {
+  hipStream_t s = e->ctx->stream;
+  const int ns = (int)e->plan.tally_slots.size();
+  u32* d_out = nullptr;
+  HIPCHK(hipMalloc((void**)&d_out, (size_t)ns * 32));
+  hipLaunchKernelGGL(k_tally_encode, dim3(1), dim3(NT), 0, s, e->tally, ns, d_out);
+  HIPCHK(hipMemcpyAsync(out, d_out, (size_t)ns * 32, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  (void)hipFree(d_out);
+  return EG_OK;
+}
+
+static int engine_verify_host(Engine* e, size_t n, const uint8_t* ballots, uint32_t* status, uint8_t* tally_out) {
+  hipStream_t s = e->ctx->stream;
+  HIPCHK(hipSetDevice(e->ctx->device));
+  if (n > e->staging_ballots) {
+    if (e->d_wire) (void)hipFree(e->d_wire);
+    if (e->d_status) (void)hipFree(e->d_status);
+    e->d_wire = nullptr; e->d_status = nullptr;
+    HIPCHK(hipMalloc((void**)&e->d_wire, std::max<size_t>(n, 1) * e->plan.stride));
+    HIPCHK(hipMalloc((void**)&e->d_status, std::max<size_t>(n, 1) * sizeof(u32)));
+    e->staging_ballots = n;
+  }
+  if (tally_out) hipLaunchKernelGGL(k_tally_init, dim3(1), dim3(NT), 0, s, e->tally, (int)e->plan.tally_slots.size());
+  if (n) {
+    HIPCHK(hipMemcpyAsync(e->d_wire, ballots, n * e->plan.stride, hipMemcpyHostToDevice, s));
+    int rc = engine_verify_device(e, n, e->d_wire, e->d_status, s);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(status, e->d_status, n * sizeof(u32), hipMemcpyDeviceToHost, s));
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  if (tally_out) return engine_tally_encode(e, tally_out);
+  return EG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+struct eg_choice_params { Engine* eng; int n_options; int single; };
+struct eg_qv_params { Engine* eng; int n_options; uint64_t credits; eghost::QvShape shape; };
+
+extern "C" {
+
+const char* eg_last_error(void) { return g_err.c_str(); }
+
+int eg_init(int device, eg_ctx** out) {
+  if (!out) return fail(EG_ERR_BAD_ARG, "out is null");
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(EG_ERR_NO_DEVICE, "no HIP device visible");
+  if (device < 0 || device >= count) return fail(EG_ERR_BAD_ARG, "device index out of range");
+  HIPCHK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  std::unique_ptr<eg_ctx> c(new eg_ctx());
+  c->device = device;
+  c->cus = prop.multiProcessorCount;
+  c->name = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+  if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos && !getenv("EG_ALLOW_ANY_ARCH"))
+    return fail(EG_ERR_NO_DEVICE, "device is " + c->name + ", this library is built for gfx950 (MI355X) only");
+  HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIPCHK(hipMalloc((void**)&c->gen_words, 80 * sizeof(u32)));
+  HIPCHK(hipMalloc((void**)&c->tabG, 64 * 8 * 8 * sizeof(uint4)));
+  hipLaunchKernelGGL(k_setup_points, dim3(1), dim3(64), 0, c->stream, (const u32*)nullptr, c->gen_words, (u32*)nullptr);
+  hipLaunchKernelGGL(k_build_fixed_table, dim3(2), dim3(NT), 0, c->stream, c->gen_words, c->tabG);
+  int per_cu = 0;
+  HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_msm_jobs, NT, 0));
+  if (per_cu < 1) per_cu = 1;
+  const char* env = getenv("EG_MSM_BLOCKS_PER_CU");
+  if (env) per_cu = std::max(1, atoi(env));
+  c->msm_blocks = per_cu * c->cus;
+  HIPCHK(hipMalloc((void**)&c->ws, (size_t)c->msm_blocks * WS_QUADS * NT * sizeof(uint4)));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipGetLastError());
+  *out = c.release();
+  return EG_OK;
+}
+
+void eg_destroy(eg_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (auto& sp : c->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+  for (auto& ev : c->event_pool) (void)hipEventDestroy(ev);
+  if (c->tabG) (void)hipFree(c->tabG);
+  if (c->gen_words) (void)hipFree(c->gen_words);
+  if (c->ws) (void)hipFree(c->ws);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int eg_device_name(eg_ctx* c, char* buf, size_t cap) {
+  if (!c || !buf || !cap) return fail(EG_ERR_BAD_ARG, "bad argument");
+  snprintf(buf, cap, "%s, %d CUs, msm grid %d blocks", c->name.c_str(), c->cus, c->msm_blocks);
+  return EG_OK;
+}
+
+int eg_synchronize(eg_ctx* c) {
+  if (!c) return fail(EG_ERR_BAD_ARG, "ctx is null");
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return EG_OK;
+}
+
+int eg_profile_enable(eg_ctx* c, int enable) {
+  if (!c) return fail(EG_ERR_BAD_ARG, "ctx is null");
+  c->prof = enable != 0;
+  return EG_OK;
+}
+
+int eg_profile_read(eg_ctx* c, double* msm_ms_total, uint64_t* msm_launches, double* all_ms_total) {
+  if (!c) return fail(EG_ERR_BAD_ARG, "ctx is null");
+  HIPCHK(hipDeviceSynchronize());
+  for (auto& sp : c->spans) {
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, sp.a, sp.b));
+    if (sp.msm) { c->msm_ms += ms; c->msm_launches++; } else c->all_ms += ms;
+    c->event_pool.push_back(sp.a);
+    c->event_pool.push_back(sp.b);
+  }
+  c->spans.clear();
+  if (msm_ms_total) *msm_ms_total = c->msm_ms;
+  if (msm_launches) *msm_launches = c->msm_launches;
+  if (all_ms_total) *all_ms_total = c->all_ms;
+  c->msm_ms = 0; c->all_ms = 0; c->msm_launches = 0;
+  return EG_OK;
+}
+
+// ---- primitive tier ---------------------------------------------------------------------------------------------
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  int alloc(size_t bytes) { HIPCHK(hipMalloc(&p, std::max<size_t>(bytes, 16))); return EG_OK; }
+  int put(const void* src, size_t bytes, hipStream_t s) { if (bytes) HIPCHK(hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, s)); return EG_OK; }
+  int get(void* dst, size_t bytes, hipStream_t s) { if (bytes) HIPCHK(hipMemcpyAsync(dst, p, bytes, hipMemcpyDeviceToHost, s)); return EG_OK; }
+};
+#define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+static unsigned blocks_of(size_t n) { return (unsigned)std::max<size_t>(1, (n + NT - 1) / NT); }
+
+int eg_scalar_from_wide_batch(eg_ctx* c, size_t n, const uint8_t* wide, uint8_t* out) {
+  if (!c || (n && (!wide || !out))) return fail(EG_ERR_BAD_ARG, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  DevBuf a, o;
+  TRY(a.alloc(n * 64)); TRY(o.alloc(n * 32)); TRY(a.put(wide, n * 64, c->stream));
+  hipLaunchKernelGGL(k_prim_scalar_from_wide, dim3(blocks_of(n)), dim3(NT), 0, c->stream, n, (const u32*)a.p, (u32*)o.p);
+  TRY(o.get(out, n * 32, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return EG_OK;
+}
+int eg_scalar_is_canonical_batch(eg_ctx* c, size_t n, const uint8_t* s_, uint8_t* ok) {
+  if (!c || (n && (!s_ || !ok))) return fail(EG_ERR_BAD_ARG, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  DevBuf a, o;
+  TRY(a.alloc(n * 32)); TRY(o.alloc(n)); TRY(a.put(s_, n * 32, c->stream));
+  hipLaunchKernelGGL(k_prim_scalar_canonical, dim3(blocks_of(n)), dim3(NT), 0, c->stream, n, (const u32*)a.p, (unsigned char*)o.p);
+  TRY(o.get(ok, n, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return EG_OK;
+}
+int eg_scalar_muladd_batch(eg_ctx* c, size_t n, const uint8_t* a_, const uint8_t* b_, const uint8_t* c_, uint8_t* out) {
+  if (!c || (n && (!a_ || !b_ || !c_ || !out))) return fail(EG_ERR_BAD_ARG, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  DevBuf a, b, cc, o;
+  TRY(a.alloc(n * 32)); TRY(b.alloc(n * 32)); TRY(cc.alloc(n * 32)); TRY(o.alloc(n * 32));
+  TRY(a.put(a_, n * 32, c->stream)); TRY(b.put(b_, n * 32, c->stream)); TRY(cc.put(c_, n * 32, c->stream));
+  hipLaunchKernelGGL(k_prim_scalar_muladd, dim3(blocks_of(n)), dim3(NT), 0, c->stream, n, (const u32*)a.p, (const u32*)b.p,
+                     (const u32*)cc.p, (u32*)o.p);
+  TRY(o.get(out, n * 32, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return EG_OK;
+}
+int eg_scalar_neg_batch(eg_ctx* c, size_t n, const uint8_t* a_, uint8_t* out) {
+  if (!c || (n && (!a_ || !out))) return fail(EG_ERR_BAD_ARG, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  DevBuf a, o;
+  TRY(a.alloc(n * 32)); TRY(o.alloc(n * 32)); TRY(a.put(a_, n * 32, c->stream));
+  hipLaunchKernelGGL(k_prim_scalar_neg, dim3(blocks_of(n)), dim3(NT), 0, c->stream, n, (const u32*)a.p, (u32*)o.p);
+  TRY(o.get(out, n * 32, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return EG_OK;
+}
+int eg_point_roundtrip_batch(eg_ctx* c, size_t n, const uint8_t* in, uint8_t* out, uint8_t* ok) {
+  if (!c || (n && (!in || !out || !ok))) return fail(EG_ERR_BAD_ARG, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  DevBuf a, o, k;
+  TRY(a.alloc(n * 32)); TRY(o.alloc(n * 32)); TRY(k.alloc(n)); TRY(a.put(in, n * 32, c->stream));
+  hipLaunchKernelGGL(k_prim_point_roundtrip, dim3(blocks_of(n)), dim3(NT), 0, c->stream, n, (const u32*)a.p, (u32*)o.p,
+                     (unsigned char*)k.p);
+  TRY(o.get(out, n * 32, c->stream)); TRY(k.get(ok, n, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return EG_OK;
+}
+int eg_point_add_batch(eg_ctx* c, size_t n, const uint8_t* a_, const uint8_t* b_, int subtract, uint8_t* out, uint8_t* ok) {
+  if (!c || (n && (!a_ || !b_ || !out || !ok))) return fail(EG_ERR_BAD_ARG, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  DevBuf a, b, o, k;
+  TRY(a.alloc(n * 32)); TRY(b.alloc(n * 32)); TRY(o.alloc(n * 32)); TRY(k.alloc(n));
+  TRY(a.put(a_, n * 32, c->stream)); TRY(b.put(b_, n * 32, c->stream));
+  hipLaunchKernelGGL(k_prim_point_add, dim3(blocks_of(n)), dim3(NT), 0, c->stream, n, (const u32*)a.p, (const u32*)b.p, subtract,
+                     (u32*)o.p, (unsigned char*)k.p);
+  TRY(o.get(out, n * 32, c->stream)); TRY(k.get(ok, n, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return EG_OK;
+}
+static int prim_msm(eg_ctx* c, size_t n, size_t terms, const uint8_t* scalars, const uint8_t* points, const uint8_t* r,
+                    uint8_t* out, uint8_t* ok) {
+  HIPCHK(hipSetDevice(c->device));
+  DevBuf sc, pt, rr, o, k;
+  TRY(sc.alloc(n * terms * 32)); TRY(pt.alloc(n * terms * 32)); TRY(rr.alloc(n * 32)); TRY(o.alloc(n * 32)); TRY(k.alloc(n));
+  TRY(sc.put(scalars, n * terms * 32, c->stream)); TRY(pt.put(points, n * terms * 32, c->stream));
+  if (r) TRY(rr.put(r, n * 32, c->stream));
+  hipLaunchKernelGGL(k_prim_msm, dim3(grid_for(n, c->msm_blocks)), dim3(NT), 0, c->stream, n, (int)terms, (const u32*)sc.p,
+                     (const u32*)pt.p, r ? (const u32*)rr.p : (const u32*)nullptr, c->tabG, c->ws, (u32*)o.p, (unsigned char*)k.p);
+  TRY(o.get(out, n * 32, c->stream));
+  if (ok) TRY(k.get(ok, n, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipGetLastError());
+  return EG_OK;
+}
+int eg_mul_generator_batch(eg_ctx* c, size_t n, const uint8_t* k, uint8_t* out) {
+  if (!c || (n && (!k || !out))) return fail(EG_ERR_BAD_ARG, "bad argument");
+  return prim_msm(c, n, 0, nullptr, nullptr, k, out, nullptr);
+}
+int eg_vartime_double_mul_generator_batch(eg_ctx* c, size_t n, const uint8_t* k, const uint8_t* p, const uint8_t* r, uint8_t* out,
+                                          uint8_t* ok) {
+  if (!c || (n && (!k || !p || !r || !out || !ok))) return fail(EG_ERR_BAD_ARG, "bad argument");
+  return prim_msm(c, n, 1, k, p, r, out, ok);
+}
+int eg_vartime_multi_mul_batch(eg_ctx* c, size_t n, size_t terms, const uint8_t* scalars, const uint8_t* points, uint8_t* out,
+                               uint8_t* ok) {
+  if (!c || (n && !out) || (n && terms && (!scalars || !points))) return fail(EG_ERR_BAD_ARG, "bad argument");
+  return prim_msm(c, n, terms, scalars, points, nullptr, out, ok);
+}
+
+// ---- batch tier: choice ---------------------------------------------------------------------------------------------------
+size_t eg_choice_ballot_size(int n_options, int single) { return eghost::choice_ballot_size(n_options, single != 0); }
+
+int eg_choice_params_create(eg_ctx* c, const uint8_t pk[32], int n_options, int single, eg_choice_params** out) {
+  if (!c || !pk || !out) return fail(EG_ERR_BAD_ARG, "bad argument");
+  if (n_options < 1 || n_options > 4000) return fail(EG_ERR_BAD_ARG, "n_options must be in 1..4000");
+  Engine* e = nullptr;
+  TRY(engine_create(c, eghost::build_choice_plan(n_options, single != 0), pk, n_options, &e));
+  *out = new eg_choice_params{e, n_options, single};
+  return EG_OK;
+}
+void eg_choice_params_destroy(eg_choice_params* p) { if (p) { engine_free(p->eng); delete p; } }
+int eg_verify_choice_batch(eg_choice_params* p, size_t n, const uint8_t* ballots, uint32_t* status, uint8_t* tally_out) {
+  if (!p || (n && (!ballots || !status))) return fail(EG_ERR_BAD_ARG, "bad argument");
+  return engine_verify_host(p->eng, n, ballots, status, tally_out);
+}
+int eg_verify_choice_batch_device(eg_choice_params* p, size_t n, const void* d_ballots, void* d_status, void* stream) {
+  if (!p || (n && (!d_ballots || !d_status))) return fail(EG_ERR_BAD_ARG, "bad argument");
+  HIPCHK(hipSetDevice(p->eng->ctx->device));
+  return engine_verify_device(p->eng, n, d_ballots, d_status, (hipStream_t)stream);
+}
+static int tally_reset(Engine* e) {
+  hipLaunchKernelGGL(k_tally_init, dim3(1), dim3(NT), 0, e->ctx->stream, e->tally, (int)e->plan.tally_slots.size());
+  HIPCHK(hipStreamSynchronize(e->ctx->stream));
+  return EG_OK;
+}
+static int tally_merge(Engine* e, const void* d_gathered, int n_ranks, hipStream_t s) {
+  if (!s) s = e->ctx->stream;
+  hipLaunchKernelGGL(k_tally_merge, dim3(1), dim3(NT), 0, s, (const u32*)d_gathered, n_ranks, (int)e->plan.tally_slots.size(), e->tally);
+  HIPCHK(hipGetLastError());
+  return EG_OK;
+}
+int eg_choice_tally_reset(eg_choice_params* p) { return p ? tally_reset(p->eng) : fail(EG_ERR_BAD_ARG, "null"); }
+int eg_choice_tally_device_ptr(eg_choice_params* p, void** d, size_t* nb) {
+  if (!p || !d || !nb) return fail(EG_ERR_BAD_ARG, "bad argument");
+  *d = p->eng->tally; *nb = p->eng->plan.tally_slots.size() * EG_TALLY_POINT_BYTES;
+  return EG_OK;
+}
+int eg_choice_tally_merge_device(eg_choice_params* p, const void* g, int n_ranks, void* stream) {
+  if (!p || !g || n_ranks < 1) return fail(EG_ERR_BAD_ARG, "bad argument");
+  return tally_merge(p->eng, g, n_ranks, (hipStream_t)stream);
+}
+int eg_choice_tally_encode(eg_choice_params* p, uint8_t* out) {
+  if (!p || !out) return fail(EG_ERR_BAD_ARG, "bad argument");
+  return engine_tally_encode(p->eng, out);
+}
+
+// ---- batch tier: quadratic voting --------------------------------------------------------------------------------------------
+int eg_qv_params_create(eg_ctx* c, const uint8_t pk[32], int n_options, uint64_t credits, eg_qv_params** out) {
+  if (!c || !pk || !out) return fail(EG_ERR_BAD_ARG, "bad argument");
+  if (n_options < 1 || n_options > 256 || credits < 1 || credits > 100000) return fail(EG_ERR_BAD_ARG, "options in 1..256, credits in 1..100000");
+  Engine* e = nullptr;
+  TRY(engine_create(c, eghost::build_qv_plan(n_options, credits), pk, n_options, &e));
+  *out = new eg_qv_params{e, n_options, credits, eghost::qv_shape(n_options, credits)};
+  return EG_OK;
+}
+void eg_qv_params_destroy(eg_qv_params* p) { if (p) { engine_free(p->eng); delete p; } }
+size_t eg_qv_ballot_size(const eg_qv_params* p) { return p ? p->shape.ballot_size : 0; }
+int eg_verify_qv_batch(eg_qv_params* p, size_t n, const uint8_t* ballots, uint32_t* status, uint8_t* tally_out) {
+  if (!p || (n && (!ballots || !status))) return fail(EG_ERR_BAD_ARG, "bad argument");
+  return engine_verify_host(p->eng, n, ballots, status, tally_out);
+}
+int eg_verify_qv_batch_device(eg_qv_params* p, size_t n, const void* d_ballots, void* d_status, void* stream) {
+  if (!p || (n && (!d_ballots || !d_status))) return fail(EG_ERR_BAD_ARG, "bad argument");
+  HIPCHK(hipSetDevice(p->eng->ctx->device));
+  return engine_verify_device(p->eng, n, d_ballots, d_status, (hipStream_t)stream);
+}
+int eg_qv_tally_reset(eg_qv_params* p) { return p ? tally_reset(p->eng) : fail(EG_ERR_BAD_ARG, "null"); }
+int eg_qv_tally_device_ptr(eg_qv_params* p, void** d, size_t* nb) {
+  if (!p || !d || !nb) return fail(EG_ERR_BAD_ARG, "bad argument");
+  *d = p->eng->tally; *nb = p->eng->plan.tally_slots.size() * EG_TALLY_POINT_BYTES;
+  return EG_OK;
+}
+int eg_qv_tally_merge_device(eg_qv_params* p, const void* g, int n_ranks, void* stream) {
+  if (!p || !g || n_ranks < 1) return fail(EG_ERR_BAD_ARG, "bad argument");
+  return tally_merge(p->eng, g, n_ranks, (hipStream_t)stream);
+}
+int eg_qv_tally_encode(eg_qv_params* p, uint8_t* out) {
+  if (!p || !out) return fail(EG_ERR_BAD_ARG, "bad argument");
+  return engine_tally_encode(p->eng, out);
+}
+
+// ---- synthetic ballots ---------------------------------------------------------------------------------------------------------
+int eg_choice_encrypt_batch_device(eg_choice_params* p, uint64_t base_seed, size_t first, size_t n, int n_selected, void* d_out,
+                                   void* stream) {
+  if (!p || (n && !d_out)) return fail(EG_ERR_BAD_ARG, "bad argument");
+  Engine* e = p->eng;
+  HIPCHK(hipSetDevice(e->ctx->device));
+  hipStream_t s = stream ? (hipStream_t)stream : e->ctx->stream;
+  if (!p->single && (n_selected < 0 || n_selected > p->n_options)) return fail(EG_ERR_BAD_ARG, "n_selected out of range");
+  if (n == 0) return EG_OK;
+  hipLaunchKernelGGL(k_choice_encrypt, dim3(grid_for(n, e->ctx->msm_blocks)), dim3(NT), 0, s, base_seed + first, n, p->n_options,
+                     p->single, n_selected, e->ctx->tabG, e->d_tabK, e->d_key_words, e->d_prefixes, e->ctx->ws,
+                     reinterpret_cast<u32*>(d_out), (u32)(e->plan.stride / 4));
+  HIPCHK(hipGetLastError());
+  return EG_OK;
+}
+int eg_qv_encrypt_batch_device(eg_qv_params*, uint64_t, size_t, size_t, void*, void*) {
+  return fail(EG_ERR_BAD_ARG, "QuadraticVotingBallot::new on the GPU is not implemented yet (SURVEY 8f row 1)");
+}
+
+}  // extern "C"

@@ -1,0 +1,371 @@
+// ge25519.cuh -- twisted Edwards (a = -1) point arithmetic, ristretto255 codec and scalar
+// multiplication for gfx950.
+//
+// Replaces what src/group/ristretto.rs:65-146 of the reference delegates to curve25519-dalek:
+// identity/generator/add/sub (ristretto.rs:76-86), compress (:88-90), decompress (:93-95),
+// mul_generator (:105-107), vartime_double_scalar_mul_basepoint (:131-137),
+// vartime_multiscalar_mul (:139-145).
+// Formulas: hwcd-2008 unified addition / dedicated doubling in extended coordinates; RFC 9496
+// 4.3.1 / 4.3.2 / 4.2 codec.  Ristretto encodings are canonical, so any correct scalar-multiplication
+// schedule is bit-exact with dalek's.  The schedule here is a UNIFORM signed radix-16
+// ladder: every lane of a wavefront runs the same instruction stream; digit signs and zero digits are
+// handled with selects instead of branches (dalek's NAF is data dependent and would diverge).
+//
+// [n] annotations are limb classes, see the bound discipline in fe25519.cuh.
+#pragma once
+#include "fe25519.cuh"
+
+namespace eg {
+
+struct ge { fe X, Y, Z, T; };              // extended, all [1]
+struct ge_p2 { fe X, Y, Z; };              // projective, all [1]
+struct ge_p1p1 { fe X, Y, Z, T; };         // completed: x = X/Z, y = Y/T
+struct ge_cached { fe YpX, YmX, Z2, T2d; };  // (Y+X, Y-X, 2Z, 2dT), all [1]
+struct ge_niels { fe ypx, ymx, xy2d; };    // affine (y+x, y-x, 2dxy), all [1]
+
+EG_HD void ge_identity(ge& p) { fe_0(p.X); fe_1(p.Y); fe_1(p.Z); fe_0(p.T); }
+EG_HD void ge_generator(ge& p) {
+  const fe bx = EG_FE_BASE_X, by = EG_FE_BASE_Y, bt = EG_FE_BASE_T;
+  p.X = bx; p.Y = by; fe_1(p.Z); p.T = bt;
+}
+
+// ---- conversions out of the completed form ---------------------------------------------------------
+// result of ge_dbl: {X [5], Y [2], Z [3], T [1]}
+EG_HD void ge_dbl_to_p2(ge_p2& r, const ge_p1p1& p) {
+  fe_mul(r.X, p.X, p.T);
+  fe_mul(r.Y, p.Z, p.Y);
+  fe_mul(r.Z, p.Z, p.T);
+}
+EG_HD void ge_dbl_to_p3(ge& r, const ge_p1p1& p) {
+  fe_mul(r.X, p.X, p.T);
+  fe_mul(r.Y, p.Z, p.Y);
+  fe_mul(r.Z, p.Z, p.T);
+  fe_mul(r.T, p.X, p.Y);
+}
+// result of ge_add / ge_madd: {X [3], Y [2], Z [2..3], T [3..4]}
+EG_HD void ge_add_to_p2(ge_p2& r, const ge_p1p1& p) {
+  fe_mul(r.X, p.T, p.X);
+  fe_mul(r.Y, p.Z, p.Y);
+  fe_mul(r.Z, p.T, p.Z);
+}
+EG_HD void ge_add_to_p3(ge& r, const ge_p1p1& p) {
+  fe_mul(r.X, p.T, p.X);
+  fe_mul(r.Y, p.Z, p.Y);
+  fe_mul(r.Z, p.T, p.Z);
+  fe_mul(r.T, p.X, p.Y);
+}
+
+EG_HD void ge_to_cached(ge_cached& c, const ge& p) {
+  const fe d2 = EG_FE_2D;
+  fe_add(c.YpX, p.Y, p.X); fe_carry(c.YpX);
+  fe_sub(c.YmX, p.Y, p.X); fe_carry(c.YmX);
+  fe_add(c.Z2, p.Z, p.Z); fe_carry(c.Z2);
+  fe_mul(c.T2d, p.T, d2);
+}
+EG_HD void ge_cached_identity(ge_cached& c) { fe_1(c.YpX); fe_1(c.YmX); fe_0(c.Z2); c.Z2.v[0] = 2; fe_0(c.T2d); }
+EG_HD void ge_niels_identity(ge_niels& c) { fe_1(c.ypx); fe_1(c.ymx); fe_0(c.xy2d); }
+
+// conditional negation of an addend (branch-free: lanes of one wave differ in digit sign)
+EG_HD void ge_cached_cneg(ge_cached& c, bool neg) {
+  fe t = c.YpX; fe_cmov(c.YpX, c.YmX, neg); fe_cmov(c.YmX, t, neg);
+  fe n; fe_neg(n, c.T2d);          // [3]
+  fe_cmov(c.T2d, n, neg);
+}
+EG_HD void ge_niels_cneg(ge_niels& c, bool neg) {
+  fe t = c.ypx; fe_cmov(c.ypx, c.ymx, neg); fe_cmov(c.ymx, t, neg);
+  fe n; fe_neg(n, c.xy2d);
+  fe_cmov(c.xy2d, n, neg);
+}
+
+// r = p + q   (q.T2d may be [3] after a conditional negation)
+EG_HD void ge_add(ge_p1p1& r, const ge& p, const ge_cached& q) {
+  fe a, b, t0;
+  fe_add(a, p.Y, p.X);             // [2]
+  fe_sub(b, p.Y, p.X);             // [3]
+  fe_mul(r.Z, a, q.YpX);           // PP
+  fe_mul(r.Y, b, q.YmX);           // MM
+  fe_mul(r.T, p.T, q.T2d);         // TT
+  fe_mul(t0, p.Z, q.Z2);           // D = 2 Z1 Z2 [1]
+  fe_sub(r.X, r.Z, r.Y);           // E = PP - MM [3]
+  fe_add(r.Y, r.Z, r.Y);           // H = PP + MM [2]
+  fe_add(r.Z, t0, r.T);            // G = D + TT  [2]
+  fe_sub(r.T, t0, r.T);            // F = D - TT  [3]
+}
+// mixed addition with an affine table entry (Z2 = 1)
+EG_HD void ge_madd(ge_p1p1& r, const ge& p, const ge_niels& q) {
+  fe a, b, t0;
+  fe_add(a, p.Y, p.X);
+  fe_sub(b, p.Y, p.X);
+  fe_mul(r.Z, a, q.ypx);
+  fe_mul(r.Y, b, q.ymx);
+  fe_mul(r.T, p.T, q.xy2d);
+  fe_add(t0, p.Z, p.Z);            // D = 2 Z1 [2]
+  fe_sub(r.X, r.Z, r.Y);           // E [3]
+  fe_add(r.Y, r.Z, r.Y);           // H [2]
+  fe_add(r.Z, t0, r.T);            // G [3]
+  fe_sub(r.T, t0, r.T);            // F [4]
+}
+// r = 2p  (needs X, Y, Z only)
+EG_HD void ge_dbl(ge_p1p1& r, const fe& X, const fe& Y, const fe& Z) {
+  fe xx, yy, b2, a;
+  fe_sq(xx, X);
+  fe_sq(yy, Y);
+  fe_sq(b2, Z); fe_add(b2, b2, b2);   // [2]
+  fe_add(a, X, Y);                    // [2]
+  fe_sq(a, a);                        // AA [1]
+  fe_add(r.Y, yy, xx);                // H [2]
+  fe_sub(r.Z, yy, xx);                // G [3]
+  fe_sub4(r.X, a, r.Y);               // E = AA - H [5]
+  fe_sub4(r.T, b2, r.Z);              // F = 2ZZ - G [6]
+  fe_carry(r.T);                      // [1]
+}
+
+// full-width helpers (not on the hot loop)
+EG_HD void ge_add_full(ge& r, const ge& p, const ge& q) {
+  ge_cached c; ge_p1p1 t;
+  ge_to_cached(c, q);
+  ge_add(t, p, c);
+  ge_add_to_p3(r, t);
+}
+EG_HD void ge_neg(ge& r, const ge& p) {
+  r = p;
+  fe_neg(r.X, p.X); fe_carry(r.X);
+  fe_neg(r.T, p.T); fe_carry(r.T);
+}
+EG_HD void ge_sub_full(ge& r, const ge& p, const ge& q) {
+  ge n; ge_neg(n, q);
+  ge_add_full(r, p, n);
+}
+EG_HD void ge_dbl_full(ge& r, const ge& p) {
+  ge_p1p1 t;
+  ge_dbl(t, p.X, p.Y, p.Z);
+  ge_dbl_to_p3(r, t);
+}
+
+// ---- SQRT_RATIO_M1 (RFC 9496 4.2) ----------------------------------------------------------------------
+// u, v must be [1].  r = non-negative sqrt(u/v) or sqrt(i*u/v); returns was_square.
+EG_HD bool fe_sqrt_ratio_m1(fe& r, const fe& u, const fe& v) {
+  const fe sqrtm1 = EG_FE_SQRTM1;
+  fe v3, v7, t, check, neg_u, neg_u_i, ri;
+  fe_sq(v3, v); fe_mul(v3, v3, v);
+  fe_sq(v7, v3); fe_mul(v7, v7, v);
+  fe_mul(t, u, v7);
+  fe_pow22523(t, t);
+  fe_mul(r, u, v3);
+  fe_mul(r, r, t);
+  fe_sq(check, r);
+  fe_mul(check, check, v);
+  fe_neg(neg_u, u);                 // [3]
+  fe_mul(neg_u_i, neg_u, sqrtm1);   // [1]
+  const bool correct = fe_eq(check, u);
+  const bool flipped = fe_eq(check, neg_u);
+  const bool flipped_i = fe_eq(check, neg_u_i);
+  fe_mul(ri, r, sqrtm1);
+  fe_cmov(r, ri, flipped | flipped_i);
+  fe n; fe_neg(n, r); fe_carry(n);
+  fe_cmov(r, n, fe_isnegative(r));
+  return correct | flipped;
+}
+
+// ---- ristretto255 decode (deserialize_element, ristretto.rs:93-95) ------------------------------------------
+// w = little-endian words of the 32-byte encoding.  Returns false for an invalid encoding (p is then the
+// identity so that downstream arithmetic stays well defined).
+EG_HD bool ristretto_decode(ge& p, const u32 w[8]) {
+  const fe d = EG_FE_D;
+  fe s, one;
+  fe_1(one);
+  fe_from_words(s, w);
+  u32 chk[8];
+  fe_to_words(chk, s);
+  u32 diff = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) diff |= chk[i] ^ w[i];
+  bool ok = (diff == 0) & ((w[0] & 1u) == 0);   // canonical and non-negative
+  fe ss, u1, u2, u2s, v, t, inv, dx, dy, x, y, tt;
+  fe_sq(ss, s);
+  fe_sub(u1, one, ss); fe_carry(u1);
+  fe_add(u2, one, ss); fe_carry(u2);
+  fe_sq(u2s, u2);
+  fe_sq(t, u1);
+  fe_mul(t, t, d);
+  fe_add(t, t, u2s);                // d*u1^2 + u2^2 [2]
+  fe_carry(t);
+  fe_neg(v, t); fe_carry(v);        // v = -(d*u1^2) - u2^2
+  fe_mul(t, v, u2s);
+  const bool was_square = fe_sqrt_ratio_m1(inv, one, t);
+  fe_mul(dx, inv, u2);
+  fe_mul(dy, inv, dx);
+  fe_mul(dy, dy, v);
+  fe_mul(x, s, dx);
+  fe_add(x, x, x); fe_carry(x);
+  fe n; fe_neg(n, x); fe_carry(n);
+  fe_cmov(x, n, fe_isnegative(x));
+  fe_mul(y, u1, dy);
+  fe_mul(tt, x, y);
+  ok = ok & was_square & !fe_isnegative(tt) & !fe_iszero(y);
+  ge id; ge_identity(id);
+  p.X = x; p.Y = y; fe_1(p.Z); p.T = tt;
+  fe_cmov(p.X, id.X, !ok); fe_cmov(p.Y, id.Y, !ok); fe_cmov(p.T, id.T, !ok);
+  return ok;
+}
+
+// ---- ristretto255 encode (serialize_element, ristretto.rs:88-90) ------------------------------------------------
+EG_HD void ristretto_encode(u32 w[8], const ge& p) {
+  const fe sqrtm1 = EG_FE_SQRTM1, invsqrt_amd = EG_FE_INVSQRT_A_MINUS_D;
+  fe one; fe_1(one);
+  fe u1, u2, t0, t1, inv, d1, d2, zinv, x, y, dinv, s;
+  fe_add(t0, p.Z, p.Y);             // [2]
+  fe_sub(t1, p.Z, p.Y);             // [3]
+  fe_mul(u1, t0, t1);
+  fe_mul(u2, p.X, p.Y);
+  fe_sq(t0, u2);
+  fe_mul(t0, t0, u1);
+  fe_sqrt_ratio_m1(inv, one, t0);
+  fe_mul(d1, inv, u1);
+  fe_mul(d2, inv, u2);
+  fe_mul(zinv, d1, d2);
+  fe_mul(zinv, zinv, p.T);
+  fe_mul(t0, p.T, zinv);
+  const bool rotate = fe_isnegative(t0);
+  fe ix, iy, dr;
+  fe_mul(ix, p.Y, sqrtm1);
+  fe_mul(iy, p.X, sqrtm1);
+  fe_mul(dr, d1, invsqrt_amd);
+  x = p.X; y = p.Y; dinv = d2;
+  fe_cmov(x, ix, rotate); fe_cmov(y, iy, rotate); fe_cmov(dinv, dr, rotate);
+  fe_mul(t0, x, zinv);
+  fe n; fe_neg(n, y); fe_carry(n);
+  fe_cmov(y, n, fe_isnegative(t0));
+  fe_sub(t0, p.Z, y);               // [3]
+  fe_mul(s, t0, dinv);
+  fe_neg(n, s); fe_carry(n);
+  fe_cmov(s, n, fe_isnegative(s));
+  fe_to_words(w, s);
+}
+
+// Ristretto equality / identity test (ristretto.rs:80-82); only used off the hot path
+EG_HD bool ge_ristretto_eq(const ge& p, const ge& q) {
+  fe a, b;
+  fe_mul(a, p.X, q.Y); fe_mul(b, p.Y, q.X);
+  const bool e1 = fe_eq(a, b);
+  fe_mul(a, p.Y, q.Y); fe_mul(b, p.X, q.X);
+  return e1 | fe_eq(a, b);
+}
+
+// ---- scalar recoding -------------------------------------------------------------------------------------
+// 256-bit scalar (< 2^253) -> 64 signed radix-16 digits in [-8, 7], packed as nibbles (two's complement).
+EG_HD void sc_recode_radix16(u32 out[8], const u32 k[8]) {
+  u32 carry = 0;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) {
+    u32 o = 0;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+      u32 dgt = ((k[w] >> (4 * n)) & 15u) + carry;   // 0..16
+      carry = (dgt + 8u) >> 4;
+      o |= (dgt & 15u) << (4 * n);
+    }
+    out[w] = o;
+  }
+  // carry out of digit 63 is 0 for scalars < 2^255 - 2^251 (all canonical scalars are < 2^253)
+}
+// signed value of digit i (0..63)
+EG_HD int sc_digit16(const u32 d[8], int i) {
+  u32 w = d[0];
+#pragma unroll
+  for (int j = 1; j < 8; ++j) w = ((i >> 3) == j) ? d[j] : w;
+  const int nib = (int)((w >> (4 * (i & 7))) & 15u);
+  return nib >= 8 ? nib - 16 : nib;
+}
+
+// ---- variable-base scalar multiplication ------------------------------------------------------------------------
+// The per-lane table {1P..8P} (cached form, 160 words per entry) does not fit registers or LDS at useful
+// occupancy (1.25 KiB per lane), so it lives in a per-lane slice of a global workspace through the TableIO
+// policy: device code uses a coalesced [entry][word4][lane] layout (kernels.hip); host tests use an array.
+template <class TableIO>
+EG_HD void ge_var_table_build(TableIO& io, const ge& p) {
+  // entries k = 1..8 by repeated addition of P (one rolled add body; no indexed point arrays, which
+  // hipcc would place in scratch)
+  ge_cached pc; ge_to_cached(pc, p);
+  io.store(0, pc);
+  ge cur = p;
+#pragma unroll 1
+  for (int k = 2; k <= 8; ++k) {
+    ge_p1p1 t;
+    ge_add(t, cur, pc);
+    ge_add_to_p3(cur, t);
+    ge_cached c; ge_to_cached(c, cur);
+    io.store(k - 1, c);
+  }
+}
+
+// acc = [k]P with the table already built; digits = sc_recode_radix16(k)
+template <class TableIO>
+EG_HD void ge_var_mul(ge& acc, TableIO& io, const u32 digits[8]) {
+  ge_cached ident; ge_cached_identity(ident);
+  // top digit
+  {
+    const int d = sc_digit16(digits, 63);
+    const int ad = d < 0 ? -d : d;
+    ge_cached c; io.load(c, ad == 0 ? 0 : ad - 1);
+    fe_cmov(c.YpX, ident.YpX, ad == 0); fe_cmov(c.YmX, ident.YmX, ad == 0);
+    fe_cmov(c.Z2, ident.Z2, ad == 0); fe_cmov(c.T2d, ident.T2d, ad == 0);
+    ge_cached_cneg(c, d < 0);
+    ge id; ge_identity(id);
+    ge_p1p1 t; ge_add(t, id, c);
+    ge_add_to_p3(acc, t);
+  }
+#pragma unroll 1
+  for (int i = 62; i >= 0; --i) {
+    const int d = sc_digit16(digits, i);
+    const int ad = d < 0 ? -d : d;
+    ge_cached c; io.load(c, ad == 0 ? 0 : ad - 1);   // issued before the doublings: latency hidden
+    ge_p1p1 t; ge_p2 q;
+    q.X = acc.X; q.Y = acc.Y; q.Z = acc.Z;
+#pragma unroll 1
+    for (int r = 0; r < 3; ++r) {
+      ge_dbl(t, q.X, q.Y, q.Z);
+      ge_dbl_to_p2(q, t);
+    }
+    ge_dbl(t, q.X, q.Y, q.Z);
+    ge_dbl_to_p3(acc, t);
+    fe_cmov(c.YpX, ident.YpX, ad == 0); fe_cmov(c.YmX, ident.YmX, ad == 0);
+    fe_cmov(c.Z2, ident.Z2, ad == 0); fe_cmov(c.T2d, ident.T2d, ad == 0);
+    ge_cached_cneg(c, d < 0);
+    ge_add(t, acc, c);
+    ge_add_to_p3(acc, t);
+  }
+}
+
+// ---- fixed-base scalar multiplication -----------------------------------------------------------------------------
+// Table layout: tab[(window * 8 + (|digit| - 1)) * 32 + word], 30 words used (ypx, ymx, xy2d), built once per
+// base on the device (k_build_fixed_table).  acc += [k]Base.
+template <class NielsIO>
+EG_HD void ge_fixed_mul_add(ge& acc, NielsIO& io, const u32 digits[8]) {
+  ge_niels ident; ge_niels_identity(ident);
+#pragma unroll 1
+  for (int i = 0; i < 64; ++i) {
+    const int d = sc_digit16(digits, i);
+    const int ad = d < 0 ? -d : d;
+    ge_niels c; io.load(c, i * 8 + (ad == 0 ? 0 : ad - 1));
+    fe_cmov(c.ypx, ident.ypx, ad == 0); fe_cmov(c.ymx, ident.ymx, ad == 0); fe_cmov(c.xy2d, ident.xy2d, ad == 0);
+    ge_niels_cneg(c, d < 0);
+    ge_p1p1 t; ge_madd(t, acc, c);
+    ge_add_to_p3(acc, t);
+  }
+}
+
+// affine niels entry from a projective point (one inversion; table construction only)
+EG_HD void ge_to_niels(ge_niels& n, const ge& p) {
+  const fe d2 = EG_FE_2D;
+  fe zi, x, y;
+  fe_invert(zi, p.Z);
+  fe_mul(x, p.X, zi);
+  fe_mul(y, p.Y, zi);
+  fe_add(n.ypx, y, x); fe_carry(n.ypx);
+  fe_sub(n.ymx, y, x); fe_carry(n.ymx);
+  fe_mul(n.xy2d, x, y);
+  fe_mul(n.xy2d, n.xy2d, d2);
+}
+
+}  // namespace eg

@@ -1,0 +1,427 @@
+// host_plan.hpp -- host-side mirror of the reference's election parameter objects and the flattening of
+// their verify() walks into a device plan (plan.h).  Pure host logic, no arithmetic on secrets or points:
+// all curve / hash work happens in the kernels.
+//
+// Mirrors: ChoiceParams::{single,multi} (choice.rs:132-196), RangeDecomposition::optimal + Display
+// (range.rs:110-124,148-305), PreparedRange (range.rs:329-355), QuadraticVotingParams::new + isqrt
+// (quadratic_voting.rs:63-76,127-143), and the transcript label schedules of ring.rs:290-293,317-368,
+// log_equality.rs:167-173, range.rs:561-562, mul.rs:96-99,204-253.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+#include "plan.h"
+
+namespace eghost {
+
+using namespace egplan;
+
+// ---- RangeDecomposition (range.rs) ---------------------------------------------------------------------
+struct RingSpec { uint64_t size, step; };
+struct RangeDecomposition {
+  std::vector<RingSpec> rings;
+  std::string to_string() const {  // Display, range.rs:110-124 (hashed into the transcript at :562)
+    std::string s;
+    for (size_t i = 0; i < rings.size(); ++i) {
+      if (rings[i].step > 1) s += std::to_string(rings[i].step) + " * ";
+      s += "0.." + std::to_string(rings[i].size);
+      if (i + 1 < rings.size()) s += " + ";
+    }
+    return s;
+  }
+  uint64_t rings_size() const { uint64_t t = 0; for (auto& r : rings) t += r.size; return t; }
+  uint64_t upper_bound() const { uint64_t t = 0; for (auto& r : rings) t += (r.size - 1) * r.step; return t + 1; }
+};
+struct OptimalDecomposition { RangeDecomposition d; uint64_t len; };
+
+inline uint64_t lower_len_estimate(uint64_t ub) { return (uint64_t)std::ceil(std::log2((double)ub) * 3.0); }  // range.rs:302-305
+
+inline OptimalDecomposition optimize_range(uint64_t ub, std::map<uint64_t, OptimalDecomposition>& memo) {  // range.rs:238-300
+  auto it = memo.find(ub);
+  if (it != memo.end()) return it->second;
+  OptimalDecomposition opt;
+  opt.len = ub + 2;
+  opt.d.rings = {{ub, 1}};
+  for (uint64_t first = 2;; ++first) {
+    if (first + 2 > opt.len) break;
+    const uint64_t remaining = ub - first;
+    for (uint64_t mult = 2; mult <= first; ++mult) {
+      if (remaining % mult) continue;
+      const uint64_t inner_ub = remaining / mult + 1;
+      if (inner_ub < 2) break;
+      if (first + 2 + lower_len_estimate(inner_ub) > opt.len) continue;
+      OptimalDecomposition inner = optimize_range(inner_ub, memo);
+      const uint64_t cand = first + 2 + inner.len;
+      if (cand < opt.len || (cand == opt.len && 1 + inner.d.rings.size() < opt.d.rings.size())) {
+        opt.len = cand;
+        opt.d = inner.d;
+        for (auto& r : opt.d.rings) r.step *= mult;
+        opt.d.rings.push_back({first, 1});
+      }
+    }
+  }
+  memo[ub] = opt;
+  return opt;
+}
+inline RangeDecomposition optimal_range(uint64_t upper_bound) {
+  std::map<uint64_t, OptimalDecomposition> memo;
+  return optimize_range(upper_bound, memo).d;
+}
+inline uint64_t isqrt(uint64_t x) {  // quadratic_voting.rs:127-143
+  uint64_t root = 0, p4 = 1ull << 62;
+  while (p4 > x) p4 /= 4;
+  while (p4 > 0) {
+    if (x >= root + p4) { x -= root + p4; root = root / 2 + p4; } else root /= 2;
+    p4 /= 4;
+  }
+  return root;
+}
+
+// ---- plan under construction ---------------------------------------------------------------------------------
+struct Stage {
+  std::vector<JobClass> jobs;
+  std::vector<std::vector<HashOp>> insts;
+};
+
+struct Plan {
+  size_t stride = 0;  // bytes per ballot
+  std::vector<WireItem> pt_items, sc_items;
+  std::vector<std::vector<DeriveClass>> derive_levels;
+  std::vector<DeriveTerm> dterms;
+  std::vector<VarTerm> vterms;
+  std::vector<Stage> stages;
+  std::vector<StatusRule> rules;
+  std::vector<uint32_t> tally_slots;
+  std::vector<uint8_t> blob;
+  std::vector<uint64_t> const_mults;          // election-constant points [m]G
+  std::vector<std::vector<HashOp>> prefix_programs;
+  int n_pt_slots = 0, n_cmp_slots = 0, n_chal_slots = 0, n_state_slots = 0, n_flag_slots = 0, n_prefixes = 0;
+  std::map<std::string, uint32_t> blob_index;
+  std::map<uint64_t, uint16_t> const_index;
+
+  uint32_t ref(const std::string& s) {  // label / constant message in the blob
+    auto it = blob_index.find(s);
+    if (it != blob_index.end()) return it->second;
+    const uint32_t r = blob_ref((uint32_t)blob.size(), (uint32_t)s.size());
+    blob.insert(blob.end(), s.begin(), s.end());
+    blob_index[s] = r;
+    return r;
+  }
+  int pk_off = -1;
+  uint32_t pk_ref() {  // 32 bytes of the election key; filled in when the params object is created
+    if (pk_off < 0) { pk_off = (int)blob.size(); blob.insert(blob.end(), 32, 0); }
+    return blob_ref((uint32_t)pk_off, 32);
+  }
+  uint16_t const_point(uint64_t m) {
+    auto it = const_index.find(m);
+    if (it != const_index.end()) return it->second;
+    const uint16_t i = (uint16_t)const_mults.size();
+    const_mults.push_back(m);
+    const_index[m] = i;
+    return i;
+  }
+  Stage& stage(size_t s) { if (stages.size() <= s) stages.resize(s + 1); return stages[s]; }
+  uint16_t new_pt() { return (uint16_t)n_pt_slots++; }
+  uint16_t new_cmp() { return (uint16_t)n_cmp_slots++; }
+  uint16_t new_chal() { return (uint16_t)n_chal_slots++; }
+  uint16_t new_state() { return (uint16_t)n_state_slots++; }
+  uint16_t new_flag() { return (uint16_t)n_flag_slots++; }
+  uint32_t new_prefix() { return (uint32_t)n_prefixes++; }
+
+  uint16_t wire_point(uint16_t item) { const uint16_t s = new_pt(); pt_items.push_back({item, s}); return s; }
+  void wire_scalar(uint16_t item) { sc_items.push_back({item, 0}); }
+
+  uint16_t derive(int level, const std::vector<DeriveTerm>& terms) {
+    if ((int)derive_levels.size() <= level) derive_levels.resize(level + 1);
+    DeriveClass dc;
+    dc.term_first = (uint16_t)dterms.size();
+    dc.term_count = (uint16_t)terms.size();
+    dc.out_slot = new_pt();
+    dc.pad = 0;
+    dterms.insert(dterms.end(), terms.begin(), terms.end());
+    derive_levels[level].push_back(dc);
+    return dc.out_slot;
+  }
+  // out = encode(sum terms + [g]G + [k]K); returns the compressed slot
+  uint16_t job(size_t st, const std::vector<VarTerm>& terms, ScalarSrc g, ScalarSrc k) {
+    JobClass jc;
+    jc.term_first = (uint16_t)vterms.size();
+    jc.term_count = (uint16_t)terms.size();
+    jc.g = g; jc.k = k;
+    jc.out_slot = new_cmp();
+    jc.enc_slot = 0xffff;
+    vterms.insert(vterms.end(), terms.begin(), terms.end());
+    stage(st).jobs.push_back(jc);
+    return jc.out_slot;
+  }
+  uint16_t encode_job(size_t st, uint16_t pt_slot) {
+    JobClass jc{};
+    jc.term_first = 0; jc.term_count = 0;
+    jc.g = ScalarSrc{SRC_NONE, 0, 0}; jc.k = ScalarSrc{SRC_NONE, 0, 0};
+    jc.out_slot = new_cmp();
+    jc.enc_slot = pt_slot;
+    stage(st).jobs.push_back(jc);
+    return jc.out_slot;
+  }
+};
+
+inline ScalarSrc wire_src(uint16_t item, bool neg = false) { return ScalarSrc{SRC_WIRE, (uint8_t)neg, item}; }
+inline ScalarSrc chal_src(uint16_t slot, bool neg = false) { return ScalarSrc{SRC_CHAL, (uint8_t)neg, slot}; }
+inline ScalarSrc no_src() { return ScalarSrc{SRC_NONE, 0, 0}; }
+
+// one ring of a RingProof
+struct RingIn {
+  uint16_t ptR, ptB;             // point slots of the ring's ciphertext
+  bool enc_from_wire;            // "enc" bytes: wire items (canonical) or encodings of derived points
+  uint16_t enc_item;             // first wire item (R then B) when enc_from_wire
+  int derive_level;              // level at which ptB is available (0 = wire)
+  std::vector<uint64_t> admissible;  // x_j = [admissible[j]] G  (admissible[0] == 0)
+  uint16_t resp_item;            // wire item of s_0
+};
+
+// RingProof::verify (ring.rs:302-374) appended to the plan.  `setup` are the ops that bring a fresh transcript
+// to the state the reference passes in (Transcript::new(label) [+ range header]).  Returns the verdict flag.
+inline uint16_t add_ring_proof(Plan& P, const std::vector<HashOp>& setup, const std::vector<RingIn>& rings,
+                               uint16_t challenge_item, size_t first_stage = 0) {
+  // hoisted, election-constant prefixes (ring.rs:290-293, :329)
+  const uint32_t pre_main = P.new_prefix(), pre_ring = P.new_prefix();
+  {
+    std::vector<HashOp> prog = setup;
+    prog.push_back({OP_APPEND_BLOB, P.ref("dom-sep"), P.ref("multi_ring_enc"), 0});
+    prog.push_back({OP_APPEND_BLOB, P.ref("K"), P.pk_ref(), 0});   // "\x01pk" is patched to the key bytes
+    prog.push_back({OP_SAVE_PREFIX, 0, pre_main, 0});
+    prog.push_back({OP_APPEND_BLOB, P.ref("dom-sep"), P.ref("ring_enc"), 0});
+    prog.push_back({OP_SAVE_PREFIX, 0, pre_ring, 0});
+    P.prefix_programs.push_back(prog);
+  }
+  size_t max_size = 0;
+  for (auto& r : rings) max_size = std::max(max_size, r.admissible.size());
+  std::vector<std::pair<uint16_t, uint16_t>> terminal(rings.size());
+  for (size_t ri = 0; ri < rings.size(); ++ri) {
+    const RingIn& r = rings[ri];
+    const size_t s = r.admissible.size();
+    uint16_t enc_r = 0, enc_b = 0;
+    if (!r.enc_from_wire) {
+      enc_r = P.encode_job(first_stage, r.ptR);
+      enc_b = P.encode_job(first_stage, r.ptB);
+    }
+    const uint16_t state = s > 2 ? P.new_state() : 0;
+    uint16_t chal = 0;
+    for (size_t j = 0; j < s; ++j) {
+      // dh = B - x_j (ring.rs:338)
+      uint16_t dh = r.ptB;
+      if (r.admissible[j] != 0)
+        dh = P.derive(r.derive_level, {{r.ptB, 0, 0}, {P.const_point(r.admissible[j]), 1, 1}});
+      const ScalarSrc e = j == 0 ? wire_src(challenge_item, true) : chal_src(chal, true);
+      const ScalarSrc resp = wire_src((uint16_t)(r.resp_item + j));
+      // R_G = [s]G - [e]R ; R_K = [s]K - [e]dh   (ring.rs:342-350)
+      const uint16_t cg = P.job(first_stage + j, {{r.ptR, e}}, resp, no_src());
+      const uint16_t ck = P.job(first_stage + j, {{dh, e}}, no_src(), resp);
+      if (j + 1 < s) {   // ring.rs:354-360
+        std::vector<HashOp> ops;
+        if (j == 0) {
+          ops.push_back({OP_LOAD_PREFIX, 0, pre_ring, 0});
+          if (r.enc_from_wire) ops.push_back({OP_APPEND_WIRE, P.ref("enc"), r.enc_item, 2});
+          else ops.push_back({OP_APPEND_CMP, P.ref("enc"), enc_r, enc_b});
+          ops.push_back({OP_APPEND_U64, P.ref("i"), (uint32_t)ri, 0});
+          if (s > 2) ops.push_back({OP_SAVE_STATE, 0, state, 0});
+        } else {
+          ops.push_back({OP_LOAD_STATE, 0, state, 0});
+        }
+        ops.push_back({OP_APPEND_U64, P.ref("j"), (uint32_t)j, 0});
+        ops.push_back({OP_APPEND_CMP, P.ref("R_G"), cg, 0xffff});
+        ops.push_back({OP_APPEND_CMP, P.ref("R_K"), ck, 0xffff});
+        chal = P.new_chal();
+        ops.push_back({OP_CHALLENGE, P.ref("c"), chal, 0});
+        P.stage(first_stage + j).insts.push_back(ops);
+      } else {
+        terminal[ri] = {cg, ck};
+      }
+    }
+  }
+  // common challenge (ring.rs:364-373)
+  const uint16_t flag = P.new_flag();
+  std::vector<HashOp> fin;
+  fin.push_back({OP_LOAD_PREFIX, 0, pre_main, 0});
+  for (auto& t : terminal) {
+    fin.push_back({OP_APPEND_CMP, P.ref("R_G"), t.first, 0xffff});
+    fin.push_back({OP_APPEND_CMP, P.ref("R_K"), t.second, 0xffff});
+  }
+  fin.push_back({OP_CHALLENGE_CHECK, P.ref("c"), challenge_item, flag});
+  P.stage(first_stage + max_size - 1).insts.push_back(fin);
+  return flag;
+}
+
+// ---- EncryptedChoice (choice.rs:358-380) ----------------------------------------------------------------------------
+inline size_t choice_ballot_size(int n, bool single) { return (size_t)n * 64 + 32 * (size_t)(1 + 2 * n) + (single ? 64 : 0); }
+
+inline Plan build_choice_plan(int n, bool single) {
+  Plan P;
+  P.stride = choice_ballot_size(n, single);
+  std::vector<uint16_t> R(n), B(n);
+  for (int k = 0; k < n; ++k) { R[k] = P.wire_point((uint16_t)(2 * k)); B[k] = P.wire_point((uint16_t)(2 * k + 1)); }
+  const uint16_t ring_items = (uint16_t)(2 * n);   // e0, then 2n responses
+  for (int i = 0; i < 1 + 2 * n; ++i) P.wire_scalar((uint16_t)(ring_items + i));
+  const uint16_t sum_items = (uint16_t)(ring_items + 1 + 2 * n);
+  if (single) { P.wire_scalar(sum_items); P.wire_scalar((uint16_t)(sum_items + 1)); }
+  for (int k = 0; k < n; ++k) { P.tally_slots.push_back(R[k]); P.tally_slots.push_back(B[k]); }
+
+  uint16_t sum_flag = 0;
+  if (single) {
+    // sum of ciphertexts (choice.rs:363), powers = (sum.R, sum.B - G) (choice.rs:83-86)
+    std::vector<DeriveTerm> tr, tb;
+    for (int k = 0; k < n; ++k) { tr.push_back({R[k], 0, 0}); tb.push_back({B[k], 0, 0}); }
+    tb.push_back({P.const_point(1), 1, 1});
+    const uint16_t p0 = P.derive(0, tr), p1 = P.derive(0, tb);
+    const uint32_t pre = P.new_prefix();
+    P.prefix_programs.push_back({{OP_NEW, P.ref("choice_encryption_sum"), 0, 0},
+                                 {OP_APPEND_BLOB, P.ref("dom-sep"), P.ref("log_eq"), 0},
+                                 {OP_APPEND_BLOB, P.ref("K"), P.pk_ref(), 0},
+                                 {OP_SAVE_PREFIX, 0, pre, 0}});
+    // LogEqualityProof::verify (log_equality.rs:153-180)
+    const ScalarSrc c = wire_src(sum_items, true), s = wire_src((uint16_t)(sum_items + 1));
+    const uint16_t xg = P.job(0, {{p0, c}}, s, no_src());
+    const uint16_t xk = P.job(0, {{p1, c}}, no_src(), s);
+    const uint16_t e0 = P.encode_job(0, p0), e1 = P.encode_job(0, p1);
+    sum_flag = P.new_flag();
+    P.stage(0).insts.push_back({{OP_LOAD_PREFIX, 0, pre, 0},
+                                {OP_APPEND_CMP, P.ref("[r]G"), e0, 0xffff},
+                                {OP_APPEND_CMP, P.ref("[r]K"), e1, 0xffff},
+                                {OP_APPEND_CMP, P.ref("[x]G"), xg, 0xffff},
+                                {OP_APPEND_CMP, P.ref("[x]K"), xk, 0xffff},
+                                {OP_CHALLENGE_CHECK, P.ref("c"), sum_items, sum_flag}});
+    P.rules.push_back({sum_flag, 4 /* EG_ST_SUM_CHALLENGE */});
+  }
+  std::vector<RingIn> rings;
+  for (int k = 0; k < n; ++k) {
+    RingIn r;
+    r.ptR = R[k]; r.ptB = B[k]; r.enc_from_wire = true; r.enc_item = (uint16_t)(2 * k); r.derive_level = 0;
+    r.admissible = {0, 1};   // [O, G] (choice.rs:370)
+    r.resp_item = (uint16_t)(ring_items + 1 + 2 * k);
+    rings.push_back(r);
+  }
+  const uint16_t flag = add_ring_proof(P, {{OP_NEW, P.ref("encrypted_choice_ranges"), 0, 0}}, rings, ring_items);
+  P.rules.push_back({flag, 6 /* EG_ST_RANGE_CHALLENGE */});
+  return P;
+}
+
+// ---- RangeProof::verify (range.rs:547-577) on items [first_item ...): ct(2) partials(2(r-1)) e0 responses ------------------
+struct RangeOut { uint16_t flag; uint16_t ctR, ctB; uint16_t n_items; };
+inline RangeOut add_range_proof(Plan& P, const RangeDecomposition& d, const std::string& label, uint16_t first_item) {
+  const int nr = (int)d.rings.size();
+  RangeOut out;
+  uint16_t item = first_item;
+  out.ctR = P.wire_point(item); out.ctB = P.wire_point((uint16_t)(item + 1));
+  item += 2;
+  std::vector<uint16_t> pR(nr), pB(nr);
+  for (int i = 0; i < nr - 1; ++i) { pR[i] = P.wire_point(item); pB[i] = P.wire_point((uint16_t)(item + 1)); item += 2; }
+  const uint16_t chal_item = item++;
+  P.wire_scalar(chal_item);
+  const uint16_t resp0 = item;
+  for (uint64_t i = 0; i < d.rings_size(); ++i) P.wire_scalar(item++);
+  out.n_items = (uint16_t)(item - first_item);
+  // last = ct - sum(partials)  (range.rs:564-572)
+  bool last_wire = nr == 1;
+  if (nr == 1) { pR[0] = out.ctR; pB[0] = out.ctB; }
+  else {
+    std::vector<DeriveTerm> tr{{out.ctR, 0, 0}}, tb{{out.ctB, 0, 0}};
+    for (int i = 0; i < nr - 1; ++i) { tr.push_back({pR[i], 0, 1}); tb.push_back({pB[i], 0, 1}); }
+    pR[nr - 1] = P.derive(0, tr);
+    pB[nr - 1] = P.derive(0, tb);
+  }
+  std::vector<RingIn> rings;
+  uint16_t resp = resp0;
+  for (int i = 0; i < nr; ++i) {
+    RingIn r;
+    r.ptR = pR[i]; r.ptB = pB[i];
+    const bool derived = (i == nr - 1) && !last_wire;
+    r.enc_from_wire = !derived;
+    r.enc_item = (i == nr - 1) ? first_item : (uint16_t)(first_item + 2 + 2 * i);
+    r.derive_level = derived ? 1 : 0;
+    for (uint64_t j = 0; j < d.rings[i].size; ++j) r.admissible.push_back(j * d.rings[i].step);  // range.rs:343-349
+    r.resp_item = resp;
+    resp = (uint16_t)(resp + d.rings[i].size);
+    rings.push_back(r);
+  }
+  const std::vector<HashOp> setup = {{OP_NEW, P.ref(label), 0, 0},
+                                     {OP_APPEND_BLOB, P.ref("dom-sep"), P.ref("encryption_range_proof"), 0},
+                                     {OP_APPEND_BLOB, P.ref("range"), P.ref(d.to_string()), 0}};   // range.rs:561-562
+  out.flag = add_ring_proof(P, setup, rings, chal_item);
+  return out;
+}
+
+// ---- QuadraticVotingBallot::verify (quadratic_voting.rs:291-329) ---------------------------------------------------------
+struct QvShape { RangeDecomposition vote_range, credit_range; size_t vote_size, credit_size, ballot_size; };
+inline QvShape qv_shape(int n, uint64_t credits) {
+  QvShape s;
+  s.vote_range = optimal_range(isqrt(credits) + 1);     // quadratic_voting.rs:67-69
+  s.credit_range = optimal_range(credits + 1);
+  auto sz = [](const RangeDecomposition& d) { return 64 + 64 * (d.rings.size() - 1) + 32 * (1 + d.rings_size()); };
+  s.vote_size = sz(s.vote_range);
+  s.credit_size = sz(s.credit_range);
+  s.ballot_size = (size_t)n * s.vote_size + s.credit_size + 32 * (size_t)(2 * n + 2);
+  return s;
+}
+
+inline Plan build_qv_plan(int n, uint64_t credits) {
+  Plan P;
+  const QvShape sh = qv_shape(n, credits);
+  P.stride = sh.ballot_size;
+  uint16_t item = 0;
+  std::vector<RangeOut> votes;
+  for (int i = 0; i < n; ++i) {   // :297-307
+    RangeOut r = add_range_proof(P, sh.vote_range, "quadratic_voting_variant", item);
+    item = (uint16_t)(item + r.n_items);
+    votes.push_back(r);
+    P.rules.push_back({r.flag, 8u /* EG_ST_QV_VARIANT_CHALLENGE */ | ((uint32_t)i << 8)});
+    P.tally_slots.push_back(r.ctR);
+    P.tally_slots.push_back(r.ctB);
+  }
+  RangeOut credit = add_range_proof(P, sh.credit_range, "quadratic_voting_credit_range", item);   // :309-317
+  item = (uint16_t)(item + credit.n_items);
+  P.rules.push_back({credit.flag, 10 /* EG_ST_QV_CREDIT_RANGE_CHALLENGE */});
+  // SumOfSquaresProof::verify (mul.rs:190-260)
+  const uint16_t c_item = item;
+  for (int i = 0; i < 2 * n + 2; ++i) P.wire_scalar((uint16_t)(c_item + i));
+  const uint16_t sz_item = (uint16_t)(c_item + 1 + 2 * n);
+  const uint32_t pre = P.new_prefix();
+  P.prefix_programs.push_back({{OP_NEW, P.ref("quadratic_voting_credit_equiv"), 0, 0},
+                               {OP_APPEND_BLOB, P.ref("dom-sep"), P.ref("sum_of_squares"), 0},
+                               {OP_APPEND_BLOB, P.ref("K"), P.pk_ref(), 0},
+                               {OP_SAVE_PREFIX, 0, pre, 0}});
+  std::vector<HashOp> ops{{OP_LOAD_PREFIX, 0, pre, 0}};
+  const ScalarSrc neg_c = wire_src(c_item, true);
+  std::vector<VarTerm> trz, tz;
+  // wire items of the vote ciphertexts
+  uint16_t vitem = 0;
+  for (int i = 0; i < n; ++i) {
+    const ScalarSrc s_r = wire_src((uint16_t)(c_item + 1 + 2 * i)), s_x = wire_src((uint16_t)(c_item + 2 + 2 * i));
+    const uint16_t er = P.job(0, {{votes[i].ctR, neg_c}}, s_r, no_src());                 // mul.rs:213-217
+    const uint16_t ex = P.job(0, {{votes[i].ctB, neg_c}}, s_x, s_r);                      // mul.rs:219-226
+    ops.push_back({OP_APPEND_WIRE, P.ref("R_x"), vitem, 1});
+    ops.push_back({OP_APPEND_WIRE, P.ref("X"), (uint32_t)(vitem + 1), 1});
+    ops.push_back({OP_APPEND_CMP, P.ref("[e_r]G"), er, 0xffff});
+    ops.push_back({OP_APPEND_CMP, P.ref("[e_x]G + [e_r]K"), ex, 0xffff});
+    trz.push_back({votes[i].ctR, s_x});
+    tz.push_back({votes[i].ctB, s_x});
+    vitem = (uint16_t)(vitem + votes[i].n_items);
+  }
+  trz.push_back({credit.ctR, neg_c});
+  tz.push_back({credit.ctB, neg_c});
+  const uint16_t erz = P.job(0, trz, wire_src(sz_item), no_src());   // mul.rs:232-240
+  const uint16_t ez = P.job(0, tz, no_src(), wire_src(sz_item));     // mul.rs:241-247
+  ops.push_back({OP_APPEND_WIRE, P.ref("R_z"), vitem, 1});
+  ops.push_back({OP_APPEND_WIRE, P.ref("Z"), (uint32_t)(vitem + 1), 1});
+  ops.push_back({OP_APPEND_CMP, P.ref("[e_x]R_x + [e_z]G"), erz, 0xffff});
+  ops.push_back({OP_APPEND_CMP, P.ref("[e_x]X + [e_z]K"), ez, 0xffff});
+  const uint16_t flag = P.new_flag();
+  ops.push_back({OP_CHALLENGE_CHECK, P.ref("c"), c_item, flag});
+  P.stage(0).insts.push_back(ops);
+  P.rules.push_back({flag, 12 /* EG_ST_QV_CREDIT_EQUIV_CHALLENGE */});
+  return P;
+}
+
+}  // namespace eghost

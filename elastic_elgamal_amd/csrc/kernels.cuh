@@ -1,0 +1,601 @@
+// kernels.cuh -- the gfx950 kernels of the batch verifier.  Hand-written HIP for CDNA4; no MFMA (every
+// product has two per-lane operands: this is modular-integer VALU work), wave64 throughout.
+//
+// Data layout in HBM (all per chunk of `cap` ballots, SoA so that lane == ballot is always coalesced):
+//   pts   [slot][10][cap] uint4   extended points, 40 limbs (X,Y,Z,T x 10 x 25.5 bit)   160 B / point
+//   cmp   [slot][2][cap]  uint4   compressed outputs of the group equations               32 B
+//   chal  [slot][2][cap]  uint4   derived challenges e_j                                   32 B
+//   states[slot][52][cap] u32     saved ring transcripts (only when a ring has > 2 equations)
+//   flags [slot][cap]     u32     proof verdict flags;  bad_item[cap] first malformed wire item
+// The packed ballots themselves stay in wire (AoS) order and are read exactly where the reference reads
+// them: decode, canonical checks, transcript appends and scalar operands.
+//
+// Kernels and what bounds them (DESIGN.md has the numbers):
+//   k_decode_points / k_check_scalars / k_derive_points   VALU (1 inverse square root per point)
+//   k_msm_jobs     VALU-bound integer multiply-add: the dominant kernel (>90 % of the time)
+//   k_hash         LDS + VALU (Keccak-f[1600])
+//   k_status, k_tally_*   trivial
+#pragma once
+#include <hip/hip_runtime.h>
+#include "ge25519.cuh"
+#include "sc25519.cuh"
+#include "merlin.cuh"
+#include "plan.h"
+
+namespace eg {
+
+constexpr int NT = 256;               // threads per block everywhere (4 wavefronts, one per SIMD)
+constexpr int WS_QUADS = 8 * 10;      // var-base table: 8 entries x 10 uint4 per lane
+
+struct EngineBufs {
+  const u32* wire;      // packed ballots of this chunk
+  u32 stride_words;     // ballot stride / 4
+  u32 n;                // ballots in this chunk
+  u32 cap;              // SoA pitch (chunk capacity)
+  uint4* pts;
+  uint4* cmp;
+  uint4* chal;
+  u32* states;
+  u32* flags;
+  u32* bad_item;
+  u32* status;          // [n] output
+  const uint4* tabG;    // fixed-base table of the generator   [64][8] x 8 uint4
+  const uint4* tabK;    // fixed-base table of the election key
+  const uint4* cpts;    // election-constant points [idx][10]
+  u32* prefixes;        // hoisted transcript prefixes [idx][52]
+  const unsigned char* blob;  // labels and constant messages
+  uint4* ws;            // per-lane variable-base tables [block][80][NT]
+};
+
+// ---- SoA accessors ------------------------------------------------------------------------------------
+__device__ __forceinline__ void words_to_ge(ge& p, const u32 w[40]) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) { p.X.v[i] = w[i]; p.Y.v[i] = w[10 + i]; p.Z.v[i] = w[20 + i]; p.T.v[i] = w[30 + i]; }
+}
+__device__ __forceinline__ void ge_to_words(u32 w[40], const ge& p) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) { w[i] = p.X.v[i]; w[10 + i] = p.Y.v[i]; w[20 + i] = p.Z.v[i]; w[30 + i] = p.T.v[i]; }
+}
+__device__ __forceinline__ void load_pt(ge& p, const uint4* pts, u32 cap, u32 slot, u32 b) {
+  u32 w[40];
+#pragma unroll
+  for (int q = 0; q < 10; ++q) {
+    const uint4 v = pts[((size_t)slot * 10 + q) * cap + b];
+    w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+  }
+  words_to_ge(p, w);
+}
+__device__ __forceinline__ void store_pt(uint4* pts, u32 cap, u32 slot, u32 b, const ge& p) {
+  u32 w[40];
+  ge_to_words(w, p);
+#pragma unroll
+  for (int q = 0; q < 10; ++q) pts[((size_t)slot * 10 + q) * cap + b] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+}
+__device__ __forceinline__ void load_const_pt(ge& p, const uint4* cpts, u32 idx) {
+  u32 w[40];
+#pragma unroll
+  for (int q = 0; q < 10; ++q) {
+    const uint4 v = cpts[(size_t)idx * 10 + q];
+    w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+  }
+  words_to_ge(p, w);
+}
+__device__ __forceinline__ void load32(u32 w[8], const uint4* arr, u32 cap, u32 slot, u32 b) {
+  const uint4 a = arr[((size_t)slot * 2) * cap + b], c = arr[((size_t)slot * 2 + 1) * cap + b];
+  w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = c.x; w[5] = c.y; w[6] = c.z; w[7] = c.w;
+}
+__device__ __forceinline__ void store32(uint4* arr, u32 cap, u32 slot, u32 b, const u32 w[8]) {
+  arr[((size_t)slot * 2) * cap + b] = make_uint4(w[0], w[1], w[2], w[3]);
+  arr[((size_t)slot * 2 + 1) * cap + b] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+__device__ __forceinline__ void load_wire_item(u32 w[8], const EngineBufs& B, u32 b, u32 item) {
+  const uint4* p = reinterpret_cast<const uint4*>(B.wire + (size_t)b * B.stride_words + (size_t)item * 8);
+  const uint4 a = p[0], c = p[1];
+  w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = c.x; w[5] = c.y; w[6] = c.z; w[7] = c.w;
+}
+
+// ---- table I/O policies --------------------------------------------------------------------------------------
+// per-lane variable-base table in the global workspace: [entry][quad][lane] -> every access of a wave that
+// agrees on the entry is one contiguous 1 KiB row; lanes that differ touch at most 8 rows.
+struct WsTable {
+  uint4* base;
+  __device__ __forceinline__ void store(int e, const ge_cached& c) {
+    u32 w[40];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) { w[i] = c.YpX.v[i]; w[10 + i] = c.YmX.v[i]; w[20 + i] = c.Z2.v[i]; w[30 + i] = c.T2d.v[i]; }
+#pragma unroll
+    for (int q = 0; q < 10; ++q) base[(size_t)(e * 10 + q) * NT] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+  }
+  __device__ __forceinline__ void load(ge_cached& c, int e) const {
+    u32 w[40];
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {
+      const uint4 v = base[(size_t)(e * 10 + q) * NT];
+      w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 10; ++i) { c.YpX.v[i] = w[i]; c.YmX.v[i] = w[10 + i]; c.Z2.v[i] = w[20 + i]; c.T2d.v[i] = w[30 + i]; }
+  }
+};
+// fixed-base table shared by every lane (L2 resident, 64 KiB per base): entry = 8 uint4 (30 limbs used)
+struct FixedTable {
+  const uint4* tab;
+  __device__ __forceinline__ void load(ge_niels& c, int idx) const {
+    u32 w[32];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const uint4 v = tab[(size_t)idx * 8 + q];
+      w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 10; ++i) { c.ypx.v[i] = w[i]; c.ymx.v[i] = w[10 + i]; c.xy2d.v[i] = w[20 + i]; }
+  }
+};
+// transcript state: word-interleaved LDS column per lane (positions are wave-uniform => conflict free)
+struct LdsState {
+  u32* base;
+  __device__ __forceinline__ u32 rd(int i) const { return base[i * NT]; }
+  __device__ __forceinline__ void wr(int i, u32 v) { base[i * NT] = v; }
+};
+
+// ---- scalar operand fetch ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_scalar(u32 s[8], const EngineBufs& B, u32 b, egplan::ScalarSrc src) {
+  if (src.kind == egplan::SRC_WIRE) load_wire_item(s, B, b, src.idx);
+  else load32(s, B.chal, B.cap, src.idx, b);
+  if (src.neg) { u32 t[8]; sc_neg(t, s);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = t[i]; }
+}
+
+// ---- k_decode_points: deserialize_element for every wire point (ristretto.rs:93-95) --------------------------------
+__global__ void __launch_bounds__(NT) k_decode_points(EngineBufs B, const egplan::WireItem* items, int n_items) {
+  const size_t total = (size_t)n_items * B.n;
+  for (size_t j = (size_t)blockIdx.x * NT + threadIdx.x; j < total; j += (size_t)gridDim.x * NT) {
+    const u32 k = (u32)(j / B.n), b = (u32)(j % B.n);
+    const egplan::WireItem it = items[k];
+    u32 w[8];
+    load_wire_item(w, B, b, it.item);
+    ge p;
+    const bool ok = ristretto_decode(p, w);
+    store_pt(B.pts, B.cap, it.slot, b, p);
+    if (!ok) atomicMin(&B.bad_item[b], (u32)it.item * 4u + 2u);
+  }
+}
+
+// ---- k_check_scalars: deserialize_scalar canonical check (ristretto.rs:59-62) -------------------------------------------
+__global__ void __launch_bounds__(NT) k_check_scalars(EngineBufs B, const egplan::WireItem* items, int n_items) {
+  const size_t total = (size_t)n_items * B.n;
+  for (size_t j = (size_t)blockIdx.x * NT + threadIdx.x; j < total; j += (size_t)gridDim.x * NT) {
+    const u32 k = (u32)(j / B.n), b = (u32)(j % B.n);
+    const egplan::WireItem it = items[k];
+    u32 w[8];
+    load_wire_item(w, B, b, it.item);
+    if (!sc_is_canonical(w)) atomicMin(&B.bad_item[b], (u32)it.item * 4u + 1u);
+  }
+}
+
+// ---- k_derive_points: sums / differences of points (choice.rs:363, ring.rs:338, range.rs:564-572) ----------------------------
+__global__ void __launch_bounds__(NT) k_derive_points(EngineBufs B, const egplan::DeriveClass* classes,
+                                                      const egplan::DeriveTerm* terms, int class_first, int n_classes) {
+  const size_t total = (size_t)n_classes * B.n;
+  for (size_t j = (size_t)blockIdx.x * NT + threadIdx.x; j < total; j += (size_t)gridDim.x * NT) {
+    const u32 c = class_first + (u32)(j / B.n), b = (u32)(j % B.n);
+    const egplan::DeriveClass dc = classes[c];
+    ge acc;
+    ge_identity(acc);
+#pragma unroll 1
+    for (u32 t = 0; t < dc.term_count; ++t) {
+      const egplan::DeriveTerm dt = terms[dc.term_first + t];
+      ge p;
+      if (dt.is_const) load_const_pt(p, B.cpts, dt.slot);
+      else load_pt(p, B.pts, B.cap, dt.slot, b);
+      ge_cached pc;
+      ge_to_cached(pc, p);
+      ge_cached_cneg(pc, dt.neg != 0);
+      ge_p1p1 r;
+      ge_add(r, acc, pc);
+      ge_add_to_p3(acc, r);
+    }
+    store_pt(B.pts, B.cap, dc.out_slot, b, acc);
+  }
+}
+
+// ---- k_msm_jobs: out = encode( sum_i [a_i]P_i + [g]G + [k]K ) -----------------------------------------------------------------
+// One lane = one group equation of one ballot: vartime_double_mul_generator / vartime_multi_mul followed by
+// serialize_element (ring.rs:342-350, log_equality.rs:160-164, mul.rs:213-247 + proofs/mod.rs:48-52).
+// Persistent blocks stride over (class, ballot); lanes of a wave share the class, so control flow is uniform.
+__global__ void __launch_bounds__(NT) k_msm_jobs(EngineBufs B, const egplan::JobClass* classes,
+                                                    const egplan::VarTerm* terms, int class_first, int n_classes) {
+  const size_t total = (size_t)n_classes * B.n;
+  WsTable tab;
+  tab.base = B.ws + (size_t)blockIdx.x * (WS_QUADS * NT) + threadIdx.x;
+  const FixedTable tg{B.tabG}, tk{B.tabK};
+  for (size_t j = (size_t)blockIdx.x * NT + threadIdx.x; j < total; j += (size_t)gridDim.x * NT) {
+    const u32 c = class_first + (u32)(j / B.n), b = (u32)(j % B.n);
+    const egplan::JobClass jc = classes[c];
+    ge acc;
+    if (jc.term_count == 0) {
+      if (jc.enc_slot != 0xffffu) load_pt(acc, B.pts, B.cap, jc.enc_slot, b);
+      else ge_identity(acc);
+    }
+#pragma unroll 1
+    for (u32 t = 0; t < jc.term_count; ++t) {
+      const egplan::VarTerm vt = terms[jc.term_first + t];
+      ge p;
+      load_pt(p, B.pts, B.cap, vt.slot, b);
+      u32 s[8], dg[8];
+      load_scalar(s, B, b, vt.s);
+      sc_recode_radix16(dg, s);
+      ge_var_table_build(tab, p);
+      ge part;
+      ge_var_mul(part, tab, dg);
+      if (t == 0) acc = part;
+      else { ge sum; ge_add_full(sum, acc, part); acc = sum; }
+    }
+    if (jc.g.kind != egplan::SRC_NONE) {
+      u32 s[8], dg[8];
+      load_scalar(s, B, b, jc.g);
+      sc_recode_radix16(dg, s);
+      ge_fixed_mul_add(acc, tg, dg);
+    }
+    if (jc.k.kind != egplan::SRC_NONE) {
+      u32 s[8], dg[8];
+      load_scalar(s, B, b, jc.k);
+      sc_recode_radix16(dg, s);
+      ge_fixed_mul_add(acc, tk, dg);
+    }
+    u32 out[8];
+    ristretto_encode(out, acc);
+    store32(B.cmp, B.cap, jc.out_slot, b, out);
+  }
+}
+
+// ---- k_hash: Merlin transcript programs (proofs/mod.rs:39-57 + the per-proof label schedules) --------------------------------------
+__global__ void __launch_bounds__(NT) k_hash(EngineBufs B, const egplan::HashInst* insts, const egplan::HashOp* ops,
+                                             int inst_first, int n_insts) {
+  __shared__ u32 lds[50 * NT];
+  const size_t j = (size_t)blockIdx.x * NT + threadIdx.x;
+  if (j >= (size_t)n_insts * B.n) return;
+  const u32 b = (u32)(j % B.n);
+  const egplan::HashInst hi = insts[inst_first + (u32)(j / B.n)];
+  Transcript<LdsState> t;
+  t.st.base = lds + threadIdx.x;
+  t.pos = 0; t.pos_begin = 0; t.cur_flags = 0;
+#pragma unroll 1
+  for (u32 o = 0; o < hi.op_count; ++o) {
+    const egplan::HashOp op = ops[hi.op_first + o];
+    const char* label = reinterpret_cast<const char*>(B.blob) + (op.a >> 12);
+    const int label_len = (int)(op.a & 0xfffu);
+    switch (op.op) {
+      case egplan::OP_NEW:
+        merlin_init(t, label, label_len);
+        break;
+      case egplan::OP_APPEND_BLOB:
+        merlin_append_bytes(t, label, label_len, reinterpret_cast<const char*>(B.blob) + (op.b >> 12), (int)(op.b & 0xfffu));
+        break;
+      case egplan::OP_APPEND_WIRE: {
+        merlin_frame(t, label, label_len, op.c * 32u);
+        strobe_begin_op(t, EG_FLAG_AD);
+#pragma unroll 1
+        for (u32 it = 0; it < op.c; ++it) {
+          u32 w[8];
+          load_wire_item(w, B, b, op.b + it);
+          strobe_absorb_words(t, w, 32);
+        }
+        break;
+      }
+      case egplan::OP_APPEND_CMP: {
+        const u32 n = (op.c == 0xffffu) ? 1u : 2u;
+        merlin_frame(t, label, label_len, n * 32u);
+        strobe_begin_op(t, EG_FLAG_AD);
+        u32 w[8];
+        load32(w, B.cmp, B.cap, op.b, b);
+        strobe_absorb_words(t, w, 32);
+        if (n == 2) { load32(w, B.cmp, B.cap, op.c, b); strobe_absorb_words(t, w, 32); }
+        break;
+      }
+      case egplan::OP_APPEND_U64:
+        merlin_append_u64(t, label, label_len, (u64)op.b);
+        break;
+      case egplan::OP_CHALLENGE: {
+        u32 wide[16], e[8];
+        merlin_challenge64(t, label, label_len, wide);
+        sc_from_wide(e, wide);
+        store32(B.chal, B.cap, op.b, b, e);
+        break;
+      }
+      case egplan::OP_CHALLENGE_CHECK: {
+        u32 wide[16], e[8], want[8];
+        merlin_challenge64(t, label, label_len, wide);
+        sc_from_wide(e, wide);
+        load_wire_item(want, B, b, op.b);
+        B.flags[(size_t)op.c * B.cap + b] = sc_eq(e, want) ? 1u : 0u;
+        break;
+      }
+      case egplan::OP_LOAD_PREFIX:
+        merlin_import(t, B.prefixes + (size_t)op.b * 52);
+        break;
+      case egplan::OP_SAVE_PREFIX: {
+        u32 w[52];
+        merlin_export(t, w);
+#pragma unroll 1
+        for (int i = 0; i < 52; ++i) B.prefixes[(size_t)op.b * 52 + i] = w[i];
+        break;
+      }
+      case egplan::OP_LOAD_STATE: {
+#pragma unroll 1
+        for (int i = 0; i < 50; ++i) t.st.wr(i, B.states[((size_t)op.b * 52 + i) * B.cap + b]);
+        const u32 m = B.states[((size_t)op.b * 52 + 50) * B.cap + b];
+        t.pos = m & 0xffu; t.pos_begin = (m >> 8) & 0xffu; t.cur_flags = (m >> 16) & 0xffu;
+        break;
+      }
+      case egplan::OP_SAVE_STATE: {
+#pragma unroll 1
+        for (int i = 0; i < 50; ++i) B.states[((size_t)op.b * 52 + i) * B.cap + b] = t.st.rd(i);
+        B.states[((size_t)op.b * 52 + 50) * B.cap + b] = t.pos | (t.pos_begin << 8) | (t.cur_flags << 16);
+        break;
+      }
+      default: break;
+    }
+  }
+}
+
+// ---- k_status: first failing check wins, in the reference's order (choice.rs:358-380, quadratic_voting.rs:291-329) ---------------------
+__global__ void __launch_bounds__(NT) k_status(EngineBufs B, const egplan::StatusRule* rules, int n_rules) {
+  const u32 b = blockIdx.x * NT + threadIdx.x;
+  if (b >= B.n) return;
+  const u32 bad = B.bad_item[b];
+  u32 st = 0;
+  if (bad != 0xffffffffu) {
+    st = (bad & 3u) | ((bad >> 2) << 8);
+  } else {
+#pragma unroll 1
+    for (int r = 0; r < n_rules; ++r) {
+      if (B.flags[(size_t)rules[r].flag_slot * B.cap + b] == 0u) { st = rules[r].status; break; }
+    }
+  }
+  B.status[b] = st;
+}
+
+// ---- tally: totals[k] += vote[k] over accepted ballots (examples/voting.rs:199-203) ---------------------------------------------------------
+__device__ __forceinline__ void block_reduce_points(ge& acc, u32* lds /* [40][NT] */) {
+  u32 w[40];
+#pragma unroll 1
+  for (int s = NT / 2; s >= 1; s >>= 1) {
+    ge_to_words(w, acc);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 40; ++i) lds[i * NT + threadIdx.x] = w[i];
+    __syncthreads();
+    if ((int)threadIdx.x < s) {
+#pragma unroll
+      for (int i = 0; i < 40; ++i) w[i] = lds[i * NT + threadIdx.x + s];
+      ge other, sum;
+      words_to_ge(other, w);
+      ge_add_full(sum, acc, other);
+      acc = sum;
+    }
+  }
+}
+
+// grid (G, n_slots): block (x, k) sums point slot tally_slots[k] over its share of accepted ballots
+__global__ void __launch_bounds__(NT) k_tally_partial(EngineBufs B, const u32* tally_slots, u32* partial /* [n_slots][G][40] */) {
+  __shared__ u32 lds[40 * NT];
+  const u32 slot = tally_slots[blockIdx.y];
+  ge acc;
+  ge_identity(acc);
+  for (u32 b = blockIdx.x * NT + threadIdx.x; b < B.n; b += gridDim.x * NT) {
+    if (B.status[b] != 0u) continue;
+    ge p, sum;
+    load_pt(p, B.pts, B.cap, slot, b);
+    ge_add_full(sum, acc, p);
+    acc = sum;
+  }
+  block_reduce_points(acc, lds);
+  if (threadIdx.x == 0) {
+    u32 w[40];
+    ge_to_words(w, acc);
+    for (int i = 0; i < 40; ++i) partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 40 + i] = w[i];
+  }
+}
+// one block per slot: tally[k] += sum_x partial[k][x]
+__global__ void __launch_bounds__(NT) k_tally_final(const u32* partial, int G, u32* tally /* [n_slots][40] */) {
+  __shared__ u32 lds[40 * NT];
+  ge acc;
+  ge_identity(acc);
+  for (int x = threadIdx.x; x < G; x += NT) {
+    u32 w[40];
+    for (int i = 0; i < 40; ++i) w[i] = partial[((size_t)blockIdx.x * G + x) * 40 + i];
+    ge p, sum;
+    words_to_ge(p, w);
+    ge_add_full(sum, acc, p);
+    acc = sum;
+  }
+  block_reduce_points(acc, lds);
+  if (threadIdx.x == 0) {
+    u32 w[40];
+    for (int i = 0; i < 40; ++i) w[i] = tally[(size_t)blockIdx.x * 40 + i];
+    ge cur, sum;
+    words_to_ge(cur, w);
+    ge_add_full(sum, cur, acc);
+    ge_to_words(w, sum);
+    for (int i = 0; i < 40; ++i) tally[(size_t)blockIdx.x * 40 + i] = w[i];
+  }
+}
+__global__ void k_tally_init(u32* tally, int n_slots) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_slots) return;
+  ge id; ge_identity(id);
+  u32 w[40]; ge_to_words(w, id);
+  for (int i = 0; i < 40; ++i) tally[(size_t)k * 40 + i] = w[i];
+}
+// tally[k] = sum over ranks of gathered[rank][k]   (after the all-gather of per-GPU partial tallies)
+__global__ void k_tally_merge(const u32* gathered, int n_ranks, int n_slots, u32* tally) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_slots) return;
+  ge acc; ge_identity(acc);
+  for (int r = 0; r < n_ranks; ++r) {
+    u32 w[40];
+    for (int i = 0; i < 40; ++i) w[i] = gathered[((size_t)r * n_slots + k) * 40 + i];
+    ge p, sum; words_to_ge(p, w);
+    ge_add_full(sum, acc, p); acc = sum;
+  }
+  u32 w[40]; ge_to_words(w, acc);
+  for (int i = 0; i < 40; ++i) tally[(size_t)k * 40 + i] = w[i];
+}
+__global__ void k_tally_encode(const u32* tally, int n_slots, u32* out /* [n_slots][8] */) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_slots) return;
+  u32 w[40];
+  for (int i = 0; i < 40; ++i) w[i] = tally[(size_t)k * 40 + i];
+  ge p; words_to_ge(p, w);
+  u32 o[8]; ristretto_encode(o, p);
+  for (int i = 0; i < 8; ++i) out[(size_t)k * 8 + i] = o[i];
+}
+
+// ---- election setup --------------------------------------------------------------------------------------------------------------------------------
+// tab[(w*8 + k-1)] = niels([k * 16^w] Base): one lane per entry
+__global__ void __launch_bounds__(NT) k_build_fixed_table(const u32* base_words /* 40 */, uint4* tab) {
+  const int lane = blockIdx.x * NT + threadIdx.x;
+  if (lane >= 64 * 8) return;
+  const int w = lane >> 3, k = (lane & 7) + 1;
+  u32 bw[40];
+  for (int i = 0; i < 40; ++i) bw[i] = base_words[i];
+  ge p; words_to_ge(p, bw);
+#pragma unroll 1
+  for (int i = 0; i < 4 * w; ++i) { ge d; ge_dbl_full(d, p); p = d; }
+  ge q = p;
+#pragma unroll 1
+  for (int i = 1; i < k; ++i) { ge s; ge_add_full(s, q, p); q = s; }
+  ge_niels n; ge_to_niels(n, q);
+  u32 o[32];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) { o[i] = n.ypx.v[i]; o[10 + i] = n.ymx.v[i]; o[20 + i] = n.xy2d.v[i]; }
+  o[30] = 0; o[31] = 0;
+#pragma unroll
+  for (int qd = 0; qd < 8; ++qd) tab[(size_t)lane * 8 + qd] = make_uint4(o[4 * qd], o[4 * qd + 1], o[4 * qd + 2], o[4 * qd + 3]);
+}
+// out[0] = generator words (always); if pk != null: out[1] = decoded key, flags[0] = valid, flags[1] = identity
+__global__ void k_setup_points(const u32* pk_words, u32* out_words, u32* flags) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  ge g; ge_generator(g);
+  u32 w[40]; ge_to_words(w, g);
+  for (int i = 0; i < 40; ++i) out_words[i] = w[i];
+  if (pk_words) {
+    u32 pw[8];
+    for (int i = 0; i < 8; ++i) pw[i] = pk_words[i];
+    ge k;
+    const bool ok = ristretto_decode(k, pw);
+    ge_to_words(w, k);
+    for (int i = 0; i < 40; ++i) out_words[40 + i] = w[i];
+    flags[0] = ok ? 1u : 0u;
+    flags[1] = (fe_iszero(k.X) | fe_iszero(k.Y)) ? 1u : 0u;
+  }
+}
+// cpts[i] = [m_i] G for small multipliers (admissible values, range.rs:341-355)
+__global__ void __launch_bounds__(NT) k_const_points(const u64* mults, int n, const uint4* tabG, uint4* cpts) {
+  const int i = blockIdx.x * NT + threadIdx.x;
+  if (i >= n) return;
+  u32 s[8], dg[8];
+  sc_from_u64(s, mults[i]);
+  sc_recode_radix16(dg, s);
+  ge acc; ge_identity(acc);
+  const FixedTable tg{tabG};
+  ge_fixed_mul_add(acc, tg, dg);
+  u32 w[40]; ge_to_words(w, acc);
+  for (int q = 0; q < 10; ++q) cpts[(size_t)i * 10 + q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+}
+
+// ---- primitive tier kernels (AoS 32-byte items, one lane per problem) ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void ld8(u32 w[8], const u32* p) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) w[i] = p[i];
+}
+__device__ __forceinline__ void st8(u32* p, const u32 w[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) p[i] = w[i];
+}
+__global__ void __launch_bounds__(NT) k_prim_scalar_from_wide(size_t n, const u32* wide, u32* out) {
+  const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+  if (i >= n) return;
+  u32 w[16], o[8];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) w[k] = wide[i * 16 + k];
+  sc_from_wide(o, w);
+  st8(out + i * 8, o);
+}
+__global__ void __launch_bounds__(NT) k_prim_scalar_canonical(size_t n, const u32* s, unsigned char* ok) {
+  const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+  if (i >= n) return;
+  u32 w[8]; ld8(w, s + i * 8);
+  ok[i] = sc_is_canonical(w) ? 1 : 0;
+}
+__global__ void __launch_bounds__(NT) k_prim_scalar_muladd(size_t n, const u32* a, const u32* b, const u32* c, u32* out) {
+  const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+  if (i >= n) return;
+  u32 aw[8], bw[8], cw[8], o[8];
+  ld8(aw, a + i * 8); ld8(bw, b + i * 8); ld8(cw, c + i * 8);
+  sc_muladd(o, aw, bw, cw);
+  st8(out + i * 8, o);
+}
+__global__ void __launch_bounds__(NT) k_prim_scalar_neg(size_t n, const u32* a, u32* out) {
+  const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+  if (i >= n) return;
+  u32 aw[8], o[8]; ld8(aw, a + i * 8);
+  sc_neg(o, aw);
+  st8(out + i * 8, o);
+}
+__global__ void __launch_bounds__(NT) k_prim_point_roundtrip(size_t n, const u32* in, u32* out, unsigned char* ok) {
+  const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+  if (i >= n) return;
+  u32 w[8], o[8]; ld8(w, in + i * 8);
+  ge p;
+  ok[i] = ristretto_decode(p, w) ? 1 : 0;
+  ristretto_encode(o, p);
+  st8(out + i * 8, o);
+}
+__global__ void __launch_bounds__(NT) k_prim_point_add(size_t n, const u32* a, const u32* b, int subtract, u32* out, unsigned char* ok) {
+  const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+  if (i >= n) return;
+  u32 aw[8], bw[8], o[8]; ld8(aw, a + i * 8); ld8(bw, b + i * 8);
+  ge p, q, r;
+  const bool okk = ristretto_decode(p, aw) & ristretto_decode(q, bw);
+  if (subtract) ge_sub_full(r, p, q); else ge_add_full(r, p, q);
+  ristretto_encode(o, r);
+  st8(out + i * 8, o);
+  ok[i] = okk ? 1 : 0;
+}
+// out = enc( sum_t [k_t]P_t + [r]G ); terms may be 0 (then r must be given).  Group::mul_generator,
+// vartime_double_mul_generator and vartime_multi_mul all map onto this kernel.
+__global__ void __launch_bounds__(NT) k_prim_msm(size_t n, int terms, const u32* scalars, const u32* points, const u32* r,
+                                                    const uint4* tabG, uint4* ws, u32* out, unsigned char* ok) {
+  WsTable tab;
+  tab.base = ws + (size_t)blockIdx.x * (WS_QUADS * NT) + threadIdx.x;
+  for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
+    ge acc; ge_identity(acc);
+    bool okk = true;
+#pragma unroll 1
+    for (int t = 0; t < terms; ++t) {
+      u32 pw[8], s[8], dg[8];
+      ld8(pw, points + (i * terms + t) * 8);
+      ld8(s, scalars + (i * terms + t) * 8);
+      ge p;
+      okk = okk & ristretto_decode(p, pw);
+      sc_recode_radix16(dg, s);
+      ge_var_table_build(tab, p);
+      ge part; ge_var_mul(part, tab, dg);
+      ge sum; ge_add_full(sum, acc, part); acc = sum;
+    }
+    if (r) {
+      u32 s[8], dg[8]; ld8(s, r + i * 8);
+      sc_recode_radix16(dg, s);
+      const FixedTable tg{tabG};
+      ge_fixed_mul_add(acc, tg, dg);
+    }
+    u32 o[8]; ristretto_encode(o, acc);
+    st8(out + i * 8, o);
+    if (ok) ok[i] = okk ? 1 : 0;
+  }
+}
+
+}  // namespace eg

@@ -1,0 +1,153 @@
+/*
+ * eg_hip.h -- C ABI of libeg_hip.so: the MI355X (gfx950) Ristretto255 backend and batch ballot verifier
+ * that stands in for the hot path of slowli/elastic-elgamal.
+ *
+ * Two tiers:
+ *
+ *  PRIMITIVE TIER -- batched equivalents of the reference's `Group` plugin trait for `Ristretto`
+ *  (src/group/mod.rs:65-255, src/group/ristretto.rs:23-146).  A Rust shim
+ *  `impl ScalarOps/ElementOps/Group for HipRistretto` binds these one-to-one.  All
+ *  buffers are caller-owned HOST memory, 32-byte little-endian encodings exactly as
+ *  serialize_scalar / serialize_element produce them; `n` independent problems per call run on the GPU.
+ *
+ *  BATCH TIER -- `for ballot in ballots { ballot.verify(&params) }` as one call: the reference has no
+ *  equivalent entry point (it verifies one ballot at a time on one thread, examples/voting.rs:189-204);
+ *  these are what a Rust host calls instead of the loop.  Ballots are packed back to back in the
+ *  reference's own byte formats (see "wire layout" below).  `_device` variants take DEVICE pointers and a
+ *  hipStream_t (as void*), so that torch / RCCL owned buffers can be passed without copies.
+ *
+ * Every function returns EG_OK (0) or a negative eg_error.  Nothing here falls back to the CPU: if no
+ * gfx950 device is usable eg_init fails with EG_ERR_NO_DEVICE.
+ */
+#ifndef EG_HIP_H
+#define EG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  EG_OK = 0,
+  EG_ERR_NO_DEVICE = -1,
+  EG_ERR_HIP = -2,
+  EG_ERR_BAD_ARG = -3,
+  EG_ERR_BAD_PUBLIC_KEY = -4, /* PublicKey::from_bytes: invalid element or identity (keys/mod.rs:161-176) */
+  EG_ERR_NOMEM = -5
+} eg_error;
+
+/* ---- per-ballot status words (uint32): low byte = kind, bits 8.. = detail ------------------------------
+ * Kinds mirror the reference's error enums; precedence = order of checks in EncryptedChoice::verify
+ * (choice.rs:358-380) and QuadraticVotingBallot::verify (quadratic_voting.rs:291-329), preceded by the
+ * deserialisation-time rejections of serde (serde.rs:191-206,254-269) in wire order. */
+enum {
+  EG_ST_OK = 0,
+  EG_ST_BAD_SCALAR = 1,           /* non-canonical scalar; detail = index of the 32-byte item in the ballot */
+  EG_ST_BAD_POINT = 2,            /* invalid ristretto encoding; detail = item index */
+  EG_ST_OPTIONS_LEN = 3,          /* ChoiceVerificationError::OptionsLenMismatch (choice.rs:409) */
+  EG_ST_SUM_CHALLENGE = 4,        /* ChoiceVerificationError::Sum(ChallengeMismatch) (choice.rs:416) */
+  EG_ST_RANGE_LEN = 5,            /* ...::Range(LenMismatch) (choice.rs:418, proofs/mod.rs:73-80) */
+  EG_ST_RANGE_CHALLENGE = 6,      /* ...::Range(ChallengeMismatch) */
+  EG_ST_QV_VARIANT_LEN = 7,       /* QuadraticVotingError::Variant{index, LenMismatch}; detail = index */
+  EG_ST_QV_VARIANT_CHALLENGE = 8, /* QuadraticVotingError::Variant{index, ChallengeMismatch} */
+  EG_ST_QV_CREDIT_RANGE_LEN = 9,
+  EG_ST_QV_CREDIT_RANGE_CHALLENGE = 10, /* QuadraticVotingError::CreditRange (quadratic_voting.rs:341) */
+  EG_ST_QV_CREDIT_EQUIV_LEN = 11,
+  EG_ST_QV_CREDIT_EQUIV_CHALLENGE = 12  /* QuadraticVotingError::CreditEquivalence (:343) */
+};
+#define EG_STATUS_KIND(s) ((s) & 0xffu)
+#define EG_STATUS_DETAIL(s) ((s) >> 8)
+
+typedef struct eg_ctx eg_ctx;           /* one per process and GPU: device, stream, fixed-base table of G */
+typedef struct eg_choice_params eg_choice_params; /* ChoiceParams<Ristretto, S> (choice.rs:132-196) */
+typedef struct eg_qv_params eg_qv_params;         /* QuadraticVotingParams<Ristretto> (quadratic_voting.rs:47-76) */
+
+/* ---- context ------------------------------------------------------------------------------------------------ */
+int eg_init(int device, eg_ctx** out);   /* no reference analogue: the backend is a ZST */
+void eg_destroy(eg_ctx* ctx);
+const char* eg_last_error(void);         /* text of the last failure on this thread */
+int eg_device_name(eg_ctx* ctx, char* buf, size_t cap);
+int eg_synchronize(eg_ctx* ctx);
+
+/* ---- primitive tier (host buffers; n problems per call) ------------------------------------------------------- */
+/* ScalarOps::scalar_from_random_bytes / Scalar::from_bytes_mod_order_wide (ristretto.rs:34-38) */
+int eg_scalar_from_wide_batch(eg_ctx*, size_t n, const uint8_t* wide /*64n*/, uint8_t* out /*32n*/);
+/* ScalarOps::deserialize_scalar -> is Some (ristretto.rs:59-62) */
+int eg_scalar_is_canonical_batch(eg_ctx*, size_t n, const uint8_t* s /*32n*/, uint8_t* ok /*n*/);
+/* a*b + c, -a  (Scalar Mul/Add/Neg used at ring.rs:192-193,339) */
+int eg_scalar_muladd_batch(eg_ctx*, size_t n, const uint8_t* a, const uint8_t* b, const uint8_t* c, uint8_t* out);
+int eg_scalar_neg_batch(eg_ctx*, size_t n, const uint8_t* a, uint8_t* out);
+/* ElementOps::deserialize_element then serialize_element (ristretto.rs:88-95): ok[i] = 1 for a valid
+ * encoding, and out = re-encoding (equal to the input for every valid encoding) */
+int eg_point_roundtrip_batch(eg_ctx*, size_t n, const uint8_t* in /*32n*/, uint8_t* out /*32n*/, uint8_t* ok /*n*/);
+/* Element Add / Sub (ristretto.rs:76-86 via RistrettoPoint ops); ok[i]=0 if an input fails to decode */
+int eg_point_add_batch(eg_ctx*, size_t n, const uint8_t* a, const uint8_t* b, int subtract, uint8_t* out, uint8_t* ok);
+/* Group::mul_generator / vartime_mul_generator (ristretto.rs:105-121) */
+int eg_mul_generator_batch(eg_ctx*, size_t n, const uint8_t* k /*32n*/, uint8_t* out /*32n*/);
+/* Group::vartime_double_mul_generator(k, P, r) = [k]P + [r]G (ristretto.rs:131-137) */
+int eg_vartime_double_mul_generator_batch(eg_ctx*, size_t n, const uint8_t* k, const uint8_t* p, const uint8_t* r,
+                                          uint8_t* out, uint8_t* ok);
+/* Group::vartime_multi_mul(scalars, elements) (ristretto.rs:139-145): n problems of `terms` terms each,
+ * scalars/points laid out [problem][term][32] */
+int eg_vartime_multi_mul_batch(eg_ctx*, size_t n, size_t terms, const uint8_t* scalars, const uint8_t* points,
+                               uint8_t* out, uint8_t* ok);
+
+/* ---- batch tier: EncryptedChoice --------------------------------------------------------------------------------
+ * wire layout of one ballot (stride = eg_choice_ballot_size):
+ *   n_options x Ciphertext::to_bytes (R || B, encryption.rs:155-160)
+ *   RingProof::to_bytes            (e0 || s_0 .. s_{2n-1}, ring.rs:383-392)
+ *   LogEqualityProof::to_bytes     (c || s, log_equality.rs:184-189)      -- SingleChoice only */
+int eg_choice_params_create(eg_ctx*, const uint8_t pk[32], int n_options, int single, eg_choice_params** out);
+void eg_choice_params_destroy(eg_choice_params*);
+size_t eg_choice_ballot_size(int n_options, int single);
+/* EncryptedChoice::verify over a batch + homomorphic tally of the accepted ballots
+ * (examples/voting.rs:199-203).  status: n words.  tally_out (may be NULL): n_options x 64 bytes (R || B). */
+int eg_verify_choice_batch(eg_choice_params*, size_t n, const uint8_t* ballots, uint32_t* status, uint8_t* tally_out);
+/* device-resident variant: d_ballots / d_status are device pointers; the running tally stays on the device
+ * inside `params` until eg_choice_tally_* is called.  Asynchronous on `stream`. */
+int eg_verify_choice_batch_device(eg_choice_params*, size_t n, const void* d_ballots, void* d_status, void* stream);
+int eg_choice_tally_reset(eg_choice_params*);
+/* running tally as 2*n_options extended points, EG_TALLY_POINT_BYTES each, in device memory (for the
+ * multi-GPU exchange: all-gather these, then eg_choice_tally_merge_device on every rank) */
+#define EG_TALLY_POINT_BYTES 160
+int eg_choice_tally_device_ptr(eg_choice_params*, void** d_points, size_t* n_bytes);
+int eg_choice_tally_merge_device(eg_choice_params*, const void* d_gathered, int n_ranks, void* stream);
+int eg_choice_tally_encode(eg_choice_params*, uint8_t* out /* n_options*64 */);
+
+/* ---- batch tier: QuadraticVotingBallot ------------------------------------------------------------------------------
+ * wire layout (stride = eg_qv_ballot_size), serde field order of quadratic_voting.rs:205-217 / range.rs:446-450 /
+ * mul.rs:86-93:
+ *   n_options x [ ciphertext(64) || partial_ciphertexts(64 each) || common_challenge(32) || ring_responses ]
+ *   credit:      [ ciphertext(64) || partial_ciphertexts          || common_challenge     || ring_responses ]
+ *   SumOfSquaresProof: challenge(32) || ciphertext_responses(2n x 32) || sum_response(32) */
+int eg_qv_params_create(eg_ctx*, const uint8_t pk[32], int n_options, uint64_t credits, eg_qv_params** out);
+void eg_qv_params_destroy(eg_qv_params*);
+size_t eg_qv_ballot_size(const eg_qv_params*);
+int eg_verify_qv_batch(eg_qv_params*, size_t n, const uint8_t* ballots, uint32_t* status, uint8_t* tally_out);
+int eg_verify_qv_batch_device(eg_qv_params*, size_t n, const void* d_ballots, void* d_status, void* stream);
+int eg_qv_tally_reset(eg_qv_params*);
+int eg_qv_tally_device_ptr(eg_qv_params*, void** d_points, size_t* n_bytes);
+int eg_qv_tally_merge_device(eg_qv_params*, const void* d_gathered, int n_ranks, void* stream);
+int eg_qv_tally_encode(eg_qv_params*, uint8_t* out);
+
+/* ---- synthetic ballots on the GPU (EncryptedChoice::new / QuadraticVotingBallot::new) ---------
+ * Ballot i of the call is produced from ChaChaRng::seed_from_u64(base_seed + first + i) with the reference's
+ * RNG draw order (choice.rs:313-349, ring.rs:54-194, log_equality.rs:114-139, range.rs:462-534, mul.rs:107-181);
+ * the voter's selection comes from a second stream seeded with the complemented seed.  n_selected is only
+ * used for multi-choice params. */
+int eg_choice_encrypt_batch_device(eg_choice_params*, uint64_t base_seed, size_t first, size_t n, int n_selected,
+                                   void* d_out, void* stream);
+int eg_qv_encrypt_batch_device(eg_qv_params*, uint64_t base_seed, size_t first, size_t n, void* d_out, void* stream);
+
+/* ---- measurement hooks (bench.py) ------------------------------------------------------------------------------------------
+ * Average duration in milliseconds of the dominant kernel (k_msm_jobs) over the launches since the last reset,
+ * measured with HIP events on the stream the kernel was launched on; launches = number of launches averaged. */
+int eg_profile_enable(eg_ctx*, int enable);
+int eg_profile_read(eg_ctx*, double* msm_ms_total, uint64_t* msm_launches, double* all_ms_total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

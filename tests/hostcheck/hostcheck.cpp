@@ -1,0 +1,124 @@
+// hostcheck.cpp -- TEST-ONLY host build of the device arithmetic headers with -DEG_BOUNDCHECK.
+// Every fe carries its limb class and each operation asserts its precondition, so running the
+// code paths below proves the bound discipline of fe25519.cuh/ge25519.cuh; results are compared with
+// the oracle by tests/test_hostcheck.py.  This library is never loaded by the product.
+#include <string.h>
+#include <vector>
+#include "../../elastic_elgamal_amd/csrc/ge25519.cuh"
+#include "../../elastic_elgamal_amd/csrc/sc25519.cuh"
+#include "../../elastic_elgamal_amd/csrc/merlin.cuh"
+
+using namespace eg;
+
+struct ArrTable {
+  ge_cached e[8];
+  void store(int i, const ge_cached& c) { e[i] = c; }
+  void load(ge_cached& c, int i) const { c = e[i]; }
+};
+struct ArrNiels {
+  std::vector<ge_niels> e;
+  void load(ge_niels& c, int i) const { c = e[i]; }
+};
+struct ArrState {
+  u32 w[50];
+  u32 rd(int i) const { return w[i]; }
+  void wr(int i, u32 v) { w[i] = v; }
+};
+
+static void words_from_bytes(u32* w, const uint8_t* b, int nwords) {
+  for (int i = 0; i < nwords; ++i) w[i] = (u32)b[4 * i] | ((u32)b[4 * i + 1] << 8) | ((u32)b[4 * i + 2] << 16) | ((u32)b[4 * i + 3] << 24);
+}
+static void bytes_from_words(uint8_t* b, const u32* w, int nwords) {
+  for (int i = 0; i < nwords; ++i) for (int j = 0; j < 4; ++j) b[4 * i + j] = (uint8_t)(w[i] >> (8 * j));
+}
+
+static ArrNiels g_base_table;
+static void build_fixed(ArrNiels& t, const ge& base) {
+  t.e.resize(64 * 8);
+  ge win = base;
+  for (int w = 0; w < 64; ++w) {
+    ge cur = win;
+    for (int k = 1; k <= 8; ++k) {
+      ge_to_niels(t.e[w * 8 + k - 1], cur);
+      ge nxt; ge_add_full(nxt, cur, win); cur = nxt;
+    }
+    for (int d = 0; d < 4; ++d) { ge nxt; ge_dbl_full(nxt, win); win = nxt; }
+  }
+}
+
+extern "C" {
+
+int hc_point_roundtrip(const uint8_t in[32], uint8_t out[32]) {
+  u32 w[8], o[8]; words_from_bytes(w, in, 8);
+  ge p; bool ok = ristretto_decode(p, w);
+  ristretto_encode(o, p);
+  bytes_from_words(out, o, 8);
+  return ok ? 1 : 0;
+}
+
+// out = enc([k]P + [r]G)   (Group::vartime_double_mul_generator)
+int hc_double_mul_generator(const uint8_t k[32], const uint8_t p_enc[32], const uint8_t r[32], uint8_t out[32]) {
+  if (g_base_table.e.empty()) { ge g; ge_generator(g); build_fixed(g_base_table, g); }
+  u32 kw[8], rw[8], pw[8], o[8];
+  words_from_bytes(kw, k, 8); words_from_bytes(rw, r, 8); words_from_bytes(pw, p_enc, 8);
+  ge p; if (!ristretto_decode(p, pw)) return 0;
+  ArrTable tab; ge_var_table_build(tab, p);
+  u32 dk[8], dr[8]; sc_recode_radix16(dk, kw); sc_recode_radix16(dr, rw);
+  ge acc; ge_var_mul(acc, tab, dk);
+  ge_fixed_mul_add(acc, g_base_table, dr);
+  ristretto_encode(o, acc);
+  bytes_from_words(out, o, 8);
+  return 1;
+}
+
+int hc_point_add(const uint8_t a[32], const uint8_t b[32], int sub, uint8_t out[32]) {
+  u32 aw[8], bw[8], o[8]; words_from_bytes(aw, a, 8); words_from_bytes(bw, b, 8);
+  ge p, q, r; if (!ristretto_decode(p, aw) || !ristretto_decode(q, bw)) return 0;
+  if (sub) ge_sub_full(r, p, q); else ge_add_full(r, p, q);
+  ge d; ge_dbl_full(d, r); (void)d;
+  ristretto_encode(o, r); bytes_from_words(out, o, 8);
+  return 1;
+}
+
+void hc_sc_from_wide(const uint8_t in[64], uint8_t out[32]) {
+  u32 w[16], o[8]; words_from_bytes(w, in, 16); sc_from_wide(o, w); bytes_from_words(out, o, 8);
+}
+void hc_sc_muladd(const uint8_t a[32], const uint8_t b[32], const uint8_t c[32], uint8_t out[32]) {
+  u32 aw[8], bw[8], cw[8], o[8]; words_from_bytes(aw, a, 8); words_from_bytes(bw, b, 8); words_from_bytes(cw, c, 8);
+  sc_muladd(o, aw, bw, cw); bytes_from_words(out, o, 8);
+}
+void hc_sc_neg(const uint8_t a[32], uint8_t out[32]) {
+  u32 aw[8], o[8]; words_from_bytes(aw, a, 8); sc_neg(o, aw); bytes_from_words(out, o, 8);
+}
+int hc_sc_is_canonical(const uint8_t a[32]) { u32 aw[8]; words_from_bytes(aw, a, 8); return sc_is_canonical(aw) ? 1 : 0; }
+
+// transcript: new(label); append(l1, m1); append_u64(l2, x); challenge(l3) -> 64 bytes; also exports pos
+int hc_merlin(const char* label, const char* l1, const uint8_t* m1, int m1_len, const char* l2, uint64_t x,
+              const char* l3, uint8_t out[64]) {
+  Transcript<ArrState> t;
+  merlin_init(t, label, (int)strlen(label));
+  std::vector<u32> mw((m1_len + 3) / 4 + 1, 0);
+  std::vector<uint8_t> pad(mw.size() * 4, 0); memcpy(pad.data(), m1, m1_len);
+  words_from_bytes(mw.data(), pad.data(), (int)mw.size());
+  merlin_append_words(t, l1, (int)strlen(l1), mw.data(), m1_len);
+  if (l2) merlin_append_u64(t, l2, (int)strlen(l2), x);
+  Transcript<ArrState> c; merlin_clone(c, t);
+  u32 o[16]; merlin_challenge64(c, l3, (int)strlen(l3), o);
+  bytes_from_words(out, o, 16);
+  return (int)t.pos;
+}
+
+void hc_fe_roundtrip(const uint8_t in[32], uint8_t out[32]) {
+  u32 w[8], o[8]; words_from_bytes(w, in, 8); fe f; fe_from_words(f, w); fe_to_words(o, f); bytes_from_words(out, o, 8);
+}
+// (a*b, a^2, 1/a, a+b, a-b) canonical bytes
+void hc_fe_ops(const uint8_t a[32], const uint8_t b[32], uint8_t out[160]) {
+  u32 aw[8], bw[8], o[8]; words_from_bytes(aw, a, 8); words_from_bytes(bw, b, 8);
+  fe x, y, r; fe_from_words(x, aw); fe_from_words(y, bw);
+  fe_mul(r, x, y); fe_to_words(o, r); bytes_from_words(out, o, 8);
+  fe_sq(r, x); fe_to_words(o, r); bytes_from_words(out + 32, o, 8);
+  fe_invert(r, x); fe_to_words(o, r); bytes_from_words(out + 64, o, 8);
+  fe_add(r, x, y); fe_to_words(o, r); bytes_from_words(out + 96, o, 8);
+  fe_sub(r, x, y); fe_to_words(o, r); bytes_from_words(out + 128, o, 8);
+}
+}

@@ -1,0 +1,260 @@
+"""GPU parity tests: the HIP path (through the C ABI, include/eg_hip.h) against the CPU oracle on the same
+seeded inputs, against the committed golden fixtures, and through size-independent properties.
+Bit-exact everywhere: this path is integer/byte work."""
+import base64
+import random
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+L = 2**252 + 27742317777372353535851937790883648493
+P = 2**255 - 19
+
+
+def unb64(s):
+    return base64.urlsafe_b64decode(s + "=" * (-len(s) % 4))
+
+
+@pytest.fixture(scope="module")
+def eg():
+    import elastic_elgamal_amd as m
+
+    return m
+
+
+@pytest.fixture(scope="module")
+def ctx(eg):
+    c = eg.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def grp(eg, ctx):
+    return eg.Ristretto(ctx)
+
+
+@pytest.fixture(scope="module")
+def pk(golden):
+    return unb64(golden["public_key_b64"])
+
+
+def sc(x):
+    return (x % L).to_bytes(32, "little")
+
+
+# ------------------------------------------------------------------ primitive tier
+def test_scalars(grp, oracle):
+    rnd = random.Random(1)
+    wides = [rnd.getrandbits(512).to_bytes(64, "little") for _ in range(500)] + [b"\xff" * 64, b"\0" * 64]
+    got = grp.scalar_from_random_bytes(b"".join(wides))
+    for i, w in enumerate(wides):
+        assert got[32 * i : 32 * i + 32] == oracle.sc_from_wide(w)
+    vals = [0, 1, L - 1, 2**252] + [rnd.randrange(L) for _ in range(200)]
+    a = b"".join(sc(v) for v in vals)
+    b = b"".join(sc(rnd.randrange(L)) for _ in vals)
+    c = b"".join(sc(rnd.randrange(L)) for _ in vals)
+    got = grp.scalar_muladd(a, b, c)
+    neg = grp.scalar_neg(a)
+    for i, v in enumerate(vals):
+        bi = int.from_bytes(b[32 * i : 32 * i + 32], "little")
+        ci = int.from_bytes(c[32 * i : 32 * i + 32], "little")
+        assert int.from_bytes(got[32 * i : 32 * i + 32], "little") == (v * bi + ci) % L
+        assert int.from_bytes(neg[32 * i : 32 * i + 32], "little") == (-v) % L
+    cand = [sc(0), sc(L - 1), L.to_bytes(32, "little"), (L + 1).to_bytes(32, "little"), b"\xff" * 32]
+    assert list(grp.deserialize_scalar_ok(b"".join(cand))) == [1, 1, 0, 0, 0]
+
+
+def test_element_codec(grp, oracle):
+    rnd = random.Random(2)
+    valid = [oracle.point_mul_generator(sc(rnd.randrange(L))) for _ in range(64)] + [b"\0" * 32, oracle.const_bytes(4)]
+    junk = [rnd.getrandbits(255).to_bytes(32, "little") for _ in range(400)] + [b"\xff" * 32, P.to_bytes(32, "little"), (1).to_bytes(32, "little")]
+    items = valid + junk
+    out, ok = grp.element_roundtrip(b"".join(items))
+    for i, e in enumerate(items):
+        want = oracle.point_roundtrip(e)
+        assert bool(ok[i]) == (want is not None), i
+        if want is not None:
+            assert out[32 * i : 32 * i + 32] == want == e
+    a, b = valid[:32], valid[32:64]
+    s, ok = grp.element_add(b"".join(a), b"".join(b))
+    d, _ = grp.element_add(b"".join(a), b"".join(b), subtract=True)
+    for i in range(32):
+        assert s[32 * i : 32 * i + 32] == oracle.point_add(a[i], b[i])
+        assert d[32 * i : 32 * i + 32] == oracle.point_add(a[i], b[i], sub=True)
+
+
+def test_scalar_multiplication(grp, oracle):
+    rnd = random.Random(3)
+    n = 300
+    edge = [0, 1, 8, 15, 16, L - 1, 2**252, 0x0888888888888888888888888888888888888888888888888888888888888888, 2**252 + 2**128]
+    ks = [edge[i % len(edge)] if i < 2 * len(edge) else rnd.randrange(L) for i in range(n)]
+    rs = [rnd.randrange(L) if i % 7 else edge[i % len(edge)] for i in range(n)]
+    pts = [oracle.point_mul_generator(sc(rnd.randrange(L))) if i % 11 else b"\0" * 32 for i in range(n)]
+    got = grp.mul_generator(b"".join(sc(k) for k in ks))
+    for i in range(n):
+        assert got[32 * i : 32 * i + 32] == oracle.point_mul_generator(sc(ks[i]))
+    got, ok = grp.vartime_double_mul_generator(b"".join(sc(k) for k in ks), b"".join(pts), b"".join(sc(r) for r in rs))
+    assert set(ok) == {1}
+    for i in range(n):
+        assert got[32 * i : 32 * i + 32] == oracle.point_double_mul_generator(sc(ks[i]), pts[i], sc(rs[i])), i
+    for terms in (1, 2, 3, 7):
+        m = 40
+        scal = [[sc(rnd.randrange(L)) for _ in range(terms)] for _ in range(m)]
+        pp = [[rnd.choice(pts) for _ in range(terms)] for _ in range(m)]
+        got, ok = grp.vartime_multi_mul(terms, b"".join(b"".join(x) for x in scal), b"".join(b"".join(x) for x in pp))
+        for i in range(m):
+            assert got[32 * i : 32 * i + 32] == oracle.point_multi_mul(b"".join(scal[i]), b"".join(pp[i])), (terms, i)
+    # invalid input points are flagged
+    got, ok = grp.vartime_double_mul_generator(sc(5), b"\xff" * 32, sc(7))
+    assert ok == b"\0"
+
+
+# ------------------------------------------------------------------ golden fixtures through the batch tier
+def test_golden_encrypted_choice(eg, ctx, golden, pk):
+    p = eg.ChoiceParams(ctx, pk, 5, True)
+    ballot = bytes.fromhex(golden["encrypted-choice"]["packed"])
+    st, tally = p.verify_batch(ballot)
+    assert st == [0]
+    assert tally == ballot[:320]          # a single accepted ballot: tally == its ciphertexts (canonical encodings)
+    m = eg.ChoiceParams(ctx, pk, 5, False)
+    mb = bytes.fromhex(golden["encrypted-multi-choice"]["packed"])
+    st, tally = m.verify_batch(mb)
+    assert st == [0] and tally == mb[:320]
+
+
+def test_golden_qv_ballot(eg, ctx, golden, pk):
+    q = eg.QuadraticVotingParams(ctx, pk, 5, 15)
+    ballot = bytes.fromhex(golden["qv-ballot"]["packed"])
+    assert q.ballot_size == len(ballot)
+    st, tally = q.verify_batch(ballot)
+    assert st == [0]
+    vote_size = 64 + 32 * 5
+    assert tally == b"".join(ballot[i * vote_size : i * vote_size + 64] for i in range(5))
+
+
+def test_bad_public_key_is_rejected(eg, ctx):
+    with pytest.raises(eg.EgError):
+        eg.ChoiceParams(ctx, b"\xff" * 32, 5, True)      # invalid element (keys/mod.rs:169-170)
+    with pytest.raises(eg.EgError):
+        eg.ChoiceParams(ctx, b"\0" * 32, 5, True)        # identity key (keys/mod.rs:171-172)
+
+
+# ------------------------------------------------------------------ batches vs the oracle, with tampering
+def _tamper_choice(ballots, size, oracle, rnd):
+    """Mutations mirroring choice.rs:452-475 + wire-level corruption; returns mutated bytes."""
+    b = bytearray(ballots)
+    n = len(b) // size
+    g10 = oracle.point_mul_generator((10).to_bytes(32, "little"))
+    for i in range(n):
+        o = i * size
+        kind = i % 10
+        if kind == 1:
+            b[o + 320 + 32 * rnd.randrange(1, 11)] ^= 1                   # response bit
+        elif kind == 2:
+            b[o + size - 32] ^= 4                                        # sum response
+        elif kind == 3:
+            b[o + 64 : o + 96] = b"\xff" * 32                            # invalid point
+        elif kind == 4:
+            b[o + 320 + 32 * 4 + 31] = 0xFF                              # non-canonical scalar
+        elif kind == 5:                                                 # +10G / -10G keeps the sum proof valid
+            b[o + 288 : o + 320] = oracle.point_add(bytes(b[o + 288 : o + 320]), g10)
+            b[o + 224 : o + 256] = oracle.point_add(bytes(b[o + 224 : o + 256]), g10, sub=True)
+        elif kind == 6:
+            b[o + 32 : o + 64], b[o + 96 : o + 128] = b[o + 96 : o + 128], b[o + 32 : o + 64]   # swap two B's
+        elif kind == 7:
+            b[o + 320] ^= 0x10                                           # common challenge
+    return bytes(b)
+
+
+@pytest.mark.parametrize("n_ballots", [1, 63, 300])
+def test_choice_batch_vs_oracle(eg, ctx, oracle, pk, n_ballots):
+    rnd = random.Random(n_ballots)
+    op = oracle.ChoiceParams(pk, 5, True)
+    ballots = _tamper_choice(op.generate_batch(77, 0, n_ballots), op.ballot_size, oracle, rnd)
+    want = op.verify_batch(ballots)
+    p = eg.ChoiceParams(ctx, pk, 5, True)
+    got, tally = p.verify_batch(ballots)
+    assert got == want
+    assert tally == op.tally(ballots, want)
+    if n_ballots >= 63:
+        kinds = {eg.status_kind(s) for s in got}
+        assert {0, eg.BAD_POINT, eg.BAD_SCALAR, eg.SUM_CHALLENGE, eg.RANGE_CHALLENGE} <= kinds
+
+
+def test_choice_empty_batch(eg, ctx, pk):
+    p = eg.ChoiceParams(ctx, pk, 5, True)
+    st, tally = p.verify_batch(b"")
+    assert st == [] and tally == b"\0" * 320          # identity ciphertexts (Ciphertext::zero, encryption.rs:123-128)
+
+
+def test_multi_choice_3_of_16_vs_oracle(eg, ctx, oracle, pk):
+    op = oracle.ChoiceParams(pk, 16, False)
+    ballots = bytearray(op.generate_batch(5, 0, 40, n_selected=3))
+    ballots[3 * 2080 + 1024 + 32 * 5] ^= 1
+    ballots[9 * 2080 + 100] ^= 0x80
+    ballots = bytes(ballots)
+    want = op.verify_batch(ballots)
+    p = eg.ChoiceParams(ctx, pk, 16, False)
+    got, tally = p.verify_batch(ballots)
+    assert got == want and want.count(0) >= 37
+    assert tally == op.tally(ballots, want)
+
+
+def test_options_2_3_10_15(eg, ctx, oracle, pk):
+    # sizes of tests/integration/basic.rs:164-260
+    for n in (2, 3, 10, 15):
+        for single in (True, False):
+            op = oracle.ChoiceParams(pk, n, single)
+            ballots = op.generate_batch(1000 + n, 0, 6, n_selected=max(1, n // 3))
+            p = eg.ChoiceParams(ctx, pk, n, single)
+            got, tally = p.verify_batch(ballots)
+            assert got == [0] * 6 == op.verify_batch(ballots)
+            assert tally == op.tally(ballots, got)
+
+
+def test_qv_batch_vs_oracle(eg, ctx, oracle, pk):
+    oq = oracle.QvParams(pk, 5, 20)
+    n = 48
+    ballots = bytearray(oq.generate_batch(9, 0, n))
+    g = oracle.const_bytes(4)
+    sz = oq.ballot_size
+    vs = oq.vote_size
+    # quadratic_voting.rs:433-464 style mutations
+    b1 = 1 * sz
+    ballots[b1 + 32 : b1 + 64] = oracle.point_add(bytes(ballots[b1 + 32 : b1 + 64]), g)                   # vote 0 ct
+    b2 = 2 * sz + 5 * vs
+    ballots[b2 + 32 : b2 + 64] = oracle.point_add(bytes(ballots[b2 + 32 : b2 + 64]), g, sub=True)         # credit ct
+    b3 = 3 * sz + 2 * vs
+    ballots[b3 + 32 : b3 + 64] = oracle.point_add(bytes(ballots[b3 + 32 : b3 + 64]), g)                   # vote 2 ct
+    ballots[4 * sz + sz - 32] ^= 1                                                                       # sum response
+    ballots[5 * sz + 5 * vs + 64 : 5 * sz + 5 * vs + 96] = b"\xff" * 32                                  # bad partial point
+    donor = oq.generate_batch(1234, 0, 1)
+    ballots[6 * sz : 6 * sz + vs] = donor[:vs]                                                           # valid proof, other value
+    ballots = bytes(ballots)
+    want = oq.verify_batch(ballots)
+    q = eg.QuadraticVotingParams(ctx, pk, 5, 20)
+    assert q.ballot_size == sz == 2144
+    got, tally = q.verify_batch(ballots)
+    assert got == want
+    assert tally == oq.tally(ballots, want)
+    assert got[1] == eg.QV_VARIANT_CHALLENGE and got[3] == (eg.QV_VARIANT_CHALLENGE | (2 << 8))
+    assert got[2] == eg.QV_CREDIT_RANGE_CHALLENGE and got[4] == eg.QV_CREDIT_EQUIV_CHALLENGE
+    assert eg.status_kind(got[5]) == eg.BAD_POINT
+
+
+def test_tally_linearity_and_chunking(eg, ctx, oracle, pk, monkeypatch):
+    # size-independent property: tally(A ++ B) == tally(A) + tally(B); small chunk forces the multi-chunk path
+    monkeypatch.setenv("EG_CHUNK", "256")
+    op = oracle.ChoiceParams(pk, 5, True)
+    ballots = op.generate_batch(4242, 0, 700)
+    p = eg.ChoiceParams(ctx, pk, 5, True)
+    st, tally = p.verify_batch(ballots)
+    assert st == [0] * 700
+    half = 350 * op.ballot_size
+    _, ta = p.verify_batch(ballots[:half])
+    _, tb = p.verify_batch(ballots[half:])
+    grp = eg.Ristretto(ctx)
+    summed, ok = grp.element_add(ta, tb)
+    assert summed == tally == op.tally(ballots, st)

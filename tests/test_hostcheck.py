@@ -1,0 +1,138 @@
+"""Host build of the DEVICE arithmetic headers (elastic_elgamal_amd/csrc/*.cuh) with -DEG_BOUNDCHECK,
+checked against the oracle.  Test-only: proves the limb-bound discipline on every executed path and
+lets the device math be validated without a GPU.  The product never loads this library."""
+import ctypes as C
+import random
+import subprocess
+from pathlib import Path
+
+import pytest
+
+HERE = Path(__file__).resolve().parent / "hostcheck"
+L = 2**252 + 27742317777372353535851937790883648493
+P = 2**255 - 19
+
+
+@pytest.fixture(scope="module")
+def hc():
+    lib = HERE / "libhostcheck.so"
+    srcs = [HERE / "hostcheck.cpp"] + list((HERE.parent.parent / "elastic_elgamal_amd" / "csrc").glob("*.cuh"))
+    if not lib.exists() or any(s.stat().st_mtime > lib.stat().st_mtime for s in srcs):
+        subprocess.check_call(
+            ["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-DEG_BOUNDCHECK", "-fsanitize=undefined",
+             "-fno-sanitize-recover=undefined", "-o", str(lib), str(HERE / "hostcheck.cpp")]
+        )
+    return C.CDLL(str(lib))
+
+
+def _b(n=32):
+    return C.create_string_buffer(n)
+
+
+def test_field_ops(hc):
+    rnd = random.Random(1)
+    edge = [0, 1, 2, P - 1, P - 2, 2**255 - 20, 2**254, (1 << 255) - 1, 19, 2**26 - 1, 2**51 - 1]
+    vals = edge + [rnd.randrange(2**255) for _ in range(100)]
+    for a in vals:
+        out = _b()
+        hc.hc_fe_roundtrip(a.to_bytes(32, "little"), out)
+        assert int.from_bytes(out.raw, "little") == a % P
+    for a in vals:
+        for b in vals[:14]:
+            out = _b(160)
+            hc.hc_fe_ops(a.to_bytes(32, "little"), b.to_bytes(32, "little"), out)
+            r = [int.from_bytes(out.raw[32 * i : 32 * i + 32], "little") for i in range(5)]
+            assert r[0] == a * b % P
+            assert r[1] == a * a % P
+            assert r[2] == pow(a, P - 2, P)
+            assert r[3] == (a + b) % P
+            assert r[4] == (a - b) % P
+
+
+def test_scalar_ops(hc):
+    rnd = random.Random(2)
+    for _ in range(300):
+        w = rnd.getrandbits(512).to_bytes(64, "little")
+        out = _b()
+        hc.hc_sc_from_wide(w, out)
+        assert int.from_bytes(out.raw, "little") == int.from_bytes(w, "little") % L
+    for w in [b"\xff" * 64, b"\x00" * 64, (L).to_bytes(64, "little"), (L - 1).to_bytes(64, "little"), (2**512 - 1 - 12345).to_bytes(64, "little")]:
+        out = _b()
+        hc.hc_sc_from_wide(w, out)
+        assert int.from_bytes(out.raw, "little") == int.from_bytes(w, "little") % L
+    vals = [0, 1, L - 1, L - 2, 2**252, 2**252 - 1] + [rnd.randrange(L) for _ in range(40)]
+    for a in vals:
+        out = _b()
+        hc.hc_sc_neg(a.to_bytes(32, "little"), out)
+        assert int.from_bytes(out.raw, "little") == (-a) % L
+        for b in vals[:10]:
+            c = rnd.randrange(L)
+            hc.hc_sc_muladd(a.to_bytes(32, "little"), b.to_bytes(32, "little"), c.to_bytes(32, "little"), out)
+            assert int.from_bytes(out.raw, "little") == (a * b + c) % L
+    assert hc.hc_sc_is_canonical((L - 1).to_bytes(32, "little")) == 1
+    assert hc.hc_sc_is_canonical(L.to_bytes(32, "little")) == 0
+    assert hc.hc_sc_is_canonical((L + 1).to_bytes(32, "little")) == 0
+    assert hc.hc_sc_is_canonical(b"\xff" * 32) == 0
+    assert hc.hc_sc_is_canonical(b"\x00" * 32) == 1
+
+
+def test_ristretto_codec_and_group(hc, oracle):
+    rnd = random.Random(3)
+    g = oracle.const_bytes(4)
+    pts = [b"\x00" * 32, g] + [oracle.point_mul_generator(rnd.randrange(L).to_bytes(32, "little")) for _ in range(40)]
+    for p in pts:
+        out = _b()
+        assert hc.hc_point_roundtrip(p, out) == 1 and out.raw == p
+    # invalid encodings agree with the oracle
+    bad = [b"\xff" * 32, (P).to_bytes(32, "little"), (1).to_bytes(32, "little"), (P - 1).to_bytes(32, "little")]
+    bad += [rnd.getrandbits(255).to_bytes(32, "little") for _ in range(200)]
+    for e in bad:
+        out = _b()
+        ok = hc.hc_point_roundtrip(e, out)
+        want = oracle.point_roundtrip(e)
+        assert bool(ok) == (want is not None)
+        if want is not None:
+            assert out.raw == want
+    for a, b in zip(pts[:20], pts[20:40]):
+        out = _b()
+        assert hc.hc_point_add(a, b, 0, out) == 1 and out.raw == oracle.point_add(a, b)
+        assert hc.hc_point_add(a, b, 1, out) == 1 and out.raw == oracle.point_add(a, b, sub=True)
+    # doubling through the unified addition (P + P) and adding the identity
+    out = _b()
+    assert hc.hc_point_add(g, g, 0, out) == 1 and out.raw == oracle.point_mul_generator((2).to_bytes(32, "little"))
+    assert hc.hc_point_add(g, b"\x00" * 32, 0, out) == 1 and out.raw == g
+    assert hc.hc_point_add(g, g, 1, out) == 1 and out.raw == b"\x00" * 32
+
+
+def test_double_mul_generator(hc, oracle):
+    rnd = random.Random(4)
+    cases = []
+    edge_scalars = [0, 1, 8, 16, L - 1, 2**252, 2**252 - 1, 0x8888888888888888888888888888888888888888888888888888888888888888 % L,
+                    0x0777777777777777777777777777777777777777777777777777777777777777]
+    pts = [oracle.point_mul_generator(rnd.randrange(L).to_bytes(32, "little")) for _ in range(6)] + [b"\x00" * 32]
+    for k in edge_scalars:
+        cases.append((k, pts[0], rnd.randrange(L)))
+        cases.append((rnd.randrange(L), pts[1], k))
+    for _ in range(24):
+        cases.append((rnd.randrange(L), rnd.choice(pts), rnd.randrange(L)))
+    for k, p, r in cases:
+        out = _b()
+        kb, rb = k.to_bytes(32, "little"), r.to_bytes(32, "little")
+        assert hc.hc_double_mul_generator(kb, p, rb, out) == 1
+        assert out.raw == oracle.point_double_mul_generator(kb, p, rb), (k, r)
+
+
+def test_merlin(hc, oracle):
+    out = _b(64)
+    hc.hc_merlin.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_uint64, C.c_char_p, C.c_char_p]
+    # upstream KAT prefix
+    hc.hc_merlin(b"test protocol", b"some label", b"some data", 9, None, 0, b"challenge", out)
+    m = oracle.Merlin(b"test protocol"); m.append(b"some label", b"some data")
+    assert out.raw == m.challenge(b"challenge", 64)
+    rnd = random.Random(5)
+    for n in [0, 1, 31, 32, 64, 100, 165, 166, 167, 400]:
+        msg = bytes(rnd.getrandbits(8) for _ in range(n))
+        pos = hc.hc_merlin(b"encrypted_choice_ranges", b"enc", msg, n, b"i", 7, b"c", out)
+        m = oracle.Merlin(b"encrypted_choice_ranges"); m.append(b"enc", msg); m.append_u64(b"i", 7)
+        assert pos == m.pos
+        assert out.raw == m.challenge(b"c", 64)
