@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- EncryptedChoice ballot verifications/sec on MI355X (BASELINE.json metric).
+
+A step = one pass of the hot path (EncryptedChoice::verify for every ballot + homomorphic tally + the one
+tally exchange) over one batch of synthetic ballots that is already resident in HBM.  Workload at N = 1:
+BASELINE.json configs[1], 1M single-choice 5-option ballots.  With N ranks each rank holds its own 1M-ballot
+shard (weak scaling; ballots are independent, no data-path collective) and the per-rank tallies are
+all-gathered over RCCL once per step.
+
+    python bench.py --gpus 1 --steps 5 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  Inputs are generated on the GPU by the library's own prover kernel
+(eg_choice_encrypt_batch_device); the CPU oracle is used only for the cpu_baseline leg and as a checker.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+PUBLIC_KEY_HEX = "a6adb6e9c0ae8d54c26e6e56b5ccd7a16bb0e1951abe4d7ee7028e3d4eca8531"  # seed-12345 key of the snapshots
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FMUL_PEAK_G = 256.0            # profiles/r01_ubench_fmul_candidates.txt: radix-25.5 field multiply, chip-wide
+ALG_BYTES_PER_BALLOT = {"single5": 736 + 4, "multi16": 2080 + 4, "qv5": 2144 + 4}   # SURVEY 8d (+ 4 B status word)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--ballots", type=int, default=1_000_000, help="ballots per GPU per step")
+    ap.add_argument("--options", type=int, default=5)
+    ap.add_argument("--seed", type=int, default=20260612)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def effective_cores() -> int:
+    """Hardware threads this process may actually use (affinity mask and cgroup CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    import elastic_elgamal_amd as eg
+    from elastic_elgamal_amd import distributed as egd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    ctx = eg.Context(local_rank)
+    pk = bytes.fromhex(PUBLIC_KEY_HEX)
+    n_opt = args.options
+    params = eg.ChoiceParams.single_choice(ctx, pk, n_opt)
+    B = args.ballots
+    stream = torch.cuda.current_stream().cuda_stream
+
+    # ---- synthetic input, generated on the GPU and left resident in HBM ------------------------------------
+    first, _ = egd.shard_range(B * world, rank, world)   # rank r owns voters [r*B, (r+1)*B)
+    ballots = torch.empty(B * params.ballot_size, dtype=torch.uint8, device=dev)
+    t0 = time.time()
+    params.encrypt_batch_device(args.seed, first, B, ballots.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    gen_s = time.time() - t0
+    status = torch.empty(B, dtype=torch.int32, device=dev)
+    local_tally = torch.empty(64 * n_opt, dtype=torch.uint8, device=dev)
+    final_tally = torch.empty(64 * n_opt, dtype=torch.uint8, device=dev)
+
+    def step():
+        params.tally_reset(stream)
+        params.verify_batch_device(B, ballots.data_ptr(), status.data_ptr(), stream)
+        params.tally_encode_device(local_tally.data_ptr(), stream)
+        gathered = egd.gather_tallies(local_tally)            # the ONE collective (RCCL all-gather, 64*n bytes/rank)
+        ctx.points_sum_device(gathered.shape[0], 2 * n_opt, gathered.data_ptr(), final_tally.data_ptr(), stream)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.profile_enable(True)
+    ctx.profile_read()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    msm_ms, msm_launches, all_ms = ctx.profile_read()
+    ctx.profile_enable(False)
+    elapsed = egd.max_over_ranks(elapsed, dev)
+
+    accepted = int((status == 0).sum().item())
+    accepted_all = egd.sum_over_ranks(accepted, dev)
+    value = B * world * args.steps / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel (k_msm_jobs), HIP events on the launch stream ------------------------
+    chunk = int(os.environ.get("EG_CHUNK", "131072"))
+    launches_per_step = max(1, msm_launches // max(args.steps, 1))
+    avg_launch_ms = msm_ms / max(msm_launches, 1)
+    units_per_launch = min(chunk, B)
+    alg_bytes = ALG_BYTES_PER_BALLOT["single5"] if n_opt == 5 else (n_opt * 64 + 32 * (1 + 2 * n_opt) + 64 + 4)
+    achieved_gbs = alg_bytes * units_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+    # field-multiplication throughput of the same kernel: counts from tests/hostcheck (fe_mul + fe_sq per equation)
+    fmul_per_ballot = float(os.environ.get("EG_FMUL_PER_BALLOT", "0") or 0)
+    out = {
+        "metric": "EncryptedChoice ballot verifications/sec",
+        "value": value,
+        "unit": "ballots/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{B} single-choice {n_opt}-option EncryptedChoice ballots per GPU per step, resident in HBM "
+                        "(BASELINE.json configs[1]); verify + homomorphic tally + tally all-gather",
+            "ballots_per_gpu": B,
+            "options": n_opt,
+            "ballot_bytes": params.ballot_size,
+            "chunk_ballots": chunk,
+            "seed": args.seed,
+            "accepted": accepted_all,
+            "generator_s": round(gen_s, 3),
+            "parallelism": f"shard{world}" if world > 1 else "single",
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "eg::k_msm_jobs",
+            "achieved": achieved_gbs,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved_gbs / HBM_PEAK_GBS,
+            "traffic": None,
+            "avg_launch_ms": avg_launch_ms,
+            "launches_per_step": launches_per_step,
+            "units_per_launch": units_per_launch,
+            "kernel_share_of_step": msm_ms / max(all_ms, 1e-9),
+            "note": "modular-integer VALU work: ~740 algorithmic bytes but ~6e4 field multiplications per ballot, so the "
+                    "HBM fraction is ~1e-3 by construction (SURVEY 0.6); the binding roof is VALU integer multiply-add "
+                    "throughput, see DESIGN.md",
+        },
+    }
+
+    # ---- CPU baseline: the oracle ("port": CPU restatement, not curve25519-dalek) on a bounded sample --------------
+    if not args.no_cpu_baseline and world == 1:
+        from oracle import oracle as o
+
+        cores = effective_cores()
+        op = o.ChoiceParams(pk, n_opt, True)
+        # bounded sample: verify slices of the same batch until ~cpu_seconds of wall time have been spent
+        slice_n = max(64, 32 * cores)
+        cpu_status, cpu_s, sample = [], 0.0, 0
+        while cpu_s < args.cpu_seconds and sample < B:
+            m = min(slice_n, B - sample)
+            host = bytes(ballots[sample * params.ballot_size : (sample + m) * params.ballot_size].cpu().numpy())
+            t0 = time.perf_counter()
+            cpu_status += op.verify_batch(host, threads=cores)
+            cpu_s += time.perf_counter() - t0
+            sample += m
+        one = min(sample, 256)
+        host = bytes(ballots[: one * params.ballot_size].cpu().numpy())
+        t0 = time.perf_counter()
+        op.verify_batch(host, threads=1)
+        one_s = time.perf_counter() - t0
+        gpu_status = status[:sample].cpu().tolist()
+        out["cpu_baseline"] = {
+            "value": sample / cpu_s,
+            "unit": "ballots/s",
+            "cores": cores,
+            "kind": "port",
+            "sample": f"first {sample} ballots of the same batch, oracle/ C restatement (not curve25519-dalek), "
+                      f"{cores} threads, {cpu_s:.1f} s",
+            "single_thread_value": one / one_s,
+            "verdicts_match_gpu": cpu_status == gpu_status,
+        }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

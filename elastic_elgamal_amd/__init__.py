@@ -59,14 +59,14 @@ def build(verbose: bool = False) -> Path:
     """Compile csrc/eg_hip.hip for gfx950 with hipcc into the in-tree libeg_hip.so (no GPU needed)."""
     import subprocess
 
-    src = _PKG / "csrc" / "eg_hip.hip"
-    deps = list((_PKG / "csrc").glob("*")) + [_PKG.parent / "include" / "eg_hip.h"]
+    deps = list((_PKG / "csrc").glob("*.hip")) + list((_PKG / "csrc").glob("*.cuh")) + list((_PKG / "csrc").glob("*.h*"))
+    deps.append(_PKG.parent / "include" / "eg_hip.h")
     if _LIB.exists() and all(d.stat().st_mtime <= _LIB.stat().st_mtime for d in deps):
         return _LIB
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", str(_LIB), str(src)]
+    cmd = ["make", "-C", str(_PKG / "csrc"), "-j4"]
     if verbose:
         print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)
     return _LIB
 
 
@@ -117,6 +117,11 @@ def _load() -> C.CDLL:
         "eg_qv_tally_device_ptr": (C.c_int, [vp, C.POINTER(vp), C.POINTER(sz)]),
         "eg_qv_tally_merge_device": (C.c_int, [vp, vp, C.c_int, vp]),
         "eg_qv_tally_encode": (C.c_int, [vp, cp]),
+        "eg_choice_tally_reset_async": (C.c_int, [vp, vp]),
+        "eg_choice_tally_encode_device": (C.c_int, [vp, vp, vp]),
+        "eg_qv_tally_reset_async": (C.c_int, [vp, vp]),
+        "eg_qv_tally_encode_device": (C.c_int, [vp, vp, vp]),
+        "eg_points_sum_device": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp]),
         "eg_choice_encrypt_batch_device": (C.c_int, [vp, C.c_uint64, sz, sz, C.c_int, vp, vp]),
         "eg_qv_encrypt_batch_device": (C.c_int, [vp, C.c_uint64, sz, sz, vp, vp]),
         "eg_profile_enable": (C.c_int, [vp, C.c_int]),
@@ -171,6 +176,10 @@ class Context:
 
     def synchronize(self):
         _check(_load().eg_synchronize(self._h))
+
+    def points_sum_device(self, n_ranks: int, n_points: int, d_in: int, d_out: int, stream: int = 0):
+        """d_out[k] = sum over ranks of d_in[r][k] (32-byte encodings): merge of all-gathered per-GPU tallies."""
+        _check(_load().eg_points_sum_device(self._h, n_ranks, n_points, d_in, d_out, stream))
 
     def profile_enable(self, on: bool = True):
         _check(_load().eg_profile_enable(self._h, int(on)))
@@ -272,8 +281,15 @@ class _BatchParams:
         fn = getattr(_load(), f"eg_verify_{self._prefix}_batch_device")
         _check(fn(self._h, n, d_ballots, d_status, stream))
 
-    def tally_reset(self):
-        _check(self._fn("tally_reset")(self._h))
+    def tally_reset(self, stream: int = 0):
+        if stream:
+            _check(self._fn("tally_reset_async")(self._h, stream))
+        else:
+            _check(self._fn("tally_reset")(self._h))
+
+    def tally_encode_device(self, d_out: int, stream: int = 0):
+        """Canonical encodings of the running tally (n_options x 64 bytes) into device memory, asynchronously."""
+        _check(self._fn("tally_encode_device")(self._h, d_out, stream))
 
     def tally_device_ptr(self):
         p, nb = C.c_void_p(), C.c_size_t()

@@ -1,0 +1,126 @@
+// device_io.cuh -- HBM / LDS layouts shared by the verifier and generator kernels (see kernels.cuh header).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "ge25519.cuh"
+#include "sc25519.cuh"
+#include "merlin.cuh"
+#include "plan.h"
+
+namespace eg {
+
+constexpr int NT = 256;               // threads per block everywhere (4 wavefronts, one per SIMD)
+constexpr int WS_QUADS = 8 * 10;      // var-base table: 8 entries x 10 uint4 per lane
+
+struct EngineBufs {
+  const u32* wire;      // packed ballots of this chunk
+  u32 stride_words;     // ballot stride / 4
+  u32 n;                // ballots in this chunk
+  u32 cap;              // SoA pitch (chunk capacity)
+  uint4* pts;
+  uint4* cmp;
+  uint4* chal;
+  u32* states;
+  u32* flags;
+  u32* bad_item;
+  u32* status;          // [n] output
+  const uint4* tabG;    // fixed-base table of the generator   [64][8] x 8 uint4
+  const uint4* tabK;    // fixed-base table of the election key
+  const uint4* cpts;    // election-constant points [idx][10]
+  u32* prefixes;        // hoisted transcript prefixes [idx][52]
+  const unsigned char* blob;  // labels and constant messages
+  uint4* ws;            // per-lane variable-base tables [block][80][NT]
+};
+
+// ---- SoA accessors ------------------------------------------------------------------------------------
+__device__ __forceinline__ void words_to_ge(ge& p, const u32 w[40]) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) { p.X.v[i] = w[i]; p.Y.v[i] = w[10 + i]; p.Z.v[i] = w[20 + i]; p.T.v[i] = w[30 + i]; }
+}
+__device__ __forceinline__ void ge_to_words(u32 w[40], const ge& p) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) { w[i] = p.X.v[i]; w[10 + i] = p.Y.v[i]; w[20 + i] = p.Z.v[i]; w[30 + i] = p.T.v[i]; }
+}
+__device__ __forceinline__ void load_pt(ge& p, const uint4* pts, u32 cap, u32 slot, u32 b) {
+  u32 w[40];
+#pragma unroll
+  for (int q = 0; q < 10; ++q) {
+    const uint4 v = pts[((size_t)slot * 10 + q) * cap + b];
+    w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+  }
+  words_to_ge(p, w);
+}
+__device__ __forceinline__ void store_pt(uint4* pts, u32 cap, u32 slot, u32 b, const ge& p) {
+  u32 w[40];
+  ge_to_words(w, p);
+#pragma unroll
+  for (int q = 0; q < 10; ++q) pts[((size_t)slot * 10 + q) * cap + b] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+}
+__device__ __forceinline__ void load_const_pt(ge& p, const uint4* cpts, u32 idx) {
+  u32 w[40];
+#pragma unroll
+  for (int q = 0; q < 10; ++q) {
+    const uint4 v = cpts[(size_t)idx * 10 + q];
+    w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+  }
+  words_to_ge(p, w);
+}
+__device__ __forceinline__ void load32(u32 w[8], const uint4* arr, u32 cap, u32 slot, u32 b) {
+  const uint4 a = arr[((size_t)slot * 2) * cap + b], c = arr[((size_t)slot * 2 + 1) * cap + b];
+  w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = c.x; w[5] = c.y; w[6] = c.z; w[7] = c.w;
+}
+__device__ __forceinline__ void store32(uint4* arr, u32 cap, u32 slot, u32 b, const u32 w[8]) {
+  arr[((size_t)slot * 2) * cap + b] = make_uint4(w[0], w[1], w[2], w[3]);
+  arr[((size_t)slot * 2 + 1) * cap + b] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+__device__ __forceinline__ void load_wire_item(u32 w[8], const EngineBufs& B, u32 b, u32 item) {
+  const uint4* p = reinterpret_cast<const uint4*>(B.wire + (size_t)b * B.stride_words + (size_t)item * 8);
+  const uint4 a = p[0], c = p[1];
+  w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = c.x; w[5] = c.y; w[6] = c.z; w[7] = c.w;
+}
+
+// ---- table I/O policies --------------------------------------------------------------------------------------
+// per-lane variable-base table in the global workspace: [entry][quad][lane] -> every access of a wave that
+// agrees on the entry is one contiguous 1 KiB row; lanes that differ touch at most 8 rows.
+struct WsTable {
+  uint4* base;
+  __device__ __forceinline__ void store(int e, const ge_cached& c) {
+    u32 w[40];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) { w[i] = c.YpX.v[i]; w[10 + i] = c.YmX.v[i]; w[20 + i] = c.Z2.v[i]; w[30 + i] = c.T2d.v[i]; }
+#pragma unroll
+    for (int q = 0; q < 10; ++q) base[(size_t)(e * 10 + q) * NT] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+  }
+  __device__ __forceinline__ void load(ge_cached& c, int e) const {
+    u32 w[40];
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {
+      const uint4 v = base[(size_t)(e * 10 + q) * NT];
+      w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 10; ++i) { c.YpX.v[i] = w[i]; c.YmX.v[i] = w[10 + i]; c.Z2.v[i] = w[20 + i]; c.T2d.v[i] = w[30 + i]; }
+  }
+};
+// fixed-base table shared by every lane (L2 resident, 64 KiB per base): entry = 8 uint4 (30 limbs used)
+struct FixedTable {
+  const uint4* tab;
+  __device__ __forceinline__ void load(ge_niels& c, int idx) const {
+    u32 w[32];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const uint4 v = tab[(size_t)idx * 8 + q];
+      w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 10; ++i) { c.ypx.v[i] = w[i]; c.ymx.v[i] = w[10 + i]; c.xy2d.v[i] = w[20 + i]; }
+  }
+};
+// transcript state: word-interleaved LDS column per lane (positions are wave-uniform => conflict free)
+struct LdsState {
+  u32* base;
+  __device__ __forceinline__ u32 rd(int i) const { return base[i * NT]; }
+  __device__ __forceinline__ void wr(int i, u32 v) { base[i * NT] = v; }
+};
+
+
+}  // namespace eg

@@ -17,9 +17,13 @@
 #include "../../include/eg_hip.h"
 #include "host_plan.hpp"
 #include "kernels.cuh"
-#include "prover_kernels.cuh"
 
 using namespace eg;
+
+// defined in eg_gen.hip (separate translation unit so the two compile in parallel)
+void eg_launch_choice_encrypt(int blocks, hipStream_t s, u64 seed0, size_t n, int n_options, int single, int n_selected,
+                              const uint4* tabG, const uint4* tabK, const u32* prefixes, int pre_main, int pre_ring,
+                              int pre_logeq, u32* out, u32 stride_words);
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
@@ -547,9 +551,11 @@ int eg_verify_choice_batch_device(eg_choice_params* p, size_t n, const void* d_b
   HIPCHK(hipSetDevice(p->eng->ctx->device));
   return engine_verify_device(p->eng, n, d_ballots, d_status, (hipStream_t)stream);
 }
-static int tally_reset(Engine* e) {
-  hipLaunchKernelGGL(k_tally_init, dim3(1), dim3(NT), 0, e->ctx->stream, e->tally, (int)e->plan.tally_slots.size());
-  HIPCHK(hipStreamSynchronize(e->ctx->stream));
+static int tally_reset(Engine* e, hipStream_t s = nullptr) {
+  const bool own = (s == nullptr);
+  if (own) s = e->ctx->stream;
+  hipLaunchKernelGGL(k_tally_init, dim3(1), dim3(NT), 0, s, e->tally, (int)e->plan.tally_slots.size());
+  if (own) HIPCHK(hipStreamSynchronize(s));
   return EG_OK;
 }
 static int tally_merge(Engine* e, const void* d_gathered, int n_ranks, hipStream_t s) {
@@ -558,7 +564,30 @@ static int tally_merge(Engine* e, const void* d_gathered, int n_ranks, hipStream
   HIPCHK(hipGetLastError());
   return EG_OK;
 }
+static int tally_encode_device(Engine* e, void* d_out, hipStream_t s) {
+  if (!s) s = e->ctx->stream;
+  hipLaunchKernelGGL(k_tally_encode, dim3(1), dim3(NT), 0, s, e->tally, (int)e->plan.tally_slots.size(), (u32*)d_out);
+  HIPCHK(hipGetLastError());
+  return EG_OK;
+}
+int eg_choice_tally_encode_device(eg_choice_params* p, void* d_out, void* stream) {
+  if (!p || !d_out) return fail(EG_ERR_BAD_ARG, "bad argument");
+  return tally_encode_device(p->eng, d_out, (hipStream_t)stream);
+}
+int eg_qv_tally_encode_device(eg_qv_params* p, void* d_out, void* stream) {
+  if (!p || !d_out) return fail(EG_ERR_BAD_ARG, "bad argument");
+  return tally_encode_device(p->eng, d_out, (hipStream_t)stream);
+}
+int eg_points_sum_device(eg_ctx* c, int n_ranks, int n_points, const void* d_in, void* d_out, void* stream) {
+  if (!c || n_ranks < 1 || n_points < 1 || !d_in || !d_out) return fail(EG_ERR_BAD_ARG, "bad argument");
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  hipLaunchKernelGGL(k_points_sum, dim3((n_points + 63) / 64), dim3(64), 0, s, (const u32*)d_in, n_ranks, n_points, (u32*)d_out,
+                     (u32*)nullptr);
+  HIPCHK(hipGetLastError());
+  return EG_OK;
+}
 int eg_choice_tally_reset(eg_choice_params* p) { return p ? tally_reset(p->eng) : fail(EG_ERR_BAD_ARG, "null"); }
+int eg_choice_tally_reset_async(eg_choice_params* p, void* stream) { return p && stream ? tally_reset(p->eng, (hipStream_t)stream) : fail(EG_ERR_BAD_ARG, "null"); }
 int eg_choice_tally_device_ptr(eg_choice_params* p, void** d, size_t* nb) {
   if (!p || !d || !nb) return fail(EG_ERR_BAD_ARG, "bad argument");
   *d = p->eng->tally; *nb = p->eng->plan.tally_slots.size() * EG_TALLY_POINT_BYTES;
@@ -594,6 +623,7 @@ int eg_verify_qv_batch_device(eg_qv_params* p, size_t n, const void* d_ballots, 
   return engine_verify_device(p->eng, n, d_ballots, d_status, (hipStream_t)stream);
 }
 int eg_qv_tally_reset(eg_qv_params* p) { return p ? tally_reset(p->eng) : fail(EG_ERR_BAD_ARG, "null"); }
+int eg_qv_tally_reset_async(eg_qv_params* p, void* stream) { return p && stream ? tally_reset(p->eng, (hipStream_t)stream) : fail(EG_ERR_BAD_ARG, "null"); }
 int eg_qv_tally_device_ptr(eg_qv_params* p, void** d, size_t* nb) {
   if (!p || !d || !nb) return fail(EG_ERR_BAD_ARG, "bad argument");
   *d = p->eng->tally; *nb = p->eng->plan.tally_slots.size() * EG_TALLY_POINT_BYTES;
@@ -617,9 +647,10 @@ int eg_choice_encrypt_batch_device(eg_choice_params* p, uint64_t base_seed, size
   hipStream_t s = stream ? (hipStream_t)stream : e->ctx->stream;
   if (!p->single && (n_selected < 0 || n_selected > p->n_options)) return fail(EG_ERR_BAD_ARG, "n_selected out of range");
   if (n == 0) return EG_OK;
-  hipLaunchKernelGGL(k_choice_encrypt, dim3(grid_for(n, e->ctx->msm_blocks)), dim3(NT), 0, s, base_seed + first, n, p->n_options,
-                     p->single, n_selected, e->ctx->tabG, e->d_tabK, e->d_key_words, e->d_prefixes, e->ctx->ws,
-                     reinterpret_cast<u32*>(d_out), (u32)(e->plan.stride / 4));
+  if (p->n_options > 32) return fail(EG_ERR_BAD_ARG, "the generator supports at most 32 options");
+  eg_launch_choice_encrypt(grid_for(n, e->ctx->cus * 4), s, base_seed + first, n, p->n_options, p->single, n_selected, e->ctx->tabG,
+                           e->d_tabK, e->d_prefixes, e->plan.gen_pre_main, e->plan.gen_pre_ring, e->plan.gen_pre_logeq,
+                           reinterpret_cast<u32*>(d_out), (u32)(e->plan.stride / 4));
   HIPCHK(hipGetLastError());
   return EG_OK;
 }

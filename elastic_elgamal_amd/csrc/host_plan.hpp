@@ -111,6 +111,7 @@ struct Plan {
     return r;
   }
   int pk_off = -1;
+  int gen_pre_main = -1, gen_pre_ring = -1, gen_pre_logeq = -1;  // prefix indices used by the ballot generator
   uint32_t pk_ref() {  // 32 bytes of the election key; filled in when the params object is created
     if (pk_off < 0) { pk_off = (int)blob.size(); blob.insert(blob.end(), 32, 0); }
     return blob_ref((uint32_t)pk_off, 32);
@@ -185,9 +186,12 @@ struct RingIn {
 // RingProof::verify (ring.rs:302-374) appended to the plan.  `setup` are the ops that bring a fresh transcript
 // to the state the reference passes in (Transcript::new(label) [+ range header]).  Returns the verdict flag.
 inline uint16_t add_ring_proof(Plan& P, const std::vector<HashOp>& setup, const std::vector<RingIn>& rings,
-                               uint16_t challenge_item, size_t first_stage = 0) {
+                               uint16_t challenge_item, size_t first_stage = 0, int* out_pre_main = nullptr,
+                               int* out_pre_ring = nullptr) {
   // hoisted, election-constant prefixes (ring.rs:290-293, :329)
   const uint32_t pre_main = P.new_prefix(), pre_ring = P.new_prefix();
+  if (out_pre_main) *out_pre_main = (int)pre_main;
+  if (out_pre_ring) *out_pre_ring = (int)pre_ring;
   {
     std::vector<HashOp> prog = setup;
     prog.push_back({OP_APPEND_BLOB, P.ref("dom-sep"), P.ref("multi_ring_enc"), 0});
@@ -277,6 +281,7 @@ inline Plan build_choice_plan(int n, bool single) {
     tb.push_back({P.const_point(1), 1, 1});
     const uint16_t p0 = P.derive(0, tr), p1 = P.derive(0, tb);
     const uint32_t pre = P.new_prefix();
+    P.gen_pre_logeq = (int)pre;
     P.prefix_programs.push_back({{OP_NEW, P.ref("choice_encryption_sum"), 0, 0},
                                  {OP_APPEND_BLOB, P.ref("dom-sep"), P.ref("log_eq"), 0},
                                  {OP_APPEND_BLOB, P.ref("K"), P.pk_ref(), 0},
@@ -303,7 +308,8 @@ inline Plan build_choice_plan(int n, bool single) {
     r.resp_item = (uint16_t)(ring_items + 1 + 2 * k);
     rings.push_back(r);
   }
-  const uint16_t flag = add_ring_proof(P, {{OP_NEW, P.ref("encrypted_choice_ranges"), 0, 0}}, rings, ring_items);
+  const uint16_t flag = add_ring_proof(P, {{OP_NEW, P.ref("encrypted_choice_ranges"), 0, 0}}, rings, ring_items, 0,
+                                       &P.gen_pre_main, &P.gen_pre_ring);
   P.rules.push_back({flag, 6 /* EG_ST_RANGE_CHALLENGE */});
   return P;
 }

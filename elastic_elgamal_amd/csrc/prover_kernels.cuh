@@ -1,8 +1,237 @@
-// prover_kernels.cuh -- synthetic-ballot generation on the GPU (EncryptedChoice::new); filled in below.
+// prover_kernels.cuh -- synthetic-ballot generation on the GPU: EncryptedChoice::new for one voter per lane
+// (SURVEY.md 8f row 1).  Follows the reference's construction and RNG draw order exactly
+//   choice.rs:313-349 (EncryptedChoice::new), ring.rs:54-194 (Ring::new / aggregate / finalize),
+//   ring.rs:440-506 (RingProofBuilder), encryption.rs:310-327 (ExtendedCiphertext::new),
+//   log_equality.rs:114-139 (LogEqualityProof::new), ristretto.rs:28-32 (generate_scalar)
+// so that ballot i equals what the reference produces from ChaChaRng::seed_from_u64(seed0 + i) given the
+// same selection; the selection itself comes from a second ChaCha stream seeded with the complemented seed.
+// Because the prover knows r with R = [r]G and B = x_v + [r]K, every simulated commitment
+//   R_G = [s]G - [e]R = [s - e r]G          R_K = [s]K - [e](B - x_j) = [s - e r]K - [e (v - j) step]G
+// is computed with fixed-base tables only; group elements are equal, hence the canonical encodings that are
+// hashed and the resulting proof bytes are identical to the reference's.
 #pragma once
-#include "kernels.cuh"
+#include "device_io.cuh"
+
 namespace eg {
-__global__ void __launch_bounds__(NT, 2) k_choice_encrypt(u64 seed0, size_t n, int n_options, int single, int n_selected,
-                                                          const uint4* tabG, const uint4* tabK, const u32* key_words,
-                                                          const u32* prefixes, uint4* ws, u32* out, u32 stride_words) {}
+
+// ---- ChaCha20 block RNG as rand_chacha::ChaCha20Rng + SeedableRng::seed_from_u64 (tests/snapshots.rs:32) ----
+struct ChaChaRng {
+  u32 key[8];
+  u64 counter;
+};
+__device__ __forceinline__ u32 rotl32(u32 x, int n) { return (x << n) | (x >> (32 - n)); }
+#define EG_QR(a, b, c, d) a += b; d ^= a; d = rotl32(d, 16); c += d; b ^= c; b = rotl32(b, 12); a += b; d ^= a; d = rotl32(d, 8); c += d; b ^= c; b = rotl32(b, 7);
+__device__ __forceinline__ void chacha_seed_from_u64(ChaChaRng& r, u64 state) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {   // PCG32 expansion of the u64 seed
+    state = state * 6364136223846793005ULL + 11634580027462260723ULL;
+    const u32 xorshifted = (u32)(((state >> 18) ^ state) >> 27);
+    const u32 rot = (u32)(state >> 59);
+    r.key[i] = (xorshifted >> rot) | (xorshifted << ((32 - rot) & 31));
+  }
+  r.counter = 0;
+}
+__device__ __forceinline__ void chacha_block(ChaChaRng& r, u32 out[16]) {
+  u32 s[16], x[16];
+  s[0] = 0x61707865u; s[1] = 0x3320646eu; s[2] = 0x79622d32u; s[3] = 0x6b206574u;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s[4 + i] = r.key[i];
+  s[12] = (u32)r.counter; s[13] = (u32)(r.counter >> 32); s[14] = 0; s[15] = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) x[i] = s[i];
+#pragma unroll 1
+  for (int i = 0; i < 10; ++i) {
+    EG_QR(x[0], x[4], x[8], x[12]) EG_QR(x[1], x[5], x[9], x[13]) EG_QR(x[2], x[6], x[10], x[14]) EG_QR(x[3], x[7], x[11], x[15])
+    EG_QR(x[0], x[5], x[10], x[15]) EG_QR(x[1], x[6], x[11], x[12]) EG_QR(x[2], x[7], x[8], x[13]) EG_QR(x[3], x[4], x[9], x[14])
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) out[i] = x[i] + s[i];
+  r.counter++;
+}
+// ScalarOps::generate_scalar: 64 random bytes -> from_bytes_mod_order_wide
+__device__ __noinline__ void rng_scalar(ChaChaRng& r, u32 out[8]) {
+  u32 w[16];
+  chacha_block(r, w);
+  sc_from_wide(out, w);
+}
+
+// out = encode([a]G + [b]K)   (b may be null)
+__device__ __noinline__ void fixed2_encode(u32 out[8], const FixedTable& tg, const u32* a, const FixedTable& tk, const u32* b) {
+  ge acc;
+  ge_identity(acc);
+  u32 dg[8];
+  if (a) { sc_recode_radix16(dg, a); ge_fixed_mul_add(acc, tg, dg); }
+  if (b) { sc_recode_radix16(dg, b); ge_fixed_mul_add(acc, tk, dg); }
+  ristretto_encode(out, acc);
+}
+
+// out-of-line transcript helpers: the generator is not throughput critical, keep its code (and compile time) small
+__device__ __noinline__ void gen_append32(Transcript<LdsState>& t, const char* label, int label_len, const u32* words) {
+  merlin_append_words(t, label, label_len, words, 32);
+}
+__device__ __noinline__ void gen_append_u64(Transcript<LdsState>& t, const char* label, int label_len, u64 x) {
+  merlin_append_u64(t, label, label_len, x);
+}
+__device__ __noinline__ void gen_append_ct(Transcript<LdsState>& t, const u32* encR, const u32* encB) {
+  merlin_frame(t, "enc", 3, 64u);
+  strobe_begin_op(t, EG_FLAG_AD);
+  strobe_absorb_words(t, encR, 32);
+  strobe_absorb_words(t, encB, 32);
+}
+__device__ __noinline__ void gen_challenge(Transcript<LdsState>& t, u32 e[8]) {
+  u32 wide[16];
+  merlin_challenge64(t, "c", 1, wide);
+  sc_from_wide(e, wide);
+}
+__device__ __noinline__ void gen_import(Transcript<LdsState>& t, const u32* prefix) { merlin_import(t, prefix); }
+__device__ __noinline__ void gen_muladd(u32 out[8], const u32* a, const u32* b, const u32* c) { sc_muladd(out, a, b, c); }
+
+constexpr int EG_GEN_MAX_OPTIONS = 32;
+
+// One lane = one voter.  out: packed ballot (choice wire layout of eg_hip.h).
+__global__ void __launch_bounds__(NT) k_choice_encrypt(u64 seed0, size_t n, int n_options, int single, int n_selected,
+                                                       const uint4* tabG, const uint4* tabK, const u32* prefixes,
+                                                       int pre_main, int pre_ring, int pre_logeq, u32* out, u32 stride_words) {
+  __shared__ u32 lds[50 * NT];
+  const FixedTable tg{tabG}, tk{tabK};
+  for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
+    const u64 seed = seed0 + i;
+    ChaChaRng rng;
+    chacha_seed_from_u64(rng, seed);
+    u32* ob = out + i * stride_words;
+    // ---- voter selection (second stream) ----
+    u32 flags = 0;   // bit k set <=> option k selected
+    {
+      ChaChaRng sel;
+      chacha_seed_from_u64(sel, ~seed);
+      u32 buf[16];
+      int pos = 16, got = 0;
+      const int want = single ? 1 : n_selected;
+#pragma unroll 1
+      while (got < want) {
+        if (pos >= 16) { chacha_block(sel, buf); pos = 0; }
+        u32 v = buf[0];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) v = (pos == q) ? buf[q] : v;
+        ++pos;
+        const u32 k = v % (u32)n_options;
+        if (!((flags >> k) & 1u)) { flags |= 1u << k; ++got; }
+      }
+    }
+    Transcript<LdsState> t;
+    t.st.base = lds + threadIdx.x;
+    // per-ring values that outlive the ring's construction
+    u32 rr[EG_GEN_MAX_OPTIONS][8], xx[EG_GEN_MAX_OPTIONS][8], term[EG_GEN_MAX_OPTIONS][16], resp1[EG_GEN_MAX_OPTIONS][8];
+    u32 sum_r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const u32 one[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 1
+    for (int k = 0; k < n_options; ++k) {
+      const bool vi = (flags >> k) & 1u;
+      // ExtendedCiphertext::new (encryption.rs:310-327): r, R = [r]G, B = value + [r]K
+      u32 r[8], x[8], encR[8], encB[8];
+      rng_scalar(rng, r);
+      fixed2_encode(encR, tg, r, tk, nullptr);
+      fixed2_encode(encB, tg, vi ? one : nullptr, tk, r);
+#pragma unroll
+      for (int w = 0; w < 8; ++w) { ob[(2 * k) * 8 + w] = encR[w]; ob[(2 * k + 1) * 8 + w] = encB[w]; rr[k][w] = r[w]; }
+      gen_muladd(sum_r, sum_r, one, r);
+      // Ring::new (ring.rs:54-131)
+      gen_import(t, prefixes + (size_t)pre_ring * 52);
+      gen_append_ct(t, encR, encB);
+      gen_append_u64(t, "i", 1, (u64)k);
+      rng_scalar(rng, x);
+      u32 cg[8], ck[8];
+      fixed2_encode(cg, tg, x, tk, nullptr);
+      fixed2_encode(ck, tg, nullptr, tk, x);
+#pragma unroll
+      for (int w = 0; w < 8; ++w) xx[k][w] = x[w];
+      if (!vi) {
+        // equation 1 is simulated now (ring.rs:103-118): challenge from ([x]G, [x]K), random response
+        gen_append_u64(t, "j", 1, 0);
+        gen_append32(t, "R_G", 3, cg);
+        gen_append32(t, "R_K", 3, ck);
+        u32 e[8], s1[8], ne[8], tt[8];
+        gen_challenge(t, e);
+        rng_scalar(rng, s1);
+        sc_neg(ne, e);
+        gen_muladd(tt, ne, r, s1);                // s - e r
+        fixed2_encode(cg, tg, tt, tk, nullptr);   // [s]G - [e]R
+        fixed2_encode(ck, tg, e, tk, tt);         // [s]K - [e](B - G),  B - G = [r]K - G
+#pragma unroll
+        for (int w = 0; w < 8; ++w) resp1[k][w] = s1[w];
+      }
+#pragma unroll
+      for (int w = 0; w < 8; ++w) { term[k][w] = cg[w]; term[k][8 + w] = ck[w]; }
+    }
+    // Ring::aggregate (ring.rs:138-160)
+    u32 e0[8];
+    {
+      gen_import(t, prefixes + (size_t)pre_main * 52);
+#pragma unroll 1
+      for (int k = 0; k < n_options; ++k) {
+        gen_append32(t, "R_G", 3, term[k]);
+        gen_append32(t, "R_K", 3, term[k] + 8);
+      }
+      gen_challenge(t, e0);
+    }
+    u32* proof = ob + (size_t)(2 * n_options) * 8;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) proof[w] = e0[w];
+    // Ring::finalize (ring.rs:162-194)
+#pragma unroll 1
+    for (int k = 0; k < n_options; ++k) {
+      const bool vi = (flags >> k) & 1u;
+      u32 r[8], x[8], s0[8], s1[8];
+#pragma unroll
+      for (int w = 0; w < 8; ++w) { r[w] = rr[k][w]; x[w] = xx[k][w]; }
+      if (vi) {
+        u32 ne[8], tt[8], cg[8], ck[8], encR[8], encB[8];
+        rng_scalar(rng, s0);
+        sc_neg(ne, e0);
+        gen_muladd(tt, ne, r, s0);
+        fixed2_encode(cg, tg, tt, tk, nullptr);   // [s0]G - [e0]R
+        fixed2_encode(ck, tg, ne, tk, tt);        // [s0]K - [e0](B - O),  B = G + [r]K
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { encR[w] = ob[(2 * k) * 8 + w]; encB[w] = ob[(2 * k + 1) * 8 + w]; }
+        gen_import(t, prefixes + (size_t)pre_ring * 52);
+        gen_append_ct(t, encR, encB);
+        gen_append_u64(t, "i", 1, (u64)k);
+        gen_append_u64(t, "j", 1, 0);
+        gen_append32(t, "R_G", 3, cg);
+        gen_append32(t, "R_K", 3, ck);
+        u32 e1[8];
+        gen_challenge(t, e1);
+        gen_muladd(s1, e1, r, x);                 // trapdoor response (ring.rs:192-193)
+      } else {
+        gen_muladd(s0, e0, r, x);
+#pragma unroll
+        for (int w = 0; w < 8; ++w) s1[w] = resp1[k][w];
+      }
+#pragma unroll
+      for (int w = 0; w < 8; ++w) { proof[(1 + 2 * k) * 8 + w] = s0[w]; proof[(2 + 2 * k) * 8 + w] = s1[w]; }
+    }
+    if (single) {
+      // SingleChoice::prove (choice.rs:59-75) -> LogEqualityProof::new (log_equality.rs:114-139)
+      // powers = (sum R, sum B - G) = ([sum r]G, [sum r]K + (count - 1)G); count = 1 for a single choice
+      u32 p0[8], p1[8], x[8], xg[8], xk[8];
+      fixed2_encode(p0, tg, sum_r, tk, nullptr);
+      fixed2_encode(p1, tg, nullptr, tk, sum_r);
+      gen_import(t, prefixes + (size_t)pre_logeq * 52);
+      gen_append32(t, "[r]G", 4, p0);
+      gen_append32(t, "[r]K", 4, p1);
+      rng_scalar(rng, x);
+      fixed2_encode(xg, tg, x, tk, nullptr);
+      fixed2_encode(xk, tg, nullptr, tk, x);
+      gen_append32(t, "[x]G", 4, xg);
+      gen_append32(t, "[x]K", 4, xk);
+      u32 c[8], s[8];
+      gen_challenge(t, c);
+      gen_muladd(s, c, sum_r, x);
+      u32* sp = proof + (size_t)(1 + 2 * n_options) * 8;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) { sp[w] = c[w]; sp[8 + w] = s[w]; }
+    }
+  }
+}
+
 }  // namespace eg

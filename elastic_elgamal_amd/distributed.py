@@ -1,0 +1,52 @@
+"""Multi-GPU plumbing: one process per GPU, ballots sharded contiguously, ONE exchange per batch.
+
+The path shards embarrassingly (ballots are independent): rank r verifies ballots
+[shard_range(total, r, world)) and accumulates its own homomorphic tally (examples/voting.rs:199-203).  The only
+collective is an all-gather of the per-rank tallies (n_options x 64 bytes of canonical encodings) over
+RCCL/xGMI; point addition is not an RCCL reduction op, so every rank then sums the gathered encodings itself
+(`Context.points_sum_device`).  With gloo the same helpers run on CPU tensors (tests/test_distributed_cpu.py).
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous slab [begin, end) of ballots for `rank`; slabs differ by at most one ballot."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    return total * rank // world, total * (rank + 1) // world
+
+
+def gather_tallies(local: torch.Tensor) -> torch.Tensor:
+    """All-gather of the per-rank tally encodings.  local: uint8 [n_options*64] -> uint8 [world, n_options*64],
+    rank-major (row r is rank r's tally).  A single collective per batch; no data-path collective elsewhere."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local.reshape(1, -1).clone()
+    world = dist.get_world_size()
+    flat = local.contiguous().view(-1)
+    out = torch.empty(world * flat.numel(), dtype=local.dtype, device=local.device)
+    if dist.get_backend() == "gloo":      # CPU tests: gloo has no all_gather_into_tensor for this layout
+        parts = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(parts, flat)
+        out = torch.cat(parts)
+    else:
+        dist.all_gather_into_tensor(out, flat)
+    return out.view(world, flat.numel())
+
+
+def max_over_ranks(seconds: float, device) -> float:
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value: int, device) -> int:
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())

@@ -115,6 +115,12 @@ int eg_choice_tally_reset(eg_choice_params*);
 int eg_choice_tally_device_ptr(eg_choice_params*, void** d_points, size_t* n_bytes);
 int eg_choice_tally_merge_device(eg_choice_params*, const void* d_gathered, int n_ranks, void* stream);
 int eg_choice_tally_encode(eg_choice_params*, uint8_t* out /* n_options*64 */);
+/* asynchronous forms for the multi-GPU path: reset on a stream; write the canonical encodings (n_options*64 bytes)
+ * to device memory, ready for an RCCL all-gather; then sum the gathered encodings with eg_points_sum_device. */
+int eg_choice_tally_reset_async(eg_choice_params*, void* stream);
+int eg_choice_tally_encode_device(eg_choice_params*, void* d_out, void* stream);
+/* d_out[k] = encode( sum_r decode(d_in[r][k]) ), k < n_points, r < n_ranks; 32-byte encodings */
+int eg_points_sum_device(eg_ctx*, int n_ranks, int n_points, const void* d_in, void* d_out, void* stream);
 
 /* ---- batch tier: QuadraticVotingBallot ------------------------------------------------------------------------------
  * wire layout (stride = eg_qv_ballot_size), serde field order of quadratic_voting.rs:205-217 / range.rs:446-450 /
@@ -131,6 +137,8 @@ int eg_qv_tally_reset(eg_qv_params*);
 int eg_qv_tally_device_ptr(eg_qv_params*, void** d_points, size_t* n_bytes);
 int eg_qv_tally_merge_device(eg_qv_params*, const void* d_gathered, int n_ranks, void* stream);
 int eg_qv_tally_encode(eg_qv_params*, uint8_t* out);
+int eg_qv_tally_reset_async(eg_qv_params*, void* stream);
+int eg_qv_tally_encode_device(eg_qv_params*, void* d_out, void* stream);
 
 /* ---- synthetic ballots on the GPU (EncryptedChoice::new / QuadraticVotingBallot::new) ---------
  * Ballot i of the call is produced from ChaChaRng::seed_from_u64(base_seed + first + i) with the reference's

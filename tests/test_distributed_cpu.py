@@ -1,0 +1,83 @@
+"""N > 1 path on CPU: two gloo processes shard a batch, exchange tallies with the product's helper
+(elastic_elgamal_amd.distributed) and agree on the merged tally.  The per-shard compute is done by the oracle
+here (no GPU in this container); on the GPU box the same helpers run over RCCL (bench.py)."""
+import os
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _worker(rank, world, port, total, q):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from elastic_elgamal_amd import distributed as egd
+    from oracle import oracle as o
+
+    _, pk, _ = o.keypair_from_seed(12345)
+    op = o.ChoiceParams(pk, 5, True)
+    lo, hi = egd.shard_range(total, rank, world)
+    ballots = op.generate_batch(31337, lo, hi - lo, threads=2)        # rank-local shard, generated independently
+    st = op.verify_batch(ballots, threads=2)
+    local = torch.frombuffer(bytearray(op.tally(ballots, st)), dtype=torch.uint8)
+    gathered = egd.gather_tallies(local)
+    assert gathered.shape == (world, 320)
+    assert bytes(gathered[rank].numpy()) == bytes(local.numpy())
+    # merge exactly as the GPU does (sum of decoded encodings), with the oracle's point adds
+    merged = []
+    for k in range(10):
+        acc = b"\0" * 32
+        for r in range(world):
+            acc = o.point_add(acc, bytes(gathered[r, 32 * k : 32 * k + 32].numpy()))
+        merged.append(acc)
+    merged = b"".join(merged)
+    accepted = egd.sum_over_ranks(st.count(0), "cpu")
+    slow = egd.max_over_ranks(float(rank + 1), "cpu")
+    q.put((rank, merged, accepted, slow, (lo, hi)))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_tally():
+    from oracle import oracle as o
+
+    world, total = 2, 37
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort()
+    assert res[0][4] == (0, 18) and res[1][4] == (18, 37)
+    assert res[0][1] == res[1][1]                    # every rank holds the same merged tally
+    assert res[0][2] == res[1][2] == total           # all ballots accepted, counted once
+    assert res[0][3] == res[1][3] == 2.0             # max over ranks
+    # sharding does not change the result: single-process tally of the whole batch
+    _, pk, _ = o.keypair_from_seed(12345)
+    op = o.ChoiceParams(pk, 5, True)
+    whole = op.generate_batch(31337, 0, total, threads=2)
+    assert res[0][1] == op.tally(whole, op.verify_batch(whole, threads=2))
+
+
+def test_shard_range_covers_everything():
+    from elastic_elgamal_amd.distributed import shard_range
+
+    for total in (0, 1, 7, 10_000_000):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+    with pytest.raises(ValueError):
+        shard_range(10, 2, 2)

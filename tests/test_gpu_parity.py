@@ -258,3 +258,41 @@ def test_tally_linearity_and_chunking(eg, ctx, oracle, pk, monkeypatch):
     grp = eg.Ristretto(ctx)
     summed, ok = grp.element_add(ta, tb)
     assert summed == tally == op.tally(ballots, st)
+
+
+# ------------------------------------------------------------------ GPU ballot generator (EncryptedChoice::new)
+def _gen_on_gpu(eg, p, base_seed, first, n, n_selected=0):
+    import torch
+
+    out = torch.zeros(n * p.ballot_size, dtype=torch.uint8, device="cuda")
+    p.encrypt_batch_device(base_seed, first, n, out.data_ptr(), n_selected=n_selected)
+    p.ctx.synchronize()
+    return bytes(out.cpu().numpy())
+
+
+def test_generator_matches_oracle_prover(eg, ctx, oracle, pk):
+    # the oracle's prover is pinned byte-for-byte by the reference's snapshots; the GPU prover must equal it
+    p = eg.ChoiceParams(ctx, pk, 5, True)
+    op = oracle.ChoiceParams(pk, 5, True)
+    got = _gen_on_gpu(eg, p, 555, 10, 300)
+    assert got == op.generate_batch(555, 10, 300)
+    st, _ = p.verify_batch(got)
+    assert st == [0] * 300
+    m = eg.ChoiceParams(ctx, pk, 16, False)
+    om = oracle.ChoiceParams(pk, 16, False)
+    got = _gen_on_gpu(eg, m, 77, 0, 70, n_selected=3)
+    assert got == om.generate_batch(77, 0, 70, n_selected=3)
+    for n in (2, 3, 10):
+        q = eg.ChoiceParams(ctx, pk, n, True)
+        oq = oracle.ChoiceParams(pk, n, True)
+        assert _gen_on_gpu(eg, q, 9000 + n, 0, 20) == oq.generate_batch(9000 + n, 0, 20)
+
+
+def test_snapshot_seed_reproduced_on_gpu(eg, ctx, golden, pk, oracle):
+    # Same RNG discipline as tests/snapshots.rs: the ballot drawn from seed s equals the oracle's for seed s
+    p = eg.ChoiceParams(ctx, pk, 5, True)
+    op = oracle.ChoiceParams(pk, 5, True)
+    one = _gen_on_gpu(eg, p, 12345, 0, 1)
+    rng = oracle.rng_from_u64(12345)
+    flags = oracle.select_single(12345, 5)
+    assert one == op.new_ballot(flags, rng)
