@@ -58,7 +58,13 @@ static inline void fe_check_values(const fe& f) {
     if ((double)f.v[i] > lim) { fprintf(stderr, "limb %d = %u exceeds class %.2f\n", i, f.v[i], f.cls); abort(); }
   }
 }
+// operation counters of the host check build (algorithmic work model)
+static unsigned long long g_fe_mul_count = 0, g_fe_sq_count = 0;
+#define EG_COUNT_MUL() (++g_fe_mul_count)
+#define EG_COUNT_SQ() (++g_fe_sq_count)
 #else
+#define EG_COUNT_MUL() ((void)0)
+#define EG_COUNT_SQ() ((void)0)
 #define EG_SETCLS(h, c) ((void)0)
 #define EG_GETCLS(h) (0.0f)
 #define fe_check_values(f) ((void)0)
@@ -137,6 +143,7 @@ EG_HD void fe_mul(fe& h, const fe& f, const fe& g) {
   EG_REQUIRE(EG_GETCLS(g) <= 3.31f, "fe_mul: g operand class > 3.3");
   EG_REQUIRE(EG_GETCLS(f) * EG_GETCLS(g) <= 32.0f, "fe_mul: class product > 32");
   fe_check_values(f); fe_check_values(g);
+  EG_COUNT_MUL();
   u32 g19[10], f2[10];
 #pragma unroll
   for (int i = 0; i < 10; ++i) { g19[i] = 19u * g.v[i]; f2[i] = 2u * f.v[i]; }
@@ -161,6 +168,7 @@ EG_HD void fe_mul(fe& h, const fe& f, const fe& g) {
 EG_HD void fe_sq(fe& h, const fe& f) {
   EG_REQUIRE(EG_GETCLS(f) <= 3.31f, "fe_sq: operand class > 3.3");
   fe_check_values(f);
+  EG_COUNT_SQ();
   const u32 f0 = f.v[0], f1 = f.v[1], f2 = f.v[2], f3 = f.v[3], f4 = f.v[4];
   const u32 f5 = f.v[5], f6 = f.v[6], f7 = f.v[7], f8 = f.v[8], f9 = f.v[9];
   const u32 f0_2 = 2 * f0, f1_2 = 2 * f1, f2_2 = 2 * f2, f3_2 = 2 * f3, f4_2 = 2 * f4;

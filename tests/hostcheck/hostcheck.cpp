@@ -108,6 +108,27 @@ int hc_merlin(const char* label, const char* l1, const uint8_t* m1, int m1_len, 
   return (int)t.pos;
 }
 
+// field operation counts of the hot-path building blocks: out[2*i], out[2*i+1] = (fe_mul, fe_sq) calls of
+// 0: ristretto_decode  1: table build  2: variable-base multiply  3: fixed-base multiply (64 windows)
+// 4: ristretto_encode
+void hc_op_counts(unsigned long long out[10]) {
+  if (g_base_table.e.empty()) { ge g; ge_generator(g); build_fixed(g_base_table, g); }
+  u32 gw[8] = {0x0aaef2e2u, 0x714ebc6au, 0x61a984a8u, 0x5f5100c5u, 0x6a0be358u, 0x8ddd82a5u, 0x4559a6b6u, 0x762d8de0u};
+  u32 k[8] = {0x12345678u, 0x9abcdef0u, 0x0fedcba9u, 0x87654321u, 0x11111111u, 0x22222222u, 0x33333333u, 0x04444444u};
+  auto snap = [&](int i, unsigned long long m0, unsigned long long s0) { out[2 * i] = g_fe_mul_count - m0; out[2 * i + 1] = g_fe_sq_count - s0; };
+  unsigned long long m0 = g_fe_mul_count, s0 = g_fe_sq_count;
+  ge p; ristretto_decode(p, gw); snap(0, m0, s0);
+  m0 = g_fe_mul_count; s0 = g_fe_sq_count;
+  ArrTable tab; ge_var_table_build(tab, p); snap(1, m0, s0);
+  u32 dg[8]; sc_recode_radix16(dg, k);
+  m0 = g_fe_mul_count; s0 = g_fe_sq_count;
+  ge acc; ge_var_mul(acc, tab, dg); snap(2, m0, s0);
+  m0 = g_fe_mul_count; s0 = g_fe_sq_count;
+  ge_fixed_mul_add(acc, g_base_table, dg); snap(3, m0, s0);
+  m0 = g_fe_mul_count; s0 = g_fe_sq_count;
+  u32 o[8]; ristretto_encode(o, acc); snap(4, m0, s0);
+}
+
 void hc_fe_roundtrip(const uint8_t in[32], uint8_t out[32]) {
   u32 w[8], o[8]; words_from_bytes(w, in, 8); fe f; fe_from_words(f, w); fe_to_words(o, f); bytes_from_words(out, o, 8);
 }
