@@ -25,7 +25,7 @@ __all__ = [
 ]
 
 _PKG = Path(__file__).resolve().parent
-_LIB = _PKG / "libeg_hip.so"
+_LIB = Path(os.environ.get("EG_LIB", str(_PKG / "libeg_hip.so")))   # EG_LIB: alternate build for A/B measurements
 
 OK, BAD_SCALAR, BAD_POINT, OPTIONS_LEN, SUM_CHALLENGE, RANGE_LEN, RANGE_CHALLENGE = range(7)
 QV_VARIANT_LEN, QV_VARIANT_CHALLENGE, QV_CREDIT_RANGE_LEN, QV_CREDIT_RANGE_CHALLENGE = 7, 8, 9, 10

@@ -21,7 +21,16 @@
 #include <hip/hip_runtime.h>
 #define EG_HD __host__ __device__ __forceinline__
 #define EG_D __device__ __forceinline__
+// Keeps the backend scheduler from interleaving independent field multiplications: one multiply already has
+// 10 independent 10-MAD columns of ILP, while interleaving several multiplies only inflates live registers
+// (256 VGPR + AGPR spills, 1 wave/SIMD).  See DESIGN.md section 9.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(EG_NO_SCHED_FENCE)
+#define EG_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
+#define EG_SCHED_FENCE() ((void)0)
+#endif
+#else
+#define EG_SCHED_FENCE() ((void)0)
 #define EG_HD inline
 #define EG_D inline
 #endif
@@ -144,6 +153,7 @@ EG_HD void fe_mul(fe& h, const fe& f, const fe& g) {
   EG_REQUIRE(EG_GETCLS(f) * EG_GETCLS(g) <= 32.0f, "fe_mul: class product > 32");
   fe_check_values(f); fe_check_values(g);
   EG_COUNT_MUL();
+  EG_SCHED_FENCE();
   u32 g19[10], f2[10];
 #pragma unroll
   for (int i = 0; i < 10; ++i) { g19[i] = 19u * g.v[i]; f2[i] = 2u * f.v[i]; }
@@ -163,12 +173,14 @@ EG_HD void fe_mul(fe& h, const fe& f, const fe& g) {
     c[k] = acc;
   }
   fe_reduce_columns(h, c);
+  EG_SCHED_FENCE();
 }
 
 EG_HD void fe_sq(fe& h, const fe& f) {
   EG_REQUIRE(EG_GETCLS(f) <= 3.31f, "fe_sq: operand class > 3.3");
   fe_check_values(f);
   EG_COUNT_SQ();
+  EG_SCHED_FENCE();
   const u32 f0 = f.v[0], f1 = f.v[1], f2 = f.v[2], f3 = f.v[3], f4 = f.v[4];
   const u32 f5 = f.v[5], f6 = f.v[6], f7 = f.v[7], f8 = f.v[8], f9 = f.v[9];
   const u32 f0_2 = 2 * f0, f1_2 = 2 * f1, f2_2 = 2 * f2, f3_2 = 2 * f3, f4_2 = 2 * f4;
@@ -186,6 +198,7 @@ EG_HD void fe_sq(fe& h, const fe& f) {
   c[8] = (u64)f0_2 * f8 + (u64)f1_2 * f7_2 + (u64)f2_2 * f6 + (u64)f3_2 * f5_2 + (u64)f4 * f4 + (u64)f9 * f9_38;
   c[9] = (u64)f0_2 * f9 + (u64)f1_2 * f8 + (u64)f2_2 * f7 + (u64)f3_2 * f6 + (u64)f4_2 * f5;
   fe_reduce_columns(h, c);
+  EG_SCHED_FENCE();
 }
 
 EG_HD void fe_sqn(fe& h, const fe& f, int n) {

@@ -338,16 +338,41 @@ EG_HD void ge_var_mul(ge& acc, TableIO& io, const u32 digits[8]) {
 }
 
 // ---- fixed-base scalar multiplication -----------------------------------------------------------------------------
-// Table layout: tab[(window * 8 + (|digit| - 1)) * 32 + word], 30 words used (ypx, ymx, xy2d), built once per
-// base on the device (k_build_fixed_table).  acc += [k]Base.
+// Signed radix-256 comb: 32 windows x 128 affine-Niels entries per base (512 KiB, L2 resident), built once per base
+// on the device (k_build_fixed_table).  Table index = window * 128 + (|digit| - 1).  acc += [k]Base with 32 mixed
+// additions (7M each) and no doublings.
+#define EG_FIXED_WINDOWS 32
+#define EG_FIXED_ENTRIES 128
+// 256-bit scalar (< 2^253) -> 32 signed radix-256 digits in [-128, 127], packed as bytes (two's complement)
+EG_HD void sc_recode_radix256(u32 out[8], const u32 k[8]) {
+  u32 carry = 0;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) {
+    u32 o = 0;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const u32 dgt = ((k[w] >> (8 * n)) & 255u) + carry;   // 0..256
+      carry = (dgt + 128u) >> 8;
+      o |= (dgt & 255u) << (8 * n);
+    }
+    out[w] = o;
+  }
+}
+EG_HD int sc_digit256(const u32 d[8], int i) {
+  u32 w = d[0];
+#pragma unroll
+  for (int j = 1; j < 8; ++j) w = ((i >> 2) == j) ? d[j] : w;
+  const int b = (int)((w >> (8 * (i & 3))) & 255u);
+  return b >= 128 ? b - 256 : b;
+}
 template <class NielsIO>
 EG_HD void ge_fixed_mul_add(ge& acc, NielsIO& io, const u32 digits[8]) {
   ge_niels ident; ge_niels_identity(ident);
 #pragma unroll 1
-  for (int i = 0; i < 64; ++i) {
-    const int d = sc_digit16(digits, i);
+  for (int i = 0; i < EG_FIXED_WINDOWS; ++i) {
+    const int d = sc_digit256(digits, i);
     const int ad = d < 0 ? -d : d;
-    ge_niels c; io.load(c, i * 8 + (ad == 0 ? 0 : ad - 1));
+    ge_niels c; io.load(c, i * EG_FIXED_ENTRIES + (ad == 0 ? 0 : ad - 1));
     fe_cmov(c.ypx, ident.ypx, ad == 0); fe_cmov(c.ymx, ident.ymx, ad == 0); fe_cmov(c.xy2d, ident.xy2d, ad == 0);
     ge_niels_cneg(c, d < 0);
     ge_p1p1 t; ge_madd(t, acc, c);

@@ -87,11 +87,11 @@ __global__ void __launch_bounds__(NT) k_derive_points(EngineBufs B, const egplan
 // One lane = one group equation of one ballot: vartime_double_mul_generator / vartime_multi_mul followed by
 // serialize_element (ring.rs:342-350, log_equality.rs:160-164, mul.rs:213-247 + proofs/mod.rs:48-52).
 // Persistent blocks stride over (class, ballot); lanes of a wave share the class, so control flow is uniform.
-__global__ void __launch_bounds__(NT) k_msm_jobs(EngineBufs B, const egplan::JobClass* classes,
+__global__ void __launch_bounds__(NT, 2) k_msm_jobs(EngineBufs B, const egplan::JobClass* classes,
                                                     const egplan::VarTerm* terms, int class_first, int n_classes) {
   const size_t total = (size_t)n_classes * B.n;
   WsTable tab;
-  tab.base = B.ws + (size_t)blockIdx.x * (WS_QUADS * NT) + threadIdx.x;
+  tab.init(B.ws);
   const FixedTable tg{B.tabG}, tk{B.tabK};
   for (size_t j = (size_t)blockIdx.x * NT + threadIdx.x; j < total; j += (size_t)gridDim.x * NT) {
     const u32 c = class_first + (u32)(j / B.n), b = (u32)(j % B.n);
@@ -118,13 +118,13 @@ __global__ void __launch_bounds__(NT) k_msm_jobs(EngineBufs B, const egplan::Job
     if (jc.g.kind != egplan::SRC_NONE) {
       u32 s[8], dg[8];
       load_scalar(s, B, b, jc.g);
-      sc_recode_radix16(dg, s);
+      sc_recode_radix256(dg, s);
       ge_fixed_mul_add(acc, tg, dg);
     }
     if (jc.k.kind != egplan::SRC_NONE) {
       u32 s[8], dg[8];
       load_scalar(s, B, b, jc.k);
-      sc_recode_radix16(dg, s);
+      sc_recode_radix256(dg, s);
       ge_fixed_mul_add(acc, tk, dg);
     }
     u32 out[8];
@@ -356,19 +356,22 @@ __global__ void k_points_sum(const u32* in, int n_ranks, int n_points, u32* out,
 }
 
 // ---- election setup --------------------------------------------------------------------------------------------------------------------------------
-// tab[(w*8 + k-1)] = niels([k * 16^w] Base): one lane per entry
+// tab[w*128 + k-1] = niels([k * 256^w] Base), w < 32, 1 <= k <= 128: one lane per entry
 __global__ void __launch_bounds__(NT) k_build_fixed_table(const u32* base_words /* 40 */, uint4* tab) {
   const int lane = blockIdx.x * NT + threadIdx.x;
-  if (lane >= 64 * 8) return;
-  const int w = lane >> 3, k = (lane & 7) + 1;
+  if (lane >= EG_FIXED_WINDOWS * EG_FIXED_ENTRIES) return;
+  const int w = lane / EG_FIXED_ENTRIES, k = (lane % EG_FIXED_ENTRIES) + 1;
   u32 bw[40];
   for (int i = 0; i < 40; ++i) bw[i] = base_words[i];
   ge p; words_to_ge(p, bw);
 #pragma unroll 1
-  for (int i = 0; i < 4 * w; ++i) { ge d; ge_dbl_full(d, p); p = d; }
-  ge q = p;
+  for (int i = 0; i < 8 * w; ++i) { ge d; ge_dbl_full(d, p); p = d; }
+  ge q; ge_identity(q);
 #pragma unroll 1
-  for (int i = 1; i < k; ++i) { ge s; ge_add_full(s, q, p); q = s; }
+  for (int bit = 7; bit >= 0; --bit) {        // k <= 128 fits 8 bits
+    ge d; ge_dbl_full(d, q); q = d;
+    if ((k >> bit) & 1) { ge s; ge_add_full(s, q, p); q = s; }
+  }
   ge_niels n; ge_to_niels(n, q);
   u32 o[32];
 #pragma unroll
@@ -400,7 +403,7 @@ __global__ void __launch_bounds__(NT) k_const_points(const u64* mults, int n, co
   if (i >= n) return;
   u32 s[8], dg[8];
   sc_from_u64(s, mults[i]);
-  sc_recode_radix16(dg, s);
+  sc_recode_radix256(dg, s);
   ge acc; ge_identity(acc);
   const FixedTable tg{tabG};
   ge_fixed_mul_add(acc, tg, dg);
@@ -472,7 +475,7 @@ __global__ void __launch_bounds__(NT) k_prim_point_add(size_t n, const u32* a, c
 __global__ void __launch_bounds__(NT) k_prim_msm(size_t n, int terms, const u32* scalars, const u32* points, const u32* r,
                                                     const uint4* tabG, uint4* ws, u32* out, unsigned char* ok) {
   WsTable tab;
-  tab.base = ws + (size_t)blockIdx.x * (WS_QUADS * NT) + threadIdx.x;
+  tab.init(ws);
   for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
     ge acc; ge_identity(acc);
     bool okk = true;
@@ -490,7 +493,7 @@ __global__ void __launch_bounds__(NT) k_prim_msm(size_t n, int terms, const u32*
     }
     if (r) {
       u32 s[8], dg[8]; ld8(s, r + i * 8);
-      sc_recode_radix16(dg, s);
+      sc_recode_radix256(dg, s);
       const FixedTable tg{tabG};
       ge_fixed_mul_add(acc, tg, dg);
     }

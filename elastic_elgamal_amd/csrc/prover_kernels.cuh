@@ -60,8 +60,8 @@ __device__ __noinline__ void fixed2_encode(u32 out[8], const FixedTable& tg, con
   ge acc;
   ge_identity(acc);
   u32 dg[8];
-  if (a) { sc_recode_radix16(dg, a); ge_fixed_mul_add(acc, tg, dg); }
-  if (b) { sc_recode_radix16(dg, b); ge_fixed_mul_add(acc, tk, dg); }
+  if (a) { sc_recode_radix256(dg, a); ge_fixed_mul_add(acc, tg, dg); }
+  if (b) { sc_recode_radix256(dg, b); ge_fixed_mul_add(acc, tk, dg); }
   ristretto_encode(out, acc);
 }
 

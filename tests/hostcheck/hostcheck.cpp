@@ -34,15 +34,15 @@ static void bytes_from_words(uint8_t* b, const u32* w, int nwords) {
 
 static ArrNiels g_base_table;
 static void build_fixed(ArrNiels& t, const ge& base) {
-  t.e.resize(64 * 8);
+  t.e.resize(EG_FIXED_WINDOWS * EG_FIXED_ENTRIES);
   ge win = base;
-  for (int w = 0; w < 64; ++w) {
+  for (int w = 0; w < EG_FIXED_WINDOWS; ++w) {
     ge cur = win;
-    for (int k = 1; k <= 8; ++k) {
-      ge_to_niels(t.e[w * 8 + k - 1], cur);
+    for (int k = 1; k <= EG_FIXED_ENTRIES; ++k) {
+      ge_to_niels(t.e[w * EG_FIXED_ENTRIES + k - 1], cur);
       ge nxt; ge_add_full(nxt, cur, win); cur = nxt;
     }
-    for (int d = 0; d < 4; ++d) { ge nxt; ge_dbl_full(nxt, win); win = nxt; }
+    for (int d = 0; d < 8; ++d) { ge nxt; ge_dbl_full(nxt, win); win = nxt; }
   }
 }
 
@@ -63,7 +63,7 @@ int hc_double_mul_generator(const uint8_t k[32], const uint8_t p_enc[32], const 
   words_from_bytes(kw, k, 8); words_from_bytes(rw, r, 8); words_from_bytes(pw, p_enc, 8);
   ge p; if (!ristretto_decode(p, pw)) return 0;
   ArrTable tab; ge_var_table_build(tab, p);
-  u32 dk[8], dr[8]; sc_recode_radix16(dk, kw); sc_recode_radix16(dr, rw);
+  u32 dk[8], dr[8]; sc_recode_radix16(dk, kw); sc_recode_radix256(dr, rw);
   ge acc; ge_var_mul(acc, tab, dk);
   ge_fixed_mul_add(acc, g_base_table, dr);
   ristretto_encode(o, acc);
@@ -123,8 +123,9 @@ void hc_op_counts(unsigned long long out[10]) {
   u32 dg[8]; sc_recode_radix16(dg, k);
   m0 = g_fe_mul_count; s0 = g_fe_sq_count;
   ge acc; ge_var_mul(acc, tab, dg); snap(2, m0, s0);
+  u32 dg8[8]; sc_recode_radix256(dg8, k);
   m0 = g_fe_mul_count; s0 = g_fe_sq_count;
-  ge_fixed_mul_add(acc, g_base_table, dg); snap(3, m0, s0);
+  ge_fixed_mul_add(acc, g_base_table, dg8); snap(3, m0, s0);
   m0 = g_fe_mul_count; s0 = g_fe_sq_count;
   u32 o[8]; ristretto_encode(o, acc); snap(4, m0, s0);
 }
