@@ -20,7 +20,7 @@ import os
 from pathlib import Path
 
 __all__ = [
-    "Context", "Ristretto", "ChoiceParams", "QuadraticVotingParams", "EgError", "library_path", "build",
+    "Context", "Ristretto", "ChoiceParams", "QuadraticVotingParams", "PublicKeyVerifier", "EgError", "library_path", "build",
     "STATUS_NAMES", "status_kind", "status_detail",
 ]
 
@@ -122,6 +122,12 @@ def _load() -> C.CDLL:
         "eg_qv_tally_reset_async": (C.c_int, [vp, vp]),
         "eg_qv_tally_encode_device": (C.c_int, [vp, vp, vp]),
         "eg_points_sum_device": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp]),
+        "eg_proof_params_create": (C.c_int, [vp, cp, C.c_int, C.c_uint64, C.POINTER(vp)]),
+        "eg_proof_params_destroy": (None, [vp]),
+        "eg_proof_item_size": (sz, [vp]),
+        "eg_verify_proof_batch": (C.c_int, [vp, sz, vp, vp]),
+        "eg_verify_proof_batch_device": (C.c_int, [vp, sz, vp, vp, vp]),
+        "eg_choice_encrypt_batch": (C.c_int, [vp, C.c_uint64, sz, sz, C.c_int, cp]),
         "eg_choice_encrypt_batch_device": (C.c_int, [vp, C.c_uint64, sz, sz, C.c_int, vp, vp]),
         "eg_qv_encrypt_batch_device": (C.c_int, [vp, C.c_uint64, sz, sz, vp, vp]),
         "eg_profile_enable": (C.c_int, [vp, C.c_int]),
@@ -324,6 +330,12 @@ class ChoiceParams(_BatchParams):
     def multi_choice(cls, ctx, public_key, options_count):
         return cls(ctx, public_key, options_count, False)
 
+    def encrypt_batch(self, base_seed: int, first: int, n: int, n_selected: int = 0) -> bytes:
+        """EncryptedChoice::new for n synthetic voters (GPU), returned packed in host memory."""
+        out = C.create_string_buffer(max(n * self.ballot_size, 1))
+        _check(_load().eg_choice_encrypt_batch(self._h, base_seed, first, n, n_selected, out))
+        return out.raw[: n * self.ballot_size]
+
     def encrypt_batch_device(self, base_seed: int, first: int, n: int, d_out: int, n_selected: int = 0, stream: int = 0):
         """EncryptedChoice::new for n synthetic voters, written packed to device memory."""
         _check(_load().eg_choice_encrypt_batch_device(self._h, base_seed, first, n, n_selected, d_out, stream))
@@ -331,6 +343,38 @@ class ChoiceParams(_BatchParams):
     def close(self):
         if getattr(self, "_h", None):
             _load().eg_choice_params_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PublicKeyVerifier:
+    """Batched ``PublicKey::verify_zero / verify_bool / verify_range`` (src/keys/impls.rs:59-69,100-112,142-151)."""
+
+    ZERO, BOOL, RANGE = 0, 1, 2
+
+    def __init__(self, ctx: Context, public_key: bytes, kind: int, upper_bound: int = 0):
+        self.ctx, self.kind = ctx, kind
+        self._h = C.c_void_p()
+        _check(_load().eg_proof_params_create(ctx._h, public_key, kind, upper_bound, C.byref(self._h)))
+        self.item_size = _load().eg_proof_item_size(self._h)
+
+    def verify_batch(self, items: bytes):
+        n = len(items) // self.item_size
+        if n * self.item_size != len(items):
+            raise ValueError("items is not a whole number of packed proofs")
+        st = (C.c_uint32 * max(n, 1))()
+        buf = (C.c_char * max(len(items), 1)).from_buffer_copy(items or b"\0")
+        _check(_load().eg_verify_proof_batch(self._h, n, buf, st))
+        return list(st[:n])
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _load().eg_proof_params_destroy(self._h)
             self._h = None
 
     def __del__(self):

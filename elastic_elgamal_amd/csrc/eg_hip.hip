@@ -239,8 +239,8 @@ static int engine_create(eg_ctx* ctx, eghost::Plan&& plan, const uint8_t pk[32],
   HIPCHK(hipMalloc((void**)&e->states, (size_t)std::max(P.n_state_slots, 1) * 52 * cap * sizeof(u32)));
   HIPCHK(hipMalloc((void**)&e->flags, (size_t)std::max(P.n_flag_slots, 1) * cap * sizeof(u32)));
   HIPCHK(hipMalloc((void**)&e->bad_item, cap * sizeof(u32)));
-  HIPCHK(hipMalloc((void**)&e->partial, (size_t)P.tally_slots.size() * e->tally_blocks * 40 * sizeof(u32)));
-  HIPCHK(hipMalloc((void**)&e->tally, (size_t)P.tally_slots.size() * 40 * sizeof(u32)));
+  HIPCHK(hipMalloc((void**)&e->partial, std::max<size_t>(P.tally_slots.size(), 1) * e->tally_blocks * 40 * sizeof(u32)));
+  HIPCHK(hipMalloc((void**)&e->tally, std::max<size_t>(P.tally_slots.size(), 1) * 40 * sizeof(u32)));
   HIPCHK(hipMalloc((void**)&e->d_prefixes, (size_t)std::max(P.n_prefixes, 1) * 52 * sizeof(u32)));
   hipLaunchKernelGGL(k_tally_init, dim3(1), dim3(NT), 0, s, e->tally, (int)P.tally_slots.size());
 
@@ -291,6 +291,7 @@ static int engine_verify_device(Engine* e, size_t n, const void* d_ballots, void
                            st.inst_first, st.inst_count);
     }
     hipLaunchKernelGGL(k_status, dim3((cn + NT - 1) / NT), dim3(NT), 0, s, B, e->d_rules, (int)P.rules.size());
+    if (P.tally_slots.empty()) continue;
     const int G = std::min<int>(e->tally_blocks, (int)((cn + NT - 1) / NT));
     hipLaunchKernelGGL(k_tally_partial, dim3(G, (unsigned)P.tally_slots.size()), dim3(NT), 0, s, B, e->d_tally_slots, e->partial);
     hipLaunchKernelGGL(k_tally_final, dim3((unsigned)P.tally_slots.size()), dim3(NT), 0, s, e->partial, G, e->tally);
@@ -338,6 +339,7 @@ static int engine_verify_host(Engine* e, size_t n, const uint8_t* ballots, uint3
 // ---------------------------------------------------------------------------------------------------------------
 struct eg_choice_params { Engine* eng; int n_options; int single; };
 struct eg_qv_params { Engine* eng; int n_options; uint64_t credits; eghost::QvShape shape; };
+struct eg_proof_params { Engine* eng; int kind; size_t item_size; };
 
 extern "C" {
 
@@ -638,6 +640,32 @@ int eg_qv_tally_encode(eg_qv_params* p, uint8_t* out) {
   return engine_tally_encode(p->eng, out);
 }
 
+// ---- PublicKey::verify_zero / verify_bool / verify_range in batches ---------------------------------------
+int eg_proof_params_create(eg_ctx* c, const uint8_t pk[32], int kind, uint64_t upper_bound, eg_proof_params** out) {
+  if (!c || !pk || !out) return fail(EG_ERR_BAD_ARG, "bad argument");
+  Engine* e = nullptr;
+  size_t item = 0;
+  if (kind == EG_PROOF_ZERO) { TRY(engine_create(c, eghost::build_zero_plan(), pk, 0, &e)); item = 128; }
+  else if (kind == EG_PROOF_BOOL) { TRY(engine_create(c, eghost::build_bool_plan(), pk, 0, &e)); item = 160; }
+  else if (kind == EG_PROOF_RANGE) {
+    if (upper_bound < 2 || upper_bound > 1000000) return fail(EG_ERR_BAD_ARG, "upper_bound must be in 2..1000000");
+    TRY(engine_create(c, eghost::build_range_plan(upper_bound, &item), pk, 0, &e));
+  } else return fail(EG_ERR_BAD_ARG, "unknown proof kind");
+  *out = new eg_proof_params{e, kind, item};
+  return EG_OK;
+}
+void eg_proof_params_destroy(eg_proof_params* p) { if (p) { engine_free(p->eng); delete p; } }
+size_t eg_proof_item_size(const eg_proof_params* p) { return p ? p->item_size : 0; }
+int eg_verify_proof_batch(eg_proof_params* p, size_t n, const uint8_t* items, uint32_t* status) {
+  if (!p || (n && (!items || !status))) return fail(EG_ERR_BAD_ARG, "bad argument");
+  return engine_verify_host(p->eng, n, items, status, nullptr);
+}
+int eg_verify_proof_batch_device(eg_proof_params* p, size_t n, const void* d_items, void* d_status, void* stream) {
+  if (!p || (n && (!d_items || !d_status))) return fail(EG_ERR_BAD_ARG, "bad argument");
+  HIPCHK(hipSetDevice(p->eng->ctx->device));
+  return engine_verify_device(p->eng, n, d_items, d_status, (hipStream_t)stream);
+}
+
 // ---- synthetic ballots ---------------------------------------------------------------------------------------------------------
 int eg_choice_encrypt_batch_device(eg_choice_params* p, uint64_t base_seed, size_t first, size_t n, int n_selected, void* d_out,
                                    void* stream) {
@@ -652,6 +680,17 @@ int eg_choice_encrypt_batch_device(eg_choice_params* p, uint64_t base_seed, size
                            e->d_tabK, e->d_prefixes, e->plan.gen_pre_main, e->plan.gen_pre_ring, e->plan.gen_pre_logeq,
                            reinterpret_cast<u32*>(d_out), (u32)(e->plan.stride / 4));
   HIPCHK(hipGetLastError());
+  return EG_OK;
+}
+int eg_choice_encrypt_batch(eg_choice_params* p, uint64_t base_seed, size_t first, size_t n, int n_selected, uint8_t* out) {
+  if (!p || (n && !out)) return fail(EG_ERR_BAD_ARG, "bad argument");
+  Engine* e = p->eng;
+  HIPCHK(hipSetDevice(e->ctx->device));
+  DevBuf d;
+  TRY(d.alloc(n * e->plan.stride));
+  TRY(eg_choice_encrypt_batch_device(p, base_seed, first, n, n_selected, d.p, e->ctx->stream));
+  TRY(d.get(out, n * e->plan.stride, e->ctx->stream));
+  HIPCHK(hipStreamSynchronize(e->ctx->stream));
   return EG_OK;
 }
 int eg_qv_encrypt_batch_device(eg_qv_params*, uint64_t, size_t, size_t, void*, void*) {

@@ -430,4 +430,49 @@ inline Plan build_qv_plan(int n, uint64_t credits) {
   return P;
 }
 
+// ---- PublicKey::verify_zero / verify_bool / verify_range (keys/impls.rs:59-69,100-112,142-151) ------------------------
+inline Plan build_zero_plan() {   // item = ct(64) || challenge || response
+  Plan P;
+  P.stride = 128;
+  const uint16_t R = P.wire_point(0), B = P.wire_point(1);
+  P.wire_scalar(2); P.wire_scalar(3);
+  const uint32_t pre = P.new_prefix();
+  P.prefix_programs.push_back({{OP_NEW, P.ref("zero_encryption"), 0, 0},
+                               {OP_APPEND_BLOB, P.ref("dom-sep"), P.ref("log_eq"), 0},
+                               {OP_APPEND_BLOB, P.ref("K"), P.pk_ref(), 0},
+                               {OP_SAVE_PREFIX, 0, pre, 0}});
+  const ScalarSrc c = wire_src(2, true), s = wire_src(3);
+  const uint16_t xg = P.job(0, {{R, c}}, s, no_src());
+  const uint16_t xk = P.job(0, {{B, c}}, no_src(), s);
+  const uint16_t flag = P.new_flag();
+  P.stage(0).insts.push_back({{OP_LOAD_PREFIX, 0, pre, 0},
+                              {OP_APPEND_WIRE, P.ref("[r]G"), 0, 1},
+                              {OP_APPEND_WIRE, P.ref("[r]K"), 1, 1},
+                              {OP_APPEND_CMP, P.ref("[x]G"), xg, 0xffff},
+                              {OP_APPEND_CMP, P.ref("[x]K"), xk, 0xffff},
+                              {OP_CHALLENGE_CHECK, P.ref("c"), 2, flag}});
+  P.rules.push_back({flag, 4 /* ChallengeMismatch of the log-equality proof */});
+  return P;
+}
+inline Plan build_bool_plan() {   // item = ct(64) || e0 || s0 || s1
+  Plan P;
+  P.stride = 160;
+  RingIn r;
+  r.ptR = P.wire_point(0); r.ptB = P.wire_point(1);
+  for (int i = 2; i < 5; ++i) P.wire_scalar((uint16_t)i);
+  r.enc_from_wire = true; r.enc_item = 0; r.derive_level = 0; r.admissible = {0, 1}; r.resp_item = 3;
+  const uint16_t flag = add_ring_proof(P, {{OP_NEW, P.ref("bool_encryption"), 0, 0}}, {r}, 2);
+  P.rules.push_back({flag, 6});
+  return P;
+}
+inline Plan build_range_plan(uint64_t upper_bound, size_t* item_size) {   // ct || partials || e0 || responses
+  Plan P;
+  const RangeDecomposition d = optimal_range(upper_bound);
+  RangeOut r = add_range_proof(P, d, "ciphertext_range", 0);
+  P.stride = (size_t)r.n_items * 32;
+  if (item_size) *item_size = P.stride;
+  P.rules.push_back({r.flag, 6});
+  return P;
+}
+
 }  // namespace eghost

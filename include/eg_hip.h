@@ -140,6 +140,20 @@ int eg_qv_tally_encode(eg_qv_params*, uint8_t* out);
 int eg_qv_tally_reset_async(eg_qv_params*, void* stream);
 int eg_qv_tally_encode_device(eg_qv_params*, void* d_out, void* stream);
 
+/* ---- batch tier: single-ciphertext proofs --------------------------------------------------------------
+ * PublicKey::verify_zero (keys/impls.rs:59-69)   item = ciphertext(64) || challenge || response              128 B
+ * PublicKey::verify_bool (keys/impls.rs:100-112) item = ciphertext(64) || e0 || s0 || s1                     160 B
+ * PublicKey::verify_range(keys/impls.rs:142-151) item = ciphertext(64) || partial_ciphertexts || e0 || responses
+ *   with RangeDecomposition::optimal(upper_bound) (range.rs:148-153); eg_proof_item_size gives the stride.
+ * status: EG_ST_OK, EG_ST_BAD_*, EG_ST_SUM_CHALLENGE (zero: ChallengeMismatch) or EG_ST_RANGE_CHALLENGE (bool/range). */
+typedef struct eg_proof_params eg_proof_params;
+enum { EG_PROOF_ZERO = 0, EG_PROOF_BOOL = 1, EG_PROOF_RANGE = 2 };
+int eg_proof_params_create(eg_ctx*, const uint8_t pk[32], int kind, uint64_t upper_bound, eg_proof_params** out);
+void eg_proof_params_destroy(eg_proof_params*);
+size_t eg_proof_item_size(const eg_proof_params*);
+int eg_verify_proof_batch(eg_proof_params*, size_t n, const uint8_t* items, uint32_t* status);
+int eg_verify_proof_batch_device(eg_proof_params*, size_t n, const void* d_items, void* d_status, void* stream);
+
 /* ---- synthetic ballots on the GPU (EncryptedChoice::new / QuadraticVotingBallot::new) ---------
  * Ballot i of the call is produced from ChaChaRng::seed_from_u64(base_seed + first + i) with the reference's
  * RNG draw order (choice.rs:313-349, ring.rs:54-194, log_equality.rs:114-139, range.rs:462-534, mul.rs:107-181);
@@ -147,6 +161,8 @@ int eg_qv_tally_encode_device(eg_qv_params*, void* d_out, void* stream);
  * used for multi-choice params. */
 int eg_choice_encrypt_batch_device(eg_choice_params*, uint64_t base_seed, size_t first, size_t n, int n_selected,
                                    void* d_out, void* stream);
+int eg_choice_encrypt_batch(eg_choice_params*, uint64_t base_seed, size_t first, size_t n, int n_selected,
+                            uint8_t* out /* host, n * eg_choice_ballot_size */);
 int eg_qv_encrypt_batch_device(eg_qv_params*, uint64_t base_seed, size_t first, size_t n, void* d_out, void* stream);
 
 /* ---- measurement hooks (bench.py) ------------------------------------------------------------------------------------------

@@ -1,0 +1,196 @@
+// elastic_elgamal_hip.hpp -- C++17 host-side mirror of the reference's interface for the ballot-verification
+// path, header-only on top of the C ABI (eg_hip.h).  The reference is a compiled (Rust) library and no Rust
+// toolchain exists in the build image, so this is the compiled-language face of the drop-in boundary; names,
+// argument meaning and error variants follow the reference:
+//   ChoiceParams::single / ::multi            src/app/choice.rs:160-196
+//   EncryptedChoice::verify  (batched)        src/app/choice.rs:358-380      -> verify_batch
+//   ChoiceVerificationError                   src/app/choice.rs:407-419
+//   QuadraticVotingParams::new                src/app/quadratic_voting.rs:63-76
+//   QuadraticVotingBallot::verify (batched)   src/app/quadratic_voting.rs:291-329
+//   QuadraticVotingError                      src/app/quadratic_voting.rs:335-354
+//   VerificationError                         src/proofs/mod.rs:63-80
+//   Ristretto (Group backend, batched)        src/group/ristretto.rs:23-146
+#pragma once
+#include <array>
+#include <cstdint>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "eg_hip.h"
+
+namespace elastic_elgamal_hip {
+
+using Bytes = std::vector<uint8_t>;
+using Scalar = std::array<uint8_t, 32>;    // canonical little-endian, < l
+using Element = std::array<uint8_t, 32>;   // canonical ristretto255 encoding
+
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+inline void check(int rc) { if (rc != EG_OK) throw Error(rc, eg_last_error()); }
+
+class Context {
+ public:
+  explicit Context(int device = 0) { check(eg_init(device, &ctx_)); }
+  ~Context() { eg_destroy(ctx_); }
+  Context(const Context&) = delete;
+  Context& operator=(const Context&) = delete;
+  eg_ctx* raw() const { return ctx_; }
+ private:
+  eg_ctx* ctx_ = nullptr;
+};
+
+// VerificationError (proofs/mod.rs:63-80)
+enum class VerificationError { ChallengeMismatch, LenMismatch };
+
+// ChoiceVerificationError (choice.rs:407-419) + the deserialisation failures that serde reports earlier
+struct ChoiceVerificationError {
+  enum Kind { OptionsLenMismatch, Sum, Range, MalformedScalar, MalformedElement } kind;
+  VerificationError inner = VerificationError::ChallengeMismatch;
+  size_t item = 0;   // index of the malformed 32-byte item
+  std::string to_string() const {
+    switch (kind) {
+      case OptionsLenMismatch: return "number of options in the ballot differs from expected";
+      case Sum: return "cannot verify sum proof: restored challenge scalar does not match the one provided in the proof";
+      case Range: return "cannot verify range proofs: restored challenge scalar does not match the one provided in the proof";
+      case MalformedScalar: return "non-canonical scalar at item " + std::to_string(item);
+      default: return "invalid group element at item " + std::to_string(item);
+    }
+  }
+};
+inline std::optional<ChoiceVerificationError> choice_error_from_status(uint32_t s) {
+  switch (EG_STATUS_KIND(s)) {
+    case EG_ST_OK: return std::nullopt;
+    case EG_ST_BAD_SCALAR: return ChoiceVerificationError{ChoiceVerificationError::MalformedScalar, {}, EG_STATUS_DETAIL(s)};
+    case EG_ST_BAD_POINT: return ChoiceVerificationError{ChoiceVerificationError::MalformedElement, {}, EG_STATUS_DETAIL(s)};
+    case EG_ST_OPTIONS_LEN: return ChoiceVerificationError{ChoiceVerificationError::OptionsLenMismatch};
+    case EG_ST_SUM_CHALLENGE: return ChoiceVerificationError{ChoiceVerificationError::Sum, VerificationError::ChallengeMismatch};
+    case EG_ST_RANGE_LEN: return ChoiceVerificationError{ChoiceVerificationError::Range, VerificationError::LenMismatch};
+    default: return ChoiceVerificationError{ChoiceVerificationError::Range, VerificationError::ChallengeMismatch};
+  }
+}
+
+// QuadraticVotingError (quadratic_voting.rs:335-354)
+struct QuadraticVotingError {
+  enum Kind { Variant, CreditRange, CreditEquivalence, OptionsLenMismatch, MalformedScalar, MalformedElement } kind;
+  size_t index = 0;   // Variant: zero-based option index; Malformed*: item index
+  VerificationError inner = VerificationError::ChallengeMismatch;
+};
+inline std::optional<QuadraticVotingError> qv_error_from_status(uint32_t s) {
+  const size_t d = EG_STATUS_DETAIL(s);
+  switch (EG_STATUS_KIND(s)) {
+    case EG_ST_OK: return std::nullopt;
+    case EG_ST_BAD_SCALAR: return QuadraticVotingError{QuadraticVotingError::MalformedScalar, d};
+    case EG_ST_BAD_POINT: return QuadraticVotingError{QuadraticVotingError::MalformedElement, d};
+    case EG_ST_QV_VARIANT_LEN: return QuadraticVotingError{QuadraticVotingError::Variant, d, VerificationError::LenMismatch};
+    case EG_ST_QV_VARIANT_CHALLENGE: return QuadraticVotingError{QuadraticVotingError::Variant, d};
+    case EG_ST_QV_CREDIT_RANGE_LEN: return QuadraticVotingError{QuadraticVotingError::CreditRange, 0, VerificationError::LenMismatch};
+    case EG_ST_QV_CREDIT_RANGE_CHALLENGE: return QuadraticVotingError{QuadraticVotingError::CreditRange};
+    case EG_ST_QV_CREDIT_EQUIV_LEN: return QuadraticVotingError{QuadraticVotingError::CreditEquivalence, 0, VerificationError::LenMismatch};
+    case EG_ST_QV_CREDIT_EQUIV_CHALLENGE: return QuadraticVotingError{QuadraticVotingError::CreditEquivalence};
+    default: return QuadraticVotingError{QuadraticVotingError::OptionsLenMismatch};
+  }
+}
+
+// Ciphertext (encryption.rs:96-101): random_element || blinded_element
+struct Ciphertext { Element random_element{}, blinded_element{}; };
+
+template <class E>
+struct BatchVerdict {
+  std::vector<std::optional<E>> results;   // per ballot: nullopt == Ok(..)
+  std::vector<Ciphertext> totals;          // homomorphic sum of the ciphertexts of accepted ballots, per option
+  size_t accepted() const { size_t n = 0; for (auto& r : results) n += !r.has_value(); return n; }
+};
+
+inline std::vector<Ciphertext> unpack_totals(const Bytes& t) {
+  std::vector<Ciphertext> out(t.size() / 64);
+  for (size_t k = 0; k < out.size(); ++k) {
+    std::copy(t.begin() + 64 * k, t.begin() + 64 * k + 32, out[k].random_element.begin());
+    std::copy(t.begin() + 64 * k + 32, t.begin() + 64 * k + 64, out[k].blinded_element.begin());
+  }
+  return out;
+}
+
+// ChoiceParams<G, S> (choice.rs:132-196); S is SingleChoice (sum proof) or MultiChoice
+class ChoiceParams {
+ public:
+  static ChoiceParams single(const Context& ctx, const Element& receiver, size_t options_count) { return ChoiceParams(ctx, receiver, options_count, true); }
+  static ChoiceParams multi(const Context& ctx, const Element& receiver, size_t options_count) { return ChoiceParams(ctx, receiver, options_count, false); }
+  ~ChoiceParams() { eg_choice_params_destroy(p_); }
+  ChoiceParams(ChoiceParams&& o) noexcept : p_(o.p_), n_(o.n_), single_(o.single_) { o.p_ = nullptr; }
+  ChoiceParams(const ChoiceParams&) = delete;
+  size_t options_count() const { return n_; }
+  size_t ballot_size() const { return eg_choice_ballot_size((int)n_, single_); }
+  // EncryptedChoice::verify for every packed ballot + totals[k] += vote[k] (examples/voting.rs:199-203)
+  BatchVerdict<ChoiceVerificationError> verify_batch(const Bytes& packed) const {
+    const size_t n = packed.size() / ballot_size();
+    if (n * ballot_size() != packed.size())   // the analogue of check_options_count (choice.rs:149-158)
+      throw Error(EG_ERR_BAD_ARG, "packed length is not a whole number of ballots for these parameters");
+    std::vector<uint32_t> st(n);
+    Bytes tally(64 * n_);
+    check(eg_verify_choice_batch(p_, n, packed.data(), st.data(), tally.data()));
+    BatchVerdict<ChoiceVerificationError> v;
+    for (uint32_t s : st) v.results.push_back(choice_error_from_status(s));
+    v.totals = unpack_totals(tally);
+    return v;
+  }
+  // EncryptedChoice::new for synthetic voters base_seed + first + i (choice.rs:313-349), packed
+  Bytes encrypt_batch(uint64_t base_seed, size_t first, size_t n, int n_selected = 0) const {
+    Bytes out(n * ballot_size());
+    check(eg_choice_encrypt_batch(p_, base_seed, first, n, n_selected, out.data()));
+    return out;
+  }
+ private:
+  ChoiceParams(const Context& ctx, const Element& pk, size_t n, bool single) : n_(n), single_(single) {
+    check(eg_choice_params_create(ctx.raw(), pk.data(), (int)n, single, &p_));
+  }
+  eg_choice_params* p_ = nullptr;
+  size_t n_;
+  int single_;
+};
+
+class QuadraticVotingParams {
+ public:
+  QuadraticVotingParams(const Context& ctx, const Element& receiver, size_t options, uint64_t credits) : n_(options) {
+    check(eg_qv_params_create(ctx.raw(), receiver.data(), (int)options, credits, &p_));
+  }
+  ~QuadraticVotingParams() { eg_qv_params_destroy(p_); }
+  QuadraticVotingParams(const QuadraticVotingParams&) = delete;
+  size_t options_count() const { return n_; }
+  size_t ballot_size() const { return eg_qv_ballot_size(p_); }
+  BatchVerdict<QuadraticVotingError> verify_batch(const Bytes& packed) const {
+    const size_t n = packed.size() / ballot_size();
+    if (n * ballot_size() != packed.size()) throw Error(EG_ERR_BAD_ARG, "packed length is not a whole number of ballots");
+    std::vector<uint32_t> st(n);
+    Bytes tally(64 * n_);
+    check(eg_verify_qv_batch(p_, n, packed.data(), st.data(), tally.data()));
+    BatchVerdict<QuadraticVotingError> v;
+    for (uint32_t s : st) v.results.push_back(qv_error_from_status(s));
+    v.totals = unpack_totals(tally);
+    return v;
+  }
+ private:
+  eg_qv_params* p_ = nullptr;
+  size_t n_;
+};
+
+// Ristretto: the Group backend (ristretto.rs), one problem per call shown here; *_batch in eg_hip.h for many
+struct Ristretto {
+  const Context& ctx;
+  Scalar scalar_from_random_bytes(const std::array<uint8_t, 64>& wide) const { Scalar s; check(eg_scalar_from_wide_batch(ctx.raw(), 1, wide.data(), s.data())); return s; }
+  std::optional<Scalar> deserialize_scalar(const Scalar& b) const { uint8_t ok = 0; check(eg_scalar_is_canonical_batch(ctx.raw(), 1, b.data(), &ok)); return ok ? std::optional<Scalar>(b) : std::nullopt; }
+  std::optional<Element> deserialize_element(const Element& b) const { Element o; uint8_t ok = 0; check(eg_point_roundtrip_batch(ctx.raw(), 1, b.data(), o.data(), &ok)); return ok ? std::optional<Element>(o) : std::nullopt; }
+  Element mul_generator(const Scalar& k) const { Element o; check(eg_mul_generator_batch(ctx.raw(), 1, k.data(), o.data())); return o; }
+  Element vartime_double_mul_generator(const Scalar& k, const Element& p, const Scalar& r) const { Element o; uint8_t ok; check(eg_vartime_double_mul_generator_batch(ctx.raw(), 1, k.data(), p.data(), r.data(), o.data(), &ok)); return o; }
+  Element vartime_multi_mul(const std::vector<Scalar>& s, const std::vector<Element>& e) const {
+    Bytes sb, eb; for (auto& x : s) sb.insert(sb.end(), x.begin(), x.end()); for (auto& x : e) eb.insert(eb.end(), x.begin(), x.end());
+    Element o; uint8_t ok; check(eg_vartime_multi_mul_batch(ctx.raw(), 1, s.size(), sb.data(), eb.data(), o.data(), &ok)); return o;
+  }
+  Element add(const Element& a, const Element& b) const { Element o; uint8_t ok; check(eg_point_add_batch(ctx.raw(), 1, a.data(), b.data(), 0, o.data(), &ok)); return o; }
+  Element sub(const Element& a, const Element& b) const { Element o; uint8_t ok; check(eg_point_add_batch(ctx.raw(), 1, a.data(), b.data(), 1, o.data(), &ok)); return o; }
+};
+
+}  // namespace elastic_elgamal_hip

@@ -52,3 +52,13 @@ def test_ballot_sizes_and_missing_gpu_is_loud(lib_path):
     if not torch.cuda.is_available():
         with pytest.raises(eg.EgError):
             eg.Context(0)   # no silent CPU fallback
+
+
+def test_cpp_host_header_compiles(tmp_path, lib_path):
+    # the C++ mirror of the reference interface and the voting example build against the C ABI without a GPU
+    root = ROOT
+    exe = tmp_path / "voting"
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", f"-I{root / 'include'}", str(root / "examples" / "voting.cpp"),
+                           f"-L{root / 'elastic_elgamal_amd'}", "-leg_hip", f"-Wl,-rpath,{root / 'elastic_elgamal_amd'}",
+                           "-o", str(exe)])
+    assert exe.exists()

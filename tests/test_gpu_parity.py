@@ -296,3 +296,62 @@ def test_snapshot_seed_reproduced_on_gpu(eg, ctx, golden, pk, oracle):
     rng = oracle.rng_from_u64(12345)
     flags = oracle.select_single(12345, 5)
     assert one == op.new_ballot(flags, rng)
+
+
+# ------------------------------------------------------------------ PublicKey::verify_zero / verify_bool / verify_range
+def test_golden_single_ciphertext_proofs(eg, ctx, golden, pk, oracle):
+    z = eg.PublicKeyVerifier(ctx, pk, eg.PublicKeyVerifier.ZERO)
+    b = eg.PublicKeyVerifier(ctx, pk, eg.PublicKeyVerifier.BOOL)
+    r = eg.PublicKeyVerifier(ctx, pk, eg.PublicKeyVerifier.RANGE, 100)
+    zero = bytes.fromhex(golden["zero-encryption"]["packed"])
+    boo = bytes.fromhex(golden["bool-encryption"]["packed"])
+    rng = bytes.fromhex(golden["range-encryption"]["packed"])
+    assert (z.item_size, b.item_size, r.item_size) == (128, 160, len(rng))
+    assert z.verify_batch(zero) == [0] and b.verify_batch(boo) == [0] and r.verify_batch(rng) == [0]
+    # tampering and batches against the oracle
+    k = oracle.PublicKey(pk)
+    rs = oracle.rng_from_u64(99)
+    pr = oracle.PreparedRange(100)
+    zs, bs, rgs = [], [], []
+    for i in range(40):
+        zs.append(bytearray(k.encrypt_zero(rs)))
+        bs.append(bytearray(k.encrypt_bool(bool(i & 1), rs)))
+        rgs.append(bytearray(k.encrypt_range(pr, (i * 7) % 100, rs)))
+        if i % 5 == 1:
+            zs[-1][100] ^= 1; bs[-1][70] ^= 2; rgs[-1][len(rng) - 5] ^= 1
+        if i % 5 == 2:
+            zs[-1][0:32] = b"\xff" * 32; bs[-1][96 + 31] = 0xFF; rgs[-1][64:96] = b"\xff" * 32
+    zb, bb, rb = b"".join(map(bytes, zs)), b"".join(map(bytes, bs)), b"".join(map(bytes, rgs))
+    assert z.verify_batch(zb) == [k.verify_zero(bytes(x)) for x in zs]
+    assert b.verify_batch(bb) == [k.verify_bool(bytes(x)) for x in bs]
+    want = [k.verify_range(pr, bytes(x)) for x in rgs]
+    assert r.verify_batch(rb) == want and 0 in want and eg.RANGE_CHALLENGE in want
+
+
+@pytest.mark.parametrize("upper_bound", [2, 12, 15, 20, 50, 1000])
+def test_range_proofs_various_bounds(eg, ctx, oracle, pk, upper_bound):
+    # bounds of range.rs:708 (range_proof_basics) plus the extremes
+    k = oracle.PublicKey(pk)
+    pr = oracle.PreparedRange(upper_bound)
+    rs = oracle.rng_from_u64(upper_bound)
+    items = b"".join(k.encrypt_range(pr, v % upper_bound, rs) for v in (0, 1, 10, upper_bound - 1))
+    r = eg.PublicKeyVerifier(ctx, pk, eg.PublicKeyVerifier.RANGE, upper_bound)
+    assert r.item_size == 64 + pr.proof_size
+    assert r.verify_batch(items) == [0, 0, 0, 0]
+
+
+# ------------------------------------------------------------------ C++ host mirror + the voting example
+def test_cpp_voting_example(tmp_path):
+    """examples/voting.cpp = examples/voting.rs:179-213 on the GPU backend through include/elastic_elgamal_hip.hpp"""
+    import subprocess
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    exe = tmp_path / "voting"
+    subprocess.check_call(["g++", "-std=c++17", f"-I{root / 'include'}", str(root / "examples" / "voting.cpp"),
+                           f"-L{root / 'elastic_elgamal_amd'}", "-leg_hip", f"-Wl,-rpath,{root / 'elastic_elgamal_amd'}",
+                           "-o", str(exe)])
+    out = subprocess.run([str(exe), "200", "5", "7"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "199 of 200 ballots verified" in out.stdout and "voter #4 rejected" in out.stdout
+    assert "OK: decrypted totals sum to 199" in out.stdout
