@@ -395,6 +395,10 @@ class QuadraticVotingParams(_BatchParams):
         _check(_load().eg_qv_params_create(ctx._h, public_key, options_count, credits, C.byref(self._h)))
         self.ballot_size = _load().eg_qv_ballot_size(self._h)
 
+    def encrypt_batch_device(self, base_seed: int, first: int, n: int, d_out: int, stream: int = 0):
+        """QuadraticVotingBallot::new for n synthetic voters, written packed to device memory."""
+        _check(_load().eg_qv_encrypt_batch_device(self._h, base_seed, first, n, d_out, stream))
+
     def close(self):
         if getattr(self, "_h", None):
             _load().eg_qv_params_destroy(self._h)

@@ -20,6 +20,9 @@
 
 using namespace eg;
 
+void eg_launch_qv_encrypt(int blocks, hipStream_t s, u64 seed0, size_t n, int n_options, u64 credits, const int* vote_range,
+                          const int* credit_range, int pre_sumsq, const uint4* tabG, const uint4* tabK, const u32* prefixes,
+                          u32* out, u32 stride_words, u32 vote_words, u32 credit_words);
 // defined in eg_gen.hip (separate translation unit so the two compile in parallel)
 void eg_launch_choice_encrypt(int blocks, hipStream_t s, u64 seed0, size_t n, int n_options, int single, int n_selected,
                               const uint4* tabG, const uint4* tabK, const u32* prefixes, int pre_main, int pre_ring,
@@ -693,8 +696,29 @@ int eg_choice_encrypt_batch(eg_choice_params* p, uint64_t base_seed, size_t firs
   HIPCHK(hipStreamSynchronize(e->ctx->stream));
   return EG_OK;
 }
-int eg_qv_encrypt_batch_device(eg_qv_params*, uint64_t, size_t, size_t, void*, void*) {
-  return fail(EG_ERR_BAD_ARG, "QuadraticVotingBallot::new on the GPU is not implemented yet (SURVEY 8f row 1)");
+int eg_qv_encrypt_batch_device(eg_qv_params* p, uint64_t base_seed, size_t first, size_t n, void* d_out, void* stream) {
+  if (!p || (n && !d_out)) return fail(EG_ERR_BAD_ARG, "bad argument");
+  Engine* e = p->eng;
+  HIPCHK(hipSetDevice(e->ctx->device));
+  hipStream_t s = stream ? (hipStream_t)stream : e->ctx->stream;
+  const eghost::QvShape& sh = p->shape;
+  if (p->n_options > 16 || sh.vote_range.rings.size() > 4 || sh.credit_range.rings.size() > 4)
+    return fail(EG_ERR_BAD_ARG, "the generator supports at most 16 options and 4 rings per range");
+  for (auto* d : {&sh.vote_range, &sh.credit_range})
+    for (auto& r : d->rings) if (r.size > 16) return fail(EG_ERR_BAD_ARG, "the generator supports ring sizes up to 16");
+  if (n == 0) return EG_OK;
+  auto pack = [](const eghost::RangeDecomposition& d, int pre_main, int pre_ring) {
+    std::vector<int> a{(int)d.rings.size(), pre_main, pre_ring};
+    for (auto& r : d.rings) { a.push_back((int)r.size); a.push_back((int)r.step); }
+    return a;
+  };
+  const std::vector<int> v = pack(sh.vote_range, e->plan.gen_vote_main, e->plan.gen_vote_ring);
+  const std::vector<int> c = pack(sh.credit_range, e->plan.gen_credit_main, e->plan.gen_credit_ring);
+  eg_launch_qv_encrypt(grid_for(n, e->ctx->cus * 4), s, base_seed + first, n, p->n_options, p->credits, v.data(), c.data(),
+                       e->plan.gen_pre_sumsq, e->ctx->tabG, e->d_tabK, e->d_prefixes, reinterpret_cast<u32*>(d_out),
+                       (u32)(sh.ballot_size / 4), (u32)(sh.vote_size / 4), (u32)(sh.credit_size / 4));
+  HIPCHK(hipGetLastError());
+  return EG_OK;
 }
 
 }  // extern "C"

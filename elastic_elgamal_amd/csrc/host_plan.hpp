@@ -112,6 +112,7 @@ struct Plan {
   }
   int pk_off = -1;
   int gen_pre_main = -1, gen_pre_ring = -1, gen_pre_logeq = -1;  // prefix indices used by the ballot generator
+  int gen_vote_main = -1, gen_vote_ring = -1, gen_credit_main = -1, gen_credit_ring = -1, gen_pre_sumsq = -1;
   uint32_t pk_ref() {  // 32 bytes of the election key; filled in when the params object is created
     if (pk_off < 0) { pk_off = (int)blob.size(); blob.insert(blob.end(), 32, 0); }
     return blob_ref((uint32_t)pk_off, 32);
@@ -315,7 +316,7 @@ inline Plan build_choice_plan(int n, bool single) {
 }
 
 // ---- RangeProof::verify (range.rs:547-577) on items [first_item ...): ct(2) partials(2(r-1)) e0 responses ------------------
-struct RangeOut { uint16_t flag; uint16_t ctR, ctB; uint16_t n_items; };
+struct RangeOut { uint16_t flag; uint16_t ctR, ctB; uint16_t n_items; int pre_main, pre_ring; };
 inline RangeOut add_range_proof(Plan& P, const RangeDecomposition& d, const std::string& label, uint16_t first_item) {
   const int nr = (int)d.rings.size();
   RangeOut out;
@@ -355,7 +356,7 @@ inline RangeOut add_range_proof(Plan& P, const RangeDecomposition& d, const std:
   const std::vector<HashOp> setup = {{OP_NEW, P.ref(label), 0, 0},
                                      {OP_APPEND_BLOB, P.ref("dom-sep"), P.ref("encryption_range_proof"), 0},
                                      {OP_APPEND_BLOB, P.ref("range"), P.ref(d.to_string()), 0}};   // range.rs:561-562
-  out.flag = add_ring_proof(P, setup, rings, chal_item);
+  out.flag = add_ring_proof(P, setup, rings, chal_item, 0, &out.pre_main, &out.pre_ring);
   return out;
 }
 
@@ -382,18 +383,21 @@ inline Plan build_qv_plan(int n, uint64_t credits) {
     RangeOut r = add_range_proof(P, sh.vote_range, "quadratic_voting_variant", item);
     item = (uint16_t)(item + r.n_items);
     votes.push_back(r);
+    if (i == 0) { P.gen_vote_main = r.pre_main; P.gen_vote_ring = r.pre_ring; }
     P.rules.push_back({r.flag, 8u /* EG_ST_QV_VARIANT_CHALLENGE */ | ((uint32_t)i << 8)});
     P.tally_slots.push_back(r.ctR);
     P.tally_slots.push_back(r.ctB);
   }
   RangeOut credit = add_range_proof(P, sh.credit_range, "quadratic_voting_credit_range", item);   // :309-317
   item = (uint16_t)(item + credit.n_items);
+  P.gen_credit_main = credit.pre_main; P.gen_credit_ring = credit.pre_ring;
   P.rules.push_back({credit.flag, 10 /* EG_ST_QV_CREDIT_RANGE_CHALLENGE */});
   // SumOfSquaresProof::verify (mul.rs:190-260)
   const uint16_t c_item = item;
   for (int i = 0; i < 2 * n + 2; ++i) P.wire_scalar((uint16_t)(c_item + i));
   const uint16_t sz_item = (uint16_t)(c_item + 1 + 2 * n);
   const uint32_t pre = P.new_prefix();
+  P.gen_pre_sumsq = (int)pre;
   P.prefix_programs.push_back({{OP_NEW, P.ref("quadratic_voting_credit_equiv"), 0, 0},
                                {OP_APPEND_BLOB, P.ref("dom-sep"), P.ref("sum_of_squares"), 0},
                                {OP_APPEND_BLOB, P.ref("K"), P.pk_ref(), 0},

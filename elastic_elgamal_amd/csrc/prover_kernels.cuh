@@ -234,4 +234,289 @@ __global__ void __launch_bounds__(NT) k_choice_encrypt(u64 seed0, size_t n, int 
   }
 }
 
+
+// =====================================================================================================================
+// QuadraticVotingBallot::new (quadratic_voting.rs:234-284) = RangeProof::new per option + credit (range.rs:462-534)
+// + SumOfSquaresProof::new (mul.rs:107-181), one voter per lane, fixed-base arithmetic only (see the file header).
+// =====================================================================================================================
+constexpr int EG_GEN_MAX_RINGS = 4;
+constexpr int EG_GEN_MAX_RING_SIZE = 16;
+
+struct GenRange {
+  int n_rings;
+  u32 size[EG_GEN_MAX_RINGS];
+  u32 step[EG_GEN_MAX_RINGS];
+  int pre_main, pre_ring;    // hoisted transcript prefixes of this (label, range) pair
+};
+
+__device__ __noinline__ void sc_from_small(u32 out[8], long long m) {   // m mod l for a small signed integer
+  u32 a[8];
+  sc_from_u64(a, (u64)(m < 0 ? -m : m));
+  if (m < 0) sc_neg(out, a);
+  else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = a[i];
+  }
+}
+
+// commitments of a simulated equation: R_G = [s - e r]G, R_K = [s - e r]K - [e * delta]G  with delta = (v - eq) * step
+__device__ __noinline__ void gen_sim_commitments(u32 cg[8], u32 ck[8], const FixedTable& tg, const FixedTable& tk, const u32* s,
+                                                 const u32* e, const u32* r, long long delta) {
+  u32 ne[8], tt[8], dl[8], gcoef[8];
+  sc_neg(ne, e);
+  gen_muladd(tt, ne, r, s);               // s - e r
+  sc_from_small(dl, delta);
+  const u32 zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  gen_muladd(gcoef, ne, dl, zero);        // -e * delta
+  fixed2_encode(cg, tg, tt, tk, nullptr);
+  fixed2_encode(ck, tg, gcoef, tk, tt);
+}
+
+// RangeProof::new for `value` with randomness drawn from rng; writes ct || partials || e0 || responses at `ob`
+// (words) and returns the ciphertext randomness in r_out.
+__device__ __noinline__ void gen_range_proof(Transcript<LdsState>& t, ChaChaRng& rng, const GenRange& R, u64 value,
+                                             const FixedTable& tg, const FixedTable& tk, const u32* prefixes, u32* ob,
+                                             u32 r_out[8]) {
+  const int nr = R.n_rings;
+  // CiphertextWithValue::new (encryption.rs:403-407)
+  u32 r[8], vsc[8];
+  rng_scalar(rng, r);
+  sc_from_u64(vsc, value);
+  u32 enc[8];
+  fixed2_encode(enc, tg, r, tk, nullptr);
+#pragma unroll
+  for (int w = 0; w < 8; ++w) ob[w] = enc[w];
+  fixed2_encode(enc, tg, vsc, tk, r);
+#pragma unroll
+  for (int w = 0; w < 8; ++w) { ob[8 + w] = enc[w]; r_out[w] = r[w]; }
+  // decompose (range.rs:199-210)
+  int vi[EG_GEN_MAX_RINGS];
+  {
+    u64 rem = value;
+    for (int i = 0; i < nr; ++i) {
+      u64 q = rem / R.step[i];
+      if (q > R.size[i] - 1) q = R.size[i] - 1;
+      vi[i] = (int)q;
+      rem -= q * R.step[i];
+    }
+  }
+  u32 ring_r[EG_GEN_MAX_RINGS][8], ring_x[EG_GEN_MAX_RINGS][8], term[EG_GEN_MAX_RINGS][16];
+  u32 resp[EG_GEN_MAX_RINGS][EG_GEN_MAX_RING_SIZE][8];
+  u32 cum_r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const u32 one[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+  u64 cum_v = 0;
+  u32* partials = ob + 16;
+  int total = 0;
+  for (int i = 0; i < nr; ++i) total += (int)R.size[i];
+  u32* proof = partials + (size_t)(nr - 1) * 16;    // e0 then responses
+#pragma unroll 1
+  for (int i = 0; i < nr; ++i) {
+    const u64 mval = (u64)vi[i] * R.step[i];
+    u32 rr[8], encR[8], encB[8], msc[8];
+    if (i + 1 < nr) {   // add_value (ring.rs:460-469): fresh randomness
+      rng_scalar(rng, rr);
+      gen_muladd(cum_r, cum_r, one, rr);
+      cum_v += mval;
+    } else if (nr > 1) {   // last ring: ciphertext - sum(partials)  (range.rs:520-528)
+      u32 nc[8];
+      sc_neg(nc, cum_r);
+      gen_muladd(rr, r, one, nc);
+    } else {
+#pragma unroll
+      for (int w = 0; w < 8; ++w) rr[w] = r[w];
+    }
+    sc_from_u64(msc, (i + 1 < nr || nr == 1) ? mval : value - cum_v);
+    fixed2_encode(encR, tg, rr, tk, nullptr);
+    fixed2_encode(encB, tg, msc, tk, rr);
+    if (i + 1 < nr) {
+#pragma unroll
+      for (int w = 0; w < 8; ++w) { partials[i * 16 + w] = encR[w]; partials[i * 16 + 8 + w] = encB[w]; }
+    }
+    // Ring::new (ring.rs:54-131)
+    gen_import(t, prefixes + (size_t)R.pre_ring * 52);
+    gen_append_ct(t, encR, encB);
+    gen_append_u64(t, "i", 1, (u64)i);
+    u32 x[8], cg[8], ck[8];
+    rng_scalar(rng, x);
+    fixed2_encode(cg, tg, x, tk, nullptr);
+    fixed2_encode(ck, tg, nullptr, tk, x);
+#pragma unroll
+    for (int w = 0; w < 8; ++w) { ring_r[i][w] = rr[w]; ring_x[i][w] = x[w]; }
+#pragma unroll 1
+    for (int eq = vi[i] + 1; eq < (int)R.size[i]; ++eq) {
+      // fork of the ring transcript: state is rebuilt per equation (cheap) to avoid keeping a second LDS column
+      gen_import(t, prefixes + (size_t)R.pre_ring * 52);
+      gen_append_ct(t, encR, encB);
+      gen_append_u64(t, "i", 1, (u64)i);
+      gen_append_u64(t, "j", 1, (u64)(eq - 1));
+      gen_append32(t, "R_G", 3, cg);
+      gen_append32(t, "R_K", 3, ck);
+      u32 e[8], sq[8];
+      gen_challenge(t, e);
+      rng_scalar(rng, sq);
+#pragma unroll
+      for (int w = 0; w < 8; ++w) resp[i][eq][w] = sq[w];
+      gen_sim_commitments(cg, ck, tg, tk, sq, e, rr, ((long long)vi[i] - eq) * (long long)R.step[i]);
+    }
+#pragma unroll
+    for (int w = 0; w < 8; ++w) { term[i][w] = cg[w]; term[i][8 + w] = ck[w]; }
+  }
+  // Ring::aggregate (ring.rs:138-160)
+  u32 e0[8];
+  gen_import(t, prefixes + (size_t)R.pre_main * 52);
+#pragma unroll 1
+  for (int i = 0; i < nr; ++i) { gen_append32(t, "R_G", 3, term[i]); gen_append32(t, "R_K", 3, term[i] + 8); }
+  gen_challenge(t, e0);
+#pragma unroll
+  for (int w = 0; w < 8; ++w) proof[w] = e0[w];
+  // Ring::finalize (ring.rs:162-194)
+  int off = 0;
+#pragma unroll 1
+  for (int i = 0; i < nr; ++i) {
+    u32 rr[8], x[8], ch[8], encR[8], encB[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) { rr[w] = ring_r[i][w]; x[w] = ring_x[i][w]; ch[w] = e0[w]; }
+    const u32* src = (i + 1 < nr) ? partials + i * 16 : nullptr;
+    if (src) {
+#pragma unroll
+      for (int w = 0; w < 8; ++w) { encR[w] = src[w]; encB[w] = src[8 + w]; }
+    } else {   // last ring: re-encode its ciphertext ([r_last]G, [m_last]G + [r_last]K)
+      u32 msc[8];
+      sc_from_u64(msc, nr == 1 ? (u64)vi[i] * R.step[i] : value - cum_v);
+      fixed2_encode(encR, tg, rr, tk, nullptr);
+      fixed2_encode(encB, tg, msc, tk, rr);
+    }
+#pragma unroll 1
+    for (int eq = 0; eq < vi[i]; ++eq) {
+      u32 sq[8], cg[8], ck[8];
+      rng_scalar(rng, sq);
+#pragma unroll
+      for (int w = 0; w < 8; ++w) resp[i][eq][w] = sq[w];
+      gen_sim_commitments(cg, ck, tg, tk, sq, ch, rr, ((long long)vi[i] - eq) * (long long)R.step[i]);
+      gen_import(t, prefixes + (size_t)R.pre_ring * 52);
+      gen_append_ct(t, encR, encB);
+      gen_append_u64(t, "i", 1, (u64)i);
+      gen_append_u64(t, "j", 1, (u64)eq);
+      gen_append32(t, "R_G", 3, cg);
+      gen_append32(t, "R_K", 3, ck);
+      gen_challenge(t, ch);
+    }
+    u32 sv[8];
+    gen_muladd(sv, ch, rr, x);
+#pragma unroll
+    for (int w = 0; w < 8; ++w) resp[i][vi[i]][w] = sv[w];
+#pragma unroll 1
+    for (int eq = 0; eq < (int)R.size[i]; ++eq) {
+#pragma unroll
+      for (int w = 0; w < 8; ++w) proof[(size_t)(1 + off + eq) * 8 + w] = resp[i][eq][w];
+    }
+    off += (int)R.size[i];
+  }
+}
+
+constexpr int EG_GEN_QV_MAX_OPTIONS = 16;
+
+__global__ void __launch_bounds__(NT) k_qv_encrypt(u64 seed0, size_t n, int n_options, u64 credits, GenRange vote_range,
+                                                   GenRange credit_range, int pre_sumsq, const uint4* tabG, const uint4* tabK,
+                                                   const u32* prefixes, u32* out, u32 stride_words, u32 vote_words,
+                                                   u32 credit_words) {
+  __shared__ u32 lds[50 * NT];
+  const FixedTable tg{tabG}, tk{tabK};
+  for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
+    const u64 seed = seed0 + i;
+    ChaChaRng rng;
+    chacha_seed_from_u64(rng, seed);
+    u32* ob = out + i * stride_words;
+    // votes as in tests/integration/sharing.rs:135-147 (geometric, p = 0.8), second stream
+    u64 votes[EG_GEN_QV_MAX_OPTIONS];
+    for (int k = 0; k < n_options; ++k) votes[k] = 0;
+    {
+      ChaChaRng sel;
+      chacha_seed_from_u64(sel, ~seed);
+      u32 buf[16];
+      int pos = 16;
+      auto next = [&]() -> u32 {
+        if (pos >= 16) { chacha_block(sel, buf); pos = 0; }
+        u32 v = buf[0];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) v = (pos == q) ? buf[q] : v;
+        ++pos;
+        return v;
+      };
+#pragma unroll 1
+      for (;;) {
+        if (next() % 10u >= 8u) break;
+        const u32 k = next() % (u32)n_options;
+        u64 c = 0;
+        for (int j = 0; j < n_options; ++j) { const u64 v = votes[j] + (j == (int)k ? 1 : 0); c += v * v; }
+        if (c > credits) break;
+        votes[k]++;
+      }
+    }
+    Transcript<LdsState> t;
+    t.st.base = lds + threadIdx.x;
+    u32 vr[EG_GEN_QV_MAX_OPTIONS][8], credit_r[8];
+    u64 credit = 0;
+#pragma unroll 1
+    for (int k = 0; k < n_options; ++k) {
+      gen_range_proof(t, rng, vote_range, votes[k], tg, tk, prefixes, ob + (size_t)k * vote_words, vr[k]);
+      credit += votes[k] * votes[k];
+    }
+    u32* cb = ob + (size_t)n_options * vote_words;
+    gen_range_proof(t, rng, credit_range, credit, tg, tk, prefixes, cb, credit_r);
+    // SumOfSquaresProof::new (mul.rs:107-181)
+    u32* sp = cb + credit_words;
+    gen_import(t, prefixes + (size_t)pre_sumsq * 52);
+    u32 e_z[8], sum_rand[8], er[EG_GEN_QV_MAX_OPTIONS][8], ex[EG_GEN_QV_MAX_OPTIONS][8];
+    rng_scalar(rng, e_z);
+#pragma unroll
+    for (int w = 0; w < 8; ++w) sum_rand[w] = credit_r[w];
+    u32 acc_g[8] = {0, 0, 0, 0, 0, 0, 0, 0}, acc_k[8];   // sum e_x v  and  sum e_x r + e_z
+#pragma unroll
+    for (int w = 0; w < 8; ++w) acc_k[w] = e_z[w];
+#pragma unroll 1
+    for (int k = 0; k < n_options; ++k) {
+      const u32* vct = ob + (size_t)k * vote_words;
+      gen_append32(t, "R_x", 3, vct);
+      gen_append32(t, "X", 1, vct + 8);
+      u32 c0[8], c1[8], xs[8], nx[8];
+      rng_scalar(rng, er[k]);
+      fixed2_encode(c0, tg, er[k], tk, nullptr);
+      gen_append32(t, "[e_r]G", 6, c0);
+      rng_scalar(rng, ex[k]);
+      fixed2_encode(c1, tg, ex[k], tk, er[k]);
+      gen_append32(t, "[e_x]G + [e_r]K", 15, c1);
+      sc_from_u64(xs, votes[k]);
+      sc_neg(nx, xs);
+      gen_muladd(sum_rand, vr[k], nx, sum_rand);      // sum_random_scalar += r_x * (-x)
+      gen_muladd(acc_g, ex[k], xs, acc_g);
+      gen_muladd(acc_k, ex[k], vr[k], acc_k);
+    }
+    u32 rsum[8], vsum[8];
+    fixed2_encode(rsum, tg, acc_k, tk, nullptr);        // sum e_x R_x + e_z G
+    fixed2_encode(vsum, tg, acc_g, tk, acc_k);          // sum e_x X + e_z K
+    gen_append32(t, "R_z", 3, cb);
+    gen_append32(t, "Z", 1, cb + 8);
+    gen_append32(t, "[e_x]R_x + [e_z]G", 17, rsum);
+    gen_append32(t, "[e_x]X + [e_z]K", 15, vsum);
+    u32 c[8];
+    gen_challenge(t, c);
+#pragma unroll
+    for (int w = 0; w < 8; ++w) sp[w] = c[w];
+#pragma unroll 1
+    for (int k = 0; k < n_options; ++k) {
+      u32 s_r[8], s_x[8], xs[8];
+      sc_from_u64(xs, votes[k]);
+      gen_muladd(s_r, c, vr[k], er[k]);
+      gen_muladd(s_x, c, xs, ex[k]);
+#pragma unroll
+      for (int w = 0; w < 8; ++w) { sp[(size_t)(1 + 2 * k) * 8 + w] = s_r[w]; sp[(size_t)(2 + 2 * k) * 8 + w] = s_x[w]; }
+    }
+    u32 s_z[8];
+    gen_muladd(s_z, c, sum_rand, e_z);
+#pragma unroll
+    for (int w = 0; w < 8; ++w) sp[(size_t)(1 + 2 * n_options) * 8 + w] = s_z[w];
+  }
+}
+
 }  // namespace eg

@@ -355,3 +355,18 @@ def test_cpp_voting_example(tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     assert "199 of 200 ballots verified" in out.stdout and "voter #4 rejected" in out.stdout
     assert "OK: decrypted totals sum to 199" in out.stdout
+
+
+def test_qv_generator_matches_oracle_prover(eg, ctx, oracle, pk):
+    import torch
+
+    for credits, n in ((20, 96), (15, 24), (100, 8)):
+        q = eg.QuadraticVotingParams(ctx, pk, 5, credits)
+        oq = oracle.QvParams(pk, 5, credits)
+        out = torch.zeros(n * q.ballot_size, dtype=torch.uint8, device="cuda")
+        q.encrypt_batch_device(31, 5, n, out.data_ptr())
+        ctx.synchronize()
+        got = bytes(out.cpu().numpy())
+        assert got == oq.generate_batch(31, 5, n), credits
+        st, _ = q.verify_batch(got)
+        assert st == [0] * n
