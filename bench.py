@@ -28,8 +28,7 @@ sys.path.insert(0, str(ROOT))
 
 PUBLIC_KEY_HEX = "a6adb6e9c0ae8d54c26e6e56b5ccd7a16bb0e1951abe4d7ee7028e3d4eca8531"  # seed-12345 key of the snapshots
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-FMUL_PEAK_G = 256.0            # profiles/r01_ubench_fmul_candidates.txt: radix-25.5 field multiply, chip-wide
-ALG_BYTES_PER_BALLOT = {"single5": 736 + 4, "multi16": 2080 + 4, "qv5": 2144 + 4}   # SURVEY 8d (+ 4 B status word)
+# algorithmic bytes per ballot = packed ballot + 4-byte status word: 740 (single 5), 2084 (multi 16), 2148 (qv 5/20)
 
 
 def parse():
@@ -38,7 +37,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--ballots", type=int, default=1_000_000, help="ballots per GPU per step")
-    ap.add_argument("--options", type=int, default=5)
+    ap.add_argument("--options", type=int, default=None)
+    ap.add_argument("--workload", choices=["single", "multi", "qv"], default="single",
+                    help="single = BASELINE configs[1] (the bench line); multi = 3-of-16 (configs[3]); qv = 5 options / 20 credits (configs[2])")
+    ap.add_argument("--credits", type=int, default=20)
     ap.add_argument("--seed", type=int, default=20260612)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -79,8 +81,13 @@ def main():
 
     ctx = eg.Context(local_rank)
     pk = bytes.fromhex(PUBLIC_KEY_HEX)
-    n_opt = args.options
-    params = eg.ChoiceParams.single_choice(ctx, pk, n_opt)
+    n_opt = args.options or {"single": 5, "multi": 16, "qv": 5}[args.workload]
+    if args.workload == "single":
+        params = eg.ChoiceParams.single_choice(ctx, pk, n_opt)
+    elif args.workload == "multi":
+        params = eg.ChoiceParams.multi_choice(ctx, pk, n_opt)
+    else:
+        params = eg.QuadraticVotingParams(ctx, pk, n_opt, args.credits)
     B = args.ballots
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -88,7 +95,10 @@ def main():
     first, _ = egd.shard_range(B * world, rank, world)   # rank r owns voters [r*B, (r+1)*B)
     ballots = torch.empty(B * params.ballot_size, dtype=torch.uint8, device=dev)
     t0 = time.time()
-    params.encrypt_batch_device(args.seed, first, B, ballots.data_ptr(), stream=stream)
+    if args.workload == "multi":
+        params.encrypt_batch_device(args.seed, first, B, ballots.data_ptr(), n_selected=3, stream=stream)
+    else:
+        params.encrypt_batch_device(args.seed, first, B, ballots.data_ptr(), stream=stream)
     torch.cuda.synchronize()
     gen_s = time.time() - t0
     status = torch.empty(B, dtype=torch.int32, device=dev)
@@ -137,12 +147,10 @@ def main():
     launches_per_step = max(1, msm_launches // max(args.steps, 1))
     avg_launch_ms = msm_ms / max(msm_launches, 1)
     units_per_launch = min(chunk, B)
-    alg_bytes = ALG_BYTES_PER_BALLOT["single5"] if n_opt == 5 else (n_opt * 64 + 32 * (1 + 2 * n_opt) + 64 + 4)
+    alg_bytes = params.ballot_size + 4
     achieved_gbs = alg_bytes * units_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-    # field-multiplication throughput of the same kernel: counts from tests/hostcheck (fe_mul + fe_sq per equation)
-    fmul_per_ballot = float(os.environ.get("EG_FMUL_PER_BALLOT", "0") or 0)
     out = {
-        "metric": "EncryptedChoice ballot verifications/sec",
+        "metric": "EncryptedChoice ballot verifications/sec" if args.workload != "qv" else "QuadraticVotingBallot verifications/sec",
         "value": value,
         "unit": "ballots/s",
         "n_gpus": world,
@@ -155,8 +163,12 @@ def main():
         "dtype": "u32",
         "data": "synthetic",
         "config": {
-            "workload": f"{B} single-choice {n_opt}-option EncryptedChoice ballots per GPU per step, resident in HBM "
-                        "(BASELINE.json configs[1]); verify + homomorphic tally + tally all-gather",
+            "workload": {
+                "single": f"{B} single-choice {n_opt}-option EncryptedChoice ballots per GPU per step, resident in HBM "
+                          "(BASELINE.json configs[1]); verify + homomorphic tally + tally all-gather",
+                "multi": f"{B} multi-choice 3-of-{n_opt} EncryptedChoice ballots per GPU per step (BASELINE.json configs[3])",
+                "qv": f"{B} QuadraticVotingBallot ballots, {n_opt} options / {args.credits} credits (BASELINE.json configs[2])",
+            }[args.workload],
             "ballots_per_gpu": B,
             "options": n_opt,
             "ballot_bytes": params.ballot_size,
@@ -189,7 +201,8 @@ def main():
         from oracle import oracle as o
 
         cores = effective_cores()
-        op = o.ChoiceParams(pk, n_opt, True)
+        op = (o.QvParams(pk, n_opt, args.credits) if args.workload == "qv"
+              else o.ChoiceParams(pk, n_opt, args.workload == "single"))
         # bounded sample: verify slices of the same batch until ~cpu_seconds of wall time have been spent
         slice_n = max(64, 32 * cores)
         cpu_status, cpu_s, sample = [], 0.0, 0
