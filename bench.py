@@ -143,10 +143,11 @@ def main():
         return
 
     # ---- roofline of the dominant kernel (k_msm_jobs), HIP events on the launch stream ------------------------
-    chunk = int(os.environ.get("EG_CHUNK", "131072"))
+    chunk = int(os.environ.get("EG_CHUNK", "262144"))
     launches_per_step = max(1, msm_launches // max(args.steps, 1))
     avg_launch_ms = msm_ms / max(msm_launches, 1)
-    units_per_launch = min(chunk, B)
+    n_chunks = -(-B // chunk)
+    units_per_launch = -(-B // n_chunks)
     alg_bytes = params.ballot_size + 4
     achieved_gbs = alg_bytes * units_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
     out = {

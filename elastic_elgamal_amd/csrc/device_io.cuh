@@ -28,8 +28,10 @@ struct EngineBufs {
   const uint4* cpts;    // election-constant points [idx][10]
   u32* prefixes;        // hoisted transcript prefixes [idx][52]
   const unsigned char* blob;  // labels and constant messages
-  uint4* ws;            // per-lane variable-base tables [block][80][NT]
+  uint4* ws;            // per-lane variable-base tables (direct multiplications)
+  uint4* btab;          // split tables of the ring bases [base][cap] x 320 uint4 (4 x 8 cached entries, 5 KiB)
 };
+constexpr int BTAB_QUADS = 32 * 10;
 
 // ---- SoA accessors ------------------------------------------------------------------------------------
 __device__ __forceinline__ void words_to_ge(ge& p, const u32 w[40]) {
@@ -131,6 +133,27 @@ struct WsTable {
   }
 };
 #endif
+// split tables of one (base, ballot): 32 cached entries, contiguous (ge_split_tables_build / ge_split_mul)
+struct BaseTable {
+  uint4* base;
+  __device__ __forceinline__ void store(int e, const ge_cached& c) {
+    u32 w[40];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) { w[i] = c.YpX.v[i]; w[10 + i] = c.YmX.v[i]; w[20 + i] = c.Z2.v[i]; w[30 + i] = c.T2d.v[i]; }
+#pragma unroll
+    for (int q = 0; q < 10; ++q) base[e * 10 + q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+  }
+  __device__ __forceinline__ void load(ge_cached& c, int e) const {
+    u32 w[40];
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {
+      const uint4 v = base[e * 10 + q];
+      w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 10; ++i) { c.YpX.v[i] = w[i]; c.YmX.v[i] = w[10 + i]; c.Z2.v[i] = w[20 + i]; c.T2d.v[i] = w[30 + i]; }
+  }
+};
 // fixed-base table shared by every lane (L2 resident, 512 KiB per base): entry = 8 uint4 (30 limbs used)
 struct FixedTable {
   const uint4* tab;

@@ -100,6 +100,8 @@ struct Engine {
   egplan::HashOp* d_ops = nullptr;
   egplan::StatusRule* d_rules = nullptr;
   u32* d_tally_slots = nullptr;
+  unsigned short* d_base_slots = nullptr;
+  uint4* btab = nullptr;
   unsigned char* d_blob = nullptr;
   uint4 *d_tabK = nullptr, *d_cpts = nullptr;
   u32* d_prefixes = nullptr;
@@ -123,7 +125,7 @@ struct Engine {
 static void engine_free(Engine* e) {
   if (!e) return;
   void* ptrs[] = {e->d_pt_items, e->d_sc_items, e->d_dclasses, e->d_dterms, e->d_jobs, e->d_vterms, e->d_insts, e->d_ops,
-                  e->d_rules, e->d_tally_slots, e->d_blob, e->d_tabK, e->d_cpts, e->d_prefixes, e->d_key_words, e->pts, e->cmp,
+                  e->d_rules, e->d_tally_slots, e->d_base_slots, e->btab, e->d_blob, e->d_tabK, e->d_cpts, e->d_prefixes, e->d_key_words, e->pts, e->cmp,
                   e->chal, e->states, e->flags, e->bad_item, e->partial, e->tally, e->d_wire, e->d_status};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete e;
@@ -139,6 +141,7 @@ static EngineBufs make_bufs(const Engine* e, const void* d_ballots, u32 n, void*
   B.status = reinterpret_cast<u32*>(d_status);
   B.tabG = e->ctx->tabG; B.tabK = e->d_tabK; B.cpts = e->d_cpts; B.prefixes = e->d_prefixes; B.blob = e->d_blob;
   B.ws = e->ctx->ws;
+  B.btab = e->btab;
   return B;
 }
 
@@ -197,6 +200,7 @@ static int engine_create(eg_ctx* ctx, eghost::Plan&& plan, const uint8_t pk[32],
   if ((rc = upload(&e->d_ops, ops, s))) return rc;
   if ((rc = upload(&e->d_rules, P.rules, s))) return rc;
   if ((rc = upload(&e->d_tally_slots, P.tally_slots, s))) return rc;
+  if ((rc = upload(&e->d_base_slots, P.base_slots, s))) return rc;
   if ((rc = upload(&e->d_blob, P.blob, s))) return rc;
 
   // election key: decode, reject invalid / identity (keys/mod.rs:161-176), fixed-base table
@@ -232,7 +236,7 @@ static int engine_create(eg_ctx* ctx, eghost::Plan&& plan, const uint8_t pk[32],
 
   // chunk workspace
   const char* env = getenv("EG_CHUNK");
-  e->cap = env ? (u32)strtoul(env, nullptr, 10) : 131072u;
+  e->cap = env ? (u32)strtoul(env, nullptr, 10) : 262144u;
   if (e->cap < NT) e->cap = NT;
   e->cap = (e->cap + NT - 1) / NT * NT;
   const size_t cap = e->cap;
@@ -242,6 +246,7 @@ static int engine_create(eg_ctx* ctx, eghost::Plan&& plan, const uint8_t pk[32],
   HIPCHK(hipMalloc((void**)&e->states, (size_t)std::max(P.n_state_slots, 1) * 52 * cap * sizeof(u32)));
   HIPCHK(hipMalloc((void**)&e->flags, (size_t)std::max(P.n_flag_slots, 1) * cap * sizeof(u32)));
   HIPCHK(hipMalloc((void**)&e->bad_item, cap * sizeof(u32)));
+  HIPCHK(hipMalloc((void**)&e->btab, std::max<size_t>(P.base_slots.size(), 1) * cap * BTAB_QUADS * sizeof(uint4)));
   HIPCHK(hipMalloc((void**)&e->partial, std::max<size_t>(P.tally_slots.size(), 1) * e->tally_blocks * 40 * sizeof(u32)));
   HIPCHK(hipMalloc((void**)&e->tally, std::max<size_t>(P.tally_slots.size(), 1) * 40 * sizeof(u32)));
   HIPCHK(hipMalloc((void**)&e->d_prefixes, (size_t)std::max(P.n_prefixes, 1) * 52 * sizeof(u32)));
@@ -267,8 +272,11 @@ static int engine_verify_device(Engine* e, size_t n, const void* d_ballots, void
   size_t all_idx = 0;
   int rc;
   if ((rc = prof_begin(ctx, s, false, &all_idx))) return rc;
-  for (size_t off = 0; off < n; off += e->cap) {
-    const u32 cn = (u32)std::min<size_t>(e->cap, n - off);
+  // equal-sized chunks (each a multiple of the block size) so that the persistent grids stay balanced on the last chunk
+  const size_t n_chunks = (n + e->cap - 1) / e->cap;
+  const size_t even = n_chunks ? ((n + n_chunks - 1) / n_chunks + NT - 1) / NT * NT : 0;
+  for (size_t off = 0; off < n; off += even) {
+    const u32 cn = (u32)std::min<size_t>(even, n - off);
     EngineBufs B = make_bufs(e, reinterpret_cast<const unsigned char*>(d_ballots) + off * P.stride, cn,
                              reinterpret_cast<u32*>(d_status) + off);
     const int wide = ctx->cus * 8;
@@ -281,6 +289,13 @@ static int engine_verify_device(Engine* e, size_t n, const void* d_ballots, void
       if (lv.count)
         hipLaunchKernelGGL(k_derive_points, dim3(grid_for((size_t)lv.count * cn, wide)), dim3(NT), 0, s, B, e->d_dclasses,
                            e->d_dterms, lv.first, lv.count);
+    if (!P.base_slots.empty()) {
+      size_t pi = 0;
+      if ((rc = prof_begin(ctx, s, false, &pi))) return rc;
+      hipLaunchKernelGGL(k_base_tables, dim3(grid_for((size_t)P.base_slots.size() * cn, ctx->msm_blocks)), dim3(NT), 0, s, B,
+                         e->d_base_slots, (int)P.base_slots.size());
+      if ((rc = prof_end(ctx, s, pi))) return rc;
+    }
     for (auto& st : e->stages) {
       if (st.job_count) {
         size_t pi = 0;

@@ -337,6 +337,83 @@ EG_HD void ge_var_mul(ge& acc, TableIO& io, const u32 digits[8]) {
   }
 }
 
+// ---- variable-base multiplication with per-base split tables ---------------------------------------------------------
+// A ring base (R or B of one ciphertext) is multiplied by one challenge per equation of its ring (ring.rs:333-361), and
+// equation j+1 cannot start before equation j is hashed.  The doublings are therefore amortised ACROSS equations:
+// once per base the tables of P_j = [2^(64 j)] P, j = 0..3 are built (192 doublings, 4 x 8 cached entries, 5 KiB), and
+// every later product [k]P = sum_i 16^i sum_j d_(16 j + i) P_j costs 60 doublings + 64 additions instead of 252 + 64.
+// Entry index = j * 8 + (|digit| - 1).
+template <class TableIO>
+EG_HD void ge_split_tables_build(TableIO& io, const ge& p) {
+  ge base = p;
+#pragma unroll 1
+  for (int j = 0; j < 4; ++j) {
+    ge_cached pc; ge_to_cached(pc, base);
+    io.store(j * 8, pc);
+    ge cur = base;
+#pragma unroll 1
+    for (int k = 2; k <= 8; ++k) {
+      ge_p1p1 t;
+      ge_add(t, cur, pc);
+      ge_add_to_p3(cur, t);
+      ge_cached c; ge_to_cached(c, cur);
+      io.store(j * 8 + k - 1, c);
+    }
+    if (j < 3) {
+      ge_p1p1 t; ge_p2 q;
+      q.X = base.X; q.Y = base.Y; q.Z = base.Z;
+#pragma unroll 1
+      for (int r = 0; r < 63; ++r) { ge_dbl(t, q.X, q.Y, q.Z); ge_dbl_to_p2(q, t); }
+      ge_dbl(t, q.X, q.Y, q.Z);
+      ge_dbl_to_p3(base, t);
+    }
+  }
+}
+
+// entry index and sign of digit (16 j + i); the raw load is issued early, the sign / zero fix-up happens at use
+EG_HD int ge_split_index(const u32 digits[8], int j, int i) {
+  const int d = sc_digit16(digits, 16 * j + i);
+  const int ad = d < 0 ? -d : d;
+  return j * 8 + (ad == 0 ? 0 : ad - 1);
+}
+EG_HD void ge_split_fixup(ge_cached& c, const u32 digits[8], int j, int i, const ge_cached& ident) {
+  const int d = sc_digit16(digits, 16 * j + i);
+  fe_cmov(c.YpX, ident.YpX, d == 0); fe_cmov(c.YmX, ident.YmX, d == 0);
+  fe_cmov(c.Z2, ident.Z2, d == 0); fe_cmov(c.T2d, ident.T2d, d == 0);
+  ge_cached_cneg(c, d < 0);
+}
+
+// acc = [k]P from the split tables; digits = sc_recode_radix16(k).  Every table load is issued one addition (or the
+// four doublings) ahead of its use so that HBM / Infinity-Cache latency is hidden even at 2 waves per SIMD.
+template <class TableIO>
+EG_HD void ge_split_mul(ge& acc, TableIO& io, const u32 digits[8]) {
+  ge_cached ident; ge_cached_identity(ident);
+  ge_identity(acc);
+  ge_cached nxt;
+  io.load(nxt, ge_split_index(digits, 0, 15));
+#pragma unroll 1
+  for (int i = 15; i >= 0; --i) {
+    if (i != 15) {
+      ge_p1p1 t; ge_p2 q;
+      q.X = acc.X; q.Y = acc.Y; q.Z = acc.Z;
+#pragma unroll 1
+      for (int r = 0; r < 3; ++r) { ge_dbl(t, q.X, q.Y, q.Z); ge_dbl_to_p2(q, t); }
+      ge_dbl(t, q.X, q.Y, q.Z);
+      ge_dbl_to_p3(acc, t);
+    }
+#pragma unroll 1
+    for (int j = 0; j < 4; ++j) {
+      ge_cached c = nxt;
+      const int nj = (j + 1) & 3, ni = j == 3 ? i - 1 : i;
+      if (ni >= 0) io.load(nxt, ge_split_index(digits, nj, ni));
+      ge_split_fixup(c, digits, j, i, ident);
+      ge_p1p1 t;
+      ge_add(t, acc, c);
+      ge_add_to_p3(acc, t);
+    }
+  }
+}
+
 // ---- fixed-base scalar multiplication -----------------------------------------------------------------------------
 // Signed radix-256 comb: 32 windows x 128 affine-Niels entries per base (512 KiB, L2 resident), built once per base
 // on the device (k_build_fixed_table).  Table index = window * 128 + (|digit| - 1).  acc += [k]Base with 32 mixed
@@ -365,15 +442,22 @@ EG_HD int sc_digit256(const u32 d[8], int i) {
   const int b = (int)((w >> (8 * (i & 3))) & 255u);
   return b >= 128 ? b - 256 : b;
 }
+EG_HD int ge_fixed_index(const u32 digits[8], int i) {
+  const int d = sc_digit256(digits, i);
+  const int ad = d < 0 ? -d : d;
+  return i * EG_FIXED_ENTRIES + (ad == 0 ? 0 : ad - 1);
+}
 template <class NielsIO>
 EG_HD void ge_fixed_mul_add(ge& acc, NielsIO& io, const u32 digits[8]) {
   ge_niels ident; ge_niels_identity(ident);
+  ge_niels nxt;
+  io.load(nxt, ge_fixed_index(digits, 0));
 #pragma unroll 1
   for (int i = 0; i < EG_FIXED_WINDOWS; ++i) {
+    ge_niels c = nxt;
+    if (i + 1 < EG_FIXED_WINDOWS) io.load(nxt, ge_fixed_index(digits, i + 1));   // one addition ahead of its use
     const int d = sc_digit256(digits, i);
-    const int ad = d < 0 ? -d : d;
-    ge_niels c; io.load(c, i * EG_FIXED_ENTRIES + (ad == 0 ? 0 : ad - 1));
-    fe_cmov(c.ypx, ident.ypx, ad == 0); fe_cmov(c.ymx, ident.ymx, ad == 0); fe_cmov(c.xy2d, ident.xy2d, ad == 0);
+    fe_cmov(c.ypx, ident.ypx, d == 0); fe_cmov(c.ymx, ident.ymx, d == 0); fe_cmov(c.xy2d, ident.xy2d, d == 0);
     ge_niels_cneg(c, d < 0);
     ge_p1p1 t; ge_madd(t, acc, c);
     ge_add_to_p3(acc, t);

@@ -101,6 +101,20 @@ struct Plan {
   int n_pt_slots = 0, n_cmp_slots = 0, n_chal_slots = 0, n_state_slots = 0, n_flag_slots = 0, n_prefixes = 0;
   std::map<std::string, uint32_t> blob_index;
   std::map<uint64_t, uint16_t> const_index;
+  // bases with precomputed split tables (ge_split_tables_build): point slots that several equations multiply
+  std::vector<uint16_t> base_slots;
+  std::map<uint16_t, uint16_t> base_index_of;
+  uint16_t base_index(uint16_t slot) {
+    auto it = base_index_of.find(slot);
+    if (it != base_index_of.end()) return it->second;
+    const uint16_t i = (uint16_t)base_slots.size();
+    base_slots.push_back(slot);
+    base_index_of[slot] = i;
+    return i;
+  }
+  bool has_base(uint16_t slot) const { return base_index_of.count(slot) != 0; }
+  VarTerm term(uint16_t slot, ScalarSrc sc) { return VarTerm{slot, has_base(slot) ? base_index_of[slot] : (uint16_t)0xffff, sc}; }
+  VarTerm bterm(uint16_t slot, ScalarSrc sc) { return VarTerm{slot, base_index(slot), sc}; }
 
   uint32_t ref(const std::string& s) {  // label / constant message in the blob
     auto it = blob_index.find(s);
@@ -162,7 +176,7 @@ struct Plan {
   uint16_t encode_job(size_t st, uint16_t pt_slot) {
     JobClass jc{};
     jc.term_first = 0; jc.term_count = 0;
-    jc.g = ScalarSrc{SRC_NONE, 0, 0}; jc.k = ScalarSrc{SRC_NONE, 0, 0};
+    jc.g = ScalarSrc{SRC_NONE, 0, 0, 0}; jc.k = ScalarSrc{SRC_NONE, 0, 0, 0};
     jc.out_slot = new_cmp();
     jc.enc_slot = pt_slot;
     stage(st).jobs.push_back(jc);
@@ -170,9 +184,10 @@ struct Plan {
   }
 };
 
-inline ScalarSrc wire_src(uint16_t item, bool neg = false) { return ScalarSrc{SRC_WIRE, (uint8_t)neg, item}; }
-inline ScalarSrc chal_src(uint16_t slot, bool neg = false) { return ScalarSrc{SRC_CHAL, (uint8_t)neg, slot}; }
-inline ScalarSrc no_src() { return ScalarSrc{SRC_NONE, 0, 0}; }
+inline ScalarSrc wire_src(uint16_t item, bool neg = false) { return ScalarSrc{SRC_WIRE, (uint8_t)neg, item, 0}; }
+inline ScalarSrc chal_src(uint16_t slot, bool neg = false) { return ScalarSrc{SRC_CHAL, (uint8_t)neg, slot, 0}; }
+inline ScalarSrc no_src() { return ScalarSrc{SRC_NONE, 0, 0, 0}; }
+inline ScalarSrc times(ScalarSrc s, uint64_t m) { s.mul = (uint32_t)m; return s; }
 
 // one ring of a RingProof
 struct RingIn {
@@ -216,15 +231,16 @@ inline uint16_t add_ring_proof(Plan& P, const std::vector<HashOp>& setup, const 
     const uint16_t state = s > 2 ? P.new_state() : 0;
     uint16_t chal = 0;
     for (size_t j = 0; j < s; ++j) {
-      // dh = B - x_j (ring.rs:338)
-      uint16_t dh = r.ptB;
-      if (r.admissible[j] != 0)
-        dh = P.derive(r.derive_level, {{r.ptB, 0, 0}, {P.const_point(r.admissible[j]), 1, 1}});
-      const ScalarSrc e = j == 0 ? wire_src(challenge_item, true) : chal_src(chal, true);
+      // R_G = [s]G - [e]R ;  R_K = [s]K - [e](B - x_j) = [s]K + [e m_j]G - [e]B  with x_j = [m_j]G   (ring.rs:338-350).
+      // Folding x_j into the generator term keeps B itself as the only variable base of the ring's K side, so the
+      // split tables of R and B are shared by all equations of the ring.
+      const ScalarSrc e_pos = j == 0 ? wire_src(challenge_item) : chal_src(chal);
+      ScalarSrc e = e_pos;
+      e.neg = 1;
       const ScalarSrc resp = wire_src((uint16_t)(r.resp_item + j));
-      // R_G = [s]G - [e]R ; R_K = [s]K - [e]dh   (ring.rs:342-350)
-      const uint16_t cg = P.job(first_stage + j, {{r.ptR, e}}, resp, no_src());
-      const uint16_t ck = P.job(first_stage + j, {{dh, e}}, no_src(), resp);
+      const uint16_t cg = P.job(first_stage + j, {P.bterm(r.ptR, e)}, resp, no_src());
+      const ScalarSrc fold = r.admissible[j] != 0 ? times(e_pos, r.admissible[j]) : no_src();
+      const uint16_t ck = P.job(first_stage + j, {P.bterm(r.ptB, e)}, fold, resp);
       if (j + 1 < s) {   // ring.rs:354-360
         std::vector<HashOp> ops;
         if (j == 0) {
@@ -289,8 +305,8 @@ inline Plan build_choice_plan(int n, bool single) {
                                  {OP_SAVE_PREFIX, 0, pre, 0}});
     // LogEqualityProof::verify (log_equality.rs:153-180)
     const ScalarSrc c = wire_src(sum_items, true), s = wire_src((uint16_t)(sum_items + 1));
-    const uint16_t xg = P.job(0, {{p0, c}}, s, no_src());
-    const uint16_t xk = P.job(0, {{p1, c}}, no_src(), s);
+    const uint16_t xg = P.job(0, {P.term(p0, c)}, s, no_src());
+    const uint16_t xk = P.job(0, {P.term(p1, c)}, no_src(), s);
     const uint16_t e0 = P.encode_job(0, p0), e1 = P.encode_job(0, p1);
     sum_flag = P.new_flag();
     P.stage(0).insts.push_back({{OP_LOAD_PREFIX, 0, pre, 0},
@@ -409,18 +425,18 @@ inline Plan build_qv_plan(int n, uint64_t credits) {
   uint16_t vitem = 0;
   for (int i = 0; i < n; ++i) {
     const ScalarSrc s_r = wire_src((uint16_t)(c_item + 1 + 2 * i)), s_x = wire_src((uint16_t)(c_item + 2 + 2 * i));
-    const uint16_t er = P.job(0, {{votes[i].ctR, neg_c}}, s_r, no_src());                 // mul.rs:213-217
-    const uint16_t ex = P.job(0, {{votes[i].ctB, neg_c}}, s_x, s_r);                      // mul.rs:219-226
+    const uint16_t er = P.job(0, {P.term(votes[i].ctR, neg_c)}, s_r, no_src());                 // mul.rs:213-217
+    const uint16_t ex = P.job(0, {P.term(votes[i].ctB, neg_c)}, s_x, s_r);                      // mul.rs:219-226
     ops.push_back({OP_APPEND_WIRE, P.ref("R_x"), vitem, 1});
     ops.push_back({OP_APPEND_WIRE, P.ref("X"), (uint32_t)(vitem + 1), 1});
     ops.push_back({OP_APPEND_CMP, P.ref("[e_r]G"), er, 0xffff});
     ops.push_back({OP_APPEND_CMP, P.ref("[e_x]G + [e_r]K"), ex, 0xffff});
-    trz.push_back({votes[i].ctR, s_x});
-    tz.push_back({votes[i].ctB, s_x});
+    trz.push_back(P.term(votes[i].ctR, s_x));
+    tz.push_back(P.term(votes[i].ctB, s_x));
     vitem = (uint16_t)(vitem + votes[i].n_items);
   }
-  trz.push_back({credit.ctR, neg_c});
-  tz.push_back({credit.ctB, neg_c});
+  trz.push_back(P.term(credit.ctR, neg_c));
+  tz.push_back(P.term(credit.ctB, neg_c));
   const uint16_t erz = P.job(0, trz, wire_src(sz_item), no_src());   // mul.rs:232-240
   const uint16_t ez = P.job(0, tz, no_src(), wire_src(sz_item));     // mul.rs:241-247
   ops.push_back({OP_APPEND_WIRE, P.ref("R_z"), vitem, 1});
@@ -446,8 +462,8 @@ inline Plan build_zero_plan() {   // item = ct(64) || challenge || response
                                {OP_APPEND_BLOB, P.ref("K"), P.pk_ref(), 0},
                                {OP_SAVE_PREFIX, 0, pre, 0}});
   const ScalarSrc c = wire_src(2, true), s = wire_src(3);
-  const uint16_t xg = P.job(0, {{R, c}}, s, no_src());
-  const uint16_t xk = P.job(0, {{B, c}}, no_src(), s);
+  const uint16_t xg = P.job(0, {P.term(R, c)}, s, no_src());
+  const uint16_t xk = P.job(0, {P.term(B, c)}, no_src(), s);
   const uint16_t flag = P.new_flag();
   P.stage(0).insts.push_back({{OP_LOAD_PREFIX, 0, pre, 0},
                               {OP_APPEND_WIRE, P.ref("[r]G"), 0, 1},

@@ -28,6 +28,14 @@ __device__ __forceinline__ void load_scalar(u32 s[8], const EngineBufs& B, u32 b
   if (src.neg) { u32 t[8]; sc_neg(t, s);
 #pragma unroll
     for (int i = 0; i < 8; ++i) s[i] = t[i]; }
+  if (src.mul > 1u) {
+    u32 m[8], t[8];
+    const u32 z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    sc_from_u64(m, (u64)src.mul);
+    sc_muladd(t, s, m, z);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = t[i];
+  }
 }
 
 // ---- k_decode_points: deserialize_element for every wire point (ristretto.rs:93-95) --------------------------------
@@ -83,6 +91,18 @@ __global__ void __launch_bounds__(NT) k_derive_points(EngineBufs B, const egplan
   }
 }
 
+// ---- k_base_tables: split tables of every ring base (once per base and ballot; shared by all equations of the ring) ----------
+__global__ void __launch_bounds__(NT, 2) k_base_tables(EngineBufs B, const unsigned short* base_slots, int n_bases) {
+  const size_t total = (size_t)n_bases * B.n;
+  for (size_t j = (size_t)blockIdx.x * NT + threadIdx.x; j < total; j += (size_t)gridDim.x * NT) {
+    const u32 k = (u32)(j / B.n), b = (u32)(j % B.n);
+    ge p;
+    load_pt(p, B.pts, B.cap, base_slots[k], b);
+    BaseTable bt{B.btab + ((size_t)k * B.cap + b) * BTAB_QUADS};
+    ge_split_tables_build(bt, p);
+  }
+}
+
 // ---- k_msm_jobs: out = encode( sum_i [a_i]P_i + [g]G + [k]K ) -----------------------------------------------------------------
 // One lane = one group equation of one ballot: vartime_double_mul_generator / vartime_multi_mul followed by
 // serialize_element (ring.rs:342-350, log_equality.rs:160-164, mul.rs:213-247 + proofs/mod.rs:48-52).
@@ -105,13 +125,18 @@ __global__ void __launch_bounds__(NT, 2) k_msm_jobs(EngineBufs B, const egplan::
     for (u32 t = 0; t < jc.term_count; ++t) {
       const egplan::VarTerm vt = terms[jc.term_first + t];
       ge p;
-      load_pt(p, B.pts, B.cap, vt.slot, b);
+      if (vt.base == 0xffffu) load_pt(p, B.pts, B.cap, vt.slot, b);
       u32 s[8], dg[8];
       load_scalar(s, B, b, vt.s);
       sc_recode_radix16(dg, s);
-      ge_var_table_build(tab, p);
       ge part;
-      ge_var_mul(part, tab, dg);
+      if (vt.base != 0xffffu) {
+        BaseTable bt{B.btab + ((size_t)vt.base * B.cap + b) * BTAB_QUADS};
+        ge_split_mul(part, bt, dg);
+      } else {
+        ge_var_table_build(tab, p);
+        ge_var_mul(part, tab, dg);
+      }
       if (t == 0) acc = part;
       else { ge sum; ge_add_full(sum, acc, part); acc = sum; }
     }

@@ -23,10 +23,12 @@ struct ScalarSrc {
   uint8_t kind;   // SRC_*
   uint8_t neg;    // use -scalar (ring.rs:339, log_equality.rs:160, mul.rs:205)
   uint16_t idx;   // wire item index or challenge slot
+  uint32_t mul;   // > 1: multiply by this small integer (the [e * x_j] G term of B - x_j, ring.rs:338)
 };
 
 struct VarTerm {
   uint16_t slot;  // point slot (wire or derived)
+  uint16_t base;  // 0xffff: multiply directly; else index of the base whose split tables were precomputed
   ScalarSrc s;
 };
 

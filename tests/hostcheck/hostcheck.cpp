@@ -15,6 +15,11 @@ struct ArrTable {
   void store(int i, const ge_cached& c) { e[i] = c; }
   void load(ge_cached& c, int i) const { c = e[i]; }
 };
+struct ArrSplit {
+  ge_cached e[32];
+  void store(int i, const ge_cached& c) { e[i] = c; }
+  void load(ge_cached& c, int i) const { c = e[i]; }
+};
 struct ArrNiels {
   std::vector<ge_niels> e;
   void load(ge_niels& c, int i) const { c = e[i]; }
@@ -65,6 +70,21 @@ int hc_double_mul_generator(const uint8_t k[32], const uint8_t p_enc[32], const 
   ArrTable tab; ge_var_table_build(tab, p);
   u32 dk[8], dr[8]; sc_recode_radix16(dk, kw); sc_recode_radix256(dr, rw);
   ge acc; ge_var_mul(acc, tab, dk);
+  ge_fixed_mul_add(acc, g_base_table, dr);
+  ristretto_encode(o, acc);
+  bytes_from_words(out, o, 8);
+  return 1;
+}
+
+// same as hc_double_mul_generator but through the per-base split tables (ge_split_tables_build / ge_split_mul)
+int hc_double_mul_generator_split(const uint8_t k[32], const uint8_t p_enc[32], const uint8_t r[32], uint8_t out[32]) {
+  if (g_base_table.e.empty()) { ge g; ge_generator(g); build_fixed(g_base_table, g); }
+  u32 kw[8], rw[8], pw[8], o[8];
+  words_from_bytes(kw, k, 8); words_from_bytes(rw, r, 8); words_from_bytes(pw, p_enc, 8);
+  ge p; if (!ristretto_decode(p, pw)) return 0;
+  ArrSplit tab; ge_split_tables_build(tab, p);
+  u32 dk[8], dr[8]; sc_recode_radix16(dk, kw); sc_recode_radix256(dr, rw);
+  ge acc; ge_split_mul(acc, tab, dk);
   ge_fixed_mul_add(acc, g_base_table, dr);
   ristretto_encode(o, acc);
   bytes_from_words(out, o, 8);

@@ -120,6 +120,8 @@ def test_double_mul_generator(hc, oracle):
         kb, rb = k.to_bytes(32, "little"), r.to_bytes(32, "little")
         assert hc.hc_double_mul_generator(kb, p, rb, out) == 1
         assert out.raw == oracle.point_double_mul_generator(kb, p, rb), (k, r)
+        assert hc.hc_double_mul_generator_split(kb, p, rb, out) == 1      # 4-way split tables, 60 doublings
+        assert out.raw == oracle.point_double_mul_generator(kb, p, rb), (k, r)
 
 
 def test_merlin(hc, oracle):
