@@ -110,7 +110,7 @@ struct Engine {
   std::vector<LevelDev> levels;
   int prefix_inst_first = 0, prefix_inst_count = 0;
   // chunk workspace
-  u32 cap = 0;
+  u32 cap = 0, max_cap = 0;
   uint4 *pts = nullptr, *cmp = nullptr, *chal = nullptr;
   u32 *states = nullptr, *flags = nullptr, *bad_item = nullptr;
   u32* partial = nullptr;
@@ -143,6 +143,27 @@ static EngineBufs make_bufs(const Engine* e, const void* d_ballots, u32 n, void*
   B.ws = e->ctx->ws;
   B.btab = e->btab;
   return B;
+}
+
+// (re)allocate the per-chunk SoA buffers for chunks of up to `want` ballots
+static int engine_reserve(Engine* e, u32 want) {
+  if (want <= e->cap) return EG_OK;
+  const eghost::Plan& P = e->plan;
+  HIPCHK(hipDeviceSynchronize());   // earlier batches may still be running on a caller's stream
+  void** bufs[] = {(void**)&e->pts, (void**)&e->cmp, (void**)&e->chal, (void**)&e->states, (void**)&e->flags, (void**)&e->bad_item,
+                   (void**)&e->btab};
+  for (void** b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
+  e->cap = 0;
+  const size_t cap = (want + NT - 1) / NT * NT;
+  HIPCHK(hipMalloc((void**)&e->pts, (size_t)std::max(P.n_pt_slots, 1) * 10 * cap * sizeof(uint4)));
+  HIPCHK(hipMalloc((void**)&e->cmp, (size_t)std::max(P.n_cmp_slots, 1) * 2 * cap * sizeof(uint4)));
+  HIPCHK(hipMalloc((void**)&e->chal, (size_t)std::max(P.n_chal_slots, 1) * 2 * cap * sizeof(uint4)));
+  HIPCHK(hipMalloc((void**)&e->states, (size_t)std::max(P.n_state_slots, 1) * 52 * cap * sizeof(u32)));
+  HIPCHK(hipMalloc((void**)&e->flags, (size_t)std::max(P.n_flag_slots, 1) * cap * sizeof(u32)));
+  HIPCHK(hipMalloc((void**)&e->bad_item, cap * sizeof(u32)));
+  HIPCHK(hipMalloc((void**)&e->btab, std::max<size_t>(P.base_slots.size(), 1) * cap * BTAB_QUADS * sizeof(uint4)));
+  e->cap = (u32)cap;
+  return EG_OK;
 }
 
 static int grid_for(size_t lanes, int cap_blocks) {
@@ -234,19 +255,11 @@ static int engine_create(eg_ctx* ctx, eghost::Plan&& plan, const uint8_t pk[32],
     (void)hipFree(d_m);
   }
 
-  // chunk workspace
+  // chunk workspace: sized lazily by engine_reserve() for the batches actually seen (up to EG_CHUNK ballots per chunk)
   const char* env = getenv("EG_CHUNK");
-  e->cap = env ? (u32)strtoul(env, nullptr, 10) : 262144u;
-  if (e->cap < NT) e->cap = NT;
-  e->cap = (e->cap + NT - 1) / NT * NT;
-  const size_t cap = e->cap;
-  HIPCHK(hipMalloc((void**)&e->pts, (size_t)std::max(P.n_pt_slots, 1) * 10 * cap * sizeof(uint4)));
-  HIPCHK(hipMalloc((void**)&e->cmp, (size_t)std::max(P.n_cmp_slots, 1) * 2 * cap * sizeof(uint4)));
-  HIPCHK(hipMalloc((void**)&e->chal, (size_t)std::max(P.n_chal_slots, 1) * 2 * cap * sizeof(uint4)));
-  HIPCHK(hipMalloc((void**)&e->states, (size_t)std::max(P.n_state_slots, 1) * 52 * cap * sizeof(u32)));
-  HIPCHK(hipMalloc((void**)&e->flags, (size_t)std::max(P.n_flag_slots, 1) * cap * sizeof(u32)));
-  HIPCHK(hipMalloc((void**)&e->bad_item, cap * sizeof(u32)));
-  HIPCHK(hipMalloc((void**)&e->btab, std::max<size_t>(P.base_slots.size(), 1) * cap * BTAB_QUADS * sizeof(uint4)));
+  e->max_cap = env ? (u32)strtoul(env, nullptr, 10) : 262144u;
+  if (e->max_cap < NT) e->max_cap = NT;
+  e->max_cap = (e->max_cap + NT - 1) / NT * NT;
   HIPCHK(hipMalloc((void**)&e->partial, std::max<size_t>(P.tally_slots.size(), 1) * e->tally_blocks * 40 * sizeof(u32)));
   HIPCHK(hipMalloc((void**)&e->tally, std::max<size_t>(P.tally_slots.size(), 1) * 40 * sizeof(u32)));
   HIPCHK(hipMalloc((void**)&e->d_prefixes, (size_t)std::max(P.n_prefixes, 1) * 52 * sizeof(u32)));
@@ -273,7 +286,8 @@ static int engine_verify_device(Engine* e, size_t n, const void* d_ballots, void
   int rc;
   if ((rc = prof_begin(ctx, s, false, &all_idx))) return rc;
   // equal-sized chunks (each a multiple of the block size) so that the persistent grids stay balanced on the last chunk
-  const size_t n_chunks = (n + e->cap - 1) / e->cap;
+  const size_t n_chunks = (n + e->max_cap - 1) / e->max_cap;
+  if (n) { int rr = engine_reserve(e, (u32)(((n + n_chunks - 1) / n_chunks + NT - 1) / NT * NT)); if (rr) return rr; }
   const size_t even = n_chunks ? ((n + n_chunks - 1) / n_chunks + NT - 1) / NT * NT : 0;
   for (size_t off = 0; off < n; off += even) {
     const u32 cn = (u32)std::min<size_t>(even, n - off);
