@@ -28,6 +28,29 @@ sys.path.insert(0, str(ROOT))
 
 PUBLIC_KEY_HEX = "a6adb6e9c0ae8d54c26e6e56b5ccd7a16bb0e1951abe4d7ee7028e3d4eca8531"  # seed-12345 key of the snapshots
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# VALU model: field operations per building block counted by the host-check build
+# (tests/hostcheck: hc_op_counts) as (fe_mul, fe_sq); one fe_mul = 100 and one fe_sq = 55 v_mad_u64_u32.
+OPS = {"decode": (27, 257), "direct_table": (64, 0), "direct_mul": (1331, 1008), "comb": (224, 0), "encode": (32, 255),
+       "split_tables": (835, 768), "split_mul": (707, 240)}
+MAD_PEAK_T = 33.4              # profiles/r01_ubench_valu_rates.txt: v_mad_u64_u32, 8 waves/SIMD, T lane-ops/s chip-wide
+FMUL_PEAK_G = 256.0            # profiles/r01_ubench_fmul_candidates.txt: radix-25.5 field multiply, G/s chip-wide
+
+
+def choice_field_ops(n: int, single: bool):
+    """(fe_mul, fe_sq) per EncryptedChoice ballot of the shipped pipeline."""
+    def add(*xs):
+        return (sum(x[0] for x in xs), sum(x[1] for x in xs))
+
+    def mul(x, k):
+        return (x[0] * k, x[1] * k)
+
+    ring = add(OPS["split_mul"], OPS["comb"], OPS["encode"])
+    fold = add(ring, OPS["comb"])
+    total = add(mul(OPS["split_tables"], 2 * n), mul(ring, 3 * n), mul(fold, n), mul(OPS["decode"], 2 * n))
+    if single:
+        logeq = add(OPS["direct_table"], OPS["direct_mul"], OPS["comb"], OPS["encode"])
+        total = add(total, mul(logeq, 2), mul(OPS["encode"], 2))
+    return total
 # algorithmic bytes per ballot (SURVEY 8d) = packed ballot + 4-byte status word: 740 (single 5), 2084 (multi 16), 2148 (qv 5/20)
 
 
@@ -196,6 +219,22 @@ def main():
                     "throughput, see DESIGN.md",
         },
     }
+
+    if args.workload != "qv":
+        fm, fs = choice_field_ops(n_opt, args.workload == "single")
+        mads = fm * 100 + fs * 55
+        out["valu_roofline"] = {
+            "bound": "valu-int-mad",
+            "fe_mul_per_ballot": fm,
+            "fe_sq_per_ballot": fs,
+            "mad_per_ballot": mads,
+            "achieved": value / world * mads / 1e12,
+            "peak": MAD_PEAK_T,
+            "unit": "T v_mad_u64_u32 lane-ops/s per GPU",
+            "frac": value / world * mads / 1e12 / MAD_PEAK_T,
+            "fmul_equiv_frac": value / world * (fm + 0.6 * fs) / 1e9 / FMUL_PEAK_G,
+            "note": "algorithmic multiply-adds only (no carries, adds, selects, hashing); peaks measured on this chip",
+        }
 
     # ---- CPU baseline: the oracle ("port": CPU restatement, not curve25519-dalek) on a bounded sample --------------
     if not args.no_cpu_baseline and world == 1:

@@ -129,9 +129,9 @@ int hc_merlin(const char* label, const char* l1, const uint8_t* m1, int m1_len, 
 }
 
 // field operation counts of the hot-path building blocks: out[2*i], out[2*i+1] = (fe_mul, fe_sq) calls of
-// 0: ristretto_decode  1: table build  2: variable-base multiply  3: fixed-base multiply (64 windows)
-// 4: ristretto_encode
-void hc_op_counts(unsigned long long out[10]) {
+// 0: ristretto_decode  1: direct table build  2: direct variable-base multiply  3: fixed-base comb (32 windows)
+// 4: ristretto_encode  5: split-table build (per base)  6: split multiply (per equation)
+void hc_op_counts(unsigned long long out[14]) {
   if (g_base_table.e.empty()) { ge g; ge_generator(g); build_fixed(g_base_table, g); }
   u32 gw[8] = {0x0aaef2e2u, 0x714ebc6au, 0x61a984a8u, 0x5f5100c5u, 0x6a0be358u, 0x8ddd82a5u, 0x4559a6b6u, 0x762d8de0u};
   u32 k[8] = {0x12345678u, 0x9abcdef0u, 0x0fedcba9u, 0x87654321u, 0x11111111u, 0x22222222u, 0x33333333u, 0x04444444u};
@@ -148,6 +148,10 @@ void hc_op_counts(unsigned long long out[10]) {
   ge_fixed_mul_add(acc, g_base_table, dg8); snap(3, m0, s0);
   m0 = g_fe_mul_count; s0 = g_fe_sq_count;
   u32 o[8]; ristretto_encode(o, acc); snap(4, m0, s0);
+  m0 = g_fe_mul_count; s0 = g_fe_sq_count;
+  ArrSplit st; ge_split_tables_build(st, p); snap(5, m0, s0);
+  m0 = g_fe_mul_count; s0 = g_fe_sq_count;
+  ge_split_mul(acc, st, dg); snap(6, m0, s0);
 }
 
 void hc_fe_roundtrip(const uint8_t in[32], uint8_t out[32]) {

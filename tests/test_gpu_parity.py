@@ -370,3 +370,54 @@ def test_qv_generator_matches_oracle_prover(eg, ctx, oracle, pk):
         assert got == oq.generate_batch(31, 5, n), credits
         st, _ = q.verify_batch(got)
         assert st == [0] * n
+
+
+# ------------------------------------------------------------------ BASELINE.json full sizes, size-independent properties
+@pytest.mark.parametrize("workload,n", [("single", 1_000_000), ("multi", 250_000), ("qv", 250_000)])
+def test_full_size_properties(eg, ctx, oracle, pk, workload, n):
+    """configs[1] (1M single-choice) at full size, configs[2]/[3] at 250k: ballots generated on the GPU, 1 % tampered.
+    Properties: exactly the tampered ballots are rejected; tally(A ++ B) == tally(A) + tally(B); verdicts and tally of a
+    random sample are bit-exact against the oracle."""
+    import torch
+
+    if workload == "single":
+        p = eg.ChoiceParams(ctx, pk, 5, True); op = oracle.ChoiceParams(pk, 5, True); kw = {}
+    elif workload == "multi":
+        p = eg.ChoiceParams(ctx, pk, 16, False); op = oracle.ChoiceParams(pk, 16, False); kw = {"n_selected": 3}
+    else:
+        p = eg.QuadraticVotingParams(ctx, pk, 5, 20); op = oracle.QvParams(pk, 5, 20); kw = {}
+    sz = p.ballot_size
+    d = torch.empty(n * sz, dtype=torch.uint8, device="cuda")
+    p.encrypt_batch_device(2026, 0, n, d.data_ptr(), **kw)
+    ctx.synchronize()
+    g = torch.Generator(device="cpu").manual_seed(n)
+    bad = torch.randperm(n, generator=g)[: n // 100].cuda()
+    # flip one bit of the LAST response scalar of the ballot (keeps it canonical with overwhelming probability)
+    view = d.view(n, sz)
+    view[bad, sz - 32] ^= 1
+    st = torch.empty(n, dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    p.tally_reset()
+    p.verify_batch_device(n, d.data_ptr(), st.data_ptr(), stream)
+    torch.cuda.synchronize()
+    whole = p.tally_encode()
+    rejected = torch.nonzero(st != 0).flatten()
+    assert torch.equal(torch.sort(rejected).values, torch.sort(bad).values)
+    # linearity over a split of the batch
+    half = (n // 2)
+    p.tally_reset()
+    p.verify_batch_device(half, d.data_ptr(), st.data_ptr(), stream)
+    torch.cuda.synchronize()
+    ta = p.tally_encode()
+    p.tally_reset()
+    p.verify_batch_device(n - half, d.data_ptr() + half * sz, st.data_ptr() + 4 * half, stream)
+    torch.cuda.synchronize()
+    tb = p.tally_encode()
+    summed, ok = eg.Ristretto(ctx).element_add(ta, tb)
+    assert summed == whole and set(ok) == {1}
+    # oracle on a sample that contains tampered ballots
+    idx = torch.cat([bad[:20], torch.randperm(n, generator=g)[:44].cuda()]).cpu().tolist()
+    sample = b"".join(bytes(view[i].cpu().numpy()) for i in idx)
+    got, gt = p.verify_batch(sample)
+    want = op.verify_batch(sample)
+    assert got == want and gt == op.tally(sample, want)
