@@ -94,6 +94,9 @@ def main() -> None:
         "packed": (unb64(y["challenge"]) + b"".join(unb64(s) for s in y["ciphertext_responses"])
                    + unb64(y["sum_response"])).hex(),
     }
+    serde = {name: yaml.safe_load(load(name)) for name in
+             ("encrypted-choice", "encrypted-multi-choice", "qv-ballot", "range-encryption")}
+    (OUT.parent / "snapshots_serde.json").write_text(json.dumps(serde, indent=1) + "\n")
     OUT.write_text(json.dumps(out, indent=1) + "\n")
     print(f"wrote {OUT}", file=sys.stderr)
 
