@@ -212,9 +212,13 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved_gbs / HBM_PEAK_GBS,
-            "traffic": (MSM_TRAFFIC_BYTES_PER_BALLOT_LAUNCH[args.workload] * units_per_launch / 1e9
-                        if args.workload in MSM_TRAFFIC_BYTES_PER_BALLOT_LAUNCH and n_opt == 5 else None),
-            "traffic_unit": "GB per launch (rocprofv3 PMC passes, profiles/r01_bench_pmc_counters.txt; table lookups, not ballots)",
+            "traffic": (MSM_TRAFFIC_BYTES_PER_BALLOT_LAUNCH[args.workload] * units_per_launch / (avg_launch_ms * 1e-3) / 1e9
+                        if args.workload in MSM_TRAFFIC_BYTES_PER_BALLOT_LAUNCH and n_opt == 5 and avg_launch_ms > 0 else None),
+            "traffic_bytes_per_launch": (MSM_TRAFFIC_BYTES_PER_BALLOT_LAUNCH[args.workload] * units_per_launch
+                                         if args.workload in MSM_TRAFFIC_BYTES_PER_BALLOT_LAUNCH and n_opt == 5 else None),
+            "traffic_note": "GB/s like `achieved`: memory-side bytes per launch from separate rocprofv3 PMC passes (FETCH_SIZE x2 "
+                            "gfx950 correction + WRITE_SIZE, profiles/r01_bench_pmc_counters.txt) / this run's launch time; "
+                            "it is the per-ballot table lookups, not the ballots",
             "avg_launch_ms": avg_launch_ms,
             "launches_per_step": launches_per_step,
             "units_per_launch": units_per_launch,

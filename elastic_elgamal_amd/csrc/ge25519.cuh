@@ -333,7 +333,12 @@ EG_HD void ge_var_mul(ge& acc, TableIO& io, const u32 digits[8]) {
     fe_cmov(c.Z2, ident.Z2, ad == 0); fe_cmov(c.T2d, ident.T2d, ad == 0);
     ge_cached_cneg(c, d < 0);
     ge_add(t, acc, c);
-    ge_add_to_p3(acc, t);
+    if (i > 0) {                      // next operation is a doubling: T is not needed
+      ge_p2 q2; ge_add_to_p2(q2, t);
+      acc.X = q2.X; acc.Y = q2.Y; acc.Z = q2.Z;
+    } else {
+      ge_add_to_p3(acc, t);
+    }
   }
 }
 
@@ -409,7 +414,12 @@ EG_HD void ge_split_mul(ge& acc, TableIO& io, const u32 digits[8]) {
       ge_split_fixup(c, digits, j, i, ident);
       ge_p1p1 t;
       ge_add(t, acc, c);
-      ge_add_to_p3(acc, t);
+      if (j == 3 && i > 0) {          // next operation is a doubling: T is not needed (saves one multiplication)
+        ge_p2 q; ge_add_to_p2(q, t);
+        acc.X = q.X; acc.Y = q.Y; acc.Z = q.Z;
+      } else {
+        ge_add_to_p3(acc, t);
+      }
     }
   }
 }

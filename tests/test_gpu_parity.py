@@ -421,3 +421,43 @@ def test_full_size_properties(eg, ctx, oracle, pk, workload, n):
     got, gt = p.verify_batch(sample)
     want = op.verify_batch(sample)
     assert got == want and gt == op.tally(sample, want)
+
+
+# ------------------------------------------------------------------ degenerate inputs
+def test_degenerate_points_and_scalars(eg, ctx, oracle, pk):
+    """Identity elements (all-zero encodings are valid ristretto points), zero and l-1 scalars, repeated points:
+    whatever the reference's arithmetic yields, the GPU must report the same verdict bits as the oracle."""
+    rnd = random.Random(99)
+    op = oracle.ChoiceParams(pk, 5, True)
+    p = eg.ChoiceParams(ctx, pk, 5, True)
+    base = bytearray(op.generate_batch(606, 0, 24))
+    sz = op.ballot_size
+    zero32, lm1 = b"\0" * 32, (L - 1).to_bytes(32, "little")
+    g = oracle.const_bytes(4)
+    def put(i, item, val):
+        base[i * sz + 32 * item : i * sz + 32 * item + 32] = val
+    put(0, 0, zero32)                      # R_0 = identity
+    put(1, 1, zero32)                      # B_0 = identity
+    for it in range(10): put(2, it, zero32)   # every ciphertext element = identity
+    put(3, 10, zero32)                     # common challenge = 0
+    put(4, 11, zero32); put(4, 12, zero32)  # responses = 0
+    put(5, 10, lm1)                        # challenge = l - 1
+    put(6, 13, lm1)
+    put(7, 21, zero32); put(7, 22, zero32)  # sum proof (0, 0)
+    for it in range(10): put(8, it, g)      # all elements = generator
+    put(9, 0, bytes(base[9 * sz + 32 : 9 * sz + 64]))   # R_0 = B_0
+    put(10, 2, pk); put(10, 3, pk)          # ciphertext made of the public key
+    for it in range(23): put(11, it, zero32)  # entirely zero ballot
+    ballots = bytes(base)
+    want = op.verify_batch(ballots)
+    got, tally = p.verify_batch(ballots)
+    assert got == want
+    assert tally == op.tally(ballots, want)
+    assert want[:12].count(0) == 0 and want[12:] == [0] * 12
+    # the same through the primitive tier: identity / zero-scalar corner cases of the scalar multiplication
+    grp = eg.Ristretto(ctx)
+    ks = [zero32, (1).to_bytes(32, "little"), lm1, (8).to_bytes(32, "little")]
+    pts = [zero32, g, pk, zero32]
+    out, ok = grp.vartime_double_mul_generator(b"".join(ks), b"".join(pts), b"".join(reversed(ks)))
+    for i in range(4):
+        assert out[32 * i : 32 * i + 32] == oracle.point_double_mul_generator(ks[i], pts[i], ks[3 - i])
