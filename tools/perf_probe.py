@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Developer probe (not the benchmark): time verify on GPU-generated (or, for QV, oracle-generated) ballots.
+"""Developer probe (not the benchmark): time verify on GPU-generated ballots.
 usage: perf_probe.py <n_total> <single|multi|qv> [iters]      (EG_LIB selects an alternate library build)"""
 import sys, time, os
 from pathlib import Path
@@ -20,11 +20,8 @@ elif mode == "multi":
     p = eg.ChoiceParams(ctx, pk, 16, False); d = torch.empty(n_total * p.ballot_size, dtype=torch.uint8, device="cuda")
     p.encrypt_batch_device(1, 0, n_total, d.data_ptr(), n_selected=3); ctx.synchronize()
 else:
-    from oracle import oracle as o
-    op = o.QvParams(pk, 5, 20); p = eg.QuadraticVotingParams(ctx, pk, 5, 20)
-    n_unique = min(n_total, 16384); uniq = op.generate_batch(1, 0, n_unique)
-    reps = (n_total + n_unique - 1) // n_unique
-    d = torch.frombuffer(bytearray(uniq), dtype=torch.uint8).repeat(reps)[: n_total * p.ballot_size].cuda()
+    p = eg.QuadraticVotingParams(ctx, pk, 5, 20); d = torch.empty(n_total * p.ballot_size, dtype=torch.uint8, device="cuda")
+    p.encrypt_batch_device(1, 0, n_total, d.data_ptr()); ctx.synchronize()
 st = torch.empty(n_total, dtype=torch.int32, device="cuda")
 ctx.profile_enable(True)
 best = 0
