@@ -130,6 +130,8 @@ def _load() -> C.CDLL:
         "eg_choice_encrypt_batch": (C.c_int, [vp, C.c_uint64, sz, sz, C.c_int, cp]),
         "eg_choice_encrypt_batch_device": (C.c_int, [vp, C.c_uint64, sz, sz, C.c_int, vp, vp]),
         "eg_qv_encrypt_batch_device": (C.c_int, [vp, C.c_uint64, sz, sz, vp, vp]),
+        "eg_range_decomposition": (C.c_int, [C.c_uint64, cp, sz]),
+        "eg_plan_describe": (C.c_int, [C.c_int, C.c_int, C.c_uint64, cp, sz]),
         "eg_profile_enable": (C.c_int, [vp, C.c_int]),
         "eg_profile_read": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
     }
@@ -139,6 +141,23 @@ def _load() -> C.CDLL:
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def range_decomposition(upper_bound: int) -> str:
+    """``RangeDecomposition::optimal(upper_bound).to_string()`` by the product's host code (no GPU needed)."""
+    b = C.create_string_buffer(1024)
+    _check(_load().eg_range_decomposition(upper_bound, b, 1024))
+    return b.value.decode()
+
+
+def plan_describe(kind: str, n_options: int = 0, credits_or_bound: int = 0) -> dict:
+    """Summary of the flattened verification plan (host logic only, no GPU needed)."""
+    import json
+
+    kinds = {"single": 0, "multi": 1, "qv": 2, "zero": 3, "bool": 4, "range": 5}
+    b = C.create_string_buffer(2048)
+    _check(_load().eg_plan_describe(kinds[kind], n_options, credits_or_bound, b, 2048))
+    return json.loads(b.value.decode())
 
 
 def exported_symbols():

@@ -698,6 +698,47 @@ int eg_verify_proof_batch_device(eg_proof_params* p, size_t n, const void* d_ite
   return engine_verify_device(p->eng, n, d_items, d_status, (hipStream_t)stream);
 }
 
+// ---- host-only introspection (no GPU needed): the product's own RangeDecomposition and plan builders ----------------------------
+int eg_range_decomposition(uint64_t upper_bound, char* buf, size_t cap) {
+  if (upper_bound < 2 || !buf || cap == 0) return fail(EG_ERR_BAD_ARG, "upper_bound must be >= 2");   // range.rs:160
+  const std::string t = eghost::optimal_range(upper_bound).to_string();
+  if (t.size() + 1 > cap) return fail(EG_ERR_BAD_ARG, "buffer too small");
+  memcpy(buf, t.c_str(), t.size() + 1);
+  return EG_OK;
+}
+int eg_plan_describe(int kind, int n_options, uint64_t credits_or_bound, char* buf, size_t cap) {
+  if (!buf || cap == 0) return fail(EG_ERR_BAD_ARG, "bad argument");
+  eghost::Plan P;
+  size_t item = 0;
+  switch (kind) {
+    case 0: P = eghost::build_choice_plan(n_options, true); break;
+    case 1: P = eghost::build_choice_plan(n_options, false); break;
+    case 2: P = eghost::build_qv_plan(n_options, credits_or_bound); break;
+    case 3: P = eghost::build_zero_plan(); break;
+    case 4: P = eghost::build_bool_plan(); break;
+    case 5: P = eghost::build_range_plan(credits_or_bound, &item); break;
+    default: return fail(EG_ERR_BAD_ARG, "unknown plan kind");
+  }
+  size_t jobs = 0, insts = 0, var_terms = P.vterms.size(), split_terms = 0, derived = 0;
+  std::string per_stage;
+  for (auto& st : P.stages) {
+    jobs += st.jobs.size(); insts += st.insts.size();
+    per_stage += (per_stage.empty() ? "" : ",") + std::to_string(st.jobs.size());
+  }
+  for (auto& t : P.vterms) split_terms += t.base != 0xffff;
+  for (auto& l : P.derive_levels) derived += l.size();
+  char tmp[1024];
+  snprintf(tmp, sizeof tmp,
+           "{\"stride\": %zu, \"wire_points\": %zu, \"wire_scalars\": %zu, \"derived_points\": %zu, \"bases\": %zu, "
+           "\"stages\": %zu, \"jobs\": %zu, \"jobs_per_stage\": [%s], \"var_terms\": %zu, \"split_terms\": %zu, "
+           "\"hash_programs\": %zu, \"prefixes\": %d, \"flags\": %d, \"rules\": %zu, \"tally_slots\": %zu}",
+           P.stride, P.pt_items.size(), P.sc_items.size(), derived, P.base_slots.size(), P.stages.size(), jobs, per_stage.c_str(),
+           var_terms, split_terms, insts, P.n_prefixes, P.n_flag_slots, P.rules.size(), P.tally_slots.size());
+  if (strlen(tmp) + 1 > cap) return fail(EG_ERR_BAD_ARG, "buffer too small");
+  memcpy(buf, tmp, strlen(tmp) + 1);
+  return EG_OK;
+}
+
 // ---- synthetic ballots ---------------------------------------------------------------------------------------------------------
 int eg_choice_encrypt_batch_device(eg_choice_params* p, uint64_t base_seed, size_t first, size_t n, int n_selected, void* d_out,
                                    void* stream) {

@@ -165,6 +165,13 @@ int eg_choice_encrypt_batch(eg_choice_params*, uint64_t base_seed, size_t first,
                             uint8_t* out /* host, n * eg_choice_ballot_size */);
 int eg_qv_encrypt_batch_device(eg_qv_params*, uint64_t base_seed, size_t first, size_t n, void* d_out, void* stream);
 
+/* ---- host-only introspection (no GPU needed; used by the CPU-side tests of the host logic) -------------------------------------
+ * RangeDecomposition::optimal(upper_bound).to_string() (range.rs:110-124,148-305): the string hashed into the transcript */
+int eg_range_decomposition(uint64_t upper_bound, char* buf, size_t cap);
+/* JSON summary of the verification plan: kind 0 single-choice, 1 multi-choice, 2 quadratic voting (credits), 3 verify_zero,
+ * 4 verify_bool, 5 verify_range (upper bound) */
+int eg_plan_describe(int kind, int n_options, uint64_t credits_or_bound, char* buf, size_t cap);
+
 /* ---- measurement hooks (bench.py) ------------------------------------------------------------------------------------------
  * Average duration in milliseconds of the dominant kernel (k_msm_jobs) over the launches since the last reset,
  * measured with HIP events on the stream the kernel was launched on; launches = number of launches averaged. */

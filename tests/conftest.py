@@ -25,3 +25,12 @@ def oracle():
 
     o.lib()
     return o
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _product_library_built():
+    """The in-tree libeg_hip.so normally travels with the snapshot; build it (hipcc, no GPU needed) if it is missing."""
+    import elastic_elgamal_amd as eg
+
+    if not eg.library_path().exists():
+        eg.build()

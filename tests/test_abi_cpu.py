@@ -62,3 +62,50 @@ def test_cpp_host_header_compiles(tmp_path, lib_path):
                            f"-L{root / 'elastic_elgamal_amd'}", "-leg_hip", f"-Wl,-rpath,{root / 'elastic_elgamal_amd'}",
                            "-o", str(exe)])
     assert exe.exists()
+
+
+@pytest.mark.parametrize(
+    "ub,text",
+    [
+        (5, "0..5"), (10, "2 * 0..5 + 0..2"), (16, "4 * 0..4 + 0..4"), (17, "4 * 0..4 + 0..5"), (20, "4 * 0..5 + 0..4"),
+        (21, "3 * 0..7 + 0..3"), (42, "6 * 0..7 + 0..6"), (60, "12 * 0..5 + 3 * 0..4 + 0..3"),
+        (100, "20 * 0..5 + 4 * 0..5 + 0..4"), (101, "20 * 0..5 + 4 * 0..5 + 0..5"),
+        (1000, "125 * 0..8 + 25 * 0..5 + 5 * 0..5 + 0..5"),
+        (12345, "2880 * 0..4 + 720 * 0..5 + 90 * 0..9 + 15 * 0..7 + 3 * 0..5 + 0..3"),
+        (777777, "125440 * 0..6 + 25088 * 0..6 + 3136 * 0..8 + 784 * 0..4 + 196 * 0..4 + 49 * 0..5 + 7 * 0..7 + 0..7"),
+        (12345678, "3072000 * 0..4 + 768000 * 0..4 + 192000 * 0..4 + 48000 * 0..5 + 9600 * 0..6 + 1200 * 0..8 + 300 * 0..4 + "
+                   "75 * 0..5 + 15 * 0..5 + 3 * 0..6 + 0..3"),
+    ],
+)
+def test_product_range_decomposition_known_answers(lib_path, ub, text):
+    # the reference's known answers (range.rs:592-662 and the doc table :56-65) against the PRODUCT's host code
+    import elastic_elgamal_amd as eg
+
+    assert eg.range_decomposition(ub) == text
+
+
+def test_product_range_decomposition_matches_oracle(lib_path, oracle):
+    import elastic_elgamal_amd as eg
+
+    for ub in list(range(2, 200)) + [255, 256, 257, 500, 999, 1024, 4096, 65535]:
+        assert eg.range_decomposition(ub) == oracle.PreparedRange(ub).name, ub
+    with pytest.raises(eg.EgError):
+        eg.range_decomposition(1)
+
+
+def test_plan_shapes(lib_path):
+    import elastic_elgamal_amd as eg
+
+    a = eg.plan_describe("single", 5)
+    assert a["stride"] == 736 and a["wire_points"] == 10 and a["wire_scalars"] == 13
+    assert a["stages"] == 2 and a["jobs_per_stage"] == [14, 10] and a["bases"] == 10
+    assert a["split_terms"] == 20 and a["var_terms"] == 22 and a["rules"] == 2 and a["tally_slots"] == 10
+    c = eg.plan_describe("multi", 16)
+    assert c["stride"] == 2080 and c["wire_points"] == 32 and c["wire_scalars"] == 33 and c["jobs_per_stage"] == [32, 32]
+    b = eg.plan_describe("qv", 5, 20)
+    assert b["stride"] == 2144 and b["wire_points"] == 14 and b["wire_scalars"] == 53
+    assert b["stages"] == 7                                            # longest ring: 0..7 of the credit range
+    # 35 ring equations x 2 + 5 x 2 + 2 sum-of-squares equations + 2 encodes of the derived last credit ciphertext
+    assert b["jobs"] == 70 + 12 + 2 and b["rules"] == 7
+    assert eg.plan_describe("zero")["stride"] == 128 and eg.plan_describe("bool")["stride"] == 160
+    assert eg.plan_describe("range", 0, 100)["stride"] == 672
