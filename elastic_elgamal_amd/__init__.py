@@ -20,7 +20,7 @@ import os
 from pathlib import Path
 
 __all__ = [
-    "Context", "Ristretto", "ChoiceParams", "QuadraticVotingParams", "PublicKeyVerifier", "EgError", "library_path", "build",
+    "Context", "Ristretto", "ChoiceParams", "QuadraticVotingParams", "PublicKeyVerifier", "DecryptionShareVerifier", "EgError", "library_path", "build",
     "STATUS_NAMES", "status_kind", "status_detail",
 ]
 
@@ -123,6 +123,7 @@ def _load() -> C.CDLL:
         "eg_qv_tally_encode_device": (C.c_int, [vp, vp, vp]),
         "eg_points_sum_device": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp]),
         "eg_proof_params_create": (C.c_int, [vp, cp, C.c_int, C.c_uint64, C.POINTER(vp)]),
+        "eg_share_params_create": (C.c_int, [vp, cp, C.c_uint64, C.c_uint64, C.c_uint64, cp, C.POINTER(vp)]),
         "eg_proof_params_destroy": (None, [vp]),
         "eg_proof_item_size": (sz, [vp]),
         "eg_verify_proof_batch": (C.c_int, [vp, sz, vp, vp]),
@@ -401,6 +402,17 @@ class PublicKeyVerifier:
             self.close()
         except Exception:
             pass
+
+
+class DecryptionShareVerifier(PublicKeyVerifier):
+    """Batched ``PublicKeySet::verify_share`` for one participant (src/sharing/key_set.rs:209-228).
+    item = ciphertext.random_element || dh_element || challenge || response."""
+
+    def __init__(self, ctx: Context, shared_key: bytes, shares: int, threshold: int, index: int, participant_key: bytes):
+        self.ctx, self.kind = ctx, 3
+        self._h = C.c_void_p()
+        _check(_load().eg_share_params_create(ctx._h, shared_key, shares, threshold, index, participant_key, C.byref(self._h)))
+        self.item_size = _load().eg_proof_item_size(self._h)
 
 
 class QuadraticVotingParams(_BatchParams):

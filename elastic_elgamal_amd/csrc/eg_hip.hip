@@ -686,6 +686,15 @@ int eg_proof_params_create(eg_ctx* c, const uint8_t pk[32], int kind, uint64_t u
   *out = new eg_proof_params{e, kind, item};
   return EG_OK;
 }
+int eg_share_params_create(eg_ctx* c, const uint8_t shared_key[32], uint64_t shares, uint64_t threshold, uint64_t index,
+                           const uint8_t participant_key[32], eg_proof_params** out) {
+  if (!c || !shared_key || !participant_key || !out) return fail(EG_ERR_BAD_ARG, "bad argument");
+  if (shares < 1 || threshold < 1 || threshold > shares || index >= shares) return fail(EG_ERR_BAD_ARG, "bad sharing parameters");
+  Engine* e = nullptr;
+  TRY(engine_create(c, eghost::build_share_plan(shares, threshold, shared_key, index), participant_key, 0, &e));
+  *out = new eg_proof_params{e, 3, 128};
+  return EG_OK;
+}
 void eg_proof_params_destroy(eg_proof_params* p) { if (p) { engine_free(p->eng); delete p; } }
 size_t eg_proof_item_size(const eg_proof_params* p) { return p ? p->item_size : 0; }
 int eg_verify_proof_batch(eg_proof_params* p, size_t n, const uint8_t* items, uint32_t* status) {

@@ -495,4 +495,36 @@ inline Plan build_range_plan(uint64_t upper_bound, size_t* item_size) {   // ct 
   return P;
 }
 
+// ---- PublicKeySet::verify_share (sharing/key_set.rs:209-228): item = R(32) || dh(32) || challenge || response -------------
+// LogEqualityProof with log_base = the ciphertext's random element R (per item) and powers = (participant key, dh):
+//   X_G = [s]G - [c]KS   (KS = participant key: the engine's fixed base "K")      X_K = [s]R - [c]dh
+inline Plan build_share_plan(uint64_t shares, uint64_t threshold, const uint8_t shared_key[32], uint64_t index) {
+  Plan P;
+  P.stride = 128;
+  const uint16_t R = P.wire_point(0), dh = P.wire_point(1);
+  P.wire_scalar(2); P.wire_scalar(3);
+  const uint32_t pre = P.new_prefix();
+  const std::string shared(reinterpret_cast<const char*>(shared_key), 32);
+  P.prefix_programs.push_back({{OP_NEW, P.ref("elgamal_decryption_share"), 0, 0},
+                               {OP_APPEND_U64, P.ref("n"), (uint32_t)shares, 0},          // key_set.rs:167-171
+                               {OP_APPEND_U64, P.ref("t"), (uint32_t)threshold, 0},
+                               {OP_APPEND_BLOB, P.ref("K"), P.ref(shared), 0},
+                               {OP_APPEND_U64, P.ref("i"), (uint32_t)index, 0},
+                               {OP_APPEND_BLOB, P.ref("dom-sep"), P.ref("log_eq"), 0},
+                               {OP_SAVE_PREFIX, 0, pre, 0}});
+  const ScalarSrc c = wire_src(2, true), s = wire_src(3);
+  const uint16_t xg = P.job(0, {}, s, c);                               // [s]G + [-c]KS
+  const uint16_t xk = P.job(0, {P.term(dh, c), P.term(R, s)}, no_src(), no_src());
+  const uint16_t flag = P.new_flag();
+  P.stage(0).insts.push_back({{OP_LOAD_PREFIX, 0, pre, 0},
+                              {OP_APPEND_WIRE, P.ref("K"), 0, 1},        // log_base bytes = R as sent
+                              {OP_APPEND_BLOB, P.ref("[r]G"), P.pk_ref(), 0},   // participant key bytes
+                              {OP_APPEND_WIRE, P.ref("[r]K"), 1, 1},
+                              {OP_APPEND_CMP, P.ref("[x]G"), xg, 0xffff},
+                              {OP_APPEND_CMP, P.ref("[x]K"), xk, 0xffff},
+                              {OP_CHALLENGE_CHECK, P.ref("c"), 2, flag}});
+  P.rules.push_back({flag, 4});
+  return P;
+}
+
 }  // namespace eghost

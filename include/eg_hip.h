@@ -149,6 +149,11 @@ int eg_qv_tally_encode_device(eg_qv_params*, void* d_out, void* stream);
 typedef struct eg_proof_params eg_proof_params;
 enum { EG_PROOF_ZERO = 0, EG_PROOF_BOOL = 1, EG_PROOF_RANGE = 2 };
 int eg_proof_params_create(eg_ctx*, const uint8_t pk[32], int kind, uint64_t upper_bound, eg_proof_params** out);
+/* PublicKeySet::verify_share (sharing/key_set.rs:209-228) for one participant: item = the ciphertext's
+ * random element R(32) || decryption share dh(32) || challenge || response; status EG_ST_SUM_CHALLENGE on ChallengeMismatch.
+ * Verify with eg_verify_proof_batch. */
+int eg_share_params_create(eg_ctx*, const uint8_t shared_key[32], uint64_t shares, uint64_t threshold, uint64_t index,
+                           const uint8_t participant_key[32], eg_proof_params** out);
 void eg_proof_params_destroy(eg_proof_params*);
 size_t eg_proof_item_size(const eg_proof_params*);
 int eg_verify_proof_batch(eg_proof_params*, size_t n, const uint8_t* items, uint32_t* status);

@@ -97,6 +97,8 @@ def _declare(l: C.CDLL) -> None:
         "or_choice_verify_batch": (None, [vp, C.c_size_t, vp, vp, C.c_int]),
         "or_qv_verify_batch": (None, [vp, C.c_size_t, vp, vp, C.c_int]),
         "or_tally": (None, [C.c_int, C.c_size_t, C.c_size_t, vp, vp, C.c_size_t, C.c_size_t, vp]),
+        "or_decryption_share_new": (C.c_int, [u8p, u8p, C.c_uint64, C.c_uint64, u8p, C.c_uint64, C.POINTER(ChaChaRng), u8p]),
+        "or_decryption_share_verify": (C.c_uint32, [u8p, C.c_uint64, C.c_uint64, u8p, C.c_uint64, u8p]),
         "or_point_double_mul_generator": (C.c_int, [u8p, u8p, u8p, u8p]),
         "or_point_multi_mul": (C.c_int, [C.c_size_t, u8p, u8p, u8p]),
         "or_point_mul_generator": (None, [u8p, u8p]),
@@ -405,3 +407,16 @@ def select_qv(seed: int, n: int, credits: int):
     v = (C.c_uint64 * n)()
     lib().or_select_qv(seed, n, credits, v)
     return list(v)
+
+
+def decryption_share_new(sk_share: bytes, ct_random: bytes, shares: int, threshold: int, shared_key: bytes, index: int, rng) -> bytes:
+    """dh || challenge || response for one participant and one ciphertext (participant.rs:163-186)."""
+    out = _buf(96)
+    rc = lib().or_decryption_share_new(sk_share, ct_random, shares, threshold, shared_key, index, C.byref(rng), out)
+    if rc:
+        raise ValueError("invalid ciphertext element")
+    return out.raw
+
+
+def decryption_share_verify(key_share: bytes, shares: int, threshold: int, shared_key: bytes, index: int, item: bytes) -> int:
+    return lib().or_decryption_share_verify(key_share, shares, threshold, shared_key, index, item)

@@ -434,6 +434,51 @@ void or_qv_new(const or_qv_params *p, const uint64_t *votes, chacha_rng *rng, ui
   free(cts);
 }
 
+/* ------------------------------------------------------------------ decryption shares (tally stage) */
+
+static void share_transcript(merlin_t *t, uint64_t shares, uint64_t threshold, const uint8_t shared_key[32], uint64_t index) {
+  /* PublicKeySet::verify_share / ActiveParticipant::decrypt_share: sharing/key_set.rs:209-228,167-171 */
+  or_merlin_init(t, "elgamal_decryption_share");
+  or_merlin_append_u64(t, "n", shares);
+  or_merlin_append_u64(t, "t", threshold);
+  or_merlin_append(t, "K", shared_key, 32);
+  or_merlin_append_u64(t, "i", index);
+}
+
+/* out = dh(32) || challenge || response : dh = [sk_share]R with a log-equality proof (participant.rs:163-186) */
+int or_decryption_share_new(const uint8_t sk_share[32], const uint8_t ct_random[32], uint64_t shares, uint64_t threshold,
+                            const uint8_t shared_key[32], uint64_t index, chacha_rng *rng, uint8_t out[96]) {
+  or_pubkey base;   /* log_base = PublicKey::from_element(ciphertext.random_element) */
+  if (!or_ristretto_decode(&base.element, ct_random)) return -1;
+  memcpy(base.bytes, ct_random, 32);
+  base.ktable = NULL;
+  ge dh, ks;
+  or_ge_scalarmult(&dh, (const sc *)sk_share, &base.element);
+  or_ge_mul_generator(&ks, (const sc *)sk_share);
+  or_ristretto_encode(out, &dh);
+  merlin_t t;
+  share_transcript(&t, shares, threshold, shared_key, index);
+  logeq_new(&base, (const sc *)sk_share, &ks, &dh, &t, rng, (sc *)(out + 32), (sc *)(out + 64));
+  return 0;
+}
+
+/* item = R(32) || dh(32) || challenge || response */
+uint32_t or_decryption_share_verify(const uint8_t key_share[32], uint64_t shares, uint64_t threshold,
+                                    const uint8_t shared_key[32], uint64_t index, const uint8_t item[128]) {
+  or_pubkey base;
+  ge ks, dh;
+  if (!or_ristretto_decode(&base.element, item)) return OR_STATUS(OR_BAD_POINT, 0);
+  if (!or_ristretto_decode(&dh, item + 32)) return OR_STATUS(OR_BAD_POINT, 1);
+  if (!or_sc_is_canonical(item + 64)) return OR_STATUS(OR_BAD_SCALAR, 2);
+  if (!or_sc_is_canonical(item + 96)) return OR_STATUS(OR_BAD_SCALAR, 3);
+  if (!or_ristretto_decode(&ks, key_share)) return OR_STATUS(OR_BAD_POINT, 0xffff);
+  memcpy(base.bytes, item, 32);
+  base.ktable = NULL;
+  merlin_t t;
+  share_transcript(&t, shares, threshold, shared_key, index);
+  return or_logeq_verify(&base, &ks, &dh, (const sc *)(item + 64), (const sc *)(item + 96), &t) ? OR_OK : OR_SUM_CHALLENGE;
+}
+
 /* ------------------------------------------------------------------ selection streams */
 
 static uint32_t sel_next(chacha_rng *r, uint8_t buf[64], int *pos) {

@@ -461,3 +461,47 @@ def test_degenerate_points_and_scalars(eg, ctx, oracle, pk):
     out, ok = grp.vartime_double_mul_generator(b"".join(ks), b"".join(pts), b"".join(reversed(ks)))
     for i in range(4):
         assert out[32 * i : 32 * i + 32] == oracle.point_double_mul_generator(ks[i], pts[i], ks[3 - i])
+
+
+# ------------------------------------------------------------------ tally stage: decryption shares
+def test_threshold_tally_end_to_end(eg, ctx, oracle):
+    """examples/voting.rs:122-177 shape with a 7-of-10 key: verify ballots, tally, every tallier's decryption share is
+    verified on the GPU (PublicKeySet::verify_share), 7 shares are combined (Lagrange in the exponent) and the totals
+    are read off a discrete-log table; a forged share is rejected."""
+    from elastic_elgamal_amd import tally as T
+
+    rnd = random.Random(2024)
+    shares_n, threshold, n_opt, votes = 10, 7, 5, 60
+    coeffs = [rnd.randrange(L) for _ in range(threshold)]               # Shamir polynomial, secret = coeffs[0]
+    f = lambda x: sum(c * pow(x, k, L) for k, c in enumerate(coeffs)) % L
+    sk_shares = [f(i + 1) for i in range(shares_n)]
+    shared_key = oracle.point_mul_generator(sc(coeffs[0]))
+    part_keys = [oracle.point_mul_generator(sc(s)) for s in sk_shares]
+    grp = eg.Ristretto(ctx)
+    params = eg.ChoiceParams(ctx, shared_key, n_opt, True)
+    ballots = params.encrypt_batch(55, 0, votes)
+    expected = [0] * n_opt
+    for i in range(votes):
+        expected[oracle.select_single(55 + i, n_opt).index(1)] += 1
+    st, totals = params.verify_batch(ballots)
+    assert st == [0] * votes
+    rng = oracle.rng_from_u64(1)
+    table = T.DiscreteLogTable(grp, range(votes + 1))
+    verifiers = [eg.DecryptionShareVerifier(ctx, shared_key, shares_n, threshold, i, part_keys[i]) for i in range(shares_n)]
+    got = []
+    for k in range(n_opt):
+        ct = totals[64 * k : 64 * k + 64]
+        verified = []
+        for i in rnd.sample(range(shares_n), shares_n):
+            share = oracle.decryption_share_new(sc(sk_shares[i]), ct[:32], shares_n, threshold, shared_key, i, rng)
+            item = ct[:32] + share
+            assert verifiers[i].verify_batch(item) == [oracle.decryption_share_verify(part_keys[i], shares_n, threshold, shared_key, i, item)] == [0]
+            bad = bytearray(item); bad[70] ^= 1
+            assert verifiers[i].verify_batch(bytes(bad)) == [eg.SUM_CHALLENGE]
+            assert verifiers[(i + 1) % shares_n].verify_batch(item) == [eg.SUM_CHALLENGE]     # other participant's key
+            verified.append((i, share[:32]))
+        assert T.combine_shares(grp, threshold, verified[: threshold - 1]) is None
+        dh = T.combine_shares(grp, threshold, verified)
+        assert dh == oracle.point_multi_mul(sc(coeffs[0]), ct[:32])                       # [x]R for the shared secret x
+        got.append(T.decrypt_total(grp, table, ct, dh))
+    assert got == expected and sum(got) == votes
