@@ -29,6 +29,8 @@ struct EngineBufs {
   u32* prefixes;        // hoisted transcript prefixes [idx][52]
   const unsigned char* blob;  // labels and constant messages
   uint4* ws;            // per-lane variable-base tables (direct multiplications)
+  uint4* dpt;           // deferred commitments P with out = encode(2P)   [cmp slot][10][cap]
+  u32* encw;            // k_encode_batch scratch: prefix products and N   [2 * slot][10][cap]
   uint4* btab;          // split tables of the ring bases [base][cap] x 320 uint4 (4 x 8 cached entries, 5 KiB)
 };
 constexpr int BTAB_QUADS = 32 * 10;

@@ -83,7 +83,7 @@ static int upload(T** dptr, const std::vector<T>& v, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-struct StageDev { int job_first, job_count, inst_first, inst_count; };
+struct StageDev { int job_first, job_count, inst_first, inst_count, defer_first, defer_count; };
 struct LevelDev { int first, count; };
 
 struct Engine {
@@ -101,7 +101,11 @@ struct Engine {
   egplan::StatusRule* d_rules = nullptr;
   u32* d_tally_slots = nullptr;
   unsigned short* d_base_slots = nullptr;
+  unsigned short* d_defer_slots = nullptr;
   uint4* btab = nullptr;
+  uint4* dpt = nullptr;
+  u32* encw = nullptr;
+  int max_defer = 0;
   unsigned char* d_blob = nullptr;
   uint4 *d_tabK = nullptr, *d_cpts = nullptr;
   u32* d_prefixes = nullptr;
@@ -125,7 +129,7 @@ struct Engine {
 static void engine_free(Engine* e) {
   if (!e) return;
   void* ptrs[] = {e->d_pt_items, e->d_sc_items, e->d_dclasses, e->d_dterms, e->d_jobs, e->d_vterms, e->d_insts, e->d_ops,
-                  e->d_rules, e->d_tally_slots, e->d_base_slots, e->btab, e->d_blob, e->d_tabK, e->d_cpts, e->d_prefixes, e->d_key_words, e->pts, e->cmp,
+                  e->d_rules, e->d_tally_slots, e->d_base_slots, e->d_defer_slots, e->btab, e->dpt, e->encw, e->d_blob, e->d_tabK, e->d_cpts, e->d_prefixes, e->d_key_words, e->pts, e->cmp,
                   e->chal, e->states, e->flags, e->bad_item, e->partial, e->tally, e->d_wire, e->d_status};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete e;
@@ -142,6 +146,8 @@ static EngineBufs make_bufs(const Engine* e, const void* d_ballots, u32 n, void*
   B.tabG = e->ctx->tabG; B.tabK = e->d_tabK; B.cpts = e->d_cpts; B.prefixes = e->d_prefixes; B.blob = e->d_blob;
   B.ws = e->ctx->ws;
   B.btab = e->btab;
+  B.dpt = e->dpt;
+  B.encw = e->encw;
   return B;
 }
 
@@ -151,7 +157,7 @@ static int engine_reserve(Engine* e, u32 want) {
   const eghost::Plan& P = e->plan;
   HIPCHK(hipDeviceSynchronize());   // earlier batches may still be running on a caller's stream
   void** bufs[] = {(void**)&e->pts, (void**)&e->cmp, (void**)&e->chal, (void**)&e->states, (void**)&e->flags, (void**)&e->bad_item,
-                   (void**)&e->btab};
+                   (void**)&e->btab, (void**)&e->dpt, (void**)&e->encw};
   for (void** b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
   e->cap = 0;
   const size_t cap = (want + NT - 1) / NT * NT;
@@ -162,6 +168,8 @@ static int engine_reserve(Engine* e, u32 want) {
   HIPCHK(hipMalloc((void**)&e->flags, (size_t)std::max(P.n_flag_slots, 1) * cap * sizeof(u32)));
   HIPCHK(hipMalloc((void**)&e->bad_item, cap * sizeof(u32)));
   HIPCHK(hipMalloc((void**)&e->btab, std::max<size_t>(P.base_slots.size(), 1) * cap * BTAB_QUADS * sizeof(uint4)));
+  HIPCHK(hipMalloc((void**)&e->dpt, (size_t)std::max(P.n_cmp_slots, 1) * 10 * cap * sizeof(uint4)));
+  HIPCHK(hipMalloc((void**)&e->encw, (size_t)std::max(e->max_defer, 1) * 2 * 10 * cap * sizeof(u32)));
   e->cap = (u32)cap;
   return EG_OK;
 }
@@ -188,8 +196,12 @@ static int engine_create(eg_ctx* ctx, eghost::Plan&& plan, const uint8_t pk[32],
   std::vector<egplan::JobClass> jobs;
   std::vector<egplan::HashInst> insts;
   std::vector<egplan::HashOp> ops;
+  std::vector<uint16_t> defer_slots;
   for (auto& st : P.stages) {
     StageDev sd;
+    sd.defer_first = (int)defer_slots.size(); sd.defer_count = (int)st.deferred.size();
+    defer_slots.insert(defer_slots.end(), st.deferred.begin(), st.deferred.end());
+    e->max_defer = std::max(e->max_defer, std::min(sd.defer_count, 32));
     sd.job_first = (int)jobs.size(); sd.job_count = (int)st.jobs.size();
     jobs.insert(jobs.end(), st.jobs.begin(), st.jobs.end());
     sd.inst_first = (int)insts.size(); sd.inst_count = (int)st.insts.size();
@@ -222,6 +234,7 @@ static int engine_create(eg_ctx* ctx, eghost::Plan&& plan, const uint8_t pk[32],
   if ((rc = upload(&e->d_rules, P.rules, s))) return rc;
   if ((rc = upload(&e->d_tally_slots, P.tally_slots, s))) return rc;
   if ((rc = upload(&e->d_base_slots, P.base_slots, s))) return rc;
+  if ((rc = upload(&e->d_defer_slots, defer_slots, s))) return rc;
   if ((rc = upload(&e->d_blob, P.blob, s))) return rc;
 
   // election key: decode, reject invalid / identity (keys/mod.rs:161-176), fixed-base table
@@ -318,6 +331,9 @@ static int engine_verify_device(Engine* e, size_t n, const void* d_ballots, void
                            e->d_vterms, st.job_first, st.job_count);
         if ((rc = prof_end(ctx, s, pi))) return rc;
       }
+      for (int d0 = 0; d0 < st.defer_count; d0 += 32)   // one batched inversion per ballot and group of <= 32 commitments
+        hipLaunchKernelGGL(k_encode_batch, dim3(grid_for(cn, wide)), dim3(NT), 0, s, B, e->d_defer_slots + st.defer_first + d0,
+                           std::min(32, st.defer_count - d0));
       if (st.inst_count)
         hipLaunchKernelGGL(k_hash, dim3(grid_for((size_t)st.inst_count * cn, 1 << 30)), dim3(NT), 0, s, B, e->d_insts, e->d_ops,
                            st.inst_first, st.inst_count);

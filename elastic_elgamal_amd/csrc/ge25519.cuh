@@ -243,6 +243,70 @@ EG_HD void ristretto_encode(u32 w[8], const ge& p) {
   fe_to_words(w, s);
 }
 
+// ---- encoding of a DOUBLED point with a batched inversion --------------------------------------------------------------------
+// For Q = 2P the inverse square root of the encoder is rational in P: with the doubling's intermediates
+// E = 2XY, H = Y^2 + X^2, G = Y^2 - X^2, F = 2Z^2 - G  (Q = (EF : GH : GF : EH)) one has
+//   u1 u2^2 = (Z0^2 - Y0^2)(X0 Y0)^2 = (E F G^2 H)^2 (F^2 - H^2)   and   F^2 - H^2 = 4 (Z^2 - Y^2)(Z^2 + X^2) = (a - d) E^2
+// (the last step is the curve equation), hence 1/sqrt(u1 u2^2) = +-(1/sqrt(a-d)) / N with N = E^2 F G^2 H.
+// Inversions batch (Montgomery), exponentiations do not: k_encode_batch encodes all commitments of a ballot and stage
+// with ONE field inversion instead of one 255-squaring chain each.  The equations are evaluated with halved scalars
+// (sc_halve) so that the commitment is 2P; [l]P is in the 4-torsion that ristretto quotients out, so adding l to an odd
+// scalar before halving does not change the encoding.
+// prepare: N (class 1, 0 replaced by 1 with `zero` set) from P.
+EG_HD void ge_double_encode_prepare(fe& n, bool& zero, const ge& p) {
+  ge_p1p1 t;
+  ge_dbl(t, p.X, p.Y, p.Z);           // t.X = E [5], t.Y = H [2], t.Z = G [3], t.T = F [1]
+  fe e = t.X; fe_carry(e);
+  fe e2, g2, a, b;
+  fe_sq(e2, e);
+  fe_sq(g2, t.Z);
+  fe_mul(a, e2, t.T);
+  fe_mul(b, t.Y, g2);                 // H [2] as f operand, G^2 [1] as g
+  fe_mul(n, a, b);
+  zero = fe_iszero(n);
+  fe one; fe_1(one);
+  fe_cmov(n, one, zero);
+}
+// finish: w = encode(2P) given inv_n = 1/N (ignored when zero)
+EG_HD void ge_double_encode_finish(u32 w[8], const ge& p, const fe& inv_n, bool zero) {
+  const fe sqrtm1 = EG_FE_SQRTM1, invsqrt_amd = EG_FE_INVSQRT_A_MINUS_D;
+  ge_p1p1 t;
+  ge_dbl(t, p.X, p.Y, p.Z);
+  ge q;
+  ge_dbl_to_p3(q, t);
+  fe inv, z; fe_0(z);
+  fe_mul(inv, inv_n, invsqrt_amd);
+  fe_cmov(inv, z, zero);              // SQRT_RATIO_M1(1, 0) = 0
+  fe n; fe_neg(n, inv); fe_carry(n);
+  fe_cmov(inv, n, fe_isnegative(inv)); // the non-negative root
+  // from here on identical to ristretto_encode(q)
+  fe u1, u2, t0, t1, d1, d2, zinv, x, y, dinv, s2;
+  fe_add(t0, q.Z, q.Y);
+  fe_sub(t1, q.Z, q.Y);
+  fe_mul(u1, t0, t1);
+  fe_mul(u2, q.X, q.Y);
+  fe_mul(d1, inv, u1);
+  fe_mul(d2, inv, u2);
+  fe_mul(zinv, d1, d2);
+  fe_mul(zinv, zinv, q.T);
+  fe_mul(t0, q.T, zinv);
+  const bool rotate = fe_isnegative(t0);
+  fe ix, iy, dr;
+  fe_mul(ix, q.Y, sqrtm1);
+  fe_mul(iy, q.X, sqrtm1);
+  fe_mul(dr, d1, invsqrt_amd);
+  x = q.X; y = q.Y; dinv = d2;
+  fe_cmov(x, ix, rotate); fe_cmov(y, iy, rotate); fe_cmov(dinv, dr, rotate);
+  fe_mul(t0, x, zinv);
+  fe_neg(n, y); fe_carry(n);
+  fe_cmov(y, n, fe_isnegative(t0));
+  fe_sub(t0, q.Z, y);
+  fe_mul(s2, t0, dinv);
+  fe_neg(n, s2); fe_carry(n);
+  fe_cmov(s2, n, fe_isnegative(s2));
+  fe_to_words(w, s2);
+}
+
 // Ristretto equality / identity test (ristretto.rs:80-82); only used off the hot path
 EG_HD bool ge_ristretto_eq(const ge& p, const ge& q) {
   fe a, b;

@@ -84,6 +84,7 @@ inline uint64_t isqrt(uint64_t x) {  // quadratic_voting.rs:127-143
 struct Stage {
   std::vector<JobClass> jobs;
   std::vector<std::vector<HashOp>> insts;
+  std::vector<uint16_t> deferred;   // output slots encoded by k_encode_batch (one batched inversion per ballot and stage)
 };
 
 struct Plan {
@@ -169,8 +170,10 @@ struct Plan {
     jc.g = g; jc.k = k;
     jc.out_slot = new_cmp();
     jc.enc_slot = 0xffff;
+    jc.defer = 1; jc.pad = 0;
     vterms.insert(vterms.end(), terms.begin(), terms.end());
     stage(st).jobs.push_back(jc);
+    stage(st).deferred.push_back(jc.out_slot);
     return jc.out_slot;
   }
   uint16_t encode_job(size_t st, uint16_t pt_slot) {
@@ -179,6 +182,7 @@ struct Plan {
     jc.g = ScalarSrc{SRC_NONE, 0, 0, 0}; jc.k = ScalarSrc{SRC_NONE, 0, 0, 0};
     jc.out_slot = new_cmp();
     jc.enc_slot = pt_slot;
+    jc.defer = 0; jc.pad = 0;
     stage(st).jobs.push_back(jc);
     return jc.out_slot;
   }

@@ -22,7 +22,7 @@
 namespace eg {
 
 // ---- scalar operand fetch ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void load_scalar(u32 s[8], const EngineBufs& B, u32 b, egplan::ScalarSrc src) {
+__device__ __forceinline__ void load_scalar(u32 s[8], const EngineBufs& B, u32 b, egplan::ScalarSrc src, bool halve = false) {
   if (src.kind == egplan::SRC_WIRE) load_wire_item(s, B, b, src.idx);
   else load32(s, B.chal, B.cap, src.idx, b);
   if (src.neg) { u32 t[8]; sc_neg(t, s);
@@ -36,6 +36,9 @@ __device__ __forceinline__ void load_scalar(u32 s[8], const EngineBufs& B, u32 b
 #pragma unroll
     for (int i = 0; i < 8; ++i) s[i] = t[i];
   }
+  if (halve) { u32 t[8]; sc_halve(t, s);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = t[i]; }
 }
 
 // ---- k_decode_points: deserialize_element for every wire point (ristretto.rs:93-95) --------------------------------
@@ -127,7 +130,7 @@ __global__ void __launch_bounds__(NT, 2) k_msm_jobs(EngineBufs B, const egplan::
       ge p;
       if (vt.base == 0xffffu) load_pt(p, B.pts, B.cap, vt.slot, b);
       u32 s[8], dg[8];
-      load_scalar(s, B, b, vt.s);
+      load_scalar(s, B, b, vt.s, jc.defer != 0);
       sc_recode_radix16(dg, s);
       ge part;
       if (vt.base != 0xffffu) {
@@ -142,19 +145,66 @@ __global__ void __launch_bounds__(NT, 2) k_msm_jobs(EngineBufs B, const egplan::
     }
     if (jc.g.kind != egplan::SRC_NONE) {
       u32 s[8], dg[8];
-      load_scalar(s, B, b, jc.g);
+      load_scalar(s, B, b, jc.g, jc.defer != 0);
       sc_recode_radix256(dg, s);
       ge_fixed_mul_add(acc, tg, dg);
     }
     if (jc.k.kind != egplan::SRC_NONE) {
       u32 s[8], dg[8];
-      load_scalar(s, B, b, jc.k);
+      load_scalar(s, B, b, jc.k, jc.defer != 0);
       sc_recode_radix256(dg, s);
       ge_fixed_mul_add(acc, tk, dg);
     }
-    u32 out[8];
-    ristretto_encode(out, acc);
-    store32(B.cmp, B.cap, jc.out_slot, b, out);
+    if (jc.defer) {
+      store_pt(B.dpt, B.cap, jc.out_slot, b, acc);     // encoded (as 2 * acc) by k_encode_batch
+    } else {
+      u32 out[8];
+      ristretto_encode(out, acc);
+      store32(B.cmp, B.cap, jc.out_slot, b, out);
+    }
+  }
+}
+
+// ---- k_encode_batch: serialize_element for all deferred commitments of a ballot with ONE field inversion ------------------------
+// (ge_double_encode_prepare / _finish: the commitments were evaluated with halved scalars, out = encode(2P).)
+__device__ __forceinline__ void encw_store(u32* encw, u32 cap, u32 slot, u32 b, const fe& f) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) encw[((size_t)slot * 10 + i) * cap + b] = f.v[i];
+}
+__device__ __forceinline__ void encw_load(fe& f, const u32* encw, u32 cap, u32 slot, u32 b) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) f.v[i] = encw[((size_t)slot * 10 + i) * cap + b];
+}
+__global__ void __launch_bounds__(NT) k_encode_batch(EngineBufs B, const unsigned short* slots, int n_slots) {
+  for (u32 b = blockIdx.x * NT + threadIdx.x; b < B.n; b += gridDim.x * NT) {
+    fe prod; fe_1(prod);
+    u32 zero_mask = 0;
+#pragma unroll 1
+    for (int k = 0; k < n_slots; ++k) {
+      ge p;
+      load_pt(p, B.dpt, B.cap, slots[k], b);
+      fe n; bool zero;
+      ge_double_encode_prepare(n, zero, p);
+      zero_mask |= (zero ? 1u : 0u) << (k & 31);
+      encw_store(B.encw, B.cap, 2 * k, b, prod);       // prefix product before k
+      encw_store(B.encw, B.cap, 2 * k + 1, b, n);
+      fe t; fe_mul(t, prod, n); prod = t;
+    }
+    fe inv;
+    fe_invert(inv, prod);
+#pragma unroll 1
+    for (int k = n_slots - 1; k >= 0; --k) {
+      fe pre, n, inv_n, t;
+      encw_load(pre, B.encw, B.cap, 2 * k, b);
+      encw_load(n, B.encw, B.cap, 2 * k + 1, b);
+      fe_mul(inv_n, inv, pre);                          // 1 / N_k
+      fe_mul(t, inv, n); inv = t;                       // inverse of the prefix product before k
+      ge p;
+      load_pt(p, B.dpt, B.cap, slots[k], b);
+      u32 out[8];
+      ge_double_encode_finish(out, p, inv_n, ((zero_mask >> (k & 31)) & 1u) != 0);
+      store32(B.cmp, B.cap, slots[k], b, out);
+    }
   }
 }
 

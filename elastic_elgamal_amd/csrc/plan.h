@@ -37,6 +37,8 @@ struct JobClass {
   ScalarSrc g, k;                   // fixed-base scalars for G and K
   uint16_t out_slot;                // compressed-output slot
   uint16_t enc_slot;                // if term_count == 0 and no g/k: just encode this point slot
+  uint16_t defer;                   // 1: evaluate with halved scalars and leave the point for k_encode_batch (out = encode(2P))
+  uint16_t pad;
 };
 
 struct DeriveTerm {

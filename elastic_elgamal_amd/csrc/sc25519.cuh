@@ -147,6 +147,24 @@ EG_HD void sc_sub(u32 out[8], const u32 a[8], const u32 b[8]) {
   sc_add(out, a, nb);
 }
 
+// h with 2h = s (mod l): (s + (s odd ? l : 0)) >> 1.  The result is < 2^252 + 2^251 and is used only as a
+// multiplier of points (it is not a canonical scalar when s is odd: it represents (s + l) / 2).
+EG_HD void sc_halve(u32 out[8], const u32 s[8]) {
+  const u32 l[8] = EG_L_WORDS;
+  const u32 odd = s[0] & 1u;
+  u64 carry = 0;
+  u32 t[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const u64 v = (u64)s[i] + (odd ? l[i] : 0u) + carry;
+    t[i] = (u32)v;
+    carry = v >> 32;
+  }
+#pragma unroll
+  for (int i = 0; i < 7; ++i) out[i] = (t[i] >> 1) | (t[i + 1] << 31);
+  out[7] = (t[7] >> 1) | ((u32)carry << 31);
+}
+
 // Scalar::from_canonical_bytes: value < l
 EG_HD bool sc_is_canonical(const u32 a[8]) {
   const u32 l[8] = EG_L_WORDS;

@@ -91,6 +91,38 @@ int hc_double_mul_generator_split(const uint8_t k[32], const uint8_t p_enc[32], 
   return 1;
 }
 
+// encode(2P) through the batched-inversion path vs the plain encoder; returns 1 when they agree
+int hc_double_encode(const uint8_t p_enc[32], uint8_t out[32]) {
+  u32 pw[8], o[8], ref[8]; words_from_bytes(pw, p_enc, 8);
+  ge p; if (!ristretto_decode(p, pw)) return -1;
+  fe n; bool zero;
+  ge_double_encode_prepare(n, zero, p);
+  fe inv; fe_invert(inv, n);
+  ge_double_encode_finish(o, p, inv, zero);
+  ge q; ge_dbl_full(q, p);
+  ristretto_encode(ref, q);
+  bytes_from_words(out, o, 8);
+  return memcmp(o, ref, 32) == 0 ? 1 : 0;
+}
+// [k]P + [r]G evaluated as 2 * ([k/2]P + [r/2]G) with the doubled encoder (what k_msm_jobs + k_encode_batch do)
+int hc_double_mul_generator_halved(const uint8_t k[32], const uint8_t p_enc[32], const uint8_t r[32], uint8_t out[32]) {
+  if (g_base_table.e.empty()) { ge g; ge_generator(g); build_fixed(g_base_table, g); }
+  u32 kw[8], rw[8], pw[8], o[8], kh[8], rh[8];
+  words_from_bytes(kw, k, 8); words_from_bytes(rw, r, 8); words_from_bytes(pw, p_enc, 8);
+  ge p; if (!ristretto_decode(p, pw)) return 0;
+  sc_halve(kh, kw); sc_halve(rh, rw);
+  ArrSplit tab; ge_split_tables_build(tab, p);
+  u32 dk[8], dr[8]; sc_recode_radix16(dk, kh); sc_recode_radix256(dr, rh);
+  ge acc; ge_split_mul(acc, tab, dk);
+  ge_fixed_mul_add(acc, g_base_table, dr);
+  fe n, inv; bool zero;
+  ge_double_encode_prepare(n, zero, acc);
+  fe_invert(inv, n);
+  ge_double_encode_finish(o, acc, inv, zero);
+  bytes_from_words(out, o, 8);
+  return 1;
+}
+
 int hc_point_add(const uint8_t a[32], const uint8_t b[32], int sub, uint8_t out[32]) {
   u32 aw[8], bw[8], o[8]; words_from_bytes(aw, a, 8); words_from_bytes(bw, b, 8);
   ge p, q, r; if (!ristretto_decode(p, aw) || !ristretto_decode(q, bw)) return 0;

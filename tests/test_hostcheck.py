@@ -122,6 +122,8 @@ def test_double_mul_generator(hc, oracle):
         assert out.raw == oracle.point_double_mul_generator(kb, p, rb), (k, r)
         assert hc.hc_double_mul_generator_split(kb, p, rb, out) == 1      # 4-way split tables, 60 doublings
         assert out.raw == oracle.point_double_mul_generator(kb, p, rb), (k, r)
+        assert hc.hc_double_mul_generator_halved(kb, p, rb, out) == 1     # halved scalars + doubled encoder
+        assert out.raw == oracle.point_double_mul_generator(kb, p, rb), (k, r)
 
 
 def test_merlin(hc, oracle):
@@ -138,3 +140,14 @@ def test_merlin(hc, oracle):
         m = oracle.Merlin(b"encrypted_choice_ranges"); m.append(b"enc", msg); m.append_u64(b"i", 7)
         assert pos == m.pos
         assert out.raw == m.challenge(b"c", 64)
+
+
+def test_doubled_encoder(hc, oracle):
+    """encode(2P) with the rational inverse square root (one inversion) equals the plain encoder, including the
+    degenerate points where N = 0 (identity, and points with X = 0 or Y = 0 up to torsion)."""
+    rnd = random.Random(6)
+    pts = [b"\x00" * 32, oracle.const_bytes(4)] + [oracle.point_mul_generator(rnd.randrange(L).to_bytes(32, "little")) for _ in range(200)]
+    for p in pts:
+        out = _b()
+        assert hc.hc_double_encode(p, out) == 1, p.hex()
+        assert out.raw == oracle.point_add(p, p)
