@@ -30,11 +30,8 @@ PUBLIC_KEY_HEX = "a6adb6e9c0ae8d54c26e6e56b5ccd7a16bb0e1951abe4d7ee7028e3d4eca85
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # VALU model: field operations per building block counted by the host-check build
 # (tests/hostcheck: hc_op_counts) as (fe_mul, fe_sq); one fe_mul = 100 and one fe_sq = 55 v_mad_u64_u32.
-OPS = {"decode": (27, 257), "direct_table": (64, 0), "direct_mul": (1331, 1008), "comb": (224, 0), "encode": (32, 255),
-       "split_tables": (835, 768), "split_mul": (707, 240)}
-# memory-side traffic of k_msm_jobs per ballot and launch, from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
-# of profiles/r01_bench_pmc_counters.txt: 50.57 GB per launch over 262144 single-choice ballots
-MSM_TRAFFIC_BYTES_PER_BALLOT_LAUNCH = {"single": 50.57e9 / 262144}
+OPS = {"decode": (27, 257), "direct_table": (64, 0), "direct_mul": (1269, 1008), "comb": (140, 0), "encode": (32, 255),
+       "split_tables": (835, 768), "split_mul": (692, 240), "enc_batch_each": (23, 10), "enc_batch_inversion": (11, 254)}
 MAD_PEAK_T = 33.4              # profiles/r01_ubench_valu_rates.txt: v_mad_u64_u32, 8 waves/SIMD, T lane-ops/s chip-wide
 FMUL_PEAK_G = 256.0            # profiles/r01_ubench_fmul_candidates.txt: radix-25.5 field multiply, G/s chip-wide
 
@@ -47,11 +44,13 @@ def choice_field_ops(n: int, single: bool):
     def mul(x, k):
         return (x[0] * k, x[1] * k)
 
-    ring = add(OPS["split_mul"], OPS["comb"], OPS["encode"])
+    ring = add(OPS["split_mul"], OPS["comb"], OPS["enc_batch_each"])
     fold = add(ring, OPS["comb"])
     total = add(mul(OPS["split_tables"], 2 * n), mul(ring, 3 * n), mul(fold, n), mul(OPS["decode"], 2 * n))
+    groups = 2 * (-(-(2 * n + (2 if single else 0)) // 32))           # batched inversions: per stage and group of 32
+    total = add(total, mul(OPS["enc_batch_inversion"], groups))
     if single:
-        logeq = add(OPS["direct_table"], OPS["direct_mul"], OPS["comb"], OPS["encode"])
+        logeq = add(OPS["direct_table"], OPS["direct_mul"], OPS["comb"], OPS["enc_batch_each"])
         total = add(total, mul(logeq, 2), mul(OPS["encode"], 2))
     return total
 # algorithmic bytes per ballot = packed ballot + 4-byte status word: 740 (single 5), 2084 (multi 16), 2148 (qv 5/20)

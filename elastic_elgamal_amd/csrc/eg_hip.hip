@@ -252,7 +252,7 @@ static int engine_create(eg_ctx* ctx, eghost::Plan&& plan, const uint8_t pk[32],
   if (!hflags[0]) return fail(EG_ERR_BAD_PUBLIC_KEY, "public key is not a valid ristretto255 encoding");
   if (hflags[1]) return fail(EG_ERR_BAD_PUBLIC_KEY, "public key is the identity");
   HIPCHK(hipMalloc((void**)&e->d_tabK, (size_t)EG_FIXED_WINDOWS * EG_FIXED_ENTRIES * 8 * sizeof(uint4)));
-  hipLaunchKernelGGL(k_build_fixed_table, dim3(EG_FIXED_WINDOWS * EG_FIXED_ENTRIES / NT), dim3(NT), 0, s, e->d_key_words + 40, e->d_tabK);
+  hipLaunchKernelGGL(k_build_fixed_table, dim3((EG_FIXED_WINDOWS * EG_FIXED_ENTRIES + NT - 1) / NT), dim3(NT), 0, s, e->d_key_words + 40, e->d_tabK);
 
   // election-constant points [m]G
   {
@@ -411,7 +411,7 @@ int eg_init(int device, eg_ctx** out) {
   HIPCHK(hipMalloc((void**)&c->gen_words, 80 * sizeof(u32)));
   HIPCHK(hipMalloc((void**)&c->tabG, (size_t)EG_FIXED_WINDOWS * EG_FIXED_ENTRIES * 8 * sizeof(uint4)));
   hipLaunchKernelGGL(k_setup_points, dim3(1), dim3(64), 0, c->stream, (const u32*)nullptr, c->gen_words, (u32*)nullptr);
-  hipLaunchKernelGGL(k_build_fixed_table, dim3(EG_FIXED_WINDOWS * EG_FIXED_ENTRIES / NT), dim3(NT), 0, c->stream, c->gen_words, c->tabG);
+  hipLaunchKernelGGL(k_build_fixed_table, dim3((EG_FIXED_WINDOWS * EG_FIXED_ENTRIES + NT - 1) / NT), dim3(NT), 0, c->stream, c->gen_words, c->tabG);
   int per_cu = 0;
   HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_msm_jobs, NT, 0));
   if (per_cu < 1) per_cu = 1;

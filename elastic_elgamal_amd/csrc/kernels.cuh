@@ -144,15 +144,15 @@ __global__ void __launch_bounds__(NT, 2) k_msm_jobs(EngineBufs B, const egplan::
       else { ge sum; ge_add_full(sum, acc, part); acc = sum; }
     }
     if (jc.g.kind != egplan::SRC_NONE) {
-      u32 s[8], dg[8];
+      u32 s[8], dg[EG_COMB_WORDS];
       load_scalar(s, B, b, jc.g, jc.defer != 0);
-      sc_recode_radix256(dg, s);
+      sc_recode_comb(dg, s);
       ge_fixed_mul_add(acc, tg, dg);
     }
     if (jc.k.kind != egplan::SRC_NONE) {
-      u32 s[8], dg[8];
+      u32 s[8], dg[EG_COMB_WORDS];
       load_scalar(s, B, b, jc.k, jc.defer != 0);
-      sc_recode_radix256(dg, s);
+      sc_recode_comb(dg, s);
       ge_fixed_mul_add(acc, tk, dg);
     }
     if (jc.defer) {
@@ -431,7 +431,7 @@ __global__ void k_points_sum(const u32* in, int n_ranks, int n_points, u32* out,
 }
 
 // ---- election setup --------------------------------------------------------------------------------------------------------------------------------
-// tab[w*128 + k-1] = niels([k * 256^w] Base), w < 32, 1 <= k <= 128: one lane per entry
+// tab[w*E + k-1] = niels([k * 2^(B w)] Base), w < EG_FIXED_WINDOWS, 1 <= k <= E = 2^(B-1): one lane per entry
 __global__ void __launch_bounds__(NT) k_build_fixed_table(const u32* base_words /* 40 */, uint4* tab) {
   const int lane = blockIdx.x * NT + threadIdx.x;
   if (lane >= EG_FIXED_WINDOWS * EG_FIXED_ENTRIES) return;
@@ -440,10 +440,10 @@ __global__ void __launch_bounds__(NT) k_build_fixed_table(const u32* base_words 
   for (int i = 0; i < 40; ++i) bw[i] = base_words[i];
   ge p; words_to_ge(p, bw);
 #pragma unroll 1
-  for (int i = 0; i < 8 * w; ++i) { ge d; ge_dbl_full(d, p); p = d; }
+  for (int i = 0; i < EG_COMB_BITS * w; ++i) { ge d; ge_dbl_full(d, p); p = d; }
   ge q; ge_identity(q);
 #pragma unroll 1
-  for (int bit = 7; bit >= 0; --bit) {        // k <= 128 fits 8 bits
+  for (int bit = EG_COMB_BITS - 1; bit >= 0; --bit) {        // k <= 2^(B-1)
     ge d; ge_dbl_full(d, q); q = d;
     if ((k >> bit) & 1) { ge s; ge_add_full(s, q, p); q = s; }
   }
@@ -476,9 +476,9 @@ __global__ void k_setup_points(const u32* pk_words, u32* out_words, u32* flags) 
 __global__ void __launch_bounds__(NT) k_const_points(const u64* mults, int n, const uint4* tabG, uint4* cpts) {
   const int i = blockIdx.x * NT + threadIdx.x;
   if (i >= n) return;
-  u32 s[8], dg[8];
+  u32 s[8], dg[EG_COMB_WORDS];
   sc_from_u64(s, mults[i]);
-  sc_recode_radix256(dg, s);
+  sc_recode_comb(dg, s);
   ge acc; ge_identity(acc);
   const FixedTable tg{tabG};
   ge_fixed_mul_add(acc, tg, dg);
@@ -567,8 +567,8 @@ __global__ void __launch_bounds__(NT) k_prim_msm(size_t n, int terms, const u32*
       ge sum; ge_add_full(sum, acc, part); acc = sum;
     }
     if (r) {
-      u32 s[8], dg[8]; ld8(s, r + i * 8);
-      sc_recode_radix256(dg, s);
+      u32 s[8], dg[EG_COMB_WORDS]; ld8(s, r + i * 8);
+      sc_recode_comb(dg, s);
       const FixedTable tg{tabG};
       ge_fixed_mul_add(acc, tg, dg);
     }

@@ -59,9 +59,9 @@ __device__ __noinline__ void rng_scalar(ChaChaRng& r, u32 out[8]) {
 __device__ __noinline__ void fixed2_encode(u32 out[8], const FixedTable& tg, const u32* a, const FixedTable& tk, const u32* b) {
   ge acc;
   ge_identity(acc);
-  u32 dg[8];
-  if (a) { sc_recode_radix256(dg, a); ge_fixed_mul_add(acc, tg, dg); }
-  if (b) { sc_recode_radix256(dg, b); ge_fixed_mul_add(acc, tk, dg); }
+  u32 dg[EG_COMB_WORDS];
+  if (a) { sc_recode_comb(dg, a); ge_fixed_mul_add(acc, tg, dg); }
+  if (b) { sc_recode_comb(dg, b); ge_fixed_mul_add(acc, tk, dg); }
   ristretto_encode(out, acc);
 }
 

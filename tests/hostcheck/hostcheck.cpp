@@ -47,7 +47,7 @@ static void build_fixed(ArrNiels& t, const ge& base) {
       ge_to_niels(t.e[w * EG_FIXED_ENTRIES + k - 1], cur);
       ge nxt; ge_add_full(nxt, cur, win); cur = nxt;
     }
-    for (int d = 0; d < 8; ++d) { ge nxt; ge_dbl_full(nxt, win); win = nxt; }
+    for (int d = 0; d < EG_COMB_BITS; ++d) { ge nxt; ge_dbl_full(nxt, win); win = nxt; }
   }
 }
 
@@ -68,7 +68,7 @@ int hc_double_mul_generator(const uint8_t k[32], const uint8_t p_enc[32], const 
   words_from_bytes(kw, k, 8); words_from_bytes(rw, r, 8); words_from_bytes(pw, p_enc, 8);
   ge p; if (!ristretto_decode(p, pw)) return 0;
   ArrTable tab; ge_var_table_build(tab, p);
-  u32 dk[8], dr[8]; sc_recode_radix16(dk, kw); sc_recode_radix256(dr, rw);
+  u32 dk[8], dr[EG_COMB_WORDS]; sc_recode_radix16(dk, kw); sc_recode_comb(dr, rw);
   ge acc; ge_var_mul(acc, tab, dk);
   ge_fixed_mul_add(acc, g_base_table, dr);
   ristretto_encode(o, acc);
@@ -83,7 +83,7 @@ int hc_double_mul_generator_split(const uint8_t k[32], const uint8_t p_enc[32], 
   words_from_bytes(kw, k, 8); words_from_bytes(rw, r, 8); words_from_bytes(pw, p_enc, 8);
   ge p; if (!ristretto_decode(p, pw)) return 0;
   ArrSplit tab; ge_split_tables_build(tab, p);
-  u32 dk[8], dr[8]; sc_recode_radix16(dk, kw); sc_recode_radix256(dr, rw);
+  u32 dk[8], dr[EG_COMB_WORDS]; sc_recode_radix16(dk, kw); sc_recode_comb(dr, rw);
   ge acc; ge_split_mul(acc, tab, dk);
   ge_fixed_mul_add(acc, g_base_table, dr);
   ristretto_encode(o, acc);
@@ -112,7 +112,7 @@ int hc_double_mul_generator_halved(const uint8_t k[32], const uint8_t p_enc[32],
   ge p; if (!ristretto_decode(p, pw)) return 0;
   sc_halve(kh, kw); sc_halve(rh, rw);
   ArrSplit tab; ge_split_tables_build(tab, p);
-  u32 dk[8], dr[8]; sc_recode_radix16(dk, kh); sc_recode_radix256(dr, rh);
+  u32 dk[8], dr[EG_COMB_WORDS]; sc_recode_radix16(dk, kh); sc_recode_comb(dr, rh);
   ge acc; ge_split_mul(acc, tab, dk);
   ge_fixed_mul_add(acc, g_base_table, dr);
   fe n, inv; bool zero;
@@ -163,7 +163,7 @@ int hc_merlin(const char* label, const char* l1, const uint8_t* m1, int m1_len, 
 // field operation counts of the hot-path building blocks: out[2*i], out[2*i+1] = (fe_mul, fe_sq) calls of
 // 0: ristretto_decode  1: direct table build  2: direct variable-base multiply  3: fixed-base comb (32 windows)
 // 4: ristretto_encode  5: split-table build (per base)  6: split multiply (per equation)
-void hc_op_counts(unsigned long long out[14]) {
+void hc_op_counts(unsigned long long out[18]) {
   if (g_base_table.e.empty()) { ge g; ge_generator(g); build_fixed(g_base_table, g); }
   u32 gw[8] = {0x0aaef2e2u, 0x714ebc6au, 0x61a984a8u, 0x5f5100c5u, 0x6a0be358u, 0x8ddd82a5u, 0x4559a6b6u, 0x762d8de0u};
   u32 k[8] = {0x12345678u, 0x9abcdef0u, 0x0fedcba9u, 0x87654321u, 0x11111111u, 0x22222222u, 0x33333333u, 0x04444444u};
@@ -175,7 +175,7 @@ void hc_op_counts(unsigned long long out[14]) {
   u32 dg[8]; sc_recode_radix16(dg, k);
   m0 = g_fe_mul_count; s0 = g_fe_sq_count;
   ge acc; ge_var_mul(acc, tab, dg); snap(2, m0, s0);
-  u32 dg8[8]; sc_recode_radix256(dg8, k);
+  u32 dg8[EG_COMB_WORDS]; sc_recode_comb(dg8, k);
   m0 = g_fe_mul_count; s0 = g_fe_sq_count;
   ge_fixed_mul_add(acc, g_base_table, dg8); snap(3, m0, s0);
   m0 = g_fe_mul_count; s0 = g_fe_sq_count;
@@ -184,6 +184,18 @@ void hc_op_counts(unsigned long long out[14]) {
   ArrSplit st; ge_split_tables_build(st, p); snap(5, m0, s0);
   m0 = g_fe_mul_count; s0 = g_fe_sq_count;
   ge_split_mul(acc, st, dg); snap(6, m0, s0);
+  // 7: doubled encoder per commitment (prepare + prefix/backward products + finish)   8: the shared field inversion
+  m0 = g_fe_mul_count; s0 = g_fe_sq_count;
+  fe n, inv, t1, t2; bool zero;
+  ge_double_encode_prepare(n, zero, acc);
+  fe_mul(t1, n, n); fe_mul(t2, n, n); fe_mul(t1, t1, t2);     // the three bookkeeping multiplications of the batch
+  snap(7, m0, s0);
+  unsigned long long m1 = g_fe_mul_count, s1 = g_fe_sq_count;
+  fe_invert(inv, n);
+  out[16] = g_fe_mul_count - m1; out[17] = g_fe_sq_count - s1;
+  m0 = g_fe_mul_count; s0 = g_fe_sq_count;
+  ge_double_encode_finish(o, acc, inv, zero);
+  out[14] += g_fe_mul_count - m0; out[15] += g_fe_sq_count - s0;
 }
 
 void hc_fe_roundtrip(const uint8_t in[32], uint8_t out[32]) {
