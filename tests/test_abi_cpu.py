@@ -109,3 +109,37 @@ def test_plan_shapes(lib_path):
     assert b["jobs"] == 70 + 12 + 2 and b["rules"] == 7
     assert eg.plan_describe("zero")["stride"] == 128 and eg.plan_describe("bool")["stride"] == 160
     assert eg.plan_describe("range", 0, 100)["stride"] == 672
+
+
+def test_bench_static_sanity():
+    """bench.py cannot run without a GPU; at least every global name it uses must be defined (a NameError on the GPU box
+    would cost the round its measurement) and the VALU work model must reproduce the documented per-ballot counts."""
+    import ast
+    import builtins
+    import importlib.util
+
+    path = ROOT / "bench.py"
+    tree = ast.parse(path.read_text())
+    defined = set(dir(builtins)) | {"__file__", "__name__"}
+    for node in ast.walk(tree):
+        if isinstance(node, (ast.FunctionDef, ast.ClassDef)):
+            defined.add(node.name)
+            for a in node.args.args + node.args.kwonlyargs if isinstance(node, ast.FunctionDef) else []:
+                defined.add(a.arg)
+        elif isinstance(node, (ast.Import, ast.ImportFrom)):
+            for a in node.names:
+                defined.add((a.asname or a.name).split(".")[0])
+        elif isinstance(node, ast.Name) and isinstance(node.ctx, (ast.Store, ast.Del)):
+            defined.add(node.id)
+        elif isinstance(node, ast.arg):
+            defined.add(node.arg)
+        elif isinstance(node, ast.ExceptHandler) and node.name:
+            defined.add(node.name)
+    used = {n.id for n in ast.walk(tree) if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load)}
+    assert not (used - defined), used - defined
+    spec = importlib.util.spec_from_file_location("bench_mod", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    fm, fs = mod.choice_field_ops(5, True)
+    assert 25_000 < fm < 35_000 and 15_000 < fs < 22_000
+    assert mod.effective_cores() >= 1
