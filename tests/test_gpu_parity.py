@@ -505,3 +505,35 @@ def test_threshold_tally_end_to_end(eg, ctx, oracle):
         assert dh == oracle.point_multi_mul(sc(coeffs[0]), ct[:32])                       # [x]R for the shared secret x
         got.append(T.decrypt_total(grp, table, ct, dh))
     assert got == expected and sum(got) == votes
+
+
+# ------------------------------------------------------------------ unusual election shapes
+@pytest.mark.parametrize("n,single", [(1, True), (1, False), (2, True), (7, True), (32, False), (33, True), (40, False)])
+def test_choice_unusual_option_counts(eg, ctx, oracle, pk, n, single):
+    # 1 option (one ring), 32/33/40 options (more than 32 commitments per stage: several batched inversions)
+    op = oracle.ChoiceParams(pk, n, single)
+    ballots = bytearray(op.generate_batch(n * 31, 0, 5, n_selected=min(n, 2)))
+    ballots[1 * op.ballot_size + 64 * n + 32] ^= 1          # first response of ballot 1
+    ballots[3 * op.ballot_size + 5] ^= 0x40                 # an element of ballot 3
+    ballots = bytes(ballots)
+    want = op.verify_batch(ballots)
+    p = eg.ChoiceParams(ctx, pk, n, single)
+    got, tally = p.verify_batch(ballots)
+    assert got == want and want[0] == 0 and want[1] != 0
+    assert tally == op.tally(ballots, want)
+
+
+@pytest.mark.parametrize("options,credits", [(1, 1), (2, 4), (3, 9), (5, 25), (4, 100), (8, 36)])
+def test_qv_unusual_parameters(eg, ctx, oracle, pk, options, credits):
+    # quadratic_voting.rs:420-431 uses (5, 25); others exercise 1-ring and 3-ring decompositions and long rings
+    oq = oracle.QvParams(pk, options, credits)
+    q = eg.QuadraticVotingParams(ctx, pk, options, credits)
+    assert q.ballot_size == oq.ballot_size
+    ballots = bytearray(oq.generate_batch(credits, 0, 6))
+    ballots[2 * oq.ballot_size + oq.ballot_size - 1] ^= 1 if ballots[2 * oq.ballot_size + oq.ballot_size - 1] & 0x0F else 2
+    ballots[4 * oq.ballot_size + 40] ^= 8
+    ballots = bytes(ballots)
+    want = oq.verify_batch(ballots)
+    got, tally = q.verify_batch(ballots)
+    assert got == want and want.count(0) >= 4
+    assert tally == oq.tally(ballots, want)
