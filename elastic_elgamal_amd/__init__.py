@@ -36,7 +36,6 @@ STATUS_NAMES = {
     9: "CreditRange(LenMismatch)", 10: "CreditRange(ChallengeMismatch)", 11: "CreditEquivalence(LenMismatch)",
     12: "CreditEquivalence(ChallengeMismatch)",
 }
-TALLY_POINT_BYTES = 160
 
 
 def status_kind(s: int) -> int:
@@ -105,8 +104,6 @@ def _load() -> C.CDLL:
         "eg_verify_choice_batch": (C.c_int, [vp, sz, vp, vp, vp]),
         "eg_verify_choice_batch_device": (C.c_int, [vp, sz, vp, vp, vp]),
         "eg_choice_tally_reset": (C.c_int, [vp]),
-        "eg_choice_tally_device_ptr": (C.c_int, [vp, C.POINTER(vp), C.POINTER(sz)]),
-        "eg_choice_tally_merge_device": (C.c_int, [vp, vp, C.c_int, vp]),
         "eg_choice_tally_encode": (C.c_int, [vp, cp]),
         "eg_qv_params_create": (C.c_int, [vp, cp, C.c_int, C.c_uint64, C.POINTER(vp)]),
         "eg_qv_params_destroy": (None, [vp]),
@@ -114,8 +111,6 @@ def _load() -> C.CDLL:
         "eg_verify_qv_batch": (C.c_int, [vp, sz, vp, vp, vp]),
         "eg_verify_qv_batch_device": (C.c_int, [vp, sz, vp, vp, vp]),
         "eg_qv_tally_reset": (C.c_int, [vp]),
-        "eg_qv_tally_device_ptr": (C.c_int, [vp, C.POINTER(vp), C.POINTER(sz)]),
-        "eg_qv_tally_merge_device": (C.c_int, [vp, vp, C.c_int, vp]),
         "eg_qv_tally_encode": (C.c_int, [vp, cp]),
         "eg_choice_tally_reset_async": (C.c_int, [vp, vp]),
         "eg_choice_tally_encode_device": (C.c_int, [vp, vp, vp]),
@@ -316,14 +311,6 @@ class _BatchParams:
     def tally_encode_device(self, d_out: int, stream: int = 0):
         """Canonical encodings of the running tally (n_options x 64 bytes) into device memory, asynchronously."""
         _check(self._fn("tally_encode_device")(self._h, d_out, stream))
-
-    def tally_device_ptr(self):
-        p, nb = C.c_void_p(), C.c_size_t()
-        _check(self._fn("tally_device_ptr")(self._h, C.byref(p), C.byref(nb)))
-        return p.value, nb.value
-
-    def tally_merge_device(self, d_gathered: int, n_ranks: int, stream: int = 0):
-        _check(self._fn("tally_merge_device")(self._h, d_gathered, n_ranks, stream))
 
     def tally_encode(self) -> bytes:
         out = C.create_string_buffer(64 * self.n_options)

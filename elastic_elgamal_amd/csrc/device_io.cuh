@@ -84,13 +84,9 @@ __device__ __forceinline__ void load_wire_item(u32 w[8], const EngineBufs& B, u3
 
 // ---- table I/O policies --------------------------------------------------------------------------------------
 // per-lane variable-base table {1..8}P in a global workspace (1.25 KiB per lane: too big for registers or LDS)
-#ifndef EG_WS_PER_LANE
-#define EG_WS_PER_LANE 1
-#endif
-#if EG_WS_PER_LANE
-// Each lane owns 1280 contiguous bytes (8 entries x 160 B): a lookup touches only the lane's own 2-3 cache lines.
-// (The earlier [entry][quad][lane] layout fetched ~5x more lines than it used, because lanes with different digits
-// shared 128-B lines: profiles/r01_bench_pmc_counters.txt.)
+// Each lane owns 1280 contiguous bytes (8 entries x 160 B): a lookup touches only the lane's own 2 cache lines.
+// (The first layout, [entry][quad][lane], fetched ~5x more lines than it used because lanes with different digits
+// shared 128-B lines: profiles/r01_bench_pmc_counters.txt of the first measurement.)
 struct WsTable {
   uint4* base;   // ws + global_lane * 80
   __device__ __forceinline__ void init(uint4* ws) { base = ws + ((size_t)blockIdx.x * NT + threadIdx.x) * WS_QUADS; }
@@ -112,29 +108,6 @@ struct WsTable {
     for (int i = 0; i < 10; ++i) { c.YpX.v[i] = w[i]; c.YmX.v[i] = w[10 + i]; c.Z2.v[i] = w[20 + i]; c.T2d.v[i] = w[30 + i]; }
   }
 };
-#else
-struct WsTable {
-  uint4* base;
-  __device__ __forceinline__ void init(uint4* ws) { base = ws + (size_t)blockIdx.x * (WS_QUADS * NT) + threadIdx.x; }
-  __device__ __forceinline__ void store(int e, const ge_cached& c) {
-    u32 w[40];
-#pragma unroll
-    for (int i = 0; i < 10; ++i) { w[i] = c.YpX.v[i]; w[10 + i] = c.YmX.v[i]; w[20 + i] = c.Z2.v[i]; w[30 + i] = c.T2d.v[i]; }
-#pragma unroll
-    for (int q = 0; q < 10; ++q) base[(size_t)(e * 10 + q) * NT] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
-  }
-  __device__ __forceinline__ void load(ge_cached& c, int e) const {
-    u32 w[40];
-#pragma unroll
-    for (int q = 0; q < 10; ++q) {
-      const uint4 v = base[(size_t)(e * 10 + q) * NT];
-      w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
-    }
-#pragma unroll
-    for (int i = 0; i < 10; ++i) { c.YpX.v[i] = w[i]; c.YmX.v[i] = w[10 + i]; c.Z2.v[i] = w[20 + i]; c.T2d.v[i] = w[30 + i]; }
-  }
-};
-#endif
 // split tables of one (base, ballot): 32 cached entries, contiguous (ge_split_tables_build / ge_split_mul)
 struct BaseTable {
   uint4* base;

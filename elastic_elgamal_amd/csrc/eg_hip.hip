@@ -608,12 +608,6 @@ static int tally_reset(Engine* e, hipStream_t s = nullptr) {
   if (own) HIPCHK(hipStreamSynchronize(s));
   return EG_OK;
 }
-static int tally_merge(Engine* e, const void* d_gathered, int n_ranks, hipStream_t s) {
-  if (!s) s = e->ctx->stream;
-  hipLaunchKernelGGL(k_tally_merge, dim3(1), dim3(NT), 0, s, (const u32*)d_gathered, n_ranks, (int)e->plan.tally_slots.size(), e->tally);
-  HIPCHK(hipGetLastError());
-  return EG_OK;
-}
 static int tally_encode_device(Engine* e, void* d_out, hipStream_t s) {
   if (!s) s = e->ctx->stream;
   hipLaunchKernelGGL(k_tally_encode, dim3(1), dim3(NT), 0, s, e->tally, (int)e->plan.tally_slots.size(), (u32*)d_out);
@@ -638,15 +632,6 @@ int eg_points_sum_device(eg_ctx* c, int n_ranks, int n_points, const void* d_in,
 }
 int eg_choice_tally_reset(eg_choice_params* p) { return p ? tally_reset(p->eng) : fail(EG_ERR_BAD_ARG, "null"); }
 int eg_choice_tally_reset_async(eg_choice_params* p, void* stream) { return p && stream ? tally_reset(p->eng, (hipStream_t)stream) : fail(EG_ERR_BAD_ARG, "null"); }
-int eg_choice_tally_device_ptr(eg_choice_params* p, void** d, size_t* nb) {
-  if (!p || !d || !nb) return fail(EG_ERR_BAD_ARG, "bad argument");
-  *d = p->eng->tally; *nb = p->eng->plan.tally_slots.size() * EG_TALLY_POINT_BYTES;
-  return EG_OK;
-}
-int eg_choice_tally_merge_device(eg_choice_params* p, const void* g, int n_ranks, void* stream) {
-  if (!p || !g || n_ranks < 1) return fail(EG_ERR_BAD_ARG, "bad argument");
-  return tally_merge(p->eng, g, n_ranks, (hipStream_t)stream);
-}
 int eg_choice_tally_encode(eg_choice_params* p, uint8_t* out) {
   if (!p || !out) return fail(EG_ERR_BAD_ARG, "bad argument");
   return engine_tally_encode(p->eng, out);
@@ -674,15 +659,6 @@ int eg_verify_qv_batch_device(eg_qv_params* p, size_t n, const void* d_ballots, 
 }
 int eg_qv_tally_reset(eg_qv_params* p) { return p ? tally_reset(p->eng) : fail(EG_ERR_BAD_ARG, "null"); }
 int eg_qv_tally_reset_async(eg_qv_params* p, void* stream) { return p && stream ? tally_reset(p->eng, (hipStream_t)stream) : fail(EG_ERR_BAD_ARG, "null"); }
-int eg_qv_tally_device_ptr(eg_qv_params* p, void** d, size_t* nb) {
-  if (!p || !d || !nb) return fail(EG_ERR_BAD_ARG, "bad argument");
-  *d = p->eng->tally; *nb = p->eng->plan.tally_slots.size() * EG_TALLY_POINT_BYTES;
-  return EG_OK;
-}
-int eg_qv_tally_merge_device(eg_qv_params* p, const void* g, int n_ranks, void* stream) {
-  if (!p || !g || n_ranks < 1) return fail(EG_ERR_BAD_ARG, "bad argument");
-  return tally_merge(p->eng, g, n_ranks, (hipStream_t)stream);
-}
 int eg_qv_tally_encode(eg_qv_params* p, uint8_t* out) {
   if (!p || !out) return fail(EG_ERR_BAD_ARG, "bad argument");
   return engine_tally_encode(p->eng, out);

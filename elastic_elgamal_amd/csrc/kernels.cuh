@@ -387,20 +387,6 @@ __global__ void k_tally_init(u32* tally, int n_slots) {
   u32 w[40]; ge_to_words(w, id);
   for (int i = 0; i < 40; ++i) tally[(size_t)k * 40 + i] = w[i];
 }
-// tally[k] = sum over ranks of gathered[rank][k]   (after the all-gather of per-GPU partial tallies)
-__global__ void k_tally_merge(const u32* gathered, int n_ranks, int n_slots, u32* tally) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n_slots) return;
-  ge acc; ge_identity(acc);
-  for (int r = 0; r < n_ranks; ++r) {
-    u32 w[40];
-    for (int i = 0; i < 40; ++i) w[i] = gathered[((size_t)r * n_slots + k) * 40 + i];
-    ge p, sum; words_to_ge(p, w);
-    ge_add_full(sum, acc, p); acc = sum;
-  }
-  u32 w[40]; ge_to_words(w, acc);
-  for (int i = 0; i < 40; ++i) tally[(size_t)k * 40 + i] = w[i];
-}
 __global__ void k_tally_encode(const u32* tally, int n_slots, u32* out /* [n_slots][8] */) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n_slots) return;

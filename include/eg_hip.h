@@ -109,11 +109,6 @@ int eg_verify_choice_batch(eg_choice_params*, size_t n, const uint8_t* ballots, 
  * inside `params` until eg_choice_tally_* is called.  Asynchronous on `stream`. */
 int eg_verify_choice_batch_device(eg_choice_params*, size_t n, const void* d_ballots, void* d_status, void* stream);
 int eg_choice_tally_reset(eg_choice_params*);
-/* running tally as 2*n_options extended points, EG_TALLY_POINT_BYTES each, in device memory (for the
- * multi-GPU exchange: all-gather these, then eg_choice_tally_merge_device on every rank) */
-#define EG_TALLY_POINT_BYTES 160
-int eg_choice_tally_device_ptr(eg_choice_params*, void** d_points, size_t* n_bytes);
-int eg_choice_tally_merge_device(eg_choice_params*, const void* d_gathered, int n_ranks, void* stream);
 int eg_choice_tally_encode(eg_choice_params*, uint8_t* out /* n_options*64 */);
 /* asynchronous forms for the multi-GPU path: reset on a stream; write the canonical encodings (n_options*64 bytes)
  * to device memory, ready for an RCCL all-gather; then sum the gathered encodings with eg_points_sum_device. */
@@ -134,8 +129,6 @@ size_t eg_qv_ballot_size(const eg_qv_params*);
 int eg_verify_qv_batch(eg_qv_params*, size_t n, const uint8_t* ballots, uint32_t* status, uint8_t* tally_out);
 int eg_verify_qv_batch_device(eg_qv_params*, size_t n, const void* d_ballots, void* d_status, void* stream);
 int eg_qv_tally_reset(eg_qv_params*);
-int eg_qv_tally_device_ptr(eg_qv_params*, void** d_points, size_t* n_bytes);
-int eg_qv_tally_merge_device(eg_qv_params*, const void* d_gathered, int n_ranks, void* stream);
 int eg_qv_tally_encode(eg_qv_params*, uint8_t* out);
 int eg_qv_tally_reset_async(eg_qv_params*, void* stream);
 int eg_qv_tally_encode_device(eg_qv_params*, void* d_out, void* stream);
