@@ -93,6 +93,8 @@ def _load() -> C.CDLL:
         "eg_scalar_is_canonical_batch": (C.c_int, [vp, sz, cp, cp]),
         "eg_scalar_muladd_batch": (C.c_int, [vp, sz, cp, cp, cp, cp]),
         "eg_scalar_neg_batch": (C.c_int, [vp, sz, cp, cp]),
+        "eg_scalar_invert_batch": (C.c_int, [vp, sz, cp, cp]),
+        "eg_point_is_identity_batch": (C.c_int, [vp, sz, cp, cp, cp]),
         "eg_point_roundtrip_batch": (C.c_int, [vp, sz, cp, cp, cp]),
         "eg_point_add_batch": (C.c_int, [vp, sz, cp, cp, C.c_int, cp, cp]),
         "eg_mul_generator_batch": (C.c_int, [vp, sz, cp, cp]),
@@ -245,6 +247,22 @@ class Ristretto:
         out = C.create_string_buffer(32 * n)
         _check(_load().eg_scalar_neg_batch(self.ctx._h, n, a, out))
         return out.raw
+
+    def invert_scalars(self, a: bytes) -> bytes:  # group/mod.rs:104-118, ristretto.rs:40-52
+        n = len(a) // 32
+        out = C.create_string_buffer(32 * n)
+        _check(_load().eg_scalar_invert_batch(self.ctx._h, n, a, out))
+        return out.raw
+
+    def is_identity(self, elements: bytes):
+        """ElementOps::is_identity (ristretto.rs:80-82): (is_identity flags, ok flags)."""
+        n = len(elements) // 32
+        f, ok = C.create_string_buffer(n), C.create_string_buffer(n)
+        _check(_load().eg_point_is_identity_batch(self.ctx._h, n, elements, f, ok))
+        return f.raw, ok.raw
+
+    def element_neg(self, a: bytes):
+        return self.element_add(bytes(len(a)), a, subtract=True)
 
     def element_roundtrip(self, elements: bytes):
         """deserialize_element + serialize_element (ristretto.rs:88-95): (re-encodings, ok flags)."""

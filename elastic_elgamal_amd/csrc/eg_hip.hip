@@ -121,6 +121,7 @@ struct Engine {
   int tally_blocks = 64;
   u32* tally = nullptr;        // [2n][40] running tally (extended points)
   // staging for the host-pointer API
+  hipStream_t copy_stream = nullptr;
   unsigned char* d_wire = nullptr;
   u32* d_status = nullptr;
   size_t staging_ballots = 0;
@@ -132,6 +133,7 @@ static void engine_free(Engine* e) {
                   e->d_rules, e->d_tally_slots, e->d_base_slots, e->d_defer_slots, e->btab, e->dpt, e->encw, e->d_blob, e->d_tabK, e->d_cpts, e->d_prefixes, e->d_key_words, e->pts, e->cmp,
                   e->chal, e->states, e->flags, e->bad_item, e->partial, e->tally, e->d_wire, e->d_status};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
   delete e;
 }
 
@@ -374,10 +376,31 @@ static int engine_verify_host(Engine* e, size_t n, const uint8_t* ballots, uint3
   }
   if (tally_out) hipLaunchKernelGGL(k_tally_init, dim3(1), dim3(NT), 0, s, e->tally, (int)e->plan.tally_slots.size());
   if (n) {
-    HIPCHK(hipMemcpyAsync(e->d_wire, ballots, n * e->plan.stride, hipMemcpyHostToDevice, s));
-    int rc = engine_verify_device(e, n, e->d_wire, e->d_status, s);
+    // Pipeline over the engine's chunks: the copy stream uploads chunk k+1 while chunk k is verified (SURVEY 8e:
+    // host staging, not the kernels, is the scaling risk when ballots arrive in host memory).
+    if (!e->copy_stream) HIPCHK(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+    const size_t n_chunks = (n + e->max_cap - 1) / e->max_cap;
+    const size_t even = ((n + n_chunks - 1) / n_chunks + NT - 1) / NT * NT;
+    std::vector<hipEvent_t> uploaded(n_chunks, nullptr);
+    int rc = EG_OK;
+    size_t k = 0;
+    for (size_t off = 0; off < n && rc == EG_OK; off += even, ++k) {
+      const size_t m = std::min(even, n - off);
+      hipError_t he = hipEventCreateWithFlags(&uploaded[k], hipEventDisableTiming);
+      if (he == hipSuccess) he = hipMemcpyAsync(e->d_wire + off * e->plan.stride, ballots + off * e->plan.stride, m * e->plan.stride,
+                                                hipMemcpyHostToDevice, e->copy_stream);
+      if (he == hipSuccess) he = hipEventRecord(uploaded[k], e->copy_stream);
+      if (he == hipSuccess) he = hipStreamWaitEvent(s, uploaded[k], 0);
+      if (he != hipSuccess) { rc = fail(EG_ERR_HIP, std::string("host upload: ") + hipGetErrorString(he)); break; }
+      rc = engine_verify_device(e, m, e->d_wire + off * e->plan.stride, e->d_status + off, s);
+    }
+    // one download at the end: a device-to-pageable copy would stall the host (and the next upload) behind chunk k
+    if (rc == EG_OK && hipMemcpyAsync(status, e->d_status, n * sizeof(u32), hipMemcpyDeviceToHost, s) != hipSuccess)
+      rc = fail(EG_ERR_HIP, "status download failed");
+    (void)hipStreamSynchronize(e->copy_stream);
+    (void)hipStreamSynchronize(s);
+    for (hipEvent_t ev : uploaded) if (ev) (void)hipEventDestroy(ev);
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(status, e->d_status, n * sizeof(u32), hipMemcpyDeviceToHost, s));
   }
   HIPCHK(hipStreamSynchronize(s));
   if (tally_out) return engine_tally_encode(e, tally_out);
@@ -524,6 +547,27 @@ int eg_scalar_neg_batch(eg_ctx* c, size_t n, const uint8_t* a_, uint8_t* out) {
   TRY(a.alloc(n * 32)); TRY(o.alloc(n * 32)); TRY(a.put(a_, n * 32, c->stream));
   hipLaunchKernelGGL(k_prim_scalar_neg, dim3(blocks_of(n)), dim3(NT), 0, c->stream, n, (const u32*)a.p, (u32*)o.p);
   TRY(o.get(out, n * 32, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return EG_OK;
+}
+int eg_scalar_invert_batch(eg_ctx* c, size_t n, const uint8_t* a_, uint8_t* out) {
+  if (!c || (n && (!a_ || !out))) return fail(EG_ERR_BAD_ARG, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  DevBuf a, o;
+  TRY(a.alloc(n * 32)); TRY(o.alloc(n * 32)); TRY(a.put(a_, n * 32, c->stream));
+  hipLaunchKernelGGL(k_prim_scalar_invert, dim3(blocks_of(n)), dim3(NT), 0, c->stream, n, (const u32*)a.p, (u32*)o.p);
+  TRY(o.get(out, n * 32, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return EG_OK;
+}
+int eg_point_is_identity_batch(eg_ctx* c, size_t n, const uint8_t* in, uint8_t* is_identity, uint8_t* ok) {
+  if (!c || (n && (!in || !is_identity || !ok))) return fail(EG_ERR_BAD_ARG, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  DevBuf a, f, o;
+  TRY(a.alloc(n * 32)); TRY(f.alloc(n)); TRY(o.alloc(n)); TRY(a.put(in, n * 32, c->stream));
+  hipLaunchKernelGGL(k_prim_point_is_identity, dim3(blocks_of(n)), dim3(NT), 0, c->stream, n, (const u32*)a.p,
+                     (unsigned char*)f.p, (unsigned char*)o.p);
+  TRY(f.get(is_identity, n, c->stream)); TRY(o.get(ok, n, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   return EG_OK;
 }

@@ -511,6 +511,26 @@ __global__ void __launch_bounds__(NT) k_prim_scalar_neg(size_t n, const u32* a, 
   sc_neg(o, aw);
   st8(out + i * 8, o);
 }
+__global__ void __launch_bounds__(NT) k_prim_scalar_invert(size_t n, const u32* a, u32* out) {
+  const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+  if (i >= n) return;
+  u32 aw[8], o[8]; ld8(aw, a + i * 8);
+  sc_invert(o, aw);
+  st8(out + i * 8, o);
+}
+// ElementOps::is_identity on encodings: the identity's only valid encoding is 32 zero bytes
+__global__ void __launch_bounds__(NT) k_prim_point_is_identity(size_t n, const u32* in, unsigned char* is_id, unsigned char* ok) {
+  const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+  if (i >= n) return;
+  u32 w[8]; ld8(w, in + i * 8);
+  ge p;
+  const bool valid = ristretto_decode(p, w);
+  u32 any = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) any |= w[k];
+  ok[i] = valid ? 1 : 0;
+  is_id[i] = (valid && any == 0) ? 1 : 0;
+}
 __global__ void __launch_bounds__(NT) k_prim_point_roundtrip(size_t n, const u32* in, u32* out, unsigned char* ok) {
   const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
   if (i >= n) return;

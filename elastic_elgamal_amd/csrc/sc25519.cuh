@@ -165,6 +165,27 @@ EG_HD void sc_halve(u32 out[8], const u32 s[8]) {
   out[7] = (t[7] >> 1) | ((u32)carry << 31);
 }
 
+// a^(l-2) mod l = 1/a (0 for a = 0, as Scalar::invert gives in release builds): ScalarOps::invert_scalar
+// (group/mod.rs:104-107 -> ristretto.rs:40-42).  Left-to-right square and multiply over the constant exponent.
+EG_HD void sc_invert(u32 out[8], const u32 a[8]) {
+  const u32 l[8] = EG_L_WORDS;
+  u32 e[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) e[i] = l[i];
+  e[0] -= 2u;   // l is odd and l[0] >= 2: no borrow
+  u32 r[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 252; i >= 0; --i) {
+    sc_mul(r, r, r);
+    u32 t[8];
+    sc_mul(t, r, a);
+    const bool bit = (e[i >> 5] >> (i & 31)) & 1u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[k] = bit ? t[k] : r[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) out[k] = r[k];
+}
+
 // Scalar::from_canonical_bytes: value < l
 EG_HD bool sc_is_canonical(const u32 a[8]) {
   const u32 l[8] = EG_L_WORDS;

@@ -79,10 +79,15 @@ int eg_scalar_is_canonical_batch(eg_ctx*, size_t n, const uint8_t* s /*32n*/, ui
 /* a*b + c, -a  (Scalar Mul/Add/Neg used at ring.rs:192-193,339) */
 int eg_scalar_muladd_batch(eg_ctx*, size_t n, const uint8_t* a, const uint8_t* b, const uint8_t* c, uint8_t* out);
 int eg_scalar_neg_batch(eg_ctx*, size_t n, const uint8_t* a, uint8_t* out);
+/* ScalarOps::invert_scalar / invert_scalars (group/mod.rs:104-118, ristretto.rs:40-52): 1/a mod l; 0 maps to 0 */
+int eg_scalar_invert_batch(eg_ctx*, size_t n, const uint8_t* a, uint8_t* out);
 /* ElementOps::deserialize_element then serialize_element (ristretto.rs:88-95): ok[i] = 1 for a valid
  * encoding, and out = re-encoding (equal to the input for every valid encoding) */
 int eg_point_roundtrip_batch(eg_ctx*, size_t n, const uint8_t* in /*32n*/, uint8_t* out /*32n*/, uint8_t* ok /*n*/);
-/* Element Add / Sub (ristretto.rs:76-86 via RistrettoPoint ops); ok[i]=0 if an input fails to decode */
+/* ElementOps::is_identity (ristretto.rs:80-82): is_identity[i] = 1 iff the encoding is valid and is the identity */
+int eg_point_is_identity_batch(eg_ctx*, size_t n, const uint8_t* in /*32n*/, uint8_t* is_identity /*n*/, uint8_t* ok /*n*/);
+/* Element Add / Sub (ristretto.rs:76-86 via RistrettoPoint ops); ok[i]=0 if an input fails to decode.
+ * Element Neg is `subtract` with a = identity (32 zero bytes). */
 int eg_point_add_batch(eg_ctx*, size_t n, const uint8_t* a, const uint8_t* b, int subtract, uint8_t* out, uint8_t* ok);
 /* Group::mul_generator / vartime_mul_generator (ristretto.rs:105-121) */
 int eg_mul_generator_batch(eg_ctx*, size_t n, const uint8_t* k /*32n*/, uint8_t* out /*32n*/);

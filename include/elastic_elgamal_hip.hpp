@@ -191,6 +191,12 @@ struct Ristretto {
   }
   Element add(const Element& a, const Element& b) const { Element o; uint8_t ok; check(eg_point_add_batch(ctx.raw(), 1, a.data(), b.data(), 0, o.data(), &ok)); return o; }
   Element sub(const Element& a, const Element& b) const { Element o; uint8_t ok; check(eg_point_add_batch(ctx.raw(), 1, a.data(), b.data(), 1, o.data(), &ok)); return o; }
+  Element neg(const Element& a) const { return sub(identity(), a); }
+  static Element identity() { return Element{}; }   // 32 zero bytes
+  bool is_identity(const Element& a) const { uint8_t f = 0, ok = 0; check(eg_point_is_identity_batch(ctx.raw(), 1, a.data(), &f, &ok)); return f != 0; }
+  Scalar invert_scalar(const Scalar& a) const { Scalar o; check(eg_scalar_invert_batch(ctx.raw(), 1, a.data(), o.data())); return o; }
+  Scalar scalar_muladd(const Scalar& a, const Scalar& b, const Scalar& c) const { Scalar o; check(eg_scalar_muladd_batch(ctx.raw(), 1, a.data(), b.data(), c.data(), o.data())); return o; }
+  Scalar scalar_neg(const Scalar& a) const { Scalar o; check(eg_scalar_neg_batch(ctx.raw(), 1, a.data(), o.data())); return o; }
 };
 
 }  // namespace elastic_elgamal_hip

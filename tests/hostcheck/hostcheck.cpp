@@ -142,6 +142,9 @@ void hc_sc_muladd(const uint8_t a[32], const uint8_t b[32], const uint8_t c[32],
 void hc_sc_neg(const uint8_t a[32], uint8_t out[32]) {
   u32 aw[8], o[8]; words_from_bytes(aw, a, 8); sc_neg(o, aw); bytes_from_words(out, o, 8);
 }
+void hc_sc_invert(const uint8_t a[32], uint8_t out[32]) {
+  u32 aw[8], o[8]; words_from_bytes(aw, a, 8); sc_invert(o, aw); bytes_from_words(out, o, 8);
+}
 int hc_sc_is_canonical(const uint8_t a[32]) { u32 aw[8]; words_from_bytes(aw, a, 8); return sc_is_canonical(aw) ? 1 : 0; }
 
 // transcript: new(label); append(l1, m1); append_u64(l2, x); challenge(l3) -> 64 bytes; also exports pos

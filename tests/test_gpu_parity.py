@@ -64,6 +64,9 @@ def test_scalars(grp, oracle):
         assert int.from_bytes(neg[32 * i : 32 * i + 32], "little") == (-v) % L
     cand = [sc(0), sc(L - 1), L.to_bytes(32, "little"), (L + 1).to_bytes(32, "little"), b"\xff" * 32]
     assert list(grp.deserialize_scalar_ok(b"".join(cand))) == [1, 1, 0, 0, 0]
+    inv = grp.invert_scalars(a)   # ScalarOps::invert_scalars; known answers from Fermat (l is prime)
+    for i, v in enumerate(vals):
+        assert int.from_bytes(inv[32 * i : 32 * i + 32], "little") == pow(v, L - 2, L), i
 
 
 def test_element_codec(grp, oracle):
@@ -77,7 +80,13 @@ def test_element_codec(grp, oracle):
         assert bool(ok[i]) == (want is not None), i
         if want is not None:
             assert out[32 * i : 32 * i + 32] == want == e
+    flags, ok2 = grp.is_identity(b"".join(items))
+    assert list(ok2) == list(ok)
+    assert [i for i, f in enumerate(flags) if f] == [items.index(b"\0" * 32)]
     a, b = valid[:32], valid[32:64]
+    neg, _ = grp.element_neg(b"".join(a))
+    back, _ = grp.element_add(b"".join(a), neg)
+    assert back == b"\0" * (32 * 32)
     s, ok = grp.element_add(b"".join(a), b"".join(b))
     d, _ = grp.element_add(b"".join(a), b"".join(b), subtract=True)
     for i in range(32):

@@ -2,6 +2,7 @@
 checked against the oracle.  Test-only: proves the limb-bound discipline on every executed path and
 lets the device math be validated without a GPU.  The product never loads this library."""
 import ctypes as C
+import os
 import random
 import subprocess
 from pathlib import Path
@@ -20,7 +21,8 @@ def hc():
     if not lib.exists() or any(s.stat().st_mtime > lib.stat().st_mtime for s in srcs):
         subprocess.check_call(
             ["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-DEG_BOUNDCHECK", "-fsanitize=undefined",
-             "-fno-sanitize-recover=undefined", "-o", str(lib), str(HERE / "hostcheck.cpp")]
+             "-fno-sanitize-recover=undefined", *os.environ.get("EG_HOSTCHECK_FLAGS", "").split(),
+             "-o", str(lib), str(HERE / "hostcheck.cpp")]
         )
     return C.CDLL(str(lib))
 
@@ -69,6 +71,10 @@ def test_scalar_ops(hc):
             c = rnd.randrange(L)
             hc.hc_sc_muladd(a.to_bytes(32, "little"), b.to_bytes(32, "little"), c.to_bytes(32, "little"), out)
             assert int.from_bytes(out.raw, "little") == (a * b + c) % L
+    for a in vals[:16]:
+        out = _b()
+        hc.hc_sc_invert(a.to_bytes(32, "little"), out)
+        assert int.from_bytes(out.raw, "little") == pow(a, L - 2, L)
     assert hc.hc_sc_is_canonical((L - 1).to_bytes(32, "little")) == 1
     assert hc.hc_sc_is_canonical(L.to_bytes(32, "little")) == 0
     assert hc.hc_sc_is_canonical((L + 1).to_bytes(32, "little")) == 0

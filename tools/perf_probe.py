@@ -34,3 +34,19 @@ for it in range(iters):
     best = max(best, n_total / dt)
     print(f"  iter {it}: {n_total/dt:,.0f} ballots/s  wall {dt*1e3:.1f} ms  msm {msm_ms:.1f} ms / {launches} launches  ok={int((st==0).sum())}")
 print(f"{os.environ.get('EG_LIB','default')} {mode} n={n_total}: best {best:,.0f} ballots/s   [{ctx.name}]")
+if os.environ.get("EG_PROBE_HOST"):
+    # host-buffer entry point (PCIe-inclusive): pageable numpy buffer and pinned torch buffer
+    import ctypes as C
+    lib = eg._load()
+    fn = getattr(lib, "eg_verify_qv_batch" if mode == "qv" else "eg_verify_choice_batch")
+    for kind in ("pageable", "pinned"):
+        h = d.cpu()
+        if kind == "pinned":
+            h = h.pin_memory()
+        hs = torch.empty(n_total, dtype=torch.int32)
+        tally = C.create_string_buffer(64 * p.n_options)
+        for it in range(3):
+            t0 = time.time()
+            rc = fn(p._h, n_total, C.c_void_p(h.data_ptr()), C.c_void_p(hs.data_ptr()), tally)
+            dt = time.time() - t0
+            print(f"  host[{kind}] iter {it}: rc={rc} {n_total/dt:,.0f} ballots/s  wall {dt*1e3:.1f} ms  ok={int((hs==0).sum())}")
