@@ -488,6 +488,136 @@ EG_HD void ge_split_mul(ge& acc, TableIO& io, const u32 digits[8]) {
   }
 }
 
+// ---- variable-base multiplication with a per-base signed comb ("teeth" tables) -----------------------------------------
+// Same amortisation as the split tables, arranged as a Lim-Lee comb: with P_j = [2^(43 j)] P, j = 0..5, the table holds
+// the 32 points P_5 +- P_4 +- P_3 +- P_2 +- P_1 +- P_0 (entry index = bitmask of the '+' signs of teeth 0..4), and an odd
+// multiplier k < 2^258 is written with 258 signed bits s_i = +-1 (k = sum s_i 2^i: s_i = 2 bit_(i+1)(k) - 1, s_257 = +1).
+// Column c = (s_c, s_(43+c), .., s_(215+c)) selects +-entry, so [k]P = sum_c 2^c D_c costs 42 doublings + 43 additions
+// (every digit is non-zero: no identity select), against 60 + 64 for the split tables; the table costs 215 doublings +
+// 37 additions (Gray-code walk, each step adds +-2 P_j) against 192 + 28.  Even multipliers use k + l, which changes the
+// product by the 4-torsion point [l]P only - invisible to the Ristretto encoding, like the halving in sc_halve.
+#ifndef EG_BASE_TEETH
+#define EG_BASE_TEETH 1
+#endif
+#define EG_TEETH 6
+#define EG_TEETH_COLS 43
+#define EG_TEETH_ENTRIES 32
+
+// rows[j] = the 43 sign bits of tooth j, left-aligned (bit 63 = column 42)
+EG_HD void sc_recode_teeth(u64 rows[EG_TEETH], const u32 s[8]) {
+  const u32 l[8] = EG_L_WORDS;
+  const bool even = (s[0] & 1u) == 0;
+  u32 t[8];
+  u64 carry = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const u64 v = (u64)s[i] + (even ? l[i] : 0u) + carry;
+    t[i] = (u32)v;
+    carry = v >> 32;          // no carry out of word 7: s < 2^254
+  }
+  u32 sg[9];                  // sign bits: (k >> 1) with bit 257 set
+#pragma unroll
+  for (int i = 0; i < 7; ++i) sg[i] = (t[i] >> 1) | (t[i + 1] << 31);
+  sg[7] = t[7] >> 1;
+  sg[8] = 2u;
+#pragma unroll
+  for (int j = 0; j < EG_TEETH; ++j) {
+    const int off = EG_TEETH_COLS * j, wi = off >> 5, sh = off & 31;
+    u64 v = ((u64)sg[wi] | ((u64)sg[wi + 1] << 32)) >> sh;
+    if (sh + EG_TEETH_COLS > 64) v |= (u64)sg[wi + 2] << (64 - sh);
+    rows[j] = (v & ((1ull << EG_TEETH_COLS) - 1ull)) << (64 - EG_TEETH_COLS);
+  }
+}
+// pops the next column (from column 42 downwards): table entry index and whether the entry is negated
+EG_HD void sc_teeth_next(u64 rows[EG_TEETH], int& idx, bool& neg) {
+  u32 m = 0;
+#pragma unroll
+  for (int j = 0; j < EG_TEETH - 1; ++j) m |= (u32)(rows[j] >> 63) << j;
+  const bool top = (rows[EG_TEETH - 1] >> 63) != 0;
+#pragma unroll
+  for (int j = 0; j < EG_TEETH; ++j) rows[j] <<= 1;
+  idx = (int)(top ? m : (m ^ (EG_TEETH_ENTRIES - 1)));
+  neg = !top;
+}
+
+// io: the 32-entry table of this base; tmp: scratch for the five cached points 2 P_j (entries 0..4)
+template <class TableIO, class TmpIO>
+EG_HD void ge_teeth_tables_build(TableIO& io, TmpIO& tmp, const ge& p) {
+  ge cur = p, sum;
+  ge_identity(sum);
+#pragma unroll 1
+  for (int j = 0; j < EG_TEETH - 1; ++j) {
+    ge_p1p1 t;
+    {
+      ge_cached pc; ge_to_cached(pc, cur);
+      ge_cached_cneg(pc, true);
+      ge_add(t, sum, pc);                 // sum -= P_j
+      ge_add_to_p3(sum, t);
+    }
+    ge q3;
+    ge_dbl(t, cur.X, cur.Y, cur.Z);
+    ge_dbl_to_p3(q3, t);                  // 2 P_j, the step of the Gray-code walk for tooth j
+    {
+      ge_cached qc; ge_to_cached(qc, q3);
+      tmp.store(j, qc);
+    }
+    ge_p2 q;
+    q.X = q3.X; q.Y = q3.Y; q.Z = q3.Z;
+#pragma unroll 1
+    for (int r = 0; r < EG_TEETH_COLS - 2; ++r) { ge_dbl(t, q.X, q.Y, q.Z); ge_dbl_to_p2(q, t); }
+    ge_dbl(t, q.X, q.Y, q.Z);
+    ge_dbl_to_p3(cur, t);                 // P_(j+1)
+  }
+  {
+    ge_cached pc; ge_to_cached(pc, cur);
+    ge_p1p1 t; ge_add(t, sum, pc);        // sum = P_5 - P_4 - .. - P_0 = entry 0
+    ge_add_to_p3(sum, t);
+    ge_cached e; ge_to_cached(e, sum);
+    io.store(0, e);
+  }
+#pragma unroll 1
+  for (int i = 1; i < EG_TEETH_ENTRIES; ++i) {
+    int j = 0;
+    while (((i >> j) & 1) == 0) ++j;      // Gray code: step i flips tooth ctz(i)
+    const int g = i ^ (i >> 1);
+    ge_cached qc; tmp.load(qc, j);
+    ge_cached_cneg(qc, ((g >> j) & 1) == 0);
+    ge_p1p1 t; ge_add(t, sum, qc);
+    ge_add_to_p3(sum, t);
+    ge_cached e; ge_to_cached(e, sum);
+    io.store(g, e);
+  }
+}
+
+// acc = [k]P from the teeth table; rows = sc_recode_teeth(k) (consumed).  Loads are issued one column ahead of their use.
+template <class TableIO>
+EG_HD void ge_teeth_mul(ge& acc, TableIO& io, u64 rows[EG_TEETH]) {
+  ge_identity(acc);
+  int idx; bool neg;
+  sc_teeth_next(rows, idx, neg);
+  ge_cached nxt;
+  io.load(nxt, idx);
+#pragma unroll 1
+  for (int c = EG_TEETH_COLS - 1; c >= 0; --c) {
+    ge_cached cur = nxt;
+    const bool cneg = neg;
+    if (c > 0) { sc_teeth_next(rows, idx, neg); io.load(nxt, idx); }
+    ge_p1p1 t;
+    if (c != EG_TEETH_COLS - 1) {
+      ge_dbl(t, acc.X, acc.Y, acc.Z);
+      ge_dbl_to_p3(acc, t);
+    }
+    ge_cached_cneg(cur, cneg);
+    ge_add(t, acc, cur);
+    if (c > 0) {                          // next operation is a doubling: T is not needed (saves one multiplication)
+      ge_p2 q; ge_add_to_p2(q, t);
+      acc.X = q.X; acc.Y = q.Y; acc.Z = q.Z;
+    } else {
+      ge_add_to_p3(acc, t);
+    }
+  }
+}
+
 // ---- fixed-base scalar multiplication -----------------------------------------------------------------------------
 // Signed radix-2^B comb (B = EG_COMB_BITS, default 13: 20 windows x 4096 affine-Niels entries per base, 10 MiB, L2 /
 // Infinity-Cache resident; measured 8 -> 13 bits: +3 %, flat beyond), built once per base on the device (k_build_fixed_table).  Table index = window * 2^(B-1) + (|digit| - 1).

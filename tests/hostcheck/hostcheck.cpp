@@ -91,6 +91,21 @@ int hc_double_mul_generator_split(const uint8_t k[32], const uint8_t p_enc[32], 
   return 1;
 }
 
+// same through the per-base teeth comb (ge_teeth_tables_build / ge_teeth_mul)
+int hc_double_mul_generator_teeth(const uint8_t k[32], const uint8_t p_enc[32], const uint8_t r[32], uint8_t out[32]) {
+  if (g_base_table.e.empty()) { ge g; ge_generator(g); build_fixed(g_base_table, g); }
+  u32 kw[8], rw[8], pw[8], o[8];
+  words_from_bytes(kw, k, 8); words_from_bytes(rw, r, 8); words_from_bytes(pw, p_enc, 8);
+  ge p; if (!ristretto_decode(p, pw)) return 0;
+  ArrSplit tab; ArrTable tmp; ge_teeth_tables_build(tab, tmp, p);
+  u64 rows[EG_TEETH]; u32 dr[EG_COMB_WORDS]; sc_recode_teeth(rows, kw); sc_recode_comb(dr, rw);
+  ge acc; ge_teeth_mul(acc, tab, rows);
+  ge_fixed_mul_add(acc, g_base_table, dr);
+  ristretto_encode(o, acc);
+  bytes_from_words(out, o, 8);
+  return 1;
+}
+
 // encode(2P) through the batched-inversion path vs the plain encoder; returns 1 when they agree
 int hc_double_encode(const uint8_t p_enc[32], uint8_t out[32]) {
   u32 pw[8], o[8], ref[8]; words_from_bytes(pw, p_enc, 8);

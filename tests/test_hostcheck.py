@@ -128,6 +128,8 @@ def test_double_mul_generator(hc, oracle):
         assert out.raw == oracle.point_double_mul_generator(kb, p, rb), (k, r)
         assert hc.hc_double_mul_generator_split(kb, p, rb, out) == 1      # 4-way split tables, 60 doublings
         assert out.raw == oracle.point_double_mul_generator(kb, p, rb), (k, r)
+        assert hc.hc_double_mul_generator_teeth(kb, p, rb, out) == 1      # 6-tooth signed comb, 42 doublings
+        assert out.raw == oracle.point_double_mul_generator(kb, p, rb), (k, r)
         assert hc.hc_double_mul_generator_halved(kb, p, rb, out) == 1     # halved scalars + doubled encoder
         assert out.raw == oracle.point_double_mul_generator(kb, p, rb), (k, r)
 
