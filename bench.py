@@ -31,7 +31,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # VALU model: field operations per building block counted by the host-check build
 # (tests/hostcheck: hc_op_counts) as (fe_mul, fe_sq); one fe_mul = 100 and one fe_sq = 55 v_mad_u64_u32.
 OPS = {"decode": (27, 257), "direct_table": (64, 0), "direct_mul": (1269, 1008), "comb": (140, 0), "encode": (32, 255),
-       "split_tables": (835, 768), "split_mul": (692, 240), "enc_batch_each": (23, 10), "enc_batch_inversion": (11, 254)}
+       "base_table": (994, 860), "base_mul": (470, 168), "enc_batch_each": (23, 10), "enc_batch_inversion": (11, 254)}
 # memory-side traffic of k_msm_jobs per ballot and launch, from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
 # of profiles/r01_bench_pmc_counters.txt (single-choice 5-option ballots, 262144 per launch)
 MSM_TRAFFIC_BYTES_PER_BALLOT_LAUNCH = {"single": 55.92e9 / 262144}
@@ -47,9 +47,9 @@ def choice_field_ops(n: int, single: bool):
     def mul(x, k):
         return (x[0] * k, x[1] * k)
 
-    ring = add(OPS["split_mul"], OPS["comb"], OPS["enc_batch_each"])
+    ring = add(OPS["base_mul"], OPS["comb"], OPS["enc_batch_each"])
     fold = add(ring, OPS["comb"])
-    total = add(mul(OPS["split_tables"], 2 * n), mul(ring, 3 * n), mul(fold, n), mul(OPS["decode"], 2 * n))
+    total = add(mul(OPS["base_table"], 2 * n), mul(ring, 3 * n), mul(fold, n), mul(OPS["decode"], 2 * n))
     groups = 2 * (-(-(2 * n + (2 if single else 0)) // 32))           # batched inversions: per stage and group of 32
     total = add(total, mul(OPS["enc_batch_inversion"], groups))
     if single:

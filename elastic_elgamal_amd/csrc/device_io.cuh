@@ -31,7 +31,7 @@ struct EngineBufs {
   uint4* ws;            // per-lane variable-base tables (direct multiplications)
   uint4* dpt;           // deferred commitments P with out = encode(2P)   [cmp slot][10][cap]
   u32* encw;            // k_encode_batch scratch: prefix products and N   [2 * slot][10][cap]
-  uint4* btab;          // split tables of the ring bases [base][cap] x 320 uint4 (4 x 8 cached entries, 5 KiB)
+  uint4* btab;          // comb tables of the ring bases [base][cap] x 320 uint4 (32 cached entries, 5 KiB)
 };
 constexpr int BTAB_QUADS = 32 * 10;
 
@@ -108,7 +108,7 @@ struct WsTable {
     for (int i = 0; i < 10; ++i) { c.YpX.v[i] = w[i]; c.YmX.v[i] = w[10 + i]; c.Z2.v[i] = w[20 + i]; c.T2d.v[i] = w[30 + i]; }
   }
 };
-// split tables of one (base, ballot): 32 cached entries, contiguous (ge_split_tables_build / ge_split_mul)
+// comb table of one (base, ballot): 32 cached entries, contiguous (ge_teeth_tables_build / ge_teeth_mul)
 struct BaseTable {
   uint4* base;
   __device__ __forceinline__ void store(int e, const ge_cached& c) {

@@ -764,21 +764,21 @@ int eg_plan_describe(int kind, int n_options, uint64_t credits_or_bound, char* b
     case 5: P = eghost::build_range_plan(credits_or_bound, &item); break;
     default: return fail(EG_ERR_BAD_ARG, "unknown plan kind");
   }
-  size_t jobs = 0, insts = 0, var_terms = P.vterms.size(), split_terms = 0, derived = 0;
+  size_t jobs = 0, insts = 0, var_terms = P.vterms.size(), table_terms = 0, derived = 0;
   std::string per_stage;
   for (auto& st : P.stages) {
     jobs += st.jobs.size(); insts += st.insts.size();
     per_stage += (per_stage.empty() ? "" : ",") + std::to_string(st.jobs.size());
   }
-  for (auto& t : P.vterms) split_terms += t.base != 0xffff;
+  for (auto& t : P.vterms) table_terms += t.base != 0xffff;
   for (auto& l : P.derive_levels) derived += l.size();
   char tmp[1024];
   snprintf(tmp, sizeof tmp,
            "{\"stride\": %zu, \"wire_points\": %zu, \"wire_scalars\": %zu, \"derived_points\": %zu, \"bases\": %zu, "
-           "\"stages\": %zu, \"jobs\": %zu, \"jobs_per_stage\": [%s], \"var_terms\": %zu, \"split_terms\": %zu, "
+           "\"stages\": %zu, \"jobs\": %zu, \"jobs_per_stage\": [%s], \"var_terms\": %zu, \"table_terms\": %zu, "
            "\"hash_programs\": %zu, \"prefixes\": %d, \"flags\": %d, \"rules\": %zu, \"tally_slots\": %zu}",
            P.stride, P.pt_items.size(), P.sc_items.size(), derived, P.base_slots.size(), P.stages.size(), jobs, per_stage.c_str(),
-           var_terms, split_terms, insts, P.n_prefixes, P.n_flag_slots, P.rules.size(), P.tally_slots.size());
+           var_terms, table_terms, insts, P.n_prefixes, P.n_flag_slots, P.rules.size(), P.tally_slots.size());
   if (strlen(tmp) + 1 > cap) return fail(EG_ERR_BAD_ARG, "buffer too small");
   memcpy(buf, tmp, strlen(tmp) + 1);
   return EG_OK;

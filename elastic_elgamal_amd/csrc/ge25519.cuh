@@ -406,99 +406,18 @@ EG_HD void ge_var_mul(ge& acc, TableIO& io, const u32 digits[8]) {
   }
 }
 
-// ---- variable-base multiplication with per-base split tables ---------------------------------------------------------
-// A ring base (R or B of one ciphertext) is multiplied by one challenge per equation of its ring (ring.rs:333-361), and
-// equation j+1 cannot start before equation j is hashed.  The doublings are therefore amortised ACROSS equations:
-// once per base the tables of P_j = [2^(64 j)] P, j = 0..3 are built (192 doublings, 4 x 8 cached entries, 5 KiB), and
-// every later product [k]P = sum_i 16^i sum_j d_(16 j + i) P_j costs 60 doublings + 64 additions instead of 252 + 64.
-// Entry index = j * 8 + (|digit| - 1).
-template <class TableIO>
-EG_HD void ge_split_tables_build(TableIO& io, const ge& p) {
-  ge base = p;
-#pragma unroll 1
-  for (int j = 0; j < 4; ++j) {
-    ge_cached pc; ge_to_cached(pc, base);
-    io.store(j * 8, pc);
-    ge cur = base;
-#pragma unroll 1
-    for (int k = 2; k <= 8; ++k) {
-      ge_p1p1 t;
-      ge_add(t, cur, pc);
-      ge_add_to_p3(cur, t);
-      ge_cached c; ge_to_cached(c, cur);
-      io.store(j * 8 + k - 1, c);
-    }
-    if (j < 3) {
-      ge_p1p1 t; ge_p2 q;
-      q.X = base.X; q.Y = base.Y; q.Z = base.Z;
-#pragma unroll 1
-      for (int r = 0; r < 63; ++r) { ge_dbl(t, q.X, q.Y, q.Z); ge_dbl_to_p2(q, t); }
-      ge_dbl(t, q.X, q.Y, q.Z);
-      ge_dbl_to_p3(base, t);
-    }
-  }
-}
-
-// entry index and sign of digit (16 j + i); the raw load is issued early, the sign / zero fix-up happens at use
-EG_HD int ge_split_index(const u32 digits[8], int j, int i) {
-  const int d = sc_digit16(digits, 16 * j + i);
-  const int ad = d < 0 ? -d : d;
-  return j * 8 + (ad == 0 ? 0 : ad - 1);
-}
-EG_HD void ge_split_fixup(ge_cached& c, const u32 digits[8], int j, int i, const ge_cached& ident) {
-  const int d = sc_digit16(digits, 16 * j + i);
-  fe_cmov(c.YpX, ident.YpX, d == 0); fe_cmov(c.YmX, ident.YmX, d == 0);
-  fe_cmov(c.Z2, ident.Z2, d == 0); fe_cmov(c.T2d, ident.T2d, d == 0);
-  ge_cached_cneg(c, d < 0);
-}
-
-// acc = [k]P from the split tables; digits = sc_recode_radix16(k).  Every table load is issued one addition (or the
-// four doublings) ahead of its use so that HBM / Infinity-Cache latency is hidden even at 2 waves per SIMD.
-template <class TableIO>
-EG_HD void ge_split_mul(ge& acc, TableIO& io, const u32 digits[8]) {
-  ge_cached ident; ge_cached_identity(ident);
-  ge_identity(acc);
-  ge_cached nxt;
-  io.load(nxt, ge_split_index(digits, 0, 15));
-#pragma unroll 1
-  for (int i = 15; i >= 0; --i) {
-    if (i != 15) {
-      ge_p1p1 t; ge_p2 q;
-      q.X = acc.X; q.Y = acc.Y; q.Z = acc.Z;
-#pragma unroll 1
-      for (int r = 0; r < 3; ++r) { ge_dbl(t, q.X, q.Y, q.Z); ge_dbl_to_p2(q, t); }
-      ge_dbl(t, q.X, q.Y, q.Z);
-      ge_dbl_to_p3(acc, t);
-    }
-#pragma unroll 1
-    for (int j = 0; j < 4; ++j) {
-      ge_cached c = nxt;
-      const int nj = (j + 1) & 3, ni = j == 3 ? i - 1 : i;
-      if (ni >= 0) io.load(nxt, ge_split_index(digits, nj, ni));
-      ge_split_fixup(c, digits, j, i, ident);
-      ge_p1p1 t;
-      ge_add(t, acc, c);
-      if (j == 3 && i > 0) {          // next operation is a doubling: T is not needed (saves one multiplication)
-        ge_p2 q; ge_add_to_p2(q, t);
-        acc.X = q.X; acc.Y = q.Y; acc.Z = q.Z;
-      } else {
-        ge_add_to_p3(acc, t);
-      }
-    }
-  }
-}
-
 // ---- variable-base multiplication with a per-base signed comb ("teeth" tables) -----------------------------------------
-// Same amortisation as the split tables, arranged as a Lim-Lee comb: with P_j = [2^(43 j)] P, j = 0..5, the table holds
+// A ring base (R or B of one ciphertext) is multiplied by one challenge per equation of its ring (ring.rs:333-361), and
+// equation j+1 cannot start before equation j is hashed.  The doublings are therefore amortised ACROSS equations with a
+// per-base table, arranged as a signed Lim-Lee comb: with P_j = [2^(43 j)] P, j = 0..5, the table holds
 // the 32 points P_5 +- P_4 +- P_3 +- P_2 +- P_1 +- P_0 (entry index = bitmask of the '+' signs of teeth 0..4), and an odd
 // multiplier k < 2^258 is written with 258 signed bits s_i = +-1 (k = sum s_i 2^i: s_i = 2 bit_(i+1)(k) - 1, s_257 = +1).
 // Column c = (s_c, s_(43+c), .., s_(215+c)) selects +-entry, so [k]P = sum_c 2^c D_c costs 42 doublings + 43 additions
-// (every digit is non-zero: no identity select), against 60 + 64 for the split tables; the table costs 215 doublings +
-// 37 additions (Gray-code walk, each step adds +-2 P_j) against 192 + 28.  Even multipliers use k + l, which changes the
+// (every digit is non-zero: no identity select) instead of 252 + 64 for a fresh ladder; the table costs 215 doublings +
+// 37 additions (Gray-code walk, each step adds +-2 P_j), 32 cached entries = 5 KiB per base and ballot.  (Round 1 first
+// used four radix-16 tables of P, 2^64 P, 2^128 P, 2^192 P: 192 + 28 for the tables but 60 + 64 per product; the comb
+// measured +10 % on 2-equation rings and +23 % on the QV ballot.)  Even multipliers use k + l, which changes the
 // product by the 4-torsion point [l]P only - invisible to the Ristretto encoding, like the halving in sc_halve.
-#ifndef EG_BASE_TEETH
-#define EG_BASE_TEETH 1
-#endif
 #define EG_TEETH 6
 #define EG_TEETH_COLS 43
 #define EG_TEETH_ENTRIES 32

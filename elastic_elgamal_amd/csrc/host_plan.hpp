@@ -102,7 +102,7 @@ struct Plan {
   int n_pt_slots = 0, n_cmp_slots = 0, n_chal_slots = 0, n_state_slots = 0, n_flag_slots = 0, n_prefixes = 0;
   std::map<std::string, uint32_t> blob_index;
   std::map<uint64_t, uint16_t> const_index;
-  // bases with precomputed split tables (ge_split_tables_build): point slots that several equations multiply
+  // bases with a precomputed comb table (ge_teeth_tables_build): point slots that several equations multiply
   std::vector<uint16_t> base_slots;
   std::map<uint16_t, uint16_t> base_index_of;
   uint16_t base_index(uint16_t slot) {
@@ -237,7 +237,7 @@ inline uint16_t add_ring_proof(Plan& P, const std::vector<HashOp>& setup, const 
     for (size_t j = 0; j < s; ++j) {
       // R_G = [s]G - [e]R ;  R_K = [s]K - [e](B - x_j) = [s]K + [e m_j]G - [e]B  with x_j = [m_j]G   (ring.rs:338-350).
       // Folding x_j into the generator term keeps B itself as the only variable base of the ring's K side, so the
-      // split tables of R and B are shared by all equations of the ring.
+      // comb tables of R and B are shared by all equations of the ring.
       const ScalarSrc e_pos = j == 0 ? wire_src(challenge_item) : chal_src(chal);
       ScalarSrc e = e_pos;
       e.neg = 1;

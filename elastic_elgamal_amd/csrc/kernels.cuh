@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(NT) k_derive_points(EngineBufs B, const egplan
   }
 }
 
-// ---- k_base_tables: split tables of every ring base (once per base and ballot; shared by all equations of the ring) ----------
+// ---- k_base_tables: comb tables of every ring base (once per base and ballot; shared by all equations of the ring) -----------
 __global__ void __launch_bounds__(NT, 2) k_base_tables(EngineBufs B, const unsigned short* base_slots, int n_bases) {
   const size_t total = (size_t)n_bases * B.n;
   WsTable tmp;
@@ -104,11 +104,7 @@ __global__ void __launch_bounds__(NT, 2) k_base_tables(EngineBufs B, const unsig
     ge p;
     load_pt(p, B.pts, B.cap, base_slots[k], b);
     BaseTable bt{B.btab + ((size_t)k * B.cap + b) * BTAB_QUADS};
-#if EG_BASE_TEETH
     ge_teeth_tables_build(bt, tmp, p);
-#else
-    ge_split_tables_build(bt, p);
-#endif
   }
 }
 
@@ -140,15 +136,9 @@ __global__ void __launch_bounds__(NT, 2) k_msm_jobs(EngineBufs B, const egplan::
       ge part;
       if (vt.base != 0xffffu) {
         BaseTable bt{B.btab + ((size_t)vt.base * B.cap + b) * BTAB_QUADS};
-#if EG_BASE_TEETH
         u64 rows[EG_TEETH];
         sc_recode_teeth(rows, s);
         ge_teeth_mul(part, bt, rows);
-#else
-        u32 dg[8];
-        sc_recode_radix16(dg, s);
-        ge_split_mul(part, bt, dg);
-#endif
       } else {
         u32 dg[8];
         sc_recode_radix16(dg, s);

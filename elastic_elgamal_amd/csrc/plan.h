@@ -28,7 +28,7 @@ struct ScalarSrc {
 
 struct VarTerm {
   uint16_t slot;  // point slot (wire or derived)
-  uint16_t base;  // 0xffff: multiply directly; else index of the base whose split tables were precomputed
+  uint16_t base;  // 0xffff: multiply directly; else index of the base whose comb table was precomputed (k_base_tables)
   ScalarSrc s;
 };
 

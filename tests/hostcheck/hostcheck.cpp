@@ -15,7 +15,7 @@ struct ArrTable {
   void store(int i, const ge_cached& c) { e[i] = c; }
   void load(ge_cached& c, int i) const { c = e[i]; }
 };
-struct ArrSplit {
+struct ArrBase {
   ge_cached e[32];
   void store(int i, const ge_cached& c) { e[i] = c; }
   void load(ge_cached& c, int i) const { c = e[i]; }
@@ -76,28 +76,13 @@ int hc_double_mul_generator(const uint8_t k[32], const uint8_t p_enc[32], const 
   return 1;
 }
 
-// same as hc_double_mul_generator but through the per-base split tables (ge_split_tables_build / ge_split_mul)
-int hc_double_mul_generator_split(const uint8_t k[32], const uint8_t p_enc[32], const uint8_t r[32], uint8_t out[32]) {
-  if (g_base_table.e.empty()) { ge g; ge_generator(g); build_fixed(g_base_table, g); }
-  u32 kw[8], rw[8], pw[8], o[8];
-  words_from_bytes(kw, k, 8); words_from_bytes(rw, r, 8); words_from_bytes(pw, p_enc, 8);
-  ge p; if (!ristretto_decode(p, pw)) return 0;
-  ArrSplit tab; ge_split_tables_build(tab, p);
-  u32 dk[8], dr[EG_COMB_WORDS]; sc_recode_radix16(dk, kw); sc_recode_comb(dr, rw);
-  ge acc; ge_split_mul(acc, tab, dk);
-  ge_fixed_mul_add(acc, g_base_table, dr);
-  ristretto_encode(o, acc);
-  bytes_from_words(out, o, 8);
-  return 1;
-}
-
-// same through the per-base teeth comb (ge_teeth_tables_build / ge_teeth_mul)
+// same as hc_double_mul_generator but through the per-base comb table (ge_teeth_tables_build / ge_teeth_mul)
 int hc_double_mul_generator_teeth(const uint8_t k[32], const uint8_t p_enc[32], const uint8_t r[32], uint8_t out[32]) {
   if (g_base_table.e.empty()) { ge g; ge_generator(g); build_fixed(g_base_table, g); }
   u32 kw[8], rw[8], pw[8], o[8];
   words_from_bytes(kw, k, 8); words_from_bytes(rw, r, 8); words_from_bytes(pw, p_enc, 8);
   ge p; if (!ristretto_decode(p, pw)) return 0;
-  ArrSplit tab; ArrTable tmp; ge_teeth_tables_build(tab, tmp, p);
+  ArrBase tab; ArrTable tmp; ge_teeth_tables_build(tab, tmp, p);
   u64 rows[EG_TEETH]; u32 dr[EG_COMB_WORDS]; sc_recode_teeth(rows, kw); sc_recode_comb(dr, rw);
   ge acc; ge_teeth_mul(acc, tab, rows);
   ge_fixed_mul_add(acc, g_base_table, dr);
@@ -126,9 +111,9 @@ int hc_double_mul_generator_halved(const uint8_t k[32], const uint8_t p_enc[32],
   words_from_bytes(kw, k, 8); words_from_bytes(rw, r, 8); words_from_bytes(pw, p_enc, 8);
   ge p; if (!ristretto_decode(p, pw)) return 0;
   sc_halve(kh, kw); sc_halve(rh, rw);
-  ArrSplit tab; ge_split_tables_build(tab, p);
-  u32 dk[8], dr[EG_COMB_WORDS]; sc_recode_radix16(dk, kh); sc_recode_comb(dr, rh);
-  ge acc; ge_split_mul(acc, tab, dk);
+  ArrBase tab; ArrTable tmp; ge_teeth_tables_build(tab, tmp, p);
+  u64 rows[EG_TEETH]; u32 dr[EG_COMB_WORDS]; sc_recode_teeth(rows, kh); sc_recode_comb(dr, rh);
+  ge acc; ge_teeth_mul(acc, tab, rows);
   ge_fixed_mul_add(acc, g_base_table, dr);
   fe n, inv; bool zero;
   ge_double_encode_prepare(n, zero, acc);
@@ -179,8 +164,8 @@ int hc_merlin(const char* label, const char* l1, const uint8_t* m1, int m1_len, 
 }
 
 // field operation counts of the hot-path building blocks: out[2*i], out[2*i+1] = (fe_mul, fe_sq) calls of
-// 0: ristretto_decode  1: direct table build  2: direct variable-base multiply  3: fixed-base comb (32 windows)
-// 4: ristretto_encode  5: split-table build (per base)  6: split multiply (per equation)
+// 0: ristretto_decode  1: direct table build  2: direct variable-base multiply  3: fixed-base comb
+// 4: ristretto_encode  5: comb-table build (per base)  6: comb multiply (per equation)
 void hc_op_counts(unsigned long long out[18]) {
   if (g_base_table.e.empty()) { ge g; ge_generator(g); build_fixed(g_base_table, g); }
   u32 gw[8] = {0x0aaef2e2u, 0x714ebc6au, 0x61a984a8u, 0x5f5100c5u, 0x6a0be358u, 0x8ddd82a5u, 0x4559a6b6u, 0x762d8de0u};
@@ -199,9 +184,10 @@ void hc_op_counts(unsigned long long out[18]) {
   m0 = g_fe_mul_count; s0 = g_fe_sq_count;
   u32 o[8]; ristretto_encode(o, acc); snap(4, m0, s0);
   m0 = g_fe_mul_count; s0 = g_fe_sq_count;
-  ArrSplit st; ge_split_tables_build(st, p); snap(5, m0, s0);
+  ArrBase st; ArrTable tmp; ge_teeth_tables_build(st, tmp, p); snap(5, m0, s0);
+  u64 rows[EG_TEETH]; sc_recode_teeth(rows, k);
   m0 = g_fe_mul_count; s0 = g_fe_sq_count;
-  ge_split_mul(acc, st, dg); snap(6, m0, s0);
+  ge_teeth_mul(acc, st, rows); snap(6, m0, s0);
   // 7: doubled encoder per commitment (prepare + prefix/backward products + finish)   8: the shared field inversion
   m0 = g_fe_mul_count; s0 = g_fe_sq_count;
   fe n, inv, t1, t2; bool zero;

@@ -99,7 +99,7 @@ def test_plan_shapes(lib_path):
     a = eg.plan_describe("single", 5)
     assert a["stride"] == 736 and a["wire_points"] == 10 and a["wire_scalars"] == 13
     assert a["stages"] == 2 and a["jobs_per_stage"] == [14, 10] and a["bases"] == 10
-    assert a["split_terms"] == 20 and a["var_terms"] == 22 and a["rules"] == 2 and a["tally_slots"] == 10
+    assert a["table_terms"] == 20 and a["var_terms"] == 22 and a["rules"] == 2 and a["tally_slots"] == 10
     c = eg.plan_describe("multi", 16)
     assert c["stride"] == 2080 and c["wire_points"] == 32 and c["wire_scalars"] == 33 and c["jobs_per_stage"] == [32, 32]
     b = eg.plan_describe("qv", 5, 20)

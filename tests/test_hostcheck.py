@@ -126,8 +126,6 @@ def test_double_mul_generator(hc, oracle):
         kb, rb = k.to_bytes(32, "little"), r.to_bytes(32, "little")
         assert hc.hc_double_mul_generator(kb, p, rb, out) == 1
         assert out.raw == oracle.point_double_mul_generator(kb, p, rb), (k, r)
-        assert hc.hc_double_mul_generator_split(kb, p, rb, out) == 1      # 4-way split tables, 60 doublings
-        assert out.raw == oracle.point_double_mul_generator(kb, p, rb), (k, r)
         assert hc.hc_double_mul_generator_teeth(kb, p, rb, out) == 1      # 6-tooth signed comb, 42 doublings
         assert out.raw == oracle.point_double_mul_generator(kb, p, rb), (k, r)
         assert hc.hc_double_mul_generator_halved(kb, p, rb, out) == 1     # halved scalars + doubled encoder
@@ -159,3 +157,17 @@ def test_doubled_encoder(hc, oracle):
         out = _b()
         assert hc.hc_double_encode(p, out) == 1, p.hex()
         assert out.raw == oracle.point_add(p, p)
+
+
+def test_bench_work_model_matches_the_code(hc):
+    """bench.py prices a ballot with per-building-block (fe_mul, fe_sq) counts; they must be the counts of the shipped code."""
+    import ast
+    out = (C.c_ulonglong * 18)()
+    hc.hc_op_counts(out)
+    names = ["decode", "direct_table", "direct_mul", "comb", "encode", "base_table", "base_mul", "enc_batch_each", "enc_batch_inversion"]
+    got = {n: (out[2 * i], out[2 * i + 1]) for i, n in enumerate(names)}
+    src = (HERE.parent.parent / "bench.py").read_text()
+    tree = ast.parse(src)
+    ops = next(ast.literal_eval(n.value) for n in tree.body
+               if isinstance(n, ast.Assign) and getattr(n.targets[0], "id", "") == "OPS")
+    assert ops == got
