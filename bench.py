@@ -34,7 +34,7 @@ OPS = {"decode": (27, 257), "direct_table": (64, 0), "direct_mul": (1269, 1008),
        "base_table": (994, 860), "base_mul": (470, 168), "enc_batch_each": (23, 10), "enc_batch_inversion": (11, 254)}
 # memory-side traffic of k_msm_jobs per ballot and launch, from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
 # of profiles/r01_bench_pmc_counters.txt (single-choice 5-option ballots, 262144 per launch)
-MSM_TRAFFIC_BYTES_PER_BALLOT_LAUNCH = {"single": 55.92e9 / 262144}
+MSM_TRAFFIC_BYTES_PER_BALLOT_LAUNCH = {"single": 38.35e9 / 262144}
 MAD_PEAK_T = 33.4              # profiles/r01_ubench_valu_rates.txt: v_mad_u64_u32, 8 waves/SIMD, T lane-ops/s chip-wide
 FMUL_PEAK_G = 256.0            # profiles/r01_ubench_fmul_candidates.txt: radix-25.5 field multiply, G/s chip-wide
 
@@ -150,6 +150,7 @@ def main():
         step()
     ctx.profile_enable(True)
     ctx.profile_read()
+    ctx.profile_read_tables()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -157,6 +158,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     msm_ms, msm_launches, all_ms = ctx.profile_read()
+    tables_ms, tables_launches = ctx.profile_read_tables()
     ctx.profile_enable(False)
     elapsed = egd.max_over_ranks(elapsed, dev)
 
@@ -225,7 +227,10 @@ def main():
             "launches_per_step": launches_per_step,
             "units_per_launch": units_per_launch,
             "kernel_share_of_step": msm_ms / max(all_ms, 1e-9),
-            "note": "modular-integer VALU work: ~740 algorithmic bytes but ~6e4 field multiplications per ballot, so the "
+            "second_kernel": {"kernel": "eg::k_base_tables", "avg_launch_ms": tables_ms / max(tables_launches, 1),
+                              "launches_per_step": tables_launches // max(args.steps, 1),
+                              "share_of_step": tables_ms / max(all_ms, 1e-9)},
+            "note": "modular-integer VALU work: ~740 algorithmic bytes but ~4.4e4 field multiplications per ballot, so the "
                     "HBM fraction is ~1e-3 by construction (SURVEY 0.6); the binding roof is VALU integer multiply-add "
                     "throughput, see DESIGN.md",
         },

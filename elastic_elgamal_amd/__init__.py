@@ -132,6 +132,7 @@ def _load() -> C.CDLL:
         "eg_plan_describe": (C.c_int, [C.c_int, C.c_int, C.c_uint64, cp, sz]),
         "eg_profile_enable": (C.c_int, [vp, C.c_int]),
         "eg_profile_read": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
+        "eg_profile_read_tables": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # raises AttributeError if the ABI is incomplete
@@ -212,6 +213,12 @@ class Context:
         a, n, b = C.c_double(), C.c_uint64(), C.c_double()
         _check(_load().eg_profile_read(self._h, C.byref(a), C.byref(n), C.byref(b)))
         return a.value, n.value, b.value
+
+    def profile_read_tables(self):
+        """(k_base_tables ms total, launches) for the launches folded in by the last profile_read()."""
+        a, n = C.c_double(), C.c_uint64()
+        _check(_load().eg_profile_read_tables(self._h, C.byref(a), C.byref(n)))
+        return a.value, n.value
 
 
 class Ristretto:

@@ -37,7 +37,8 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
       return fail(EG_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_) + " (" + __FILE__ + ":" + std::to_string(__LINE__) + ")"); \
   } while (0)
 
-struct ProfSpan { hipEvent_t a, b; bool msm; };
+enum { PROF_CALL = 0, PROF_MSM = 1, PROF_TABLES = 2 };
+struct ProfSpan { hipEvent_t a, b; int kind; };
 
 struct eg_ctx {
   int device = 0;
@@ -51,11 +52,11 @@ struct eg_ctx {
   bool prof = false;
   std::vector<ProfSpan> spans;
   std::vector<hipEvent_t> event_pool;
-  double msm_ms = 0, all_ms = 0;
-  uint64_t msm_launches = 0;
+  double msm_ms = 0, all_ms = 0, tables_ms = 0;
+  uint64_t msm_launches = 0, tables_launches = 0;
 };
 
-static int prof_begin(eg_ctx* c, hipStream_t s, bool msm, size_t* idx) {
+static int prof_begin(eg_ctx* c, hipStream_t s, int kind, size_t* idx) {
   if (!c->prof) return EG_OK;
   hipEvent_t a, b;
   for (hipEvent_t* e : {&a, &b}) {
@@ -64,7 +65,7 @@ static int prof_begin(eg_ctx* c, hipStream_t s, bool msm, size_t* idx) {
   }
   HIPCHK(hipEventRecord(a, s));
   *idx = c->spans.size();
-  c->spans.push_back({a, b, msm});
+  c->spans.push_back({a, b, kind});
   return EG_OK;
 }
 static int prof_end(eg_ctx* c, hipStream_t s, size_t idx) {
@@ -299,7 +300,7 @@ static int engine_verify_device(Engine* e, size_t n, const void* d_ballots, void
   const eghost::Plan& P = e->plan;
   size_t all_idx = 0;
   int rc;
-  if ((rc = prof_begin(ctx, s, false, &all_idx))) return rc;
+  if ((rc = prof_begin(ctx, s, PROF_CALL, &all_idx))) return rc;
   // equal-sized chunks (each a multiple of the block size) so that the persistent grids stay balanced on the last chunk
   const size_t n_chunks = (n + e->max_cap - 1) / e->max_cap;
   if (n) { int rr = engine_reserve(e, (u32)(((n + n_chunks - 1) / n_chunks + NT - 1) / NT * NT)); if (rr) return rr; }
@@ -320,7 +321,7 @@ static int engine_verify_device(Engine* e, size_t n, const void* d_ballots, void
                            e->d_dterms, lv.first, lv.count);
     if (!P.base_slots.empty()) {
       size_t pi = 0;
-      if ((rc = prof_begin(ctx, s, false, &pi))) return rc;
+      if ((rc = prof_begin(ctx, s, PROF_TABLES, &pi))) return rc;
       hipLaunchKernelGGL(k_base_tables, dim3(grid_for((size_t)P.base_slots.size() * cn, ctx->msm_blocks)), dim3(NT), 0, s, B,
                          e->d_base_slots, (int)P.base_slots.size());
       if ((rc = prof_end(ctx, s, pi))) return rc;
@@ -328,7 +329,7 @@ static int engine_verify_device(Engine* e, size_t n, const void* d_ballots, void
     for (auto& st : e->stages) {
       if (st.job_count) {
         size_t pi = 0;
-        if ((rc = prof_begin(ctx, s, true, &pi))) return rc;
+        if ((rc = prof_begin(ctx, s, PROF_MSM, &pi))) return rc;
         hipLaunchKernelGGL(k_msm_jobs, dim3(grid_for((size_t)st.job_count * cn, ctx->msm_blocks)), dim3(NT), 0, s, B, e->d_jobs,
                            e->d_vterms, st.job_first, st.job_count);
         if ((rc = prof_end(ctx, s, pi))) return rc;
@@ -485,7 +486,9 @@ int eg_profile_read(eg_ctx* c, double* msm_ms_total, uint64_t* msm_launches, dou
   for (auto& sp : c->spans) {
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, sp.a, sp.b));
-    if (sp.msm) { c->msm_ms += ms; c->msm_launches++; } else c->all_ms += ms;
+    if (sp.kind == PROF_MSM) { c->msm_ms += ms; c->msm_launches++; }
+    else if (sp.kind == PROF_TABLES) { c->tables_ms += ms; c->tables_launches++; }
+    else c->all_ms += ms;
     c->event_pool.push_back(sp.a);
     c->event_pool.push_back(sp.b);
   }
@@ -494,6 +497,13 @@ int eg_profile_read(eg_ctx* c, double* msm_ms_total, uint64_t* msm_launches, dou
   if (msm_launches) *msm_launches = c->msm_launches;
   if (all_ms_total) *all_ms_total = c->all_ms;
   c->msm_ms = 0; c->all_ms = 0; c->msm_launches = 0;
+  return EG_OK;
+}
+int eg_profile_read_tables(eg_ctx* c, double* tables_ms_total, uint64_t* tables_launches) {
+  if (!c) return fail(EG_ERR_BAD_ARG, "ctx is null");
+  if (tables_ms_total) *tables_ms_total = c->tables_ms;
+  if (tables_launches) *tables_launches = c->tables_launches;
+  c->tables_ms = 0; c->tables_launches = 0;
   return EG_OK;
 }
 

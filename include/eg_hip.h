@@ -180,6 +180,8 @@ int eg_plan_describe(int kind, int n_options, uint64_t credits_or_bound, char* b
  * measured with HIP events on the stream the kernel was launched on; launches = number of launches averaged. */
 int eg_profile_enable(eg_ctx*, int enable);
 int eg_profile_read(eg_ctx*, double* msm_ms_total, uint64_t* msm_launches, double* all_ms_total);
+/* same for the second kernel (k_base_tables), covering the launches folded in by the last eg_profile_read */
+int eg_profile_read_tables(eg_ctx*, double* tables_ms_total, uint64_t* tables_launches);
 
 #ifdef __cplusplus
 }
