@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -41,6 +42,7 @@ enum { PROF_CALL = 0, PROF_MSM = 1, PROF_TABLES = 2 };
 struct ProfSpan { hipEvent_t a, b; int kind; };
 
 struct eg_ctx {
+  std::recursive_mutex mu;   // serialises the C entry points of one context (and of the params created on it)
   int device = 0;
   hipStream_t stream = nullptr;
   int cus = 0;
@@ -413,6 +415,9 @@ struct eg_choice_params { Engine* eng; int n_options; int single; };
 struct eg_qv_params { Engine* eng; int n_options; uint64_t credits; eghost::QvShape shape; };
 struct eg_proof_params { Engine* eng; int kind; size_t item_size; };
 
+#define EG_LOCK(c) std::unique_lock<std::recursive_mutex> lk_; if (c) lk_ = std::unique_lock<std::recursive_mutex>((c)->mu)
+#define EG_LOCK_P(p) EG_LOCK((p) ? (p)->eng->ctx : (eg_ctx*)nullptr)
+
 extern "C" {
 
 const char* eg_last_error(void) { return g_err.c_str(); }
@@ -462,25 +467,25 @@ void eg_destroy(eg_ctx* c) {
   delete c;
 }
 
-int eg_device_name(eg_ctx* c, char* buf, size_t cap) {
+int eg_device_name(eg_ctx* c, char* buf, size_t cap) { EG_LOCK(c);
   if (!c || !buf || !cap) return fail(EG_ERR_BAD_ARG, "bad argument");
   snprintf(buf, cap, "%s, %d CUs, msm grid %d blocks", c->name.c_str(), c->cus, c->msm_blocks);
   return EG_OK;
 }
 
-int eg_synchronize(eg_ctx* c) {
+int eg_synchronize(eg_ctx* c) { EG_LOCK(c);
   if (!c) return fail(EG_ERR_BAD_ARG, "ctx is null");
   HIPCHK(hipStreamSynchronize(c->stream));
   return EG_OK;
 }
 
-int eg_profile_enable(eg_ctx* c, int enable) {
+int eg_profile_enable(eg_ctx* c, int enable) { EG_LOCK(c);
   if (!c) return fail(EG_ERR_BAD_ARG, "ctx is null");
   c->prof = enable != 0;
   return EG_OK;
 }
 
-int eg_profile_read(eg_ctx* c, double* msm_ms_total, uint64_t* msm_launches, double* all_ms_total) {
+int eg_profile_read(eg_ctx* c, double* msm_ms_total, uint64_t* msm_launches, double* all_ms_total) { EG_LOCK(c);
   if (!c) return fail(EG_ERR_BAD_ARG, "ctx is null");
   HIPCHK(hipDeviceSynchronize());
   for (auto& sp : c->spans) {
@@ -499,7 +504,7 @@ int eg_profile_read(eg_ctx* c, double* msm_ms_total, uint64_t* msm_launches, dou
   c->msm_ms = 0; c->all_ms = 0; c->msm_launches = 0;
   return EG_OK;
 }
-int eg_profile_read_tables(eg_ctx* c, double* tables_ms_total, uint64_t* tables_launches) {
+int eg_profile_read_tables(eg_ctx* c, double* tables_ms_total, uint64_t* tables_launches) { EG_LOCK(c);
   if (!c) return fail(EG_ERR_BAD_ARG, "ctx is null");
   if (tables_ms_total) *tables_ms_total = c->tables_ms;
   if (tables_launches) *tables_launches = c->tables_launches;
@@ -518,7 +523,7 @@ struct DevBuf {
 #define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 static unsigned blocks_of(size_t n) { return (unsigned)std::max<size_t>(1, (n + NT - 1) / NT); }
 
-int eg_scalar_from_wide_batch(eg_ctx* c, size_t n, const uint8_t* wide, uint8_t* out) {
+int eg_scalar_from_wide_batch(eg_ctx* c, size_t n, const uint8_t* wide, uint8_t* out) { EG_LOCK(c);
   if (!c || (n && (!wide || !out))) return fail(EG_ERR_BAD_ARG, "bad argument");
   HIPCHK(hipSetDevice(c->device));
   DevBuf a, o;
@@ -528,7 +533,7 @@ int eg_scalar_from_wide_batch(eg_ctx* c, size_t n, const uint8_t* wide, uint8_t*
   HIPCHK(hipStreamSynchronize(c->stream));
   return EG_OK;
 }
-int eg_scalar_is_canonical_batch(eg_ctx* c, size_t n, const uint8_t* s_, uint8_t* ok) {
+int eg_scalar_is_canonical_batch(eg_ctx* c, size_t n, const uint8_t* s_, uint8_t* ok) { EG_LOCK(c);
   if (!c || (n && (!s_ || !ok))) return fail(EG_ERR_BAD_ARG, "bad argument");
   HIPCHK(hipSetDevice(c->device));
   DevBuf a, o;
@@ -538,7 +543,7 @@ int eg_scalar_is_canonical_batch(eg_ctx* c, size_t n, const uint8_t* s_, uint8_t
   HIPCHK(hipStreamSynchronize(c->stream));
   return EG_OK;
 }
-int eg_scalar_muladd_batch(eg_ctx* c, size_t n, const uint8_t* a_, const uint8_t* b_, const uint8_t* c_, uint8_t* out) {
+int eg_scalar_muladd_batch(eg_ctx* c, size_t n, const uint8_t* a_, const uint8_t* b_, const uint8_t* c_, uint8_t* out) { EG_LOCK(c);
   if (!c || (n && (!a_ || !b_ || !c_ || !out))) return fail(EG_ERR_BAD_ARG, "bad argument");
   HIPCHK(hipSetDevice(c->device));
   DevBuf a, b, cc, o;
@@ -550,7 +555,7 @@ int eg_scalar_muladd_batch(eg_ctx* c, size_t n, const uint8_t* a_, const uint8_t
   HIPCHK(hipStreamSynchronize(c->stream));
   return EG_OK;
 }
-int eg_scalar_neg_batch(eg_ctx* c, size_t n, const uint8_t* a_, uint8_t* out) {
+int eg_scalar_neg_batch(eg_ctx* c, size_t n, const uint8_t* a_, uint8_t* out) { EG_LOCK(c);
   if (!c || (n && (!a_ || !out))) return fail(EG_ERR_BAD_ARG, "bad argument");
   HIPCHK(hipSetDevice(c->device));
   DevBuf a, o;
@@ -560,7 +565,7 @@ int eg_scalar_neg_batch(eg_ctx* c, size_t n, const uint8_t* a_, uint8_t* out) {
   HIPCHK(hipStreamSynchronize(c->stream));
   return EG_OK;
 }
-int eg_scalar_invert_batch(eg_ctx* c, size_t n, const uint8_t* a_, uint8_t* out) {
+int eg_scalar_invert_batch(eg_ctx* c, size_t n, const uint8_t* a_, uint8_t* out) { EG_LOCK(c);
   if (!c || (n && (!a_ || !out))) return fail(EG_ERR_BAD_ARG, "bad argument");
   HIPCHK(hipSetDevice(c->device));
   DevBuf a, o;
@@ -570,7 +575,7 @@ int eg_scalar_invert_batch(eg_ctx* c, size_t n, const uint8_t* a_, uint8_t* out)
   HIPCHK(hipStreamSynchronize(c->stream));
   return EG_OK;
 }
-int eg_point_is_identity_batch(eg_ctx* c, size_t n, const uint8_t* in, uint8_t* is_identity, uint8_t* ok) {
+int eg_point_is_identity_batch(eg_ctx* c, size_t n, const uint8_t* in, uint8_t* is_identity, uint8_t* ok) { EG_LOCK(c);
   if (!c || (n && (!in || !is_identity || !ok))) return fail(EG_ERR_BAD_ARG, "bad argument");
   HIPCHK(hipSetDevice(c->device));
   DevBuf a, f, o;
@@ -581,7 +586,7 @@ int eg_point_is_identity_batch(eg_ctx* c, size_t n, const uint8_t* in, uint8_t* 
   HIPCHK(hipStreamSynchronize(c->stream));
   return EG_OK;
 }
-int eg_point_roundtrip_batch(eg_ctx* c, size_t n, const uint8_t* in, uint8_t* out, uint8_t* ok) {
+int eg_point_roundtrip_batch(eg_ctx* c, size_t n, const uint8_t* in, uint8_t* out, uint8_t* ok) { EG_LOCK(c);
   if (!c || (n && (!in || !out || !ok))) return fail(EG_ERR_BAD_ARG, "bad argument");
   HIPCHK(hipSetDevice(c->device));
   DevBuf a, o, k;
@@ -592,7 +597,7 @@ int eg_point_roundtrip_batch(eg_ctx* c, size_t n, const uint8_t* in, uint8_t* ou
   HIPCHK(hipStreamSynchronize(c->stream));
   return EG_OK;
 }
-int eg_point_add_batch(eg_ctx* c, size_t n, const uint8_t* a_, const uint8_t* b_, int subtract, uint8_t* out, uint8_t* ok) {
+int eg_point_add_batch(eg_ctx* c, size_t n, const uint8_t* a_, const uint8_t* b_, int subtract, uint8_t* out, uint8_t* ok) { EG_LOCK(c);
   if (!c || (n && (!a_ || !b_ || !out || !ok))) return fail(EG_ERR_BAD_ARG, "bad argument");
   HIPCHK(hipSetDevice(c->device));
   DevBuf a, b, o, k;
@@ -619,17 +624,17 @@ static int prim_msm(eg_ctx* c, size_t n, size_t terms, const uint8_t* scalars, c
   HIPCHK(hipGetLastError());
   return EG_OK;
 }
-int eg_mul_generator_batch(eg_ctx* c, size_t n, const uint8_t* k, uint8_t* out) {
+int eg_mul_generator_batch(eg_ctx* c, size_t n, const uint8_t* k, uint8_t* out) { EG_LOCK(c);
   if (!c || (n && (!k || !out))) return fail(EG_ERR_BAD_ARG, "bad argument");
   return prim_msm(c, n, 0, nullptr, nullptr, k, out, nullptr);
 }
 int eg_vartime_double_mul_generator_batch(eg_ctx* c, size_t n, const uint8_t* k, const uint8_t* p, const uint8_t* r, uint8_t* out,
-                                          uint8_t* ok) {
+                                          uint8_t* ok) { EG_LOCK(c);
   if (!c || (n && (!k || !p || !r || !out || !ok))) return fail(EG_ERR_BAD_ARG, "bad argument");
   return prim_msm(c, n, 1, k, p, r, out, ok);
 }
 int eg_vartime_multi_mul_batch(eg_ctx* c, size_t n, size_t terms, const uint8_t* scalars, const uint8_t* points, uint8_t* out,
-                               uint8_t* ok) {
+                               uint8_t* ok) { EG_LOCK(c);
   if (!c || (n && !out) || (n && terms && (!scalars || !points))) return fail(EG_ERR_BAD_ARG, "bad argument");
   return prim_msm(c, n, terms, scalars, points, nullptr, out, ok);
 }
@@ -637,7 +642,7 @@ int eg_vartime_multi_mul_batch(eg_ctx* c, size_t n, size_t terms, const uint8_t*
 // ---- batch tier: choice ---------------------------------------------------------------------------------------------------
 size_t eg_choice_ballot_size(int n_options, int single) { return eghost::choice_ballot_size(n_options, single != 0); }
 
-int eg_choice_params_create(eg_ctx* c, const uint8_t pk[32], int n_options, int single, eg_choice_params** out) {
+int eg_choice_params_create(eg_ctx* c, const uint8_t pk[32], int n_options, int single, eg_choice_params** out) { EG_LOCK(c);
   if (!c || !pk || !out) return fail(EG_ERR_BAD_ARG, "bad argument");
   if (n_options < 1 || n_options > 4000) return fail(EG_ERR_BAD_ARG, "n_options must be in 1..4000");
   Engine* e = nullptr;
@@ -645,12 +650,12 @@ int eg_choice_params_create(eg_ctx* c, const uint8_t pk[32], int n_options, int 
   *out = new eg_choice_params{e, n_options, single};
   return EG_OK;
 }
-void eg_choice_params_destroy(eg_choice_params* p) { if (p) { engine_free(p->eng); delete p; } }
-int eg_verify_choice_batch(eg_choice_params* p, size_t n, const uint8_t* ballots, uint32_t* status, uint8_t* tally_out) {
+void eg_choice_params_destroy(eg_choice_params* p) { EG_LOCK_P(p); if (p) { engine_free(p->eng); delete p; } }
+int eg_verify_choice_batch(eg_choice_params* p, size_t n, const uint8_t* ballots, uint32_t* status, uint8_t* tally_out) { EG_LOCK_P(p);
   if (!p || (n && (!ballots || !status))) return fail(EG_ERR_BAD_ARG, "bad argument");
   return engine_verify_host(p->eng, n, ballots, status, tally_out);
 }
-int eg_verify_choice_batch_device(eg_choice_params* p, size_t n, const void* d_ballots, void* d_status, void* stream) {
+int eg_verify_choice_batch_device(eg_choice_params* p, size_t n, const void* d_ballots, void* d_status, void* stream) { EG_LOCK_P(p);
   if (!p || (n && (!d_ballots || !d_status))) return fail(EG_ERR_BAD_ARG, "bad argument");
   HIPCHK(hipSetDevice(p->eng->ctx->device));
   return engine_verify_device(p->eng, n, d_ballots, d_status, (hipStream_t)stream);
@@ -668,15 +673,15 @@ static int tally_encode_device(Engine* e, void* d_out, hipStream_t s) {
   HIPCHK(hipGetLastError());
   return EG_OK;
 }
-int eg_choice_tally_encode_device(eg_choice_params* p, void* d_out, void* stream) {
+int eg_choice_tally_encode_device(eg_choice_params* p, void* d_out, void* stream) { EG_LOCK_P(p);
   if (!p || !d_out) return fail(EG_ERR_BAD_ARG, "bad argument");
   return tally_encode_device(p->eng, d_out, (hipStream_t)stream);
 }
-int eg_qv_tally_encode_device(eg_qv_params* p, void* d_out, void* stream) {
+int eg_qv_tally_encode_device(eg_qv_params* p, void* d_out, void* stream) { EG_LOCK_P(p);
   if (!p || !d_out) return fail(EG_ERR_BAD_ARG, "bad argument");
   return tally_encode_device(p->eng, d_out, (hipStream_t)stream);
 }
-int eg_points_sum_device(eg_ctx* c, int n_ranks, int n_points, const void* d_in, void* d_out, void* stream) {
+int eg_points_sum_device(eg_ctx* c, int n_ranks, int n_points, const void* d_in, void* d_out, void* stream) { EG_LOCK(c);
   if (!c || n_ranks < 1 || n_points < 1 || !d_in || !d_out) return fail(EG_ERR_BAD_ARG, "bad argument");
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
   hipLaunchKernelGGL(k_points_sum, dim3((n_points + 63) / 64), dim3(64), 0, s, (const u32*)d_in, n_ranks, n_points, (u32*)d_out,
@@ -684,15 +689,15 @@ int eg_points_sum_device(eg_ctx* c, int n_ranks, int n_points, const void* d_in,
   HIPCHK(hipGetLastError());
   return EG_OK;
 }
-int eg_choice_tally_reset(eg_choice_params* p) { return p ? tally_reset(p->eng) : fail(EG_ERR_BAD_ARG, "null"); }
-int eg_choice_tally_reset_async(eg_choice_params* p, void* stream) { return p && stream ? tally_reset(p->eng, (hipStream_t)stream) : fail(EG_ERR_BAD_ARG, "null"); }
-int eg_choice_tally_encode(eg_choice_params* p, uint8_t* out) {
+int eg_choice_tally_reset(eg_choice_params* p) { EG_LOCK_P(p); return p ? tally_reset(p->eng) : fail(EG_ERR_BAD_ARG, "null"); }
+int eg_choice_tally_reset_async(eg_choice_params* p, void* stream) { EG_LOCK_P(p); return p && stream ? tally_reset(p->eng, (hipStream_t)stream) : fail(EG_ERR_BAD_ARG, "null"); }
+int eg_choice_tally_encode(eg_choice_params* p, uint8_t* out) { EG_LOCK_P(p);
   if (!p || !out) return fail(EG_ERR_BAD_ARG, "bad argument");
   return engine_tally_encode(p->eng, out);
 }
 
 // ---- batch tier: quadratic voting --------------------------------------------------------------------------------------------
-int eg_qv_params_create(eg_ctx* c, const uint8_t pk[32], int n_options, uint64_t credits, eg_qv_params** out) {
+int eg_qv_params_create(eg_ctx* c, const uint8_t pk[32], int n_options, uint64_t credits, eg_qv_params** out) { EG_LOCK(c);
   if (!c || !pk || !out) return fail(EG_ERR_BAD_ARG, "bad argument");
   if (n_options < 1 || n_options > 256 || credits < 1 || credits > 100000) return fail(EG_ERR_BAD_ARG, "options in 1..256, credits in 1..100000");
   Engine* e = nullptr;
@@ -700,26 +705,26 @@ int eg_qv_params_create(eg_ctx* c, const uint8_t pk[32], int n_options, uint64_t
   *out = new eg_qv_params{e, n_options, credits, eghost::qv_shape(n_options, credits)};
   return EG_OK;
 }
-void eg_qv_params_destroy(eg_qv_params* p) { if (p) { engine_free(p->eng); delete p; } }
+void eg_qv_params_destroy(eg_qv_params* p) { EG_LOCK_P(p); if (p) { engine_free(p->eng); delete p; } }
 size_t eg_qv_ballot_size(const eg_qv_params* p) { return p ? p->shape.ballot_size : 0; }
-int eg_verify_qv_batch(eg_qv_params* p, size_t n, const uint8_t* ballots, uint32_t* status, uint8_t* tally_out) {
+int eg_verify_qv_batch(eg_qv_params* p, size_t n, const uint8_t* ballots, uint32_t* status, uint8_t* tally_out) { EG_LOCK_P(p);
   if (!p || (n && (!ballots || !status))) return fail(EG_ERR_BAD_ARG, "bad argument");
   return engine_verify_host(p->eng, n, ballots, status, tally_out);
 }
-int eg_verify_qv_batch_device(eg_qv_params* p, size_t n, const void* d_ballots, void* d_status, void* stream) {
+int eg_verify_qv_batch_device(eg_qv_params* p, size_t n, const void* d_ballots, void* d_status, void* stream) { EG_LOCK_P(p);
   if (!p || (n && (!d_ballots || !d_status))) return fail(EG_ERR_BAD_ARG, "bad argument");
   HIPCHK(hipSetDevice(p->eng->ctx->device));
   return engine_verify_device(p->eng, n, d_ballots, d_status, (hipStream_t)stream);
 }
-int eg_qv_tally_reset(eg_qv_params* p) { return p ? tally_reset(p->eng) : fail(EG_ERR_BAD_ARG, "null"); }
-int eg_qv_tally_reset_async(eg_qv_params* p, void* stream) { return p && stream ? tally_reset(p->eng, (hipStream_t)stream) : fail(EG_ERR_BAD_ARG, "null"); }
-int eg_qv_tally_encode(eg_qv_params* p, uint8_t* out) {
+int eg_qv_tally_reset(eg_qv_params* p) { EG_LOCK_P(p); return p ? tally_reset(p->eng) : fail(EG_ERR_BAD_ARG, "null"); }
+int eg_qv_tally_reset_async(eg_qv_params* p, void* stream) { EG_LOCK_P(p); return p && stream ? tally_reset(p->eng, (hipStream_t)stream) : fail(EG_ERR_BAD_ARG, "null"); }
+int eg_qv_tally_encode(eg_qv_params* p, uint8_t* out) { EG_LOCK_P(p);
   if (!p || !out) return fail(EG_ERR_BAD_ARG, "bad argument");
   return engine_tally_encode(p->eng, out);
 }
 
 // ---- PublicKey::verify_zero / verify_bool / verify_range in batches ---------------------------------------
-int eg_proof_params_create(eg_ctx* c, const uint8_t pk[32], int kind, uint64_t upper_bound, eg_proof_params** out) {
+int eg_proof_params_create(eg_ctx* c, const uint8_t pk[32], int kind, uint64_t upper_bound, eg_proof_params** out) { EG_LOCK(c);
   if (!c || !pk || !out) return fail(EG_ERR_BAD_ARG, "bad argument");
   Engine* e = nullptr;
   size_t item = 0;
@@ -733,7 +738,7 @@ int eg_proof_params_create(eg_ctx* c, const uint8_t pk[32], int kind, uint64_t u
   return EG_OK;
 }
 int eg_share_params_create(eg_ctx* c, const uint8_t shared_key[32], uint64_t shares, uint64_t threshold, uint64_t index,
-                           const uint8_t participant_key[32], eg_proof_params** out) {
+                           const uint8_t participant_key[32], eg_proof_params** out) { EG_LOCK(c);
   if (!c || !shared_key || !participant_key || !out) return fail(EG_ERR_BAD_ARG, "bad argument");
   if (shares < 1 || threshold < 1 || threshold > shares || index >= shares) return fail(EG_ERR_BAD_ARG, "bad sharing parameters");
   Engine* e = nullptr;
@@ -741,13 +746,13 @@ int eg_share_params_create(eg_ctx* c, const uint8_t shared_key[32], uint64_t sha
   *out = new eg_proof_params{e, 3, 128};
   return EG_OK;
 }
-void eg_proof_params_destroy(eg_proof_params* p) { if (p) { engine_free(p->eng); delete p; } }
+void eg_proof_params_destroy(eg_proof_params* p) { EG_LOCK_P(p); if (p) { engine_free(p->eng); delete p; } }
 size_t eg_proof_item_size(const eg_proof_params* p) { return p ? p->item_size : 0; }
-int eg_verify_proof_batch(eg_proof_params* p, size_t n, const uint8_t* items, uint32_t* status) {
+int eg_verify_proof_batch(eg_proof_params* p, size_t n, const uint8_t* items, uint32_t* status) { EG_LOCK_P(p);
   if (!p || (n && (!items || !status))) return fail(EG_ERR_BAD_ARG, "bad argument");
   return engine_verify_host(p->eng, n, items, status, nullptr);
 }
-int eg_verify_proof_batch_device(eg_proof_params* p, size_t n, const void* d_items, void* d_status, void* stream) {
+int eg_verify_proof_batch_device(eg_proof_params* p, size_t n, const void* d_items, void* d_status, void* stream) { EG_LOCK_P(p);
   if (!p || (n && (!d_items || !d_status))) return fail(EG_ERR_BAD_ARG, "bad argument");
   HIPCHK(hipSetDevice(p->eng->ctx->device));
   return engine_verify_device(p->eng, n, d_items, d_status, (hipStream_t)stream);
@@ -796,7 +801,7 @@ int eg_plan_describe(int kind, int n_options, uint64_t credits_or_bound, char* b
 
 // ---- synthetic ballots ---------------------------------------------------------------------------------------------------------
 int eg_choice_encrypt_batch_device(eg_choice_params* p, uint64_t base_seed, size_t first, size_t n, int n_selected, void* d_out,
-                                   void* stream) {
+                                   void* stream) { EG_LOCK_P(p);
   if (!p || (n && !d_out)) return fail(EG_ERR_BAD_ARG, "bad argument");
   Engine* e = p->eng;
   HIPCHK(hipSetDevice(e->ctx->device));
@@ -810,7 +815,7 @@ int eg_choice_encrypt_batch_device(eg_choice_params* p, uint64_t base_seed, size
   HIPCHK(hipGetLastError());
   return EG_OK;
 }
-int eg_choice_encrypt_batch(eg_choice_params* p, uint64_t base_seed, size_t first, size_t n, int n_selected, uint8_t* out) {
+int eg_choice_encrypt_batch(eg_choice_params* p, uint64_t base_seed, size_t first, size_t n, int n_selected, uint8_t* out) { EG_LOCK_P(p);
   if (!p || (n && !out)) return fail(EG_ERR_BAD_ARG, "bad argument");
   Engine* e = p->eng;
   HIPCHK(hipSetDevice(e->ctx->device));
@@ -821,7 +826,7 @@ int eg_choice_encrypt_batch(eg_choice_params* p, uint64_t base_seed, size_t firs
   HIPCHK(hipStreamSynchronize(e->ctx->stream));
   return EG_OK;
 }
-int eg_qv_encrypt_batch_device(eg_qv_params* p, uint64_t base_seed, size_t first, size_t n, void* d_out, void* stream) {
+int eg_qv_encrypt_batch_device(eg_qv_params* p, uint64_t base_seed, size_t first, size_t n, void* d_out, void* stream) { EG_LOCK_P(p);
   if (!p || (n && !d_out)) return fail(EG_ERR_BAD_ARG, "bad argument");
   Engine* e = p->eng;
   HIPCHK(hipSetDevice(e->ctx->device));

@@ -18,6 +18,11 @@
  *
  * Every function returns EG_OK (0) or a negative eg_error.  Nothing here falls back to the CPU: if no
  * gfx950 device is usable eg_init fails with EG_ERR_NO_DEVICE.
+ *
+ * Threads: entry points may be called from any thread; calls on one context (and on the params objects created on
+ * it) are serialised by a lock inside the context, and eg_last_error is per thread.  Host-pointer functions return
+ * when the results are in the caller's buffers.  `_device` / `_async` functions only enqueue work; they share the
+ * context's workspaces, so a caller that uses several streams with one context must order them itself (events).
  */
 #ifndef EG_HIP_H
 #define EG_HIP_H

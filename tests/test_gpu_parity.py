@@ -546,3 +546,38 @@ def test_qv_unusual_parameters(eg, ctx, oracle, pk, options, credits):
     got, tally = q.verify_batch(ballots)
     assert got == want and want.count(0) >= 4
     assert tally == oq.tally(ballots, want)
+
+
+def test_concurrent_host_calls_are_serialised(eg, ctx, oracle, pk):
+    """eg_hip.h: entry points may be called from any thread; one context serialises them."""
+    import threading
+    op = oracle.ChoiceParams(pk, 4, True)
+    p = eg.ChoiceParams.single_choice(ctx, pk, 4)
+    q = eg.QuadraticVotingParams(ctx, pk, 3, 9)
+    oq = oracle.QvParams(pk, 3, 9)
+    ballots = op.generate_batch(77, 0, 40)
+    qballots = oq.generate_batch(78, 0, 12)
+    want, wantq = op.verify_batch(ballots), oq.verify_batch(qballots)
+    grp = eg.Ristretto(ctx)
+    ks = b"".join(sc(i + 1) for i in range(64))
+    want_pts = b"".join(oracle.point_mul_generator(sc(i + 1)) for i in range(64))
+    errors = []
+
+    def worker(kind):
+        try:
+            for _ in range(6):
+                if kind == 0:
+                    assert p.verify_batch(ballots)[0] == want
+                elif kind == 1:
+                    assert q.verify_batch(qballots)[0] == wantq
+                else:
+                    assert grp.mul_generator(ks) == want_pts
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(k % 3,)) for k in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
