@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -43,6 +44,7 @@ struct ProfSpan { hipEvent_t a, b; int kind; };
 
 struct eg_ctx {
   std::recursive_mutex mu;   // serialises the C entry points of one context (and of the params created on it)
+  std::atomic<int> refs{1};  // the caller's reference + one per live params object
   int device = 0;
   hipStream_t stream = nullptr;
   int cus = 0;
@@ -156,6 +158,14 @@ static EngineBufs make_bufs(const Engine* e, const void* d_ballots, u32 n, void*
   return B;
 }
 
+// bytes of chunk workspace per ballot (the buffers engine_reserve allocates)
+static size_t engine_bytes_per_ballot(const Engine* e) {
+  const eghost::Plan& P = e->plan;
+  return (size_t)std::max(P.n_pt_slots, 1) * 160 + (size_t)std::max(P.n_cmp_slots, 1) * (32 + 160) + (size_t)std::max(P.n_chal_slots, 1) * 32 +
+         (size_t)std::max(P.n_state_slots, 1) * 208 + (size_t)std::max(P.n_flag_slots, 1) * 4 + 4 +
+         std::max<size_t>(P.base_slots.size(), 1) * BTAB_QUADS * 16 + (size_t)std::max(e->max_defer, 1) * 80;
+}
+
 // (re)allocate the per-chunk SoA buffers for chunks of up to `want` ballots
 static int engine_reserve(Engine* e, u32 want) {
   if (want <= e->cap) return EG_OK;
@@ -179,6 +189,7 @@ static int engine_reserve(Engine* e, u32 want) {
   return EG_OK;
 }
 
+static unsigned blocks_of(size_t n) { return (unsigned)std::max<size_t>(1, (n + NT - 1) / NT); }
 static int grid_for(size_t lanes, int cap_blocks) {
   size_t blocks = (lanes + NT - 1) / NT;
   if (blocks < 1) blocks = 1;
@@ -276,12 +287,20 @@ static int engine_create(eg_ctx* ctx, eghost::Plan&& plan, const uint8_t pk[32],
   // chunk workspace: sized lazily by engine_reserve() for the batches actually seen (up to EG_CHUNK ballots per chunk)
   const char* env = getenv("EG_CHUNK");
   e->max_cap = env ? (u32)strtoul(env, nullptr, 10) : 262144u;
+  {
+    // large elections: keep the chunk workspace within half of the free device memory (it is ~58 KB per ballot for 5
+    // options, ~5.5 KB more per ring base)
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    const size_t limit = engine_bytes_per_ballot(e.get()) ? free_b / 2 / engine_bytes_per_ballot(e.get()) : e->max_cap;
+    if (limit < e->max_cap) e->max_cap = (u32)(limit / NT * NT);
+  }
   if (e->max_cap < NT) e->max_cap = NT;
   e->max_cap = (e->max_cap + NT - 1) / NT * NT;
   HIPCHK(hipMalloc((void**)&e->partial, std::max<size_t>(P.tally_slots.size(), 1) * e->tally_blocks * 40 * sizeof(u32)));
   HIPCHK(hipMalloc((void**)&e->tally, std::max<size_t>(P.tally_slots.size(), 1) * 40 * sizeof(u32)));
   HIPCHK(hipMalloc((void**)&e->d_prefixes, (size_t)std::max(P.n_prefixes, 1) * 52 * sizeof(u32)));
-  hipLaunchKernelGGL(k_tally_init, dim3(1), dim3(NT), 0, s, e->tally, (int)P.tally_slots.size());
+  hipLaunchKernelGGL(k_tally_init, dim3(blocks_of(P.tally_slots.size())), dim3(NT), 0, s, e->tally, (int)P.tally_slots.size());
 
   // hoisted transcript prefixes: run the prefix programs once (a single lane each)
   if (e->prefix_inst_count) {
@@ -292,6 +311,7 @@ static int engine_create(eg_ctx* ctx, eghost::Plan&& plan, const uint8_t pk[32],
   HIPCHK(hipStreamSynchronize(s));
   HIPCHK(hipGetLastError());
   *out = e.release();
+  ctx->refs.fetch_add(1);   // dropped by params_destroy
   return EG_OK;
 }
 
@@ -359,7 +379,7 @@ static int engine_tally_encode(Engine* e, uint8_t* out) {
   const int ns = (int)e->plan.tally_slots.size();
   u32* d_out = nullptr;
   HIPCHK(hipMalloc((void**)&d_out, (size_t)ns * 32));
-  hipLaunchKernelGGL(k_tally_encode, dim3(1), dim3(NT), 0, s, e->tally, ns, d_out);
+  hipLaunchKernelGGL(k_tally_encode, dim3(blocks_of((size_t)ns)), dim3(NT), 0, s, e->tally, ns, d_out);
   HIPCHK(hipMemcpyAsync(out, d_out, (size_t)ns * 32, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   (void)hipFree(d_out);
@@ -377,7 +397,7 @@ static int engine_verify_host(Engine* e, size_t n, const uint8_t* ballots, uint3
     HIPCHK(hipMalloc((void**)&e->d_status, std::max<size_t>(n, 1) * sizeof(u32)));
     e->staging_ballots = n;
   }
-  if (tally_out) hipLaunchKernelGGL(k_tally_init, dim3(1), dim3(NT), 0, s, e->tally, (int)e->plan.tally_slots.size());
+  if (tally_out) hipLaunchKernelGGL(k_tally_init, dim3(blocks_of(e->plan.tally_slots.size())), dim3(NT), 0, s, e->tally, (int)e->plan.tally_slots.size());
   if (n) {
     // Pipeline over the engine's chunks: the copy stream uploads chunk k+1 while chunk k is verified (SURVEY 8e:
     // host staging, not the kernels, is the scaling risk when ballots arrive in host memory).
@@ -414,6 +434,34 @@ static int engine_verify_host(Engine* e, size_t n, const uint8_t* ballots, uint3
 struct eg_choice_params { Engine* eng; int n_options; int single; };
 struct eg_qv_params { Engine* eng; int n_options; uint64_t credits; eghost::QvShape shape; };
 struct eg_proof_params { Engine* eng; int kind; size_t item_size; };
+
+// The context is reference counted: the caller holds one reference (dropped by eg_destroy) and every params object
+// created on it holds another, so params may be destroyed after the context they were created on.
+static void ctx_release(eg_ctx* c) {
+  if (!c || c->refs.fetch_sub(1) != 1) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (auto& sp : c->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+  for (auto& ev : c->event_pool) (void)hipEventDestroy(ev);
+  if (c->tabG) (void)hipFree(c->tabG);
+  if (c->gen_words) (void)hipFree(c->gen_words);
+  if (c->ws) (void)hipFree(c->ws);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+// destroys a params object: its engine under the context lock, then its reference on the context
+template <class Params>
+static void params_destroy(Params* p) {
+  if (!p) return;
+  eg_ctx* c = p->eng->ctx;
+  {
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    engine_free(p->eng);
+    delete p;
+  }
+  ctx_release(c);
+}
+
 
 #define EG_LOCK(c) std::unique_lock<std::recursive_mutex> lk_; if (c) lk_ = std::unique_lock<std::recursive_mutex>((c)->mu)
 #define EG_LOCK_P(p) EG_LOCK((p) ? (p)->eng->ctx : (eg_ctx*)nullptr)
@@ -454,18 +502,7 @@ int eg_init(int device, eg_ctx** out) {
   return EG_OK;
 }
 
-void eg_destroy(eg_ctx* c) {
-  if (!c) return;
-  (void)hipSetDevice(c->device);
-  if (c->stream) (void)hipStreamSynchronize(c->stream);
-  for (auto& sp : c->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
-  for (auto& ev : c->event_pool) (void)hipEventDestroy(ev);
-  if (c->tabG) (void)hipFree(c->tabG);
-  if (c->gen_words) (void)hipFree(c->gen_words);
-  if (c->ws) (void)hipFree(c->ws);
-  if (c->stream) (void)hipStreamDestroy(c->stream);
-  delete c;
-}
+void eg_destroy(eg_ctx* c) { ctx_release(c); }
 
 int eg_device_name(eg_ctx* c, char* buf, size_t cap) { EG_LOCK(c);
   if (!c || !buf || !cap) return fail(EG_ERR_BAD_ARG, "bad argument");
@@ -521,7 +558,6 @@ struct DevBuf {
   int get(void* dst, size_t bytes, hipStream_t s) { if (bytes) HIPCHK(hipMemcpyAsync(dst, p, bytes, hipMemcpyDeviceToHost, s)); return EG_OK; }
 };
 #define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
-static unsigned blocks_of(size_t n) { return (unsigned)std::max<size_t>(1, (n + NT - 1) / NT); }
 
 int eg_scalar_from_wide_batch(eg_ctx* c, size_t n, const uint8_t* wide, uint8_t* out) { EG_LOCK(c);
   if (!c || (n && (!wide || !out))) return fail(EG_ERR_BAD_ARG, "bad argument");
@@ -650,7 +686,7 @@ int eg_choice_params_create(eg_ctx* c, const uint8_t pk[32], int n_options, int 
   *out = new eg_choice_params{e, n_options, single};
   return EG_OK;
 }
-void eg_choice_params_destroy(eg_choice_params* p) { EG_LOCK_P(p); if (p) { engine_free(p->eng); delete p; } }
+void eg_choice_params_destroy(eg_choice_params* p) { params_destroy(p); }
 int eg_verify_choice_batch(eg_choice_params* p, size_t n, const uint8_t* ballots, uint32_t* status, uint8_t* tally_out) { EG_LOCK_P(p);
   if (!p || (n && (!ballots || !status))) return fail(EG_ERR_BAD_ARG, "bad argument");
   return engine_verify_host(p->eng, n, ballots, status, tally_out);
@@ -663,13 +699,13 @@ int eg_verify_choice_batch_device(eg_choice_params* p, size_t n, const void* d_b
 static int tally_reset(Engine* e, hipStream_t s = nullptr) {
   const bool own = (s == nullptr);
   if (own) s = e->ctx->stream;
-  hipLaunchKernelGGL(k_tally_init, dim3(1), dim3(NT), 0, s, e->tally, (int)e->plan.tally_slots.size());
+  hipLaunchKernelGGL(k_tally_init, dim3(blocks_of(e->plan.tally_slots.size())), dim3(NT), 0, s, e->tally, (int)e->plan.tally_slots.size());
   if (own) HIPCHK(hipStreamSynchronize(s));
   return EG_OK;
 }
 static int tally_encode_device(Engine* e, void* d_out, hipStream_t s) {
   if (!s) s = e->ctx->stream;
-  hipLaunchKernelGGL(k_tally_encode, dim3(1), dim3(NT), 0, s, e->tally, (int)e->plan.tally_slots.size(), (u32*)d_out);
+  hipLaunchKernelGGL(k_tally_encode, dim3(blocks_of(e->plan.tally_slots.size())), dim3(NT), 0, s, e->tally, (int)e->plan.tally_slots.size(), (u32*)d_out);
   HIPCHK(hipGetLastError());
   return EG_OK;
 }
@@ -705,7 +741,7 @@ int eg_qv_params_create(eg_ctx* c, const uint8_t pk[32], int n_options, uint64_t
   *out = new eg_qv_params{e, n_options, credits, eghost::qv_shape(n_options, credits)};
   return EG_OK;
 }
-void eg_qv_params_destroy(eg_qv_params* p) { EG_LOCK_P(p); if (p) { engine_free(p->eng); delete p; } }
+void eg_qv_params_destroy(eg_qv_params* p) { params_destroy(p); }
 size_t eg_qv_ballot_size(const eg_qv_params* p) { return p ? p->shape.ballot_size : 0; }
 int eg_verify_qv_batch(eg_qv_params* p, size_t n, const uint8_t* ballots, uint32_t* status, uint8_t* tally_out) { EG_LOCK_P(p);
   if (!p || (n && (!ballots || !status))) return fail(EG_ERR_BAD_ARG, "bad argument");
@@ -746,7 +782,7 @@ int eg_share_params_create(eg_ctx* c, const uint8_t shared_key[32], uint64_t sha
   *out = new eg_proof_params{e, 3, 128};
   return EG_OK;
 }
-void eg_proof_params_destroy(eg_proof_params* p) { EG_LOCK_P(p); if (p) { engine_free(p->eng); delete p; } }
+void eg_proof_params_destroy(eg_proof_params* p) { params_destroy(p); }
 size_t eg_proof_item_size(const eg_proof_params* p) { return p ? p->item_size : 0; }
 int eg_verify_proof_batch(eg_proof_params* p, size_t n, const uint8_t* items, uint32_t* status) { EG_LOCK_P(p);
   if (!p || (n && (!items || !status))) return fail(EG_ERR_BAD_ARG, "bad argument");

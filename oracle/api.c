@@ -9,6 +9,7 @@
 
 or_choice_params *or_choice_params_new(const uint8_t pk[32], int n_options, int single) {
   /* ChoiceParams::single / ::multi (choice.rs:160-196) */
+  if (n_options < 1 || n_options > 256) return NULL; /* batch generator keeps 256 selection flags */
   or_choice_params *p = (or_choice_params *)calloc(1, sizeof *p);
   if (or_pubkey_from_bytes(&p->pk, pk) != 0) { free(p); return NULL; }
   p->n_options = n_options;
@@ -19,6 +20,7 @@ or_choice_params *or_choice_params_new(const uint8_t pk[32], int n_options, int 
 or_qv_params *or_qv_params_new(const uint8_t pk[32], int n_options, uint64_t credits) {
   or_pubkey t;
   if (or_pubkey_from_bytes(&t, pk) != 0) return NULL;
+  if (n_options < 1 || n_options > 256) return NULL;
   or_qv_params *p = (or_qv_params *)calloc(1, sizeof *p);
   or_qv_params_init(p, pk, n_options, credits);
   return p;

@@ -251,7 +251,7 @@ class ChoiceParams:
     def __init__(self, pk: bytes, n_options: int, single: bool = True):
         self.ptr = lib().or_choice_params_new(pk, n_options, int(single))
         if not self.ptr:
-            raise ValueError("invalid public key")
+            raise ValueError("invalid public key or parameters beyond the oracle's capacity")
         self.pk, self.n_options, self.single = pk, n_options, single
         self.ballot_size = lib().or_choice_ballot_size(n_options, int(single))
         self.pk_ptr = lib().or_choice_params_pk(self.ptr)
@@ -305,7 +305,7 @@ class PublicKey:
     def __init__(self, pk: bytes):
         self.ptr = lib().or_pubkey_new(pk)
         if not self.ptr:
-            raise ValueError("invalid public key")
+            raise ValueError("invalid public key or parameters beyond the oracle's capacity")
         self.bytes = pk
 
     def encrypt_u64(self, value: int, rng) -> bytes:
@@ -354,7 +354,7 @@ class QvParams:
     def __init__(self, pk: bytes, n_options: int, credits: int):
         self.ptr = lib().or_qv_params_new(pk, n_options, credits)
         if not self.ptr:
-            raise ValueError("invalid public key")
+            raise ValueError("invalid public key or parameters beyond the oracle's capacity")
         self.pk, self.n_options, self.credits = pk, n_options, credits
         self.ballot_size = lib().or_qv_ballot_size(self.ptr)
         self.vote_range = PreparedRange(ptr=lib().or_qv_vote_range(self.ptr))

@@ -131,18 +131,19 @@ static void ring_finalize(ring_t *ring, const or_pubkey *pk, const sc *common, c
 typedef struct {
   const or_pubkey *pk;
   merlin_t *transcript;
-  ring_t rings[64];
+  ring_t *rings; /* one per ciphertext of the proof */
   int n_rings;
   sc *responses;
   size_t used;
   chacha_rng *rng;
 } builder_t;
 
-static void builder_init(builder_t *b, const or_pubkey *pk, sc *responses, merlin_t *t, chacha_rng *rng) {
+static void builder_init(builder_t *b, const or_pubkey *pk, sc *responses, merlin_t *t, chacha_rng *rng, int max_rings) {
   /* ring.rs:442-457 */
   or_t_start_proof(t, "multi_ring_enc");
   or_merlin_append(t, "K", pk->bytes, 32);
   b->pk = pk; b->transcript = t; b->n_rings = 0; b->responses = responses; b->used = 0; b->rng = rng;
+  b->rings = (ring_t *)malloc(sizeof(ring_t) * (size_t)(max_rings > 0 ? max_rings : 1));
 }
 
 static void builder_add_precomputed(builder_t *b, const ext_ct *ct, const ge *adm, int size, int vi) {
@@ -229,13 +230,13 @@ void or_encrypt_bool(const or_pubkey *pk, int value, chacha_rng *rng, uint8_t ou
   sc responses[2];
   memset(responses, 0, sizeof responses);
   builder_t *b = (builder_t *)malloc(sizeof(builder_t));
-  builder_init(b, pk, responses, &t, rng);
+  builder_init(b, pk, responses, &t, rng, 1);
   ext_ct c;
   builder_add_value(b, adm, 2, value ? 1 : 0, &c);
   builder_build(b, (sc *)(out + 64));
   put_ct(out, &c.R, &c.B);
   memcpy(out + 96, responses, 64);
-  free(b);
+  free(b->rings); free(b);
 }
 
 /* ------------------------------------------------------------------ EncryptedChoice::new */
@@ -250,7 +251,7 @@ void or_choice_new(const or_choice_params *p, const uint8_t *flags, chacha_rng *
   merlin_t t;
   or_merlin_init(&t, "encrypted_choice_ranges");
   builder_t *b = (builder_t *)malloc(sizeof(builder_t));
-  builder_init(b, &p->pk, responses, &t, rng);
+  builder_init(b, &p->pk, responses, &t, rng, n);
   ge sum_r, sum_b;
   sc sum_rand;
   or_ge_identity(&sum_r);
@@ -276,7 +277,7 @@ void or_choice_new(const or_choice_params *p, const uint8_t *flags, chacha_rng *
     uint8_t *sum_proof = ring_proof + 32 * (size_t)(1 + 2 * n);
     logeq_new(&p->pk, &sum_rand, &sum_r, &p1, &ts, rng, (sc *)sum_proof, (sc *)(sum_proof + 32));
   }
-  free(b);
+  free(b->rings); free(b);
   free(responses);
 }
 
@@ -300,7 +301,7 @@ static void range_new(const or_pubkey *pk, const or_prepared_range *r, uint64_t 
   or_merlin_append(&t, "range", (const uint8_t *)r->name, (size_t)r->name_len);
   sc *responses = (sc *)calloc((size_t)r->total_size, sizeof(sc));
   builder_t *b = (builder_t *)malloc(sizeof(builder_t));
-  builder_init(b, pk, responses, &t, rng);
+  builder_init(b, pk, responses, &t, rng, OR_MAX_RINGS);
   ext_ct cum;
   or_ge_identity(&cum.R);
   or_ge_identity(&cum.B);
@@ -323,7 +324,7 @@ static void range_new(const or_pubkey *pk, const or_prepared_range *r, uint64_t 
   uint8_t *proof = out + 64 + 64 * (size_t)(nr - 1);
   builder_build(b, (sc *)proof);
   memcpy(proof + 32, responses, 32 * (size_t)r->total_size);
-  free(b);
+  free(b->rings); free(b);
   free(responses);
   if (out_ct) *out_ct = ct;
 }

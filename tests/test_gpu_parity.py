@@ -581,3 +581,38 @@ def test_concurrent_host_calls_are_serialised(eg, ctx, oracle, pk):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_large_election_chunks_follow_device_memory(eg, ctx, oracle, pk):
+    """150 options: ~1.6 MB of comb tables per ballot, so the engine must shrink its chunks below EG_CHUNK to fit the
+    device.  48 oracle-made ballots are tiled to ~98k; verdicts, tampering and the tally stay exact."""
+    import torch
+
+    n_opt, tile, reps = 150, 48, 2048
+    n = tile * reps
+    p = eg.ChoiceParams(ctx, pk, n_opt, False)
+    op = oracle.ChoiceParams(pk, n_opt, False)
+    sz = p.ballot_size
+    base = op.generate_batch(909, 0, tile, n_selected=4, threads=8)
+    want = op.verify_batch(base, threads=8)
+    assert want == [0] * tile
+    got_st, got_tally = p.verify_batch(base)
+    assert got_st == want and got_tally == op.tally(base, want)
+    d = torch.frombuffer(bytearray(base), dtype=torch.uint8).cuda().repeat(reps)
+    st = torch.empty(n, dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    p.tally_reset()
+    p.verify_batch_device(n, d.data_ptr(), st.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert int((st != 0).sum()) == 0
+    whole = p.tally_encode()
+    grp = eg.Ristretto(ctx)
+    m = reps.to_bytes(32, "little")
+    scaled, ok = grp.vartime_multi_mul(1, m * (2 * n_opt), got_tally)       # [reps] * tally(tile), element by element
+    assert set(ok) == {1} and scaled == whole
+    view = d.view(n, sz)
+    bad = torch.tensor([0, 7, n // 2, n - 1], device="cuda")
+    view[bad, sz - 32] ^= 1
+    p.verify_batch_device(n, d.data_ptr(), st.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert torch.nonzero(st != 0).flatten().tolist() == sorted(bad.tolist())
