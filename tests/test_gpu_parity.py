@@ -337,7 +337,7 @@ def test_golden_single_ciphertext_proofs(eg, ctx, golden, pk, oracle):
     assert r.verify_batch(rb) == want and 0 in want and eg.RANGE_CHALLENGE in want
 
 
-@pytest.mark.parametrize("upper_bound", [2, 12, 15, 20, 50, 1000])
+@pytest.mark.parametrize("upper_bound", [2, 12, 15, 20, 50, 1000, 65536, 1000000])
 def test_range_proofs_various_bounds(eg, ctx, oracle, pk, upper_bound):
     # bounds of range.rs:708 (range_proof_basics) plus the extremes
     k = oracle.PublicKey(pk)
@@ -616,3 +616,54 @@ def test_large_election_chunks_follow_device_memory(eg, ctx, oracle, pk):
     p.verify_batch_device(n, d.data_ptr(), st.data_ptr(), stream)
     torch.cuda.synchronize()
     assert torch.nonzero(st != 0).flatten().tolist() == sorted(bad.tolist())
+
+
+@pytest.mark.parametrize("options,credits", [(12, 200), (20, 1000), (3, 10000)])
+def test_qv_large_parameters_oracle_ballots(eg, ctx, oracle, pk, options, credits):
+    """Beyond the GPU generator's limits (16 options): ballots from the oracle prover, tampered in every section."""
+    oq = oracle.QvParams(pk, options, credits)
+    q = eg.QuadraticVotingParams(ctx, pk, options, credits)
+    n = 24
+    ballots = bytearray(oq.generate_batch(17, 0, n, threads=8))
+    sz = q.ballot_size
+    assert sz * n == len(ballots)
+    rnd = random.Random(options * 1000 + credits)
+    for b in range(0, n, 2):                       # every other ballot: flip one bit somewhere in the ballot
+        ballots[b * sz + rnd.randrange(sz)] ^= 1 << rnd.randrange(8)
+    want = oq.verify_batch(bytes(ballots), threads=8)
+    assert any(w != 0 for w in want) and any(w == 0 for w in want)
+    got, tally = q.verify_batch(bytes(ballots))
+    assert got == want
+    assert tally == oq.tally(bytes(ballots), want)
+
+
+@pytest.mark.parametrize("workload", ["single", "multi", "qv"])
+def test_random_bit_flips_match_oracle(eg, ctx, oracle, pk, workload):
+    """Differential fuzz: 1-3 random bit flips anywhere in each ballot (points, scalars, challenges); the status words
+    (kind and detail, hence the precedence of the reference's checks) and the tally must equal the oracle's."""
+    if workload == "single":
+        p = eg.ChoiceParams(ctx, pk, 5, True); op = oracle.ChoiceParams(pk, 5, True); kw = {}
+    elif workload == "multi":
+        p = eg.ChoiceParams(ctx, pk, 6, False); op = oracle.ChoiceParams(pk, 6, False); kw = {"n_selected": 2}
+    else:
+        p = eg.QuadraticVotingParams(ctx, pk, 4, 12); op = oracle.QvParams(pk, 4, 12); kw = {}
+    n = 3000 if workload != "qv" else 1200
+    import torch
+
+    sz = p.ballot_size
+    d = torch.empty(n * sz, dtype=torch.uint8, device="cuda")
+    p.encrypt_batch_device(4242, 0, n, d.data_ptr(), **kw)
+    ctx.synchronize()
+    ballots = bytearray(d.cpu().numpy().tobytes())
+    rnd = random.Random(99)
+    for b in range(n):
+        if b % 10 == 0:
+            continue                                   # every tenth ballot stays valid
+        for _ in range(rnd.randrange(1, 4)):
+            ballots[b * sz + rnd.randrange(sz)] ^= 1 << rnd.randrange(8)
+    want = op.verify_batch(bytes(ballots), threads=8)
+    got, tally = p.verify_batch(bytes(ballots))
+    assert got == want
+    assert tally == op.tally(bytes(ballots), want)
+    kinds = {w & 0xFF for w in want}
+    assert 0 in kinds and len(kinds) >= 4              # accepted, bad scalar, bad point and at least one proof failure
