@@ -166,7 +166,9 @@ int eg_verify_proof_batch_device(eg_proof_params*, size_t n, const void* d_items
  * Ballot i of the call is produced from ChaChaRng::seed_from_u64(base_seed + first + i) with the reference's
  * RNG draw order (choice.rs:313-349, ring.rs:54-194, log_equality.rs:114-139, range.rs:462-534, mul.rs:107-181);
  * the voter's selection comes from a second stream seeded with the complemented seed.  n_selected is only
- * used for multi-choice params. */
+ * used for multi-choice params.  The generators keep a ballot's secrets in registers / scratch and therefore cap the
+ * election shape (EG_ERR_BAD_ARG beyond it): choice ballots up to 32 options; quadratic voting up to 16 options, 4 rings
+ * per range proof and ring sizes up to 16.  The verifiers have no such caps (n_options up to 4000 / 256). */
 int eg_choice_encrypt_batch_device(eg_choice_params*, uint64_t base_seed, size_t first, size_t n, int n_selected,
                                    void* d_out, void* stream);
 int eg_choice_encrypt_batch(eg_choice_params*, uint64_t base_seed, size_t first, size_t n, int n_selected,
