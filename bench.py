@@ -34,7 +34,7 @@ OPS = {"decode": (27, 257), "direct_table": (64, 0), "direct_mul": (1269, 1008),
        "base_table": (994, 860), "base_mul": (470, 168), "enc_batch_each": (23, 10), "enc_batch_inversion": (11, 254)}
 # memory-side traffic of k_msm_jobs per ballot and launch, from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
 # of profiles/r01_bench_pmc_counters.txt (single-choice 5-option ballots, 262144 per launch)
-MSM_TRAFFIC_BYTES_PER_BALLOT_LAUNCH = {"single": 38.35e9 / 262144}
+MSM_TRAFFIC_BYTES_PER_BALLOT_LAUNCH = {"single": 38.69e9 / 262144}
 MAD_PEAK_T = 33.4              # profiles/r01_ubench_valu_rates.txt: v_mad_u64_u32, 8 waves/SIMD, T lane-ops/s chip-wide
 FMUL_PEAK_G = 256.0            # profiles/r01_ubench_fmul_candidates.txt: radix-25.5 field multiply, G/s chip-wide
 
@@ -173,11 +173,13 @@ def main():
         return
 
     # ---- roofline of the dominant kernel (k_msm_jobs), HIP events on the launch stream ------------------------
-    chunk = int(os.environ.get("EG_CHUNK", "262144"))
+    kind = {"single": "single", "multi": "multi", "qv": "qv"}[args.workload]
+    n_stages = eg.plan_describe(kind, n_opt, args.credits if args.workload == "qv" else 0)["stages"]   # one k_msm_jobs launch per stage and chunk
     launches_per_step = max(1, msm_launches // max(args.steps, 1))
     avg_launch_ms = msm_ms / max(msm_launches, 1)
-    n_chunks = -(-B // chunk)
+    n_chunks = max(1, launches_per_step // n_stages)
     units_per_launch = -(-B // n_chunks)
+    chunk = units_per_launch
     alg_bytes = params.ballot_size + 4
     achieved_gbs = alg_bytes * units_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
     out = {

@@ -286,10 +286,12 @@ static int engine_create(eg_ctx* ctx, eghost::Plan&& plan, const uint8_t pk[32],
 
   // chunk workspace: sized lazily by engine_reserve() for the batches actually seen (up to EG_CHUNK ballots per chunk)
   const char* env = getenv("EG_CHUNK");
-  e->max_cap = env ? (u32)strtoul(env, nullptr, 10) : 262144u;
+  e->max_cap = env ? (u32)strtoul(env, nullptr, 10) : 1048576u;
   {
-    // large elections: keep the chunk workspace within half of the free device memory (it is ~58 KB per ballot for 5
-    // options, ~5.5 KB more per ring base)
+    // Chunks are large (default 2^20 ballots: ~61 GB of workspace for 5 options) because every kernel is a persistent grid
+    // of msm_blocks * NT lanes striding over jobs x ballots: a chunk of 250k ballots is ~20 rounds per kernel and wastes
+    // most of its last round (measured 4.53 M ballots/s at 2^18 per chunk, 4.83 M/s at 2^20).  Large elections keep the
+    // workspace within half of the free device memory (~58 KB per ballot for 5 options, ~5.5 KB more per ring base).
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
     const size_t limit = engine_bytes_per_ballot(e.get()) ? free_b / 2 / engine_bytes_per_ballot(e.get()) : e->max_cap;
@@ -399,16 +401,25 @@ static int engine_verify_host(Engine* e, size_t n, const uint8_t* ballots, uint3
   }
   if (tally_out) hipLaunchKernelGGL(k_tally_init, dim3(blocks_of(e->plan.tally_slots.size())), dim3(NT), 0, s, e->tally, (int)e->plan.tally_slots.size());
   if (n) {
-    // Pipeline over the engine's chunks: the copy stream uploads chunk k+1 while chunk k is verified (SURVEY 8e:
-    // host staging, not the kernels, is the scaling risk when ballots arrive in host memory).
+    // Pipeline: the copy stream uploads piece k+1 while piece k is verified (host staging, not the kernels, is
+    // the scaling risk when ballots arrive in host memory).  The first piece is small so that the exposed upload is short;
+    // the rest are as large as the engine's chunks (large chunks waste less of each kernel's last round).
     if (!e->copy_stream) HIPCHK(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
-    const size_t n_chunks = (n + e->max_cap - 1) / e->max_cap;
-    const size_t even = ((n + n_chunks - 1) / n_chunks + NT - 1) / NT * NT;
-    std::vector<hipEvent_t> uploaded(n_chunks, nullptr);
-    int rc = EG_OK;
-    size_t k = 0;
-    for (size_t off = 0; off < n && rc == EG_OK; off += even, ++k) {
-      const size_t m = std::min(even, n - off);
+    std::vector<std::pair<size_t, size_t>> pieces;   // (offset, count)
+    {
+      const size_t lanes = (size_t)e->ctx->msm_blocks * NT;
+      size_t off = 0;
+      if (n > 2 * lanes) { pieces.push_back({0, lanes}); off = lanes; }
+      const size_t rem = n - off, k = (rem + e->max_cap - 1) / e->max_cap;
+      const size_t even = ((rem + k - 1) / k + NT - 1) / NT * NT;
+      for (; off < n; off += even) pieces.push_back({off, std::min(even, n - off)});
+    }
+    std::vector<hipEvent_t> uploaded(pieces.size(), nullptr);
+    size_t largest = 0;
+    for (auto& pc : pieces) largest = std::max(largest, pc.second);
+    int rc = engine_reserve(e, (u32)largest);          // no regrowth of the workspace mid-pipeline
+    for (size_t k = 0; k < pieces.size() && rc == EG_OK; ++k) {
+      const size_t off = pieces[k].first, m = pieces[k].second;
       hipError_t he = hipEventCreateWithFlags(&uploaded[k], hipEventDisableTiming);
       if (he == hipSuccess) he = hipMemcpyAsync(e->d_wire + off * e->plan.stride, ballots + off * e->plan.stride, m * e->plan.stride,
                                                 hipMemcpyHostToDevice, e->copy_stream);

@@ -16,7 +16,7 @@ def short(name):
 # ---- kernel stats ------------------------------------------------------------------------------------------------
 rows = list(csv.DictReader(open(OUT / "prof_stats" / "stats_kernel_stats.csv")))
 lines = ["# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline   (MI355X)",
-         "# 1 warm-up + 3 timed steps of 1M single-choice 5-option ballots (4 chunks of 250 112), plus the untimed generator launch",
+         "# 1 warm-up + 3 timed steps of 1M single-choice 5-option ballots (one chunk: one k_base_tables and two k_msm_jobs launches per step), plus the untimed generator launch",
          f"{'kernel':64s} {'calls':>6s} {'total_ms':>12s} {'avg_ms':>11s} {'min_ms':>9s} {'max_ms':>9s} {'pct':>8s}"]
 for r in rows:
     lines.append(f"{short(r['Name']):64s} {int(r['Calls']):6d} {int(r['TotalDurationNs'])/1e6:12.3f} {float(r['AverageNs'])/1e6:11.4f} "
