@@ -72,6 +72,8 @@ def parse():
     ap.add_argument("--seed", type=int, default=20260612)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (RCCL) even for one rank: exercises the N > 1 code path on a 1-GPU box")
     return ap.parse_args()
 
 
@@ -103,9 +105,14 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if args.force_dist:
+        os.environ["EG_DIST_ALWAYS"] = "1"     # the helpers then run their collectives even with one rank
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     ctx = eg.Context(local_rank)
     pk = bytes.fromhex(PUBLIC_KEY_HEX)
@@ -142,12 +149,18 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
+    if use_dist:
+        # RCCL's version banner (NCCL_DEBUG=VERSION) sits in the C stdio buffer of every rank: push it out now so that the
+        # JSON line below stays the last line of the job's stdout
+        barrier()
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
     ctx.profile_enable(True)
     ctx.profile_read()
     ctx.profile_read_tables()
@@ -168,7 +181,7 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
 
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -287,8 +300,9 @@ def main():
             "single_thread_value": one / one_s,
             "verdicts_match_gpu": cpu_status == gpu_status,
         }
-    print(json.dumps(out))
-    if world > 1:
+    sys.stdout.flush()
+    print(json.dumps(out), flush=True)
+    if use_dist:
         dist.destroy_process_group()
 
 

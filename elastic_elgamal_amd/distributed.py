@@ -8,6 +8,8 @@ RCCL/xGMI; point addition is not an RCCL reduction op, so every rank then sums t
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -22,7 +24,7 @@ def shard_range(total: int, rank: int, world: int) -> tuple[int, int]:
 def gather_tallies(local: torch.Tensor) -> torch.Tensor:
     """All-gather of the per-rank tally encodings.  local: uint8 [n_options*64] -> uint8 [world, n_options*64],
     rank-major (row r is rank r's tally).  A single collective per batch; no data-path collective elsewhere."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not os.environ.get("EG_DIST_ALWAYS")):
         return local.reshape(1, -1).clone()
     world = dist.get_world_size()
     flat = local.contiguous().view(-1)
@@ -37,7 +39,7 @@ def gather_tallies(local: torch.Tensor) -> torch.Tensor:
 
 
 def max_over_ranks(seconds: float, device) -> float:
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not os.environ.get("EG_DIST_ALWAYS")):
         return seconds
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -45,7 +47,7 @@ def max_over_ranks(seconds: float, device) -> float:
 
 
 def sum_over_ranks(value: int, device) -> int:
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not os.environ.get("EG_DIST_ALWAYS")):
         return value
     t = torch.tensor([value], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
