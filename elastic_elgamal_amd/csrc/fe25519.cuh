@@ -85,7 +85,6 @@ EG_HD void fe_0(fe& h) {
   EG_SETCLS(h, 1.0f);
 }
 EG_HD void fe_1(fe& h) { fe_0(h); h.v[0] = 1; }
-EG_HD void fe_copy(fe& h, const fe& f) { h = f; }
 
 EG_HD void fe_add(fe& h, const fe& f, const fe& g) {
 #pragma unroll

@@ -307,15 +307,6 @@ EG_HD void ge_double_encode_finish(u32 w[8], const ge& p, const fe& inv_n, bool 
   fe_to_words(w, s2);
 }
 
-// Ristretto equality / identity test (ristretto.rs:80-82); only used off the hot path
-EG_HD bool ge_ristretto_eq(const ge& p, const ge& q) {
-  fe a, b;
-  fe_mul(a, p.X, q.Y); fe_mul(b, p.Y, q.X);
-  const bool e1 = fe_eq(a, b);
-  fe_mul(a, p.Y, q.Y); fe_mul(b, p.X, q.X);
-  return e1 | fe_eq(a, b);
-}
-
 // ---- scalar recoding -------------------------------------------------------------------------------------
 // 256-bit scalar (< 2^253) -> 64 signed radix-16 digits in [-8, 7], packed as nibbles (two's complement).
 EG_HD void sc_recode_radix16(u32 out[8], const u32 k[8]) {

@@ -141,11 +141,6 @@ EG_HD void sc_neg(u32 out[8], const u32 a[8]) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) out[i] = nz ? out[i] : 0u;
 }
-EG_HD void sc_sub(u32 out[8], const u32 a[8], const u32 b[8]) {
-  u32 nb[8];
-  sc_neg(nb, b);
-  sc_add(out, a, nb);
-}
 
 // h with 2h = s (mod l): (s + (s odd ? l : 0)) >> 1.  The result is < 2^252 + 2^251 and is used only as a
 // multiplier of points (it is not a canonical scalar when s is odd: it represents (s + l) / 2).
