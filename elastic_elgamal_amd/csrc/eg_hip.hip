@@ -176,15 +176,24 @@ static int engine_reserve(Engine* e, u32 want) {
   for (void** b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
   e->cap = 0;
   const size_t cap = (want + NT - 1) / NT * NT;
-  HIPCHK(hipMalloc((void**)&e->pts, (size_t)std::max(P.n_pt_slots, 1) * 10 * cap * sizeof(uint4)));
-  HIPCHK(hipMalloc((void**)&e->cmp, (size_t)std::max(P.n_cmp_slots, 1) * 2 * cap * sizeof(uint4)));
-  HIPCHK(hipMalloc((void**)&e->chal, (size_t)std::max(P.n_chal_slots, 1) * 2 * cap * sizeof(uint4)));
-  HIPCHK(hipMalloc((void**)&e->states, (size_t)std::max(P.n_state_slots, 1) * 52 * cap * sizeof(u32)));
-  HIPCHK(hipMalloc((void**)&e->flags, (size_t)std::max(P.n_flag_slots, 1) * cap * sizeof(u32)));
-  HIPCHK(hipMalloc((void**)&e->bad_item, cap * sizeof(u32)));
-  HIPCHK(hipMalloc((void**)&e->btab, std::max<size_t>(P.base_slots.size(), 1) * cap * BTAB_QUADS * sizeof(uint4)));
-  HIPCHK(hipMalloc((void**)&e->dpt, (size_t)std::max(P.n_cmp_slots, 1) * 10 * cap * sizeof(uint4)));
-  HIPCHK(hipMalloc((void**)&e->encw, (size_t)std::max(e->max_defer, 1) * 2 * 10 * cap * sizeof(u32)));
+  const size_t sizes[] = {(size_t)std::max(P.n_pt_slots, 1) * 10 * cap * sizeof(uint4),
+                          (size_t)std::max(P.n_cmp_slots, 1) * 2 * cap * sizeof(uint4),
+                          (size_t)std::max(P.n_chal_slots, 1) * 2 * cap * sizeof(uint4),
+                          (size_t)std::max(P.n_state_slots, 1) * 52 * cap * sizeof(u32),
+                          (size_t)std::max(P.n_flag_slots, 1) * cap * sizeof(u32),
+                          cap * sizeof(u32),
+                          std::max<size_t>(P.base_slots.size(), 1) * cap * BTAB_QUADS * sizeof(uint4),
+                          (size_t)std::max(P.n_cmp_slots, 1) * 10 * cap * sizeof(uint4),
+                          (size_t)std::max(e->max_defer, 1) * 2 * 10 * cap * sizeof(u32)};
+  for (size_t i = 0; i < sizeof(sizes) / sizeof(sizes[0]); ++i) {
+    const hipError_t he = hipMalloc(bufs[i], sizes[i]);
+    if (he == hipErrorOutOfMemory) {        // the caller retries with smaller chunks
+      (void)hipGetLastError();
+      for (void** b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
+      return fail(EG_ERR_NOMEM, "device memory exhausted while reserving the chunk workspace");
+    }
+    HIPCHK(he);
+  }
   e->cap = (u32)cap;
   return EG_OK;
 }
@@ -326,8 +335,14 @@ static int engine_verify_device(Engine* e, size_t n, const void* d_ballots, void
   int rc;
   if ((rc = prof_begin(ctx, s, PROF_CALL, &all_idx))) return rc;
   // equal-sized chunks (each a multiple of the block size) so that the persistent grids stay balanced on the last chunk
-  const size_t n_chunks = (n + e->max_cap - 1) / e->max_cap;
-  if (n) { int rr = engine_reserve(e, (u32)(((n + n_chunks - 1) / n_chunks + NT - 1) / NT * NT)); if (rr) return rr; }
+  size_t n_chunks = (n + e->max_cap - 1) / e->max_cap;
+  while (n) {
+    const int rr = engine_reserve(e, (u32)(((n + n_chunks - 1) / n_chunks + NT - 1) / NT * NT));
+    if (rr == EG_OK) break;
+    if (rr != EG_ERR_NOMEM || e->max_cap <= 16 * NT) return rr;
+    e->max_cap = (e->max_cap / 2 + NT - 1) / NT * NT;    // other allocations took the memory this engine counted on: halve the chunks
+    n_chunks = (n + e->max_cap - 1) / e->max_cap;
+  }
   const size_t even = n_chunks ? ((n + n_chunks - 1) / n_chunks + NT - 1) / NT * NT : 0;
   for (size_t off = 0; off < n; off += even) {
     const u32 cn = (u32)std::min<size_t>(even, n - off);
@@ -418,6 +433,7 @@ static int engine_verify_host(Engine* e, size_t n, const uint8_t* ballots, uint3
     size_t largest = 0;
     for (auto& pc : pieces) largest = std::max(largest, pc.second);
     int rc = engine_reserve(e, (u32)largest);          // no regrowth of the workspace mid-pipeline
+    if (rc == EG_ERR_NOMEM) rc = EG_OK;                // engine_verify_device falls back to smaller chunks
     for (size_t k = 0; k < pieces.size() && rc == EG_OK; ++k) {
       const size_t off = pieces[k].first, m = pieces[k].second;
       hipError_t he = hipEventCreateWithFlags(&uploaded[k], hipEventDisableTiming);

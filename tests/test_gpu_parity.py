@@ -667,3 +667,38 @@ def test_random_bit_flips_match_oracle(eg, ctx, oracle, pk, workload):
     assert tally == op.tally(bytes(ballots), want)
     kinds = {w & 0xFF for w in want}
     assert 0 in kinds and len(kinds) >= 4              # accepted, bad scalar, bad point and at least one proof failure
+
+
+def test_chunks_shrink_when_device_memory_is_taken(eg, ctx, oracle, pk):
+    """The chunk workspace is sized from the memory free at params creation; if another allocation takes that memory
+    before the first big batch, the engine must fall back to smaller chunks instead of failing."""
+    import torch
+
+    p = eg.ChoiceParams.single_choice(ctx, pk, 5)
+    op = oracle.ChoiceParams(pk, 5, True)
+    n = 400_000
+    sz = p.ballot_size
+    d = torch.empty(n * sz, dtype=torch.uint8, device="cuda")
+    p.encrypt_batch_device(5150, 0, n, d.data_ptr())
+    ctx.synchronize()
+    st = torch.empty(n, dtype=torch.int32, device="cuda")
+    torch.cuda.empty_cache()
+    free, _total = torch.cuda.mem_get_info()
+    hog = torch.empty(max(free - (18 << 30), 1 << 20), dtype=torch.uint8, device="cuda")   # leave ~18 GB: 400k ballots need ~23 GB
+    try:
+        p.tally_reset()
+        p.verify_batch_device(n, d.data_ptr(), st.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert int((st != 0).sum()) == 0
+        tally = p.tally_encode()
+    finally:
+        del hog
+        torch.cuda.empty_cache()
+    head = bytes(d[: 64 * sz].cpu().numpy())
+    assert st[:64].tolist() == op.verify_batch(head)
+    # tally of the whole batch = tally of two halves verified with ample memory
+    p2 = eg.ChoiceParams.single_choice(ctx, pk, 5)
+    p2.tally_reset()
+    p2.verify_batch_device(n, d.data_ptr(), st.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert p2.tally_encode() == tally
