@@ -71,6 +71,9 @@ def parse():
     ap.add_argument("--credits", type=int, default=20)
     ap.add_argument("--seed", type=int, default=20260612)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
+    ap.add_argument("--tampered-percent", type=float, default=0.0,
+                    help="flip one response bit in this share of the ballots before timing (SURVEY 8d: verdict parity and tally "
+                         "exclusion with invalid ballots in the batch); the headline line uses 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even for one rank: exercises the N > 1 code path on a 1-GPU box")
@@ -136,6 +139,11 @@ def main():
         params.encrypt_batch_device(args.seed, first, B, ballots.data_ptr(), stream=stream)
     torch.cuda.synchronize()
     gen_s = time.time() - t0
+    n_tampered = int(B * args.tampered_percent / 100.0)
+    if n_tampered:
+        g = torch.Generator(device="cpu").manual_seed(args.seed + rank)
+        bad = torch.randperm(B, generator=g)[:n_tampered].to(dev)
+        ballots.view(B, params.ballot_size)[bad, params.ballot_size - 32] ^= 1   # last response scalar stays canonical
     status = torch.empty(B, dtype=torch.int32, device=dev)
     local_tally = torch.empty(64 * n_opt, dtype=torch.uint8, device=dev)
     final_tally = torch.empty(64 * n_opt, dtype=torch.uint8, device=dev)
@@ -221,6 +229,7 @@ def main():
             "chunk_ballots": chunk,
             "seed": args.seed,
             "accepted": accepted_all,
+            "tampered": n_tampered * world,
             "generator_s": round(gen_s, 3),
             "parallelism": f"shard{world}" if world > 1 else "single",
         },
