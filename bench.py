@@ -80,6 +80,16 @@ def parse():
     return ap.parse_args()
 
 
+def cpu_model() -> str:
+    try:
+        for line in Path("/proc/cpuinfo").read_text().splitlines():
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def effective_cores() -> int:
     """Hardware threads this process may actually use (affinity mask and cgroup CPU quota)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -307,6 +317,7 @@ def main():
             "sample": f"first {sample} ballots of the same batch, oracle/ C restatement (not curve25519-dalek), "
                       f"{cores} threads, {cpu_s:.1f} s",
             "single_thread_value": one / one_s,
+            "cpu_model": cpu_model(),
             "verdicts_match_gpu": cpu_status == gpu_status,
         }
     sys.stdout.flush()
