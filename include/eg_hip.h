@@ -44,7 +44,8 @@ typedef enum {
 } eg_error;
 
 /* ---- per-ballot status words (uint32): low byte = kind, bits 8.. = detail ------------------------------
- * Kinds mirror the reference's error enums; precedence = order of checks in EncryptedChoice::verify
+ * Kinds mirror the reference's error enums (the *_LEN kinds cannot arise in a packed batch, whose shape is fixed by the
+ * params; they are produced by the object-ingest layer, elastic_elgamal_amd/ingest.py); precedence = order of checks in EncryptedChoice::verify
  * (choice.rs:358-380) and QuadraticVotingBallot::verify (quadratic_voting.rs:291-329), preceded by the
  * deserialisation-time rejections of serde (serde.rs:191-206,254-269) in wire order. */
 enum {

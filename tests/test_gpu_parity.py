@@ -702,3 +702,35 @@ def test_chunks_shrink_when_device_memory_is_taken(eg, ctx, oracle, pk):
     p2.verify_batch_device(n, d.data_ptr(), st.data_ptr(), torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert p2.tally_encode() == tally
+
+
+# ------------------------------------------------------------------ object ingest: length-mismatch verdicts
+@pytest.mark.parametrize("kind", ["single", "multi", "qv"])
+def test_object_ingest_length_mismatches(eg, ctx, oracle, pk, kind):
+    """Ballots as serde-layout objects with wrong numbers of choices / responses / partial ciphertexts: the verdicts follow
+    the reference's order of checks (tests/ingest_cases.py; the same scenarios run oracle-backed in test_ingest_cpu.py)."""
+    from elastic_elgamal_amd import ingest, serde
+    from ingest_cases import choice_cases, qv_cases
+
+    grp = eg.Ristretto(ctx)
+    if kind == "qv":
+        n, credits = 3, 9
+        op = oracle.QvParams(pk, n, credits)
+        p = eg.QuadraticVotingParams(ctx, pk, n, credits)
+        packed = op.generate_batch(12, 0, 8)
+        sz = len(packed) // 8
+        cases = qv_cases([ingest.unpack_qv_ballot(packed[i * sz : (i + 1) * sz], n, credits) for i in range(8)])
+        got, tally = ingest.verify_qv_objects(p, grp, [c[1] for c in cases])
+        accepted = b"".join(serde.pack_qv_ballot(c[1]) for c in cases if c[2] == 0)
+    else:
+        n, single = 3, kind == "single"
+        op = oracle.ChoiceParams(pk, n, single)
+        p = eg.ChoiceParams(ctx, pk, n, single)
+        packed = op.generate_batch(11, 0, 8, n_selected=0 if single else 2)
+        sz = len(packed) // 8
+        cases = choice_cases([serde.unpack_encrypted_choice(packed[i * sz : (i + 1) * sz], n, single) for i in range(8)], single)
+        got, tally = ingest.verify_choice_objects(p, grp, [c[1] for c in cases])
+        accepted = b"".join(serde.pack_encrypted_choice(c[1]) for c in cases if c[2] == 0)
+    for (name, _, want), g in zip(cases, got):
+        assert g == want, name
+    assert tally == op.tally(accepted, [0] * (len(accepted) // sz))

@@ -1,0 +1,79 @@
+"""Object ingest (elastic_elgamal_amd/ingest.py) with the library calls replaced by ORACLE-backed shims, so that the
+ordering logic (deserialisation failures, options count, length checks after the earlier proofs) runs without a GPU.
+The same scenarios run against the real library in tests/test_gpu_parity.py."""
+import pytest
+
+from elastic_elgamal_amd import ingest, serde
+
+from ingest_cases import L, choice_cases, qv_cases
+
+
+class OracleGroup:
+    def __init__(self, oracle):
+        self.o = oracle
+
+    def element_roundtrip(self, pts: bytes):
+        ok = bytes(1 if self.o.point_roundtrip(pts[i : i + 32]) is not None else 0 for i in range(0, len(pts), 32))
+        return pts, ok
+
+    def deserialize_scalar_ok(self, scs: bytes) -> bytes:
+        return bytes(1 if int.from_bytes(scs[i : i + 32], "little") < L else 0 for i in range(0, len(scs), 32))
+
+
+class OracleParams:
+    """verify_batch of the C ABI, answered by the oracle"""
+
+    def __init__(self, op, n_options, single=None, credits=None):
+        self.op, self.n_options, self.single, self.credits = op, n_options, single, credits
+
+    def verify_batch(self, ballots: bytes, with_tally: bool = True):
+        st = self.op.verify_batch(ballots) if ballots else []
+        return st, (self.op.tally(ballots, st) if with_tally else None)
+
+
+@pytest.fixture(scope="module")
+def pk(golden):
+    import base64
+    s = golden["public_key_b64"]
+    return base64.urlsafe_b64decode(s + "=" * (-len(s) % 4))
+
+
+@pytest.mark.parametrize("single", [True, False])
+def test_choice_objects(oracle, pk, single):
+    n = 3
+    op = oracle.ChoiceParams(pk, n, single)
+    packed = op.generate_batch(11, 0, 8, n_selected=0 if single else 2)
+    sz = len(packed) // 8
+    objs = [serde.unpack_encrypted_choice(packed[i * sz : (i + 1) * sz], n, single) for i in range(8)]
+    cases = choice_cases(objs, single)
+    got, tally = ingest.verify_choice_objects(OracleParams(op, n, single=single), OracleGroup(oracle), [c[1] for c in cases])
+    for (name, _, want), g in zip(cases, got):
+        assert g == want, name
+    accepted = b"".join(serde.pack_encrypted_choice(c[1]) for c in cases if c[2] == 0)
+    assert tally == op.tally(accepted, [0] * (len(accepted) // sz))
+
+
+def test_qv_objects(oracle, pk):
+    n, credits = 3, 9
+    oq = oracle.QvParams(pk, n, credits)
+    packed = oq.generate_batch(12, 0, 8)
+    sz = len(packed) // 8
+    objs = [ingest.unpack_qv_ballot(packed[i * sz : (i + 1) * sz], n, credits) for i in range(8)]
+    assert serde.pack_qv_ballot(objs[0]) == packed[:sz]
+    cases = qv_cases(objs)
+    got, tally = ingest.verify_qv_objects(OracleParams(oq, n, credits=credits), OracleGroup(oracle), [c[1] for c in cases])
+    for (name, _, want), g in zip(cases, got):
+        assert g == want, name
+    accepted = b"".join(serde.pack_qv_ballot(c[1]) for c in cases if c[2] == 0)
+    assert tally == oq.tally(accepted, [0] * (len(accepted) // sz))
+
+
+def test_structural_errors_are_deserialisation_errors(oracle, pk):
+    op = oracle.ChoiceParams(pk, 2, True)
+    packed = op.generate_batch(13, 0, 1)
+    obj = serde.unpack_encrypted_choice(packed, 2, True)
+    bad = dict(obj, range_proof=dict(obj["range_proof"], ring_responses=obj["range_proof"]["ring_responses"][:1]))
+    with pytest.raises(serde.SerdeError):
+        ingest.verify_choice_objects(OracleParams(op, 2, single=True), OracleGroup(oracle), [bad])
+    with pytest.raises(serde.SerdeError):
+        ingest.verify_choice_objects(OracleParams(op, 2, single=True), OracleGroup(oracle), [dict(obj, sum_proof=None)])
