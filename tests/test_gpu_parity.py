@@ -734,3 +734,59 @@ def test_object_ingest_length_mismatches(eg, ctx, oracle, pk, kind):
     for (name, _, want), g in zip(cases, got):
         assert g == want, name
     assert tally == op.tally(accepted, [0] * (len(accepted) // sz))
+
+
+@pytest.mark.parametrize("upper_bound", [12, 15, 20, 50])
+def test_range_proof_negative_cases(eg, ctx, oracle, pk, upper_bound):
+    """range.rs:708-795 (range_proof_basics): a proof must not verify for another receiver, another ciphertext, a mangled
+    ciphertext or another decomposition; every verdict equals the oracle's."""
+    grp = eg.Ristretto(ctx)
+    k = oracle.PublicKey(pk)
+    pr = oracle.PreparedRange(upper_bound)
+    rs = oracle.rng_from_u64(1000 + upper_bound)
+    a, b = k.encrypt_range(pr, 10, rs), k.encrypt_range(pr, 3, rs)
+    r = eg.PublicKeyVerifier(ctx, pk, eg.PublicKeyVerifier.RANGE, upper_bound)
+    gen = oracle.point_mul_generator(sc(1))
+    mangled_b, _ = grp.element_add(a[32:64], gen)                     # blinded_element += G
+    cases = [a, b,
+             b[:64] + a[64:],                                         # another ciphertext under a's proof
+             a[:32] + mangled_b + a[64:],                             # mangled ciphertext
+             a[:64] + b[64:]]                                         # a's ciphertext under another proof
+    want = [k.verify_range(pr, c) for c in cases]
+    assert want[:2] == [0, 0] and all(w != 0 for w in want[2:])
+    assert r.verify_batch(b"".join(cases)) == want
+    # another receiver
+    pk2 = oracle.point_mul_generator(sc(123456789))
+    r2 = eg.PublicKeyVerifier(ctx, pk2, eg.PublicKeyVerifier.RANGE, upper_bound)
+    k2 = oracle.PublicKey(pk2)
+    assert r2.verify_batch(a + b) == [k2.verify_range(pr, a), k2.verify_range(pr, b)] != [0, 0]
+    # another decomposition of the same wire size, where one exists among nearby bounds
+    for other in range(upper_bound + 1, upper_bound + 40):
+        pro = oracle.PreparedRange(other)
+        if pro.proof_size == pr.proof_size and eg.range_decomposition(other) != eg.range_decomposition(upper_bound):
+            ro = eg.PublicKeyVerifier(ctx, pk, eg.PublicKeyVerifier.RANGE, other)
+            got = ro.verify_batch(a + b)
+            assert got == [k.verify_range(pro, a), k.verify_range(pro, b)] and all(x != 0 for x in got)
+            break
+
+
+def test_qv_reordered_votes(eg, ctx, oracle, pk):
+    """mul.rs:332-361 (reordering the ciphertexts breaks the sum-of-squares proof): swapping two vote blocks keeps every
+    range proof valid, so the failure must be CreditEquivalence."""
+    n, credits = 4, 16
+    oq = oracle.QvParams(pk, n, credits)
+    q = eg.QuadraticVotingParams(ctx, pk, n, credits)
+    ballots = bytearray(oq.generate_batch(41, 0, 40, threads=8))
+    sz = q.ballot_size
+    from elastic_elgamal_amd import ingest
+    rings = ingest.parse_range(eg.range_decomposition(ingest.isqrt(credits) + 1))
+    vote_sz = 64 + 64 * (len(rings) - 1) + 32 * (1 + sum(s for _, s in rings))
+    for b in range(0, 40, 2):
+        o = b * sz
+        v0, v1 = bytes(ballots[o : o + vote_sz]), bytes(ballots[o + vote_sz : o + 2 * vote_sz])
+        ballots[o : o + vote_sz], ballots[o + vote_sz : o + 2 * vote_sz] = v1, v0
+    want = oq.verify_batch(bytes(ballots), threads=8)
+    got, tally = q.verify_batch(bytes(ballots))
+    assert got == want and tally == oq.tally(bytes(ballots), want)
+    kinds = {w & 0xFF for w in want[0:40:2]}
+    assert kinds == {12}                                        # CREDIT_EQUIV_CHALLENGE
