@@ -118,6 +118,8 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # one explicit stream for everything: the library's launches, torch's copies and RCCL's collective are ordered on it
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     use_dist = world > 1 or args.force_dist
     if args.force_dist:
         os.environ["EG_DIST_ALWAYS"] = "1"     # the helpers then run their collectives even with one rank
@@ -194,6 +196,15 @@ def main():
     elapsed = egd.max_over_ranks(elapsed, dev)
 
     accepted = int((status == 0).sum().item())
+    # the tally that went through encode -> all-gather -> k_points_sum must be the engine's own tally (one rank) /
+    # identical on every rank (several ranks): proves the stream ordering of the exchange
+    torch.cuda.synchronize()
+    exchanged = bytes(final_tally.cpu().numpy())
+    if world == 1:
+        tally_ok = exchanged == params.tally_encode()
+    else:
+        digest = int.from_bytes(__import__("hashlib").sha256(exchanged).digest()[:7], "big")
+        tally_ok = egd.max_over_ranks(float(digest), dev) == float(digest) and egd.sum_over_ranks(1, dev) == world
     accepted_all = egd.sum_over_ranks(accepted, dev)
     value = B * world * args.steps / elapsed
     ms_per_step = elapsed / args.steps * 1e3
@@ -239,6 +250,7 @@ def main():
             "chunk_ballots": chunk,
             "seed": args.seed,
             "accepted": accepted_all,
+            "tally_exchange_ok": bool(tally_ok),
             "tampered": n_tampered * world,
             "generator_s": round(gen_s, 3),
             "parallelism": f"shard{world}" if world > 1 else "single",

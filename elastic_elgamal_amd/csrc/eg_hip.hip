@@ -328,8 +328,7 @@ static int engine_create(eg_ctx* ctx, eghost::Plan&& plan, const uint8_t pk[32],
 
 // verify n ballots (device pointers), accumulating accepted ciphertexts into the running tally
 static int engine_verify_device(Engine* e, size_t n, const void* d_ballots, void* d_status, hipStream_t s) {
-  eg_ctx* ctx = e->ctx;
-  if (!s) s = ctx->stream;
+  eg_ctx* ctx = e->ctx;     // s may be the null stream: a NULL hipStream_t means what it means everywhere in HIP
   const eghost::Plan& P = e->plan;
   size_t all_idx = 0;
   int rc;
@@ -393,6 +392,7 @@ static int engine_verify_device(Engine* e, size_t n, const void* d_ballots, void
 
 static int engine_tally_encode(Engine* e, uint8_t* out) {
   hipStream_t s = e->ctx->stream;
+  HIPCHK(hipDeviceSynchronize());   // batches enqueued on caller streams by the _device entry points must have landed
   const int ns = (int)e->plan.tally_slots.size();
   u32* d_out = nullptr;
   HIPCHK(hipMalloc((void**)&d_out, (size_t)ns * 32));
@@ -539,7 +539,8 @@ int eg_device_name(eg_ctx* c, char* buf, size_t cap) { EG_LOCK(c);
 
 int eg_synchronize(eg_ctx* c) { EG_LOCK(c);
   if (!c) return fail(EG_ERR_BAD_ARG, "ctx is null");
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipDeviceSynchronize());      // _device / _async work may sit on caller streams, not only on the context's own
   return EG_OK;
 }
 
@@ -723,15 +724,14 @@ int eg_verify_choice_batch_device(eg_choice_params* p, size_t n, const void* d_b
   HIPCHK(hipSetDevice(p->eng->ctx->device));
   return engine_verify_device(p->eng, n, d_ballots, d_status, (hipStream_t)stream);
 }
-static int tally_reset(Engine* e, hipStream_t s = nullptr) {
-  const bool own = (s == nullptr);
-  if (own) s = e->ctx->stream;
+static int tally_reset(Engine* e, hipStream_t s, bool wait) {
+  if (wait) HIPCHK(hipDeviceSynchronize());   // host form: order after anything still running on caller streams
   hipLaunchKernelGGL(k_tally_init, dim3(blocks_of(e->plan.tally_slots.size())), dim3(NT), 0, s, e->tally, (int)e->plan.tally_slots.size());
-  if (own) HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipGetLastError());
+  if (wait) HIPCHK(hipStreamSynchronize(s));
   return EG_OK;
 }
 static int tally_encode_device(Engine* e, void* d_out, hipStream_t s) {
-  if (!s) s = e->ctx->stream;
   hipLaunchKernelGGL(k_tally_encode, dim3(blocks_of(e->plan.tally_slots.size())), dim3(NT), 0, s, e->tally, (int)e->plan.tally_slots.size(), (u32*)d_out);
   HIPCHK(hipGetLastError());
   return EG_OK;
@@ -746,14 +746,14 @@ int eg_qv_tally_encode_device(eg_qv_params* p, void* d_out, void* stream) { EG_L
 }
 int eg_points_sum_device(eg_ctx* c, int n_ranks, int n_points, const void* d_in, void* d_out, void* stream) { EG_LOCK(c);
   if (!c || n_ranks < 1 || n_points < 1 || !d_in || !d_out) return fail(EG_ERR_BAD_ARG, "bad argument");
-  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_points_sum, dim3((n_points + 63) / 64), dim3(64), 0, s, (const u32*)d_in, n_ranks, n_points, (u32*)d_out,
                      (u32*)nullptr);
   HIPCHK(hipGetLastError());
   return EG_OK;
 }
-int eg_choice_tally_reset(eg_choice_params* p) { EG_LOCK_P(p); return p ? tally_reset(p->eng) : fail(EG_ERR_BAD_ARG, "null"); }
-int eg_choice_tally_reset_async(eg_choice_params* p, void* stream) { EG_LOCK_P(p); return p && stream ? tally_reset(p->eng, (hipStream_t)stream) : fail(EG_ERR_BAD_ARG, "null"); }
+int eg_choice_tally_reset(eg_choice_params* p) { EG_LOCK_P(p); return p ? tally_reset(p->eng, p->eng->ctx->stream, true) : fail(EG_ERR_BAD_ARG, "null"); }
+int eg_choice_tally_reset_async(eg_choice_params* p, void* stream) { EG_LOCK_P(p); return p ? tally_reset(p->eng, (hipStream_t)stream, false) : fail(EG_ERR_BAD_ARG, "null"); }
 int eg_choice_tally_encode(eg_choice_params* p, uint8_t* out) { EG_LOCK_P(p);
   if (!p || !out) return fail(EG_ERR_BAD_ARG, "bad argument");
   return engine_tally_encode(p->eng, out);
@@ -779,8 +779,8 @@ int eg_verify_qv_batch_device(eg_qv_params* p, size_t n, const void* d_ballots, 
   HIPCHK(hipSetDevice(p->eng->ctx->device));
   return engine_verify_device(p->eng, n, d_ballots, d_status, (hipStream_t)stream);
 }
-int eg_qv_tally_reset(eg_qv_params* p) { EG_LOCK_P(p); return p ? tally_reset(p->eng) : fail(EG_ERR_BAD_ARG, "null"); }
-int eg_qv_tally_reset_async(eg_qv_params* p, void* stream) { EG_LOCK_P(p); return p && stream ? tally_reset(p->eng, (hipStream_t)stream) : fail(EG_ERR_BAD_ARG, "null"); }
+int eg_qv_tally_reset(eg_qv_params* p) { EG_LOCK_P(p); return p ? tally_reset(p->eng, p->eng->ctx->stream, true) : fail(EG_ERR_BAD_ARG, "null"); }
+int eg_qv_tally_reset_async(eg_qv_params* p, void* stream) { EG_LOCK_P(p); return p ? tally_reset(p->eng, (hipStream_t)stream, false) : fail(EG_ERR_BAD_ARG, "null"); }
 int eg_qv_tally_encode(eg_qv_params* p, uint8_t* out) { EG_LOCK_P(p);
   if (!p || !out) return fail(EG_ERR_BAD_ARG, "bad argument");
   return engine_tally_encode(p->eng, out);
@@ -868,7 +868,7 @@ int eg_choice_encrypt_batch_device(eg_choice_params* p, uint64_t base_seed, size
   if (!p || (n && !d_out)) return fail(EG_ERR_BAD_ARG, "bad argument");
   Engine* e = p->eng;
   HIPCHK(hipSetDevice(e->ctx->device));
-  hipStream_t s = stream ? (hipStream_t)stream : e->ctx->stream;
+  hipStream_t s = (hipStream_t)stream;
   if (!p->single && (n_selected < 0 || n_selected > p->n_options)) return fail(EG_ERR_BAD_ARG, "n_selected out of range");
   if (n == 0) return EG_OK;
   if (p->n_options > 32) return fail(EG_ERR_BAD_ARG, "the generator supports at most 32 options");
@@ -893,7 +893,7 @@ int eg_qv_encrypt_batch_device(eg_qv_params* p, uint64_t base_seed, size_t first
   if (!p || (n && !d_out)) return fail(EG_ERR_BAD_ARG, "bad argument");
   Engine* e = p->eng;
   HIPCHK(hipSetDevice(e->ctx->device));
-  hipStream_t s = stream ? (hipStream_t)stream : e->ctx->stream;
+  hipStream_t s = (hipStream_t)stream;
   const eghost::QvShape& sh = p->shape;
   if (p->n_options > 16 || sh.vote_range.rings.size() > 4 || sh.credit_range.rings.size() > 4)
     return fail(EG_ERR_BAD_ARG, "the generator supports at most 16 options and 4 rings per range");

@@ -21,8 +21,10 @@
  *
  * Threads: entry points may be called from any thread; calls on one context (and on the params objects created on
  * it) are serialised by a lock inside the context, and eg_last_error is per thread.  Host-pointer functions return
- * when the results are in the caller's buffers.  `_device` / `_async` functions only enqueue work; they share the
- * context's workspaces, so a caller that uses several streams with one context must order them itself (events).
+ * when the results are in the caller's buffers (they run on a stream owned by the context; the tally reset / encode host
+ * forms first wait for the whole device, so they may follow `_device` calls directly).  `_device` / `_async` functions only
+ * enqueue work on the hipStream_t they are given - NULL is HIP's null stream, as everywhere - and share the context's
+ * workspaces, so a caller that uses several streams with one context must order them itself (events).
  */
 #ifndef EG_HIP_H
 #define EG_HIP_H
@@ -75,7 +77,7 @@ int eg_init(int device, eg_ctx** out);   /* no reference analogue: the backend i
 void eg_destroy(eg_ctx* ctx);
 const char* eg_last_error(void);         /* text of the last failure on this thread */
 int eg_device_name(eg_ctx* ctx, char* buf, size_t cap);
-int eg_synchronize(eg_ctx* ctx);
+int eg_synchronize(eg_ctx* ctx);         /* waits for all work on the context's device, whatever stream it was enqueued on */
 
 /* ---- primitive tier (host buffers; n problems per call) ------------------------------------------------------- */
 /* ScalarOps::scalar_from_random_bytes / Scalar::from_bytes_mod_order_wide (ristretto.rs:34-38) */
