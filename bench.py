@@ -203,8 +203,8 @@ def main():
     if world == 1:
         tally_ok = exchanged == params.tally_encode()
     else:
-        digest = int.from_bytes(__import__("hashlib").sha256(exchanged).digest()[:7], "big")
-        tally_ok = egd.max_over_ranks(float(digest), dev) == float(digest) and egd.sum_over_ranks(1, dev) == world
+        digest = float(int.from_bytes(__import__("hashlib").sha256(exchanged).digest()[:6], "big"))   # exact in a double
+        tally_ok = egd.max_over_ranks(digest, dev) == digest == -egd.max_over_ranks(-digest, dev)
     accepted_all = egd.sum_over_ranks(accepted, dev)
     value = B * world * args.steps / elapsed
     ms_per_step = elapsed / args.steps * 1e3
