@@ -129,7 +129,7 @@ struct BaseTable {
     for (int i = 0; i < 10; ++i) { c.YpX.v[i] = w[i]; c.YmX.v[i] = w[10 + i]; c.Z2.v[i] = w[20 + i]; c.T2d.v[i] = w[30 + i]; }
   }
 };
-// fixed-base comb table shared by every lane (10 MiB per base at 13-bit windows): entry = 8 uint4 (30 limbs used)
+// fixed-base comb table shared by every lane (34 MiB per base at 15-bit windows): entry = 8 uint4 (30 limbs used)
 struct FixedTable {
   const uint4* tab;
   __device__ __forceinline__ void load(ge_niels& c, int idx) const {

@@ -529,11 +529,12 @@ EG_HD void ge_teeth_mul(ge& acc, TableIO& io, u64 rows[EG_TEETH]) {
 }
 
 // ---- fixed-base scalar multiplication -----------------------------------------------------------------------------
-// Signed radix-2^B comb (B = EG_COMB_BITS, default 13: 20 windows x 4096 affine-Niels entries per base, 10 MiB, L2 /
-// Infinity-Cache resident; measured 8 -> 13 bits: +3 %, flat beyond), built once per base on the device (k_build_fixed_table).  Table index = window * 2^(B-1) + (|digit| - 1).
+// Signed radix-2^B comb (B = EG_COMB_BITS, default 15: 17 windows x 16384 affine-Niels entries per base, 34 MiB, Infinity-Cache
+// resident; measured 8 -> 13 bits: +3 %, 13 -> 15: +0.9 %, 16 the same as 15), built once per base on the device
+// (k_build_fixed_table).  Table index = window * 2^(B-1) + (|digit| - 1).
 // acc += [k]Base with one mixed addition (7M) per window and no doublings.
 #ifndef EG_COMB_BITS
-#define EG_COMB_BITS 13
+#define EG_COMB_BITS 15
 #endif
 #define EG_FIXED_WINDOWS ((254 + EG_COMB_BITS - 1) / EG_COMB_BITS)     // scalars (also halved ones) are < 2^254
 #define EG_FIXED_ENTRIES (1 << (EG_COMB_BITS - 1))
