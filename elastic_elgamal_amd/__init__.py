@@ -106,6 +106,8 @@ def _load() -> C.CDLL:
         "eg_verify_choice_batch": (C.c_int, [vp, sz, vp, vp, vp]),
         "eg_verify_choice_batch_device": (C.c_int, [vp, sz, vp, vp, vp]),
         "eg_choice_tally_reset": (C.c_int, [vp]),
+        "eg_choice_tally_add": (C.c_int, [vp, cp]),
+        "eg_qv_tally_add": (C.c_int, [vp, cp]),
         "eg_choice_tally_encode": (C.c_int, [vp, cp]),
         "eg_qv_params_create": (C.c_int, [vp, cp, C.c_int, C.c_uint64, C.POINTER(vp)]),
         "eg_qv_params_destroy": (None, [vp]),
@@ -336,6 +338,12 @@ class _BatchParams:
     def tally_encode_device(self, d_out: int, stream: int = 0):
         """Canonical encodings of the running tally (n_options x 64 bytes) into device memory, asynchronously."""
         _check(self._fn("tally_encode_device")(self._h, d_out, stream))
+
+    def tally_add(self, encoded: bytes):
+        """running tally += an encoded tally (checkpoint / resume, merging batches verified elsewhere)."""
+        if len(encoded) != 64 * self.n_options:
+            raise ValueError("encoded tally must be n_options x 64 bytes")
+        _check(self._fn("tally_add")(self._h, encoded))
 
     def tally_encode(self) -> bytes:
         out = C.create_string_buffer(64 * self.n_options)

@@ -403,6 +403,24 @@ static int engine_tally_encode(Engine* e, uint8_t* out) {
   return EG_OK;
 }
 
+// running tally += the points encoded in `in` (n_slots x 32 bytes): checkpoint / resume and merging of earlier batches
+static int engine_tally_add(Engine* e, const uint8_t* in) {
+  hipStream_t s = e->ctx->stream;
+  HIPCHK(hipDeviceSynchronize());
+  const int ns = (int)e->plan.tally_slots.size();
+  u32* d_in = nullptr;
+  HIPCHK(hipMalloc((void**)&d_in, (size_t)ns * 32 + 4));
+  u32* d_bad = d_in + (size_t)ns * 8;
+  HIPCHK(hipMemsetAsync(d_bad, 0, 4, s));
+  HIPCHK(hipMemcpyAsync(d_in, in, (size_t)ns * 32, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_tally_add_encoded, dim3(blocks_of((size_t)ns)), dim3(NT), 0, s, d_in, ns, e->tally, d_bad);
+  u32 bad = 0;
+  HIPCHK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  (void)hipFree(d_in);
+  return bad ? fail(EG_ERR_BAD_ARG, "tally contains an invalid ristretto255 encoding") : EG_OK;
+}
+
 static int engine_verify_host(Engine* e, size_t n, const uint8_t* ballots, uint32_t* status, uint8_t* tally_out) {
   hipStream_t s = e->ctx->stream;
   HIPCHK(hipSetDevice(e->ctx->device));
@@ -754,6 +772,14 @@ int eg_points_sum_device(eg_ctx* c, int n_ranks, int n_points, const void* d_in,
 }
 int eg_choice_tally_reset(eg_choice_params* p) { EG_LOCK_P(p); return p ? tally_reset(p->eng, p->eng->ctx->stream, true) : fail(EG_ERR_BAD_ARG, "null"); }
 int eg_choice_tally_reset_async(eg_choice_params* p, void* stream) { EG_LOCK_P(p); return p ? tally_reset(p->eng, (hipStream_t)stream, false) : fail(EG_ERR_BAD_ARG, "null"); }
+int eg_choice_tally_add(eg_choice_params* p, const uint8_t* in) { EG_LOCK_P(p);
+  if (!p || !in) return fail(EG_ERR_BAD_ARG, "bad argument");
+  return engine_tally_add(p->eng, in);
+}
+int eg_qv_tally_add(eg_qv_params* p, const uint8_t* in) { EG_LOCK_P(p);
+  if (!p || !in) return fail(EG_ERR_BAD_ARG, "bad argument");
+  return engine_tally_add(p->eng, in);
+}
 int eg_choice_tally_encode(eg_choice_params* p, uint8_t* out) { EG_LOCK_P(p);
   if (!p || !out) return fail(EG_ERR_BAD_ARG, "bad argument");
   return engine_tally_encode(p->eng, out);

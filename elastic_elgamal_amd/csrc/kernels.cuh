@@ -402,6 +402,23 @@ __global__ void k_tally_encode(const u32* tally, int n_slots, u32* out /* [n_slo
   for (int i = 0; i < 8; ++i) out[(size_t)k * 8 + i] = o[i];
 }
 
+// tally[k] += decode(in[k]): resumes a running tally from its canonical encodings (checkpoint / merge of an earlier batch);
+// bad counts the encodings that fail to decode (the tally is then left untouched for that slot)
+__global__ void k_tally_add_encoded(const u32* in, int n_slots, u32* tally, u32* bad) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_slots) return;
+  u32 w[8];
+  for (int i = 0; i < 8; ++i) w[i] = in[(size_t)k * 8 + i];
+  ge p;
+  if (!ristretto_decode(p, w)) { atomicAdd(bad, 1u); return; }
+  u32 t[40];
+  for (int i = 0; i < 40; ++i) t[i] = tally[(size_t)k * 40 + i];
+  ge cur, sum; words_to_ge(cur, t);
+  ge_add_full(sum, cur, p);
+  ge_to_words(t, sum);
+  for (int i = 0; i < 40; ++i) tally[(size_t)k * 40 + i] = t[i];
+}
+
 // out[k] = encode( sum_r decode(in[r][k]) ): merges the per-GPU tallies after the all-gather.  Encodings are
 // canonical, so the result does not depend on the order of ranks or on how ballots were sharded.
 __global__ void k_points_sum(const u32* in, int n_ranks, int n_points, u32* out, u32* bad) {

@@ -123,6 +123,10 @@ int eg_verify_choice_batch(eg_choice_params*, size_t n, const uint8_t* ballots, 
 int eg_verify_choice_batch_device(eg_choice_params*, size_t n, const void* d_ballots, void* d_status, void* stream);
 int eg_choice_tally_reset(eg_choice_params*);
 int eg_choice_tally_encode(eg_choice_params*, uint8_t* out /* n_options*64 */);
+/* running tally += the ciphertexts encoded in `in` (n_options*64 bytes, as eg_choice_tally_encode writes them): resume
+ * from a checkpoint, or merge the tally of batches verified elsewhere.  EG_ERR_BAD_ARG (and slots with invalid encodings
+ * untouched) if an encoding does not decode. */
+int eg_choice_tally_add(eg_choice_params*, const uint8_t* in /* n_options*64 */);
 /* asynchronous forms for the multi-GPU path: reset on a stream; write the canonical encodings (n_options*64 bytes)
  * to device memory, ready for an RCCL all-gather; then sum the gathered encodings with eg_points_sum_device. */
 int eg_choice_tally_reset_async(eg_choice_params*, void* stream);
@@ -143,6 +147,7 @@ int eg_verify_qv_batch(eg_qv_params*, size_t n, const uint8_t* ballots, uint32_t
 int eg_verify_qv_batch_device(eg_qv_params*, size_t n, const void* d_ballots, void* d_status, void* stream);
 int eg_qv_tally_reset(eg_qv_params*);
 int eg_qv_tally_encode(eg_qv_params*, uint8_t* out);
+int eg_qv_tally_add(eg_qv_params*, const uint8_t* in);
 int eg_qv_tally_reset_async(eg_qv_params*, void* stream);
 int eg_qv_tally_encode_device(eg_qv_params*, void* d_out, void* stream);
 

@@ -790,3 +790,28 @@ def test_qv_reordered_votes(eg, ctx, oracle, pk):
     assert got == want and tally == oq.tally(bytes(ballots), want)
     kinds = {w & 0xFF for w in want[0:40:2]}
     assert kinds == {12}                                        # CREDIT_EQUIV_CHALLENGE
+
+
+def test_tally_checkpoint_and_resume(eg, ctx, oracle, pk):
+    """SURVEY 5 (checkpoint / resume): a running tally exported with tally_encode and re-imported with tally_add into a
+    fresh params object continues exactly; invalid encodings are refused."""
+    op = oracle.ChoiceParams(pk, 5, True)
+    ballots = bytearray(op.generate_batch(77, 0, 200, threads=8))
+    sz = len(ballots) // 200
+    ballots[3 * sz + sz - 32] ^= 1
+    want = op.verify_batch(bytes(ballots), threads=8)
+    whole = op.tally(bytes(ballots), want)
+    a = eg.ChoiceParams.single_choice(ctx, pk, 5)
+    st_a, checkpoint = a.verify_batch(bytes(ballots[: 120 * sz]))
+    b = eg.ChoiceParams.single_choice(ctx, pk, 5)           # "another process": resumes from the checkpoint bytes
+    b.tally_reset()
+    b.tally_add(checkpoint)
+    import torch
+    d = torch.frombuffer(bytearray(ballots[120 * sz :]), dtype=torch.uint8).cuda()
+    st = torch.empty(80, dtype=torch.int32, device="cuda")
+    b.verify_batch_device(80, d.data_ptr(), st.data_ptr())
+    assert st_a + st.cpu().tolist() == want
+    assert b.tally_encode() == whole
+    with pytest.raises(Exception):
+        b.tally_add(b"\xff" * (64 * 5))
+    assert b.tally_encode() == whole                         # untouched by the refused import
