@@ -62,6 +62,15 @@ EG_HD void ge_to_cached(ge_cached& c, const ge& p) {
   fe_add(c.Z2, p.Z, p.Z); fe_carry(c.Z2);
   fe_mul(c.T2d, p.T, d2);
 }
+// the same without the three carries: (Y+X [2], Y-X [3], 2Z [2], 2dT [1]).  ge_add takes these classes as they are (the
+// second operand of fe_mul may be class <= 3.3), so per-ballot table entries are stored uncarried (measured +1.3 %).
+EG_HD void ge_to_cached_lazy(ge_cached& c, const ge& p) {
+  const fe d2 = EG_FE_2D;
+  fe_add(c.YpX, p.Y, p.X);
+  fe_sub(c.YmX, p.Y, p.X);
+  fe_add(c.Z2, p.Z, p.Z);
+  fe_mul(c.T2d, p.T, d2);
+}
 EG_HD void ge_cached_identity(ge_cached& c) { fe_1(c.YpX); fe_1(c.YmX); fe_0(c.Z2); c.Z2.v[0] = 2; fe_0(c.T2d); }
 EG_HD void ge_niels_identity(ge_niels& c) { fe_1(c.ypx); fe_1(c.ymx); fe_0(c.xy2d); }
 
@@ -341,7 +350,7 @@ template <class TableIO>
 EG_HD void ge_var_table_build(TableIO& io, const ge& p) {
   // entries k = 1..8 by repeated addition of P (one rolled add body; no indexed point arrays, which
   // hipcc would place in scratch)
-  ge_cached pc; ge_to_cached(pc, p);
+  ge_cached pc; ge_to_cached_lazy(pc, p);
   io.store(0, pc);
   ge cur = p;
 #pragma unroll 1
@@ -349,7 +358,7 @@ EG_HD void ge_var_table_build(TableIO& io, const ge& p) {
     ge_p1p1 t;
     ge_add(t, cur, pc);
     ge_add_to_p3(cur, t);
-    ge_cached c; ge_to_cached(c, cur);
+    ge_cached c; ge_to_cached_lazy(c, cur);
     io.store(k - 1, c);
   }
 }
@@ -459,7 +468,7 @@ EG_HD void ge_teeth_tables_build(TableIO& io, TmpIO& tmp, const ge& p) {
   for (int j = 0; j < EG_TEETH - 1; ++j) {
     ge_p1p1 t;
     {
-      ge_cached pc; ge_to_cached(pc, cur);
+      ge_cached pc; ge_to_cached_lazy(pc, cur);
       ge_cached_cneg(pc, true);
       ge_add(t, sum, pc);                 // sum -= P_j
       ge_add_to_p3(sum, t);
@@ -468,7 +477,7 @@ EG_HD void ge_teeth_tables_build(TableIO& io, TmpIO& tmp, const ge& p) {
     ge_dbl(t, cur.X, cur.Y, cur.Z);
     ge_dbl_to_p3(q3, t);                  // 2 P_j, the step of the Gray-code walk for tooth j
     {
-      ge_cached qc; ge_to_cached(qc, q3);
+      ge_cached qc; ge_to_cached_lazy(qc, q3);
       tmp.store(j, qc);
     }
     ge_p2 q;
@@ -479,10 +488,10 @@ EG_HD void ge_teeth_tables_build(TableIO& io, TmpIO& tmp, const ge& p) {
     ge_dbl_to_p3(cur, t);                 // P_(j+1)
   }
   {
-    ge_cached pc; ge_to_cached(pc, cur);
+    ge_cached pc; ge_to_cached_lazy(pc, cur);
     ge_p1p1 t; ge_add(t, sum, pc);        // sum = P_5 - P_4 - .. - P_0 = entry 0
     ge_add_to_p3(sum, t);
-    ge_cached e; ge_to_cached(e, sum);
+    ge_cached e; ge_to_cached_lazy(e, sum);
     io.store(0, e);
   }
 #pragma unroll 1
@@ -494,7 +503,7 @@ EG_HD void ge_teeth_tables_build(TableIO& io, TmpIO& tmp, const ge& p) {
     ge_cached_cneg(qc, ((g >> j) & 1) == 0);
     ge_p1p1 t; ge_add(t, sum, qc);
     ge_add_to_p3(sum, t);
-    ge_cached e; ge_to_cached(e, sum);
+    ge_cached e; ge_to_cached_lazy(e, sum);
     io.store(g, e);
   }
 }
