@@ -508,25 +508,23 @@ EG_HD void ge_teeth_tables_build(TableIO& io, TmpIO& tmp, const ge& p) {
   }
 }
 
-// acc = [k]P from the teeth table; rows = sc_recode_teeth(k) (consumed).  Loads are issued one column ahead of their use.
+// acc = [k]P from the teeth table; rows = sc_recode_teeth(k) (consumed).  A column's entry is requested before the doubling and
+// used after it, which hides the load without a second entry buffer (an explicit one-column-ahead prefetch measured -0.4 %).
 template <class TableIO>
 EG_HD void ge_teeth_mul(ge& acc, TableIO& io, u64 rows[EG_TEETH]) {
   ge_identity(acc);
-  int idx; bool neg;
-  sc_teeth_next(rows, idx, neg);
-  ge_cached nxt;
-  io.load(nxt, idx);
 #pragma unroll 1
   for (int c = EG_TEETH_COLS - 1; c >= 0; --c) {
-    ge_cached cur = nxt;
-    const bool cneg = neg;
-    if (c > 0) { sc_teeth_next(rows, idx, neg); io.load(nxt, idx); }
+    int idx; bool neg;
+    sc_teeth_next(rows, idx, neg);
+    ge_cached cur;
+    io.load(cur, idx);
     ge_p1p1 t;
     if (c != EG_TEETH_COLS - 1) {
       ge_dbl(t, acc.X, acc.Y, acc.Z);
       ge_dbl_to_p3(acc, t);
     }
-    ge_cached_cneg(cur, cneg);
+    ge_cached_cneg(cur, neg);
     ge_add(t, acc, cur);
     if (c > 0) {                          // next operation is a doubling: T is not needed (saves one multiplication)
       ge_p2 q; ge_add_to_p2(q, t);
