@@ -34,7 +34,7 @@ OPS = {"decode": (27, 257), "direct_table": (64, 0), "direct_mul": (1269, 1008),
        "base_table": (994, 860), "base_mul": (470, 168), "enc_batch_each": (23, 10), "enc_batch_inversion": (11, 254)}
 # memory-side traffic of k_msm_jobs per ballot and launch, from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
 # of profiles/r01_bench_pmc_counters.txt (single-choice 5-option ballots, 262144 per launch)
-MSM_TRAFFIC_BYTES_PER_BALLOT_LAUNCH = {"single": 40.15e9 / 262144}
+MSM_TRAFFIC_BYTES_PER_BALLOT_LAUNCH = {"single": 38.92e9 / 262144}
 MAD_PEAK_T = 33.4              # profiles/r01_ubench_valu_rates.txt: v_mad_u64_u32, 8 waves/SIMD, T lane-ops/s chip-wide
 FMUL_PEAK_G = 256.0            # profiles/r01_ubench_fmul_candidates.txt: radix-25.5 field multiply, G/s chip-wide
 
