@@ -815,3 +815,26 @@ def test_tally_checkpoint_and_resume(eg, ctx, oracle, pk):
     with pytest.raises(Exception):
         b.tally_add(b"\xff" * (64 * 5))
     assert b.tally_encode() == whole                         # untouched by the refused import
+
+
+def test_host_buffer_path_matches_device_path(eg, ctx, pk):
+    """eg_verify_choice_batch (host buffers, pipelined uploads: a small first piece, then chunk-sized ones) must give the
+    verdicts and the tally of the device-pointer path on the same 300 000 ballots, 1 % of them tampered."""
+    import torch
+
+    n = 300_000
+    p = eg.ChoiceParams.single_choice(ctx, pk, 5)
+    sz = p.ballot_size
+    d = torch.empty(n * sz, dtype=torch.uint8, device="cuda")
+    p.encrypt_batch_device(8086, 0, n, d.data_ptr())
+    ctx.synchronize()
+    bad = torch.randperm(n, generator=torch.Generator().manual_seed(5))[: n // 100].cuda()
+    d.view(n, sz)[bad, sz - 32] ^= 1
+    st = torch.empty(n, dtype=torch.int32, device="cuda")
+    p.tally_reset()
+    p.verify_batch_device(n, d.data_ptr(), st.data_ptr())
+    want_tally = p.tally_encode()
+    want = st.cpu().tolist()
+    got, tally = p.verify_batch(d.cpu().numpy().tobytes())
+    assert got == want and tally == want_tally
+    assert sum(1 for s in got if s) == n // 100
