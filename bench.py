@@ -23,6 +23,10 @@ import sys
 import time
 from pathlib import Path
 
+# before anything can initialise the HIP/HSA runtime (importing torch does not, torch.cuda.* does): the host driver of this
+# pool only supports dmabuf IPC, which RCCL needs for its intra-node transport
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
@@ -32,30 +36,31 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # (tests/hostcheck: hc_op_counts) as (fe_mul, fe_sq); one fe_mul = 100 and one fe_sq = 55 v_mad_u64_u32.
 OPS = {"decode": (27, 257), "direct_table": (64, 0), "direct_mul": (1269, 1008), "comb": (119, 0), "encode": (32, 255),
        "base_table": (994, 860), "base_mul": (470, 168), "enc_batch_each": (23, 10), "enc_batch_inversion": (11, 254)}
-# memory-side traffic of k_msm_jobs per ballot and launch, from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
-# of profiles/r01_bench_pmc_counters.txt (single-choice 5-option ballots, 262144 per launch)
-MSM_TRAFFIC_BYTES_PER_BALLOT_LAUNCH = {"single": 38.92e9 / 262144}
+# memory-side traffic per ballot and launch of the profiled kernels comes from profiles/traffic.json, which
+# tools/profile_summary.py writes from the separate rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of tools/profile_round.sh
+TRAFFIC_JSON = ROOT / "profiles" / "traffic.json"
 MAD_PEAK_T = 33.4              # profiles/r01_ubench_valu_rates.txt: v_mad_u64_u32, 8 waves/SIMD, T lane-ops/s chip-wide
 FMUL_PEAK_G = 256.0            # profiles/r01_ubench_fmul_candidates.txt: radix-25.5 field multiply, G/s chip-wide
 
 
-def choice_field_ops(n: int, single: bool):
-    """(fe_mul, fe_sq) per EncryptedChoice ballot of the shipped pipeline."""
+def plan_field_ops(desc: dict):
+    """(fe_mul, fe_sq) per ballot of the shipped pipeline, from the flattened verification plan (eg_plan_describe) and the
+    per-building-block counts above.  Not counted: the few point additions of the derived points, scalar arithmetic, hashing."""
     def add(*xs):
         return (sum(x[0] for x in xs), sum(x[1] for x in xs))
 
     def mul(x, k):
         return (x[0] * k, x[1] * k)
 
-    ring = add(OPS["base_mul"], OPS["comb"], OPS["enc_batch_each"])
-    fold = add(ring, OPS["comb"])
-    total = add(mul(OPS["base_table"], 2 * n), mul(ring, 3 * n), mul(fold, n), mul(OPS["decode"], 2 * n))
-    groups = 2 * (-(-(2 * n + (2 if single else 0)) // 32))           # batched inversions: per stage and group of 32
-    total = add(total, mul(OPS["enc_batch_inversion"], groups))
-    if single:
-        logeq = add(OPS["direct_table"], OPS["direct_mul"], OPS["comb"], OPS["enc_batch_each"])
-        total = add(total, mul(logeq, 2), mul(OPS["encode"], 2))
-    return total
+    direct_terms = desc["var_terms"] - desc["table_terms"]
+    return add(mul(OPS["decode"], desc["wire_points"]),
+               mul(OPS["base_table"], desc["bases"]),
+               mul(OPS["base_mul"], desc["table_terms"]),
+               mul(add(OPS["direct_table"], OPS["direct_mul"]), direct_terms),
+               mul(OPS["comb"], desc["combs"]),
+               mul(OPS["enc_batch_each"], desc["deferred"]),
+               mul(OPS["enc_batch_inversion"], desc["inversion_groups"]),
+               mul(OPS["encode"], desc["plain_encodes"]))
 # algorithmic bytes per ballot (SURVEY 8d) = packed ballot + 4-byte status word: 740 (single 5), 2084 (multi 16), 2148 (qv 5/20)
 
 
@@ -64,7 +69,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--ballots", type=int, default=1_000_000, help="ballots per GPU per step")
+    ap.add_argument("--ballots", type=int, default=1_000_000, help="ballots per GPU per step (weak scaling: the default mode)")
+    ap.add_argument("--total-ballots", type=int, default=0,
+                    help="fixed-total mode (BASELINE.json configs[4]: 10M ballots sharded across the GPUs of a node): the batch of "
+                         "this many ballots is split into contiguous shards, one per rank; the line says \"scaling\": \"strong\"")
     ap.add_argument("--options", type=int, default=None)
     ap.add_argument("--workload", choices=["single", "multi", "qv"], default="single",
                     help="single = BASELINE configs[1] (the bench line); multi = 3-of-16 (configs[3]); qv = 5 options / 20 credits (configs[2])")
@@ -75,6 +83,8 @@ def parse():
                     help="flip one response bit in this share of the ballots before timing (SURVEY 8d: verdict parity and tally "
                          "exclusion with invalid ballots in the batch); the headline line uses 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-inclusive", action="store_true",
+                    help="skip the PCIe-inclusive leg (host buffers through eg_verify_*_batch) that follows the timed loop at N = 1")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even for one rank: exercises the N > 1 code path on a 1-GPU box")
     return ap.parse_args()
@@ -114,8 +124,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: N > 1 must be launched with torch.distributed.run, "
+                         "one rank per GPU, with --gpus equal to the number of ranks")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # one explicit stream for everything: the library's launches, torch's copies and RCCL's collective are ordered on it
@@ -124,7 +134,6 @@ def main():
     if args.force_dist:
         os.environ["EG_DIST_ALWAYS"] = "1"     # the helpers then run their collectives even with one rank
     if use_dist:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
@@ -138,11 +147,13 @@ def main():
         params = eg.ChoiceParams.multi_choice(ctx, pk, n_opt)
     else:
         params = eg.QuadraticVotingParams(ctx, pk, n_opt, args.credits)
-    B = args.ballots
+    strong = args.total_ballots > 0
+    total = args.total_ballots if strong else args.ballots * world
+    first, last = egd.shard_range(total, rank, world)     # rank r owns the contiguous slab of voters [first, last)
+    B = last - first
     stream = torch.cuda.current_stream().cuda_stream
 
     # ---- synthetic input, generated on the GPU and left resident in HBM ------------------------------------
-    first, _ = egd.shard_range(B * world, rank, world)   # rank r owns voters [r*B, (r+1)*B)
     ballots = torch.empty(B * params.ballot_size, dtype=torch.uint8, device=dev)
     t0 = time.time()
     if args.workload == "multi":
@@ -159,13 +170,15 @@ def main():
     status = torch.empty(B, dtype=torch.int32, device=dev)
     local_tally = torch.empty(64 * n_opt, dtype=torch.uint8, device=dev)
     final_tally = torch.empty(64 * n_opt, dtype=torch.uint8, device=dev)
+    bad_terms = torch.zeros(1, dtype=torch.int32, device=dev)   # gathered encodings that failed to decode (must stay 0)
 
     def step():
         params.tally_reset(stream)
         params.verify_batch_device(B, ballots.data_ptr(), status.data_ptr(), stream)
         params.tally_encode_device(local_tally.data_ptr(), stream)
         gathered = egd.gather_tallies(local_tally)            # the ONE collective (RCCL all-gather, 64*n bytes/rank)
-        ctx.points_sum_device(gathered.shape[0], 2 * n_opt, gathered.data_ptr(), final_tally.data_ptr(), stream)
+        ctx.points_sum_device(gathered.shape[0], 2 * n_opt, gathered.data_ptr(), final_tally.data_ptr(), stream,
+                              d_bad=bad_terms.data_ptr())
 
     def barrier():
         torch.cuda.synchronize()
@@ -205,8 +218,9 @@ def main():
     else:
         digest = float(int.from_bytes(__import__("hashlib").sha256(exchanged).digest()[:6], "big"))   # exact in a double
         tally_ok = egd.max_over_ranks(digest, dev) == digest == -egd.max_over_ranks(-digest, dev)
+    tally_ok = tally_ok and int(bad_terms.item()) == 0
     accepted_all = egd.sum_over_ranks(accepted, dev)
-    value = B * world * args.steps / elapsed
+    value = total * args.steps / elapsed
     ms_per_step = elapsed / args.steps * 1e3
 
     if rank != 0:
@@ -216,7 +230,8 @@ def main():
 
     # ---- roofline of the dominant kernel (k_msm_jobs), HIP events on the launch stream ------------------------
     kind = {"single": "single", "multi": "multi", "qv": "qv"}[args.workload]
-    n_stages = eg.plan_describe(kind, n_opt, args.credits if args.workload == "qv" else 0)["stages"]   # one k_msm_jobs launch per stage and chunk
+    desc = eg.plan_describe(kind, n_opt, args.credits if args.workload == "qv" else 0)
+    n_stages = desc["stages"]   # one k_msm_jobs launch per stage and chunk
     launches_per_step = max(1, msm_launches // max(args.steps, 1))
     avg_launch_ms = msm_ms / max(msm_launches, 1)
     n_chunks = max(1, launches_per_step // n_stages)
@@ -224,6 +239,17 @@ def main():
     chunk = units_per_launch
     alg_bytes = params.ballot_size + 4
     achieved_gbs = alg_bytes * units_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+    # memory-side bytes per ballot and launch of the dominant kernel, measured by the PMC passes of the last profile round
+    traffic_src = None
+    try:
+        tj = json.loads(TRAFFIC_JSON.read_text())
+        key = f"{args.workload}-{n_opt}" + (f"-{args.credits}" if args.workload == "qv" else "")
+        ent = tj["workloads"][key]["kernels"]["eg::k_msm_jobs"]
+        traffic_bpbl = float(ent["bytes_per_ballot_launch"])
+        traffic_src = {"file": "profiles/traffic.json", "round": tj.get("round"), "commit": tj.get("commit"),
+                       "ballots_per_launch": tj["workloads"][key].get("ballots_per_launch")}
+    except (OSError, KeyError, ValueError):
+        traffic_bpbl = None
     out = {
         "metric": "EncryptedChoice ballot verifications/sec" if args.workload != "qv" else "QuadraticVotingBallot verifications/sec",
         "value": value,
@@ -233,7 +259,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": "u32",
         "data": "synthetic",
@@ -245,6 +271,7 @@ def main():
                 "qv": f"{B} QuadraticVotingBallot ballots, {n_opt} options / {args.credits} credits (BASELINE.json configs[2])",
             }[args.workload],
             "ballots_per_gpu": B,
+            "total_ballots": total,
             "options": n_opt,
             "ballot_bytes": params.ballot_size,
             "chunk_ballots": chunk,
@@ -262,13 +289,14 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved_gbs / HBM_PEAK_GBS,
-            "traffic": (MSM_TRAFFIC_BYTES_PER_BALLOT_LAUNCH[args.workload] * units_per_launch / (avg_launch_ms * 1e-3) / 1e9
-                        if args.workload in MSM_TRAFFIC_BYTES_PER_BALLOT_LAUNCH and n_opt == 5 and avg_launch_ms > 0 else None),
-            "traffic_bytes_per_launch": (MSM_TRAFFIC_BYTES_PER_BALLOT_LAUNCH[args.workload] * units_per_launch
-                                         if args.workload in MSM_TRAFFIC_BYTES_PER_BALLOT_LAUNCH and n_opt == 5 else None),
-            "traffic_note": "GB/s like `achieved`: memory-side bytes per launch from separate rocprofv3 PMC passes (FETCH_SIZE x2 "
-                            "gfx950 correction + WRITE_SIZE, profiles/r01_bench_pmc_counters.txt) / this run's launch time; "
-                            "it is the per-ballot table lookups, not the ballots",
+            "traffic": (traffic_bpbl * units_per_launch / (avg_launch_ms * 1e-3) / 1e9
+                        if traffic_bpbl is not None and avg_launch_ms > 0 else None),
+            "traffic_bytes_per_launch": traffic_bpbl * units_per_launch if traffic_bpbl is not None else None,
+            "traffic_source": traffic_src,
+            "traffic_note": "GB/s like `achieved`: memory-side bytes per ballot and launch of this kernel from the separate rocprofv3 "
+                            "PMC passes of the last profile round (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; "
+                            "tools/profile_round.sh -> profiles/traffic.json) x this run's ballots per launch / this run's "
+                            "launch time; it is the per-ballot table lookups, not the ballots",
             "avg_launch_ms": avg_launch_ms,
             "launches_per_step": launches_per_step,
             "units_per_launch": units_per_launch,
@@ -282,8 +310,8 @@ def main():
         },
     }
 
-    if args.workload != "qv":
-        fm, fs = choice_field_ops(n_opt, args.workload == "single")
+    if True:
+        fm, fs = plan_field_ops(desc)
         mads = fm * 100 + fs * 55
         out["valu_roofline"] = {
             "bound": "valu-int-mad",
@@ -297,6 +325,24 @@ def main():
             "fmul_equiv_frac": value / world * (fm + 0.6 * fs) / 1e9 / FMUL_PEAK_G,
             "note": "algorithmic multiply-adds only (no carries, adds, selects, hashing); peaks measured on this chip",
         }
+
+    # ---- PCIe-inclusive rate (first H2D byte to last status byte D2H): the same batch from a pinned host buffer
+    # through the host-pointer entry point (pipelined uploads, eg_verify_*_batch).  Reported beside `value`, never as it.
+    if not args.no_host_inclusive and world == 1:
+        host = torch.empty(ballots.shape, dtype=torch.uint8, pin_memory=True)
+        host.copy_(ballots)
+        host_status = torch.empty(B, dtype=torch.int32, pin_memory=True)
+        torch.cuda.synchronize()
+        iters, times = 3, []
+        for it in range(iters + 1):                      # the first call sizes the staging buffers
+            t0 = time.perf_counter()
+            params.verify_batch_host_ptr(B, host.data_ptr(), host_status.data_ptr())
+            times.append(time.perf_counter() - t0)
+        hs = sum(times[1:]) / iters
+        out["host_inclusive"] = {"value": B / hs, "unit": "ballots/s", "ms": hs * 1e3, "iterations": iters, "pinned": True,
+                                 "bytes_h2d": B * params.ballot_size, "bytes_d2h": 4 * B,
+                                 "verdicts_match_device_path": bool(torch.equal(host_status, status.cpu())),
+                                 "vs_value": B / hs / value}
 
     # ---- CPU baseline: the oracle ("port": CPU restatement, not curve25519-dalek) on a bounded sample --------------
     if not args.no_cpu_baseline and world == 1:

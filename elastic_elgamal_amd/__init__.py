@@ -30,11 +30,12 @@ _LIB = Path(os.environ.get("EG_LIB", str(_PKG / "libeg_hip.so")))   # EG_LIB: al
 OK, BAD_SCALAR, BAD_POINT, OPTIONS_LEN, SUM_CHALLENGE, RANGE_LEN, RANGE_CHALLENGE = range(7)
 QV_VARIANT_LEN, QV_VARIANT_CHALLENGE, QV_CREDIT_RANGE_LEN, QV_CREDIT_RANGE_CHALLENGE = 7, 8, 9, 10
 QV_CREDIT_EQUIV_LEN, QV_CREDIT_EQUIV_CHALLENGE = 11, 12
+MALFORMED = 13
 STATUS_NAMES = {
     0: "Ok", 1: "BadScalar", 2: "BadPoint", 3: "OptionsLenMismatch", 4: "Sum(ChallengeMismatch)",
     5: "Range(LenMismatch)", 6: "Range(ChallengeMismatch)", 7: "Variant(LenMismatch)", 8: "Variant(ChallengeMismatch)",
     9: "CreditRange(LenMismatch)", 10: "CreditRange(ChallengeMismatch)", 11: "CreditEquivalence(LenMismatch)",
-    12: "CreditEquivalence(ChallengeMismatch)",
+    12: "CreditEquivalence(ChallengeMismatch)", 13: "Malformed",
 }
 
 
@@ -120,7 +121,7 @@ def _load() -> C.CDLL:
         "eg_choice_tally_encode_device": (C.c_int, [vp, vp, vp]),
         "eg_qv_tally_reset_async": (C.c_int, [vp, vp]),
         "eg_qv_tally_encode_device": (C.c_int, [vp, vp, vp]),
-        "eg_points_sum_device": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp]),
+        "eg_points_sum_device": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, vp]),
         "eg_proof_params_create": (C.c_int, [vp, cp, C.c_int, C.c_uint64, C.POINTER(vp)]),
         "eg_share_params_create": (C.c_int, [vp, cp, C.c_uint64, C.c_uint64, C.c_uint64, cp, C.POINTER(vp)]),
         "eg_proof_params_destroy": (None, [vp]),
@@ -203,9 +204,10 @@ class Context:
     def synchronize(self):
         _check(_load().eg_synchronize(self._h))
 
-    def points_sum_device(self, n_ranks: int, n_points: int, d_in: int, d_out: int, stream: int = 0):
-        """d_out[k] = sum over ranks of d_in[r][k] (32-byte encodings): merge of all-gathered per-GPU tallies."""
-        _check(_load().eg_points_sum_device(self._h, n_ranks, n_points, d_in, d_out, stream))
+    def points_sum_device(self, n_ranks: int, n_points: int, d_in: int, d_out: int, stream: int = 0, d_bad: int = 0):
+        """d_out[k] = sum over ranks of d_in[r][k] (32-byte encodings): merge of all-gathered per-GPU tallies.
+        d_bad: device uint32 counter (zeroed by the caller) of slots that received an undecodable encoding."""
+        _check(_load().eg_points_sum_device(self._h, n_ranks, n_points, d_in, d_out, d_bad or None, stream))
 
     def profile_enable(self, on: bool = True):
         _check(_load().eg_profile_enable(self._h, int(on)))
@@ -313,7 +315,9 @@ class _BatchParams:
 
     def verify_batch(self, ballots: bytes, with_tally: bool = True):
         """verify() for every packed ballot; returns (status words, tally bytes or None).
-        The tally is the component-wise sum of the ciphertexts of accepted ballots, n_options x (R || B)."""
+        The returned tally is that of THIS batch: the component-wise sum of the ciphertexts of its accepted ballots,
+        n_options x (R || B).  The running tally inside the params object accumulates them as well, exactly as
+        verify_batch_device does (tally_reset / tally_add / tally_encode operate on the running tally)."""
         n = len(ballots) // self.ballot_size
         if n * self.ballot_size != len(ballots):
             raise ValueError("ballots is not a whole number of packed ballots")
@@ -323,6 +327,11 @@ class _BatchParams:
         fn = getattr(_load(), f"eg_verify_{self._prefix}_batch")
         _check(fn(self._h, n, buf, st, tally))
         return list(st[:n]), (tally.raw if with_tally else None)
+
+    def verify_batch_host_ptr(self, n: int, ballots_ptr: int, status_ptr: int, tally_ptr: int = 0):
+        """The host-buffer entry point on raw host addresses (e.g. pinned torch tensors): no Python-side copies."""
+        fn = getattr(_load(), f"eg_verify_{self._prefix}_batch")
+        _check(fn(self._h, n, ballots_ptr, status_ptr, tally_ptr or None))
 
     def verify_batch_device(self, n: int, d_ballots: int, d_status: int, stream: int = 0):
         """Asynchronous device-pointer variant (torch tensors' data_ptr()); tally accumulates on the device."""

@@ -125,6 +125,7 @@ struct Engine {
   u32* partial = nullptr;
   int tally_blocks = 64;
   u32* tally = nullptr;        // [2n][40] running tally (extended points)
+  u32* tally_saved = nullptr;  // [2n][40] the running tally set aside while a host call computes its per-batch tally
   // staging for the host-pointer API
   hipStream_t copy_stream = nullptr;
   unsigned char* d_wire = nullptr;
@@ -136,7 +137,7 @@ static void engine_free(Engine* e) {
   if (!e) return;
   void* ptrs[] = {e->d_pt_items, e->d_sc_items, e->d_dclasses, e->d_dterms, e->d_jobs, e->d_vterms, e->d_insts, e->d_ops,
                   e->d_rules, e->d_tally_slots, e->d_base_slots, e->d_defer_slots, e->btab, e->dpt, e->encw, e->d_blob, e->d_tabK, e->d_cpts, e->d_prefixes, e->d_key_words, e->pts, e->cmp,
-                  e->chal, e->states, e->flags, e->bad_item, e->partial, e->tally, e->d_wire, e->d_status};
+                  e->chal, e->states, e->flags, e->bad_item, e->partial, e->tally, e->tally_saved, e->d_wire, e->d_status};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
   delete e;
@@ -310,6 +311,7 @@ static int engine_create(eg_ctx* ctx, eghost::Plan&& plan, const uint8_t pk[32],
   e->max_cap = (e->max_cap + NT - 1) / NT * NT;
   HIPCHK(hipMalloc((void**)&e->partial, std::max<size_t>(P.tally_slots.size(), 1) * e->tally_blocks * 40 * sizeof(u32)));
   HIPCHK(hipMalloc((void**)&e->tally, std::max<size_t>(P.tally_slots.size(), 1) * 40 * sizeof(u32)));
+  HIPCHK(hipMalloc((void**)&e->tally_saved, std::max<size_t>(P.tally_slots.size(), 1) * 40 * sizeof(u32)));
   HIPCHK(hipMalloc((void**)&e->d_prefixes, (size_t)std::max(P.n_prefixes, 1) * 52 * sizeof(u32)));
   hipLaunchKernelGGL(k_tally_init, dim3(blocks_of(P.tally_slots.size())), dim3(NT), 0, s, e->tally, (int)P.tally_slots.size());
 
@@ -424,6 +426,10 @@ static int engine_tally_add(Engine* e, const uint8_t* in) {
 static int engine_verify_host(Engine* e, size_t n, const uint8_t* ballots, uint32_t* status, uint8_t* tally_out) {
   hipStream_t s = e->ctx->stream;
   HIPCHK(hipSetDevice(e->ctx->device));
+  // The host form runs on the context's own stream but shares the engine's workspaces and running tally with whatever
+  // `_device` calls enqueued on caller streams: wait for them, like the other host forms do.
+  HIPCHK(hipDeviceSynchronize());
+  const int ns = (int)e->plan.tally_slots.size();
   if (n > e->staging_ballots) {
     if (e->d_wire) (void)hipFree(e->d_wire);
     if (e->d_status) (void)hipFree(e->d_status);
@@ -432,7 +438,15 @@ static int engine_verify_host(Engine* e, size_t n, const uint8_t* ballots, uint3
     HIPCHK(hipMalloc((void**)&e->d_status, std::max<size_t>(n, 1) * sizeof(u32)));
     e->staging_ballots = n;
   }
-  if (tally_out) hipLaunchKernelGGL(k_tally_init, dim3(blocks_of(e->plan.tally_slots.size())), dim3(NT), 0, s, e->tally, (int)e->plan.tally_slots.size());
+  // tally_out is the tally of THIS batch; the running tally keeps accumulating across calls (only eg_*_tally_reset clears
+  // it).  The running tally is set aside, the batch is tallied from the identity, and the two are merged afterwards.
+  if (tally_out && ns) {
+    HIPCHK(hipMemcpyAsync(e->tally_saved, e->tally, (size_t)ns * 40 * sizeof(u32), hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_tally_init, dim3(blocks_of((size_t)ns)), dim3(NT), 0, s, e->tally, ns);
+  }
+  auto merge_saved = [&]() {   // running tally = saved + this batch (also on the error paths: nothing is lost)
+    if (tally_out && ns) hipLaunchKernelGGL(k_tally_add_points, dim3(blocks_of((size_t)ns)), dim3(NT), 0, s, e->tally_saved, ns, e->tally);
+  };
   if (n) {
     // Pipeline: the copy stream uploads piece k+1 while piece k is verified (host staging, not the kernels, is
     // the scaling risk when ballots arrive in host memory).  The first piece is small so that the exposed upload is short;
@@ -468,10 +482,15 @@ static int engine_verify_host(Engine* e, size_t n, const uint8_t* ballots, uint3
     (void)hipStreamSynchronize(e->copy_stream);
     (void)hipStreamSynchronize(s);
     for (hipEvent_t ev : uploaded) if (ev) (void)hipEventDestroy(ev);
-    if (rc) return rc;
+    if (rc) { merge_saved(); (void)hipStreamSynchronize(s); return rc; }
   }
   HIPCHK(hipStreamSynchronize(s));
-  if (tally_out) return engine_tally_encode(e, tally_out);
+  if (tally_out) {
+    const int rc = engine_tally_encode(e, tally_out);
+    merge_saved();
+    HIPCHK(hipStreamSynchronize(s));
+    return rc;
+  }
   return EG_OK;
 }
 
@@ -762,11 +781,11 @@ int eg_qv_tally_encode_device(eg_qv_params* p, void* d_out, void* stream) { EG_L
   if (!p || !d_out) return fail(EG_ERR_BAD_ARG, "bad argument");
   return tally_encode_device(p->eng, d_out, (hipStream_t)stream);
 }
-int eg_points_sum_device(eg_ctx* c, int n_ranks, int n_points, const void* d_in, void* d_out, void* stream) { EG_LOCK(c);
+int eg_points_sum_device(eg_ctx* c, int n_ranks, int n_points, const void* d_in, void* d_out, void* d_bad, void* stream) { EG_LOCK(c);
   if (!c || n_ranks < 1 || n_points < 1 || !d_in || !d_out) return fail(EG_ERR_BAD_ARG, "bad argument");
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_points_sum, dim3((n_points + 63) / 64), dim3(64), 0, s, (const u32*)d_in, n_ranks, n_points, (u32*)d_out,
-                     (u32*)nullptr);
+                     (u32*)d_bad);
   HIPCHK(hipGetLastError());
   return EG_OK;
 }
@@ -869,20 +888,28 @@ int eg_plan_describe(int kind, int n_options, uint64_t credits_or_bound, char* b
     default: return fail(EG_ERR_BAD_ARG, "unknown plan kind");
   }
   size_t jobs = 0, insts = 0, var_terms = P.vterms.size(), table_terms = 0, derived = 0;
+  size_t combs = 0, deferred = 0, plain_encodes = 0, inversion_groups = 0, derive_terms = P.dterms.size();
   std::string per_stage;
   for (auto& st : P.stages) {
     jobs += st.jobs.size(); insts += st.insts.size();
     per_stage += (per_stage.empty() ? "" : ",") + std::to_string(st.jobs.size());
+    for (auto& j : st.jobs) {
+      combs += (j.g.kind != egplan::SRC_NONE) + (j.k.kind != egplan::SRC_NONE);
+      if (j.defer) ++deferred; else ++plain_encodes;
+    }
+    inversion_groups += (st.deferred.size() + 31) / 32;
   }
   for (auto& t : P.vterms) table_terms += t.base != 0xffff;
   for (auto& l : P.derive_levels) derived += l.size();
-  char tmp[1024];
+  char tmp[1536];
   snprintf(tmp, sizeof tmp,
-           "{\"stride\": %zu, \"wire_points\": %zu, \"wire_scalars\": %zu, \"derived_points\": %zu, \"bases\": %zu, "
+           "{\"stride\": %zu, \"wire_points\": %zu, \"wire_scalars\": %zu, \"derived_points\": %zu, \"derive_terms\": %zu, \"bases\": %zu, "
            "\"stages\": %zu, \"jobs\": %zu, \"jobs_per_stage\": [%s], \"var_terms\": %zu, \"table_terms\": %zu, "
+           "\"combs\": %zu, \"deferred\": %zu, \"plain_encodes\": %zu, \"inversion_groups\": %zu, "
            "\"hash_programs\": %zu, \"prefixes\": %d, \"flags\": %d, \"rules\": %zu, \"tally_slots\": %zu}",
-           P.stride, P.pt_items.size(), P.sc_items.size(), derived, P.base_slots.size(), P.stages.size(), jobs, per_stage.c_str(),
-           var_terms, table_terms, insts, P.n_prefixes, P.n_flag_slots, P.rules.size(), P.tally_slots.size());
+           P.stride, P.pt_items.size(), P.sc_items.size(), derived, derive_terms, P.base_slots.size(), P.stages.size(), jobs, per_stage.c_str(),
+           var_terms, table_terms, combs, deferred, plain_encodes, inversion_groups, insts, P.n_prefixes, P.n_flag_slots, P.rules.size(),
+           P.tally_slots.size());
   if (strlen(tmp) + 1 > cap) return fail(EG_ERR_BAD_ARG, "buffer too small");
   memcpy(buf, tmp, strlen(tmp) + 1);
   return EG_OK;

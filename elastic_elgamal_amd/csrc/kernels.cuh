@@ -419,8 +419,21 @@ __global__ void k_tally_add_encoded(const u32* in, int n_slots, u32* tally, u32*
   for (int i = 0; i < 40; ++i) tally[(size_t)k * 40 + i] = t[i];
 }
 
+// tally[k] += src[k] (extended points): puts a set-aside running tally back after a host call tallied its own batch
+__global__ void k_tally_add_points(const u32* src, int n_slots, u32* tally) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_slots) return;
+  u32 a[40], b[40];
+  for (int i = 0; i < 40; ++i) { a[i] = src[(size_t)k * 40 + i]; b[i] = tally[(size_t)k * 40 + i]; }
+  ge p, q, sum; words_to_ge(p, a); words_to_ge(q, b);
+  ge_add_full(sum, q, p);
+  ge_to_words(b, sum);
+  for (int i = 0; i < 40; ++i) tally[(size_t)k * 40 + i] = b[i];
+}
+
 // out[k] = encode( sum_r decode(in[r][k]) ): merges the per-GPU tallies after the all-gather.  Encodings are
-// canonical, so the result does not depend on the order of ranks or on how ballots were sharded.
+// canonical, so the result does not depend on the order of ranks or on how ballots were sharded.  An encoding that does
+// not decode counts in *bad (if given) and contributes the identity: the caller must treat bad != 0 as a failed exchange.
 __global__ void k_points_sum(const u32* in, int n_ranks, int n_points, u32* out, u32* bad) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n_points) return;

@@ -6,7 +6,10 @@ A packed batch has one shape, so `OptionsLenMismatch` (src/app/choice.rs:149-158
 They arise here, where a ballot object may carry any number of choices / responses / partial ciphertexts.  The order of
 events of the reference is kept:
 
-1. deserialisation: the first element of the object (document order) that is not a canonical scalar / valid point fails
+1. deserialisation: an object that is structurally malformed (a string that is not unpadded base64url of 32 bytes, fewer
+   than 2 `ring_responses` / `ciphertext_responses`, a `sum_proof` that does not match the election kind, a missing field)
+   fails on its own with `Malformed` - in the reference a serde failure is per object, so one voter's junk never blocks the
+   verification of the others; then the first element (document order) that is not a canonical scalar / valid point fails
    the ballot (`BadScalar` / `BadPoint` with the index of the item, serde.rs:191-206,254-269);
 2. `check_options_count`;
 3. the proofs in the order of `verify`, each beginning with its own length check.  A length mismatch in a later proof is
@@ -26,6 +29,7 @@ from .serde import SerdeError, b64url_decode
 ST_OK, ST_BAD_SCALAR, ST_BAD_POINT, ST_OPTIONS_LEN, ST_SUM_CHALLENGE, ST_RANGE_LEN, ST_RANGE_CHALLENGE = 0, 1, 2, 3, 4, 5, 6
 ST_QV_VARIANT_LEN, ST_QV_VARIANT_CHALLENGE, ST_QV_CREDIT_RANGE_LEN, ST_QV_CREDIT_RANGE_CHALLENGE = 7, 8, 9, 10
 ST_QV_CREDIT_EQUIV_LEN, ST_QV_CREDIT_EQUIV_CHALLENGE = 11, 12
+ST_MALFORMED = 13      # the object does not deserialise (EG_ST_MALFORMED): that voter's ballot only, the batch goes on
 ZERO = bytes(32)
 
 
@@ -97,14 +101,18 @@ def verify_choice_objects(params, grp, objs):
     odd_idx, odd_items, odd_objs = [], [], []
     for i, o in enumerate(objs):
         it = _Items()
-        for c in o["choices"]:
-            it.ct(c)
-        it.ring(o["range_proof"])
-        sp = o.get("sum_proof")
-        if single != (sp is not None):
-            raise SerdeError("sum_proof does not match the kind of election")      # S::Proof is a different type
-        if sp is not None:
-            it.scalar(sp["challenge"]); it.scalar(sp["response"])
+        try:
+            for c in o["choices"]:
+                it.ct(c)
+            it.ring(o["range_proof"])
+            sp = o.get("sum_proof")
+            if single != (sp is not None):
+                raise SerdeError("sum_proof does not match the kind of election")      # S::Proof is a different type
+            if sp is not None:
+                it.scalar(sp["challenge"]); it.scalar(sp["response"])
+        except (SerdeError, KeyError, TypeError, AttributeError):
+            statuses[i] = status(ST_MALFORMED)
+            continue
         if len(o["choices"]) == n and len(o["range_proof"]["ring_responses"]) == 2 * n:
             good_idx.append(i); good_packed.append(b"".join(it.data))
         else:
@@ -159,22 +167,26 @@ def verify_qv_objects(params, grp, objs):
     for i, o in enumerate(objs):
         it = _Items()
         spans = []                      # (first item, end item) of every vote / credit block and of the final proof
-        for v in list(o["votes"]) + [o["credit"]]:
+        try:
+            for v in list(o["votes"]) + [o["credit"]]:
+                a = len(it.data)
+                it.ct(v["ciphertext"])
+                for c in v["range_proof"]["partial_ciphertexts"]:
+                    it.ct(c)
+                it.ring(v["range_proof"])
+                spans.append((a, len(it.data)))
+            p = o["credit_equivalence_proof"]
             a = len(it.data)
-            it.ct(v["ciphertext"])
-            for c in v["range_proof"]["partial_ciphertexts"]:
-                it.ct(c)
-            it.ring(v["range_proof"])
+            if len(p["ciphertext_responses"]) < 2:
+                raise SerdeError("invalid length of ciphertext_responses, expected at least 2")   # VecHelper<_, 2>, mul.rs:89-90
+            it.scalar(p["challenge"])
+            for r in p["ciphertext_responses"]:
+                it.scalar(r)
+            it.scalar(p["sum_response"])
             spans.append((a, len(it.data)))
-        p = o["credit_equivalence_proof"]
-        a = len(it.data)
-        if len(p["ciphertext_responses"]) < 2:
-            raise SerdeError("invalid length of ciphertext_responses, expected at least 2")   # VecHelper<_, 2>, mul.rs:89-90
-        it.scalar(p["challenge"])
-        for r in p["ciphertext_responses"]:
-            it.scalar(r)
-        it.scalar(p["sum_response"])
-        spans.append((a, len(it.data)))
+        except (SerdeError, KeyError, TypeError, AttributeError):
+            statuses[i] = status(ST_MALFORMED)
+            continue
         shapes = [range_shape_ok(v["range_proof"], vote_rings) for v in o["votes"]]
         shapes.append(range_shape_ok(o["credit"]["range_proof"], credit_rings))
         shapes.append(len(p["ciphertext_responses"]) == 2 * len(o["votes"]))

@@ -63,7 +63,9 @@ enum {
   EG_ST_QV_CREDIT_RANGE_LEN = 9,
   EG_ST_QV_CREDIT_RANGE_CHALLENGE = 10, /* QuadraticVotingError::CreditRange (quadratic_voting.rs:341) */
   EG_ST_QV_CREDIT_EQUIV_LEN = 11,
-  EG_ST_QV_CREDIT_EQUIV_CHALLENGE = 12  /* QuadraticVotingError::CreditEquivalence (:343) */
+  EG_ST_QV_CREDIT_EQUIV_CHALLENGE = 12, /* QuadraticVotingError::CreditEquivalence (:343) */
+  EG_ST_MALFORMED = 13            /* the ballot object does not deserialise at all (bad base64url / byte length, fewer than 2
+                                     responses, wrong proof kind: serde.rs:29-80,303-355); object-ingest layer only */
 };
 #define EG_STATUS_KIND(s) ((s) & 0xffu)
 #define EG_STATUS_DETAIL(s) ((s) >> 8)
@@ -116,7 +118,11 @@ int eg_choice_params_create(eg_ctx*, const uint8_t pk[32], int n_options, int si
 void eg_choice_params_destroy(eg_choice_params*);
 size_t eg_choice_ballot_size(int n_options, int single);
 /* EncryptedChoice::verify over a batch + homomorphic tally of the accepted ballots
- * (examples/voting.rs:199-203).  status: n words.  tally_out (may be NULL): n_options x 64 bytes (R || B). */
+ * (examples/voting.rs:199-203).  status: n words.
+ * Tally semantics (the same for the host and the `_device` forms, and for eg_verify_qv_batch): every call ADDS the
+ * ciphertexts of the ballots it accepts to the running tally kept inside `params`; only eg_*_tally_reset clears the running
+ * tally, eg_*_tally_add imports into it, eg_*_tally_encode reads it.  tally_out (may be NULL) additionally receives the tally
+ * of THIS call's batch alone, n_options x 64 bytes (R || B); it never disturbs the running tally. */
 int eg_verify_choice_batch(eg_choice_params*, size_t n, const uint8_t* ballots, uint32_t* status, uint8_t* tally_out);
 /* device-resident variant: d_ballots / d_status are device pointers; the running tally stays on the device
  * inside `params` until eg_choice_tally_* is called.  Asynchronous on `stream`. */
@@ -131,8 +137,10 @@ int eg_choice_tally_add(eg_choice_params*, const uint8_t* in /* n_options*64 */)
  * to device memory, ready for an RCCL all-gather; then sum the gathered encodings with eg_points_sum_device. */
 int eg_choice_tally_reset_async(eg_choice_params*, void* stream);
 int eg_choice_tally_encode_device(eg_choice_params*, void* d_out, void* stream);
-/* d_out[k] = encode( sum_r decode(d_in[r][k]) ), k < n_points, r < n_ranks; 32-byte encodings */
-int eg_points_sum_device(eg_ctx*, int n_ranks, int n_points, const void* d_in, void* d_out, void* stream);
+/* d_out[k] = encode( sum_r decode(d_in[r][k]) ), k < n_points, r < n_ranks; 32-byte encodings.  d_bad (device uint32, may be
+ * NULL; the caller zeroes it) is incremented once per point slot that received an encoding which does not decode: such a
+ * term contributes the identity, so a caller merging tallies from other ranks must treat *d_bad != 0 as a failed exchange. */
+int eg_points_sum_device(eg_ctx*, int n_ranks, int n_points, const void* d_in, void* d_out, void* d_bad, void* stream);
 
 /* ---- batch tier: QuadraticVotingBallot ------------------------------------------------------------------------------
  * wire layout (stride = eg_qv_ballot_size), serde field order of quadratic_voting.rs:205-217 / range.rs:446-450 /

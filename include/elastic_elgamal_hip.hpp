@@ -122,6 +122,8 @@ class ChoiceParams {
   ~ChoiceParams() { eg_choice_params_destroy(p_); }
   ChoiceParams(ChoiceParams&& o) noexcept : p_(o.p_), n_(o.n_), single_(o.single_) { o.p_ = nullptr; }
   ChoiceParams(const ChoiceParams&) = delete;
+  ChoiceParams& operator=(const ChoiceParams&) = delete;
+  ChoiceParams& operator=(ChoiceParams&&) = delete;
   size_t options_count() const { return n_; }
   size_t ballot_size() const { return eg_choice_ballot_size((int)n_, single_); }
   // EncryptedChoice::verify for every packed ballot + totals[k] += vote[k] (examples/voting.rs:199-203)
@@ -159,6 +161,7 @@ class QuadraticVotingParams {
   }
   ~QuadraticVotingParams() { eg_qv_params_destroy(p_); }
   QuadraticVotingParams(const QuadraticVotingParams&) = delete;
+  QuadraticVotingParams& operator=(const QuadraticVotingParams&) = delete;
   size_t options_count() const { return n_; }
   size_t ballot_size() const { return eg_qv_ballot_size(p_); }
   BatchVerdict<QuadraticVotingError> verify_batch(const Bytes& packed) const {
@@ -177,20 +180,25 @@ class QuadraticVotingParams {
   size_t n_;
 };
 
-// Ristretto: the Group backend (ristretto.rs), one problem per call shown here; *_batch in eg_hip.h for many
+// Ristretto: the Group backend (ristretto.rs), one problem per call shown here; *_batch in eg_hip.h for many.
+// The reference's typed Elements cannot be invalid; here elements are byte strings, so the operations that take
+// elements throw Error(EG_ERR_BAD_ARG) when an operand is not a valid ristretto255 encoding instead of silently
+// treating it as the identity.
 struct Ristretto {
   const Context& ctx;
+  static void valid(uint8_t ok) { if (!ok) throw Error(EG_ERR_BAD_ARG, "operand is not a valid ristretto255 encoding"); }
   Scalar scalar_from_random_bytes(const std::array<uint8_t, 64>& wide) const { Scalar s; check(eg_scalar_from_wide_batch(ctx.raw(), 1, wide.data(), s.data())); return s; }
   std::optional<Scalar> deserialize_scalar(const Scalar& b) const { uint8_t ok = 0; check(eg_scalar_is_canonical_batch(ctx.raw(), 1, b.data(), &ok)); return ok ? std::optional<Scalar>(b) : std::nullopt; }
   std::optional<Element> deserialize_element(const Element& b) const { Element o; uint8_t ok = 0; check(eg_point_roundtrip_batch(ctx.raw(), 1, b.data(), o.data(), &ok)); return ok ? std::optional<Element>(o) : std::nullopt; }
   Element mul_generator(const Scalar& k) const { Element o; check(eg_mul_generator_batch(ctx.raw(), 1, k.data(), o.data())); return o; }
-  Element vartime_double_mul_generator(const Scalar& k, const Element& p, const Scalar& r) const { Element o; uint8_t ok; check(eg_vartime_double_mul_generator_batch(ctx.raw(), 1, k.data(), p.data(), r.data(), o.data(), &ok)); return o; }
+  Element vartime_double_mul_generator(const Scalar& k, const Element& p, const Scalar& r) const { Element o; uint8_t ok = 0; check(eg_vartime_double_mul_generator_batch(ctx.raw(), 1, k.data(), p.data(), r.data(), o.data(), &ok)); valid(ok); return o; }
   Element vartime_multi_mul(const std::vector<Scalar>& s, const std::vector<Element>& e) const {
+    if (s.size() != e.size()) throw Error(EG_ERR_BAD_ARG, "scalars and elements differ in number");
     Bytes sb, eb; for (auto& x : s) sb.insert(sb.end(), x.begin(), x.end()); for (auto& x : e) eb.insert(eb.end(), x.begin(), x.end());
-    Element o; uint8_t ok; check(eg_vartime_multi_mul_batch(ctx.raw(), 1, s.size(), sb.data(), eb.data(), o.data(), &ok)); return o;
+    Element o; uint8_t ok; check(eg_vartime_multi_mul_batch(ctx.raw(), 1, s.size(), sb.data(), eb.data(), o.data(), &ok)); valid(ok); return o;
   }
-  Element add(const Element& a, const Element& b) const { Element o; uint8_t ok; check(eg_point_add_batch(ctx.raw(), 1, a.data(), b.data(), 0, o.data(), &ok)); return o; }
-  Element sub(const Element& a, const Element& b) const { Element o; uint8_t ok; check(eg_point_add_batch(ctx.raw(), 1, a.data(), b.data(), 1, o.data(), &ok)); return o; }
+  Element add(const Element& a, const Element& b) const { Element o; uint8_t ok = 0; check(eg_point_add_batch(ctx.raw(), 1, a.data(), b.data(), 0, o.data(), &ok)); valid(ok); return o; }
+  Element sub(const Element& a, const Element& b) const { Element o; uint8_t ok = 0; check(eg_point_add_batch(ctx.raw(), 1, a.data(), b.data(), 1, o.data(), &ok)); valid(ok); return o; }
   Element neg(const Element& a) const { return sub(identity(), a); }
   static Element identity() { return Element{}; }   // 32 zero bytes
   bool is_identity(const Element& a) const { uint8_t f = 0, ok = 0; check(eg_point_is_identity_batch(ctx.raw(), 1, a.data(), &f, &ok)); return f != 0; }

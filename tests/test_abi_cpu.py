@@ -140,6 +140,12 @@ def test_bench_static_sanity():
     spec = importlib.util.spec_from_file_location("bench_mod", path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    fm, fs = mod.choice_field_ops(5, True)
+    import elastic_elgamal_amd as eg
+
+    fm, fs = mod.plan_field_ops(eg.plan_describe("single", 5))
     assert 25_000 < fm < 35_000 and 15_000 < fs < 22_000
+    qm, qs = mod.plan_field_ops(eg.plan_describe("qv", 5, 20))          # a QV ballot is 2-3x a single-choice ballot
+    assert 2 * fm < qm < 4 * fm and 1.5 * fs < qs < 4 * fs
+    mm, ms = mod.plan_field_ops(eg.plan_describe("multi", 16))          # 32 ring bases instead of 10, no sum proof
+    assert 2.5 * fm < mm < 3.5 * fm
     assert mod.effective_cores() >= 1

@@ -382,11 +382,12 @@ def test_qv_generator_matches_oracle_prover(eg, ctx, oracle, pk):
 
 
 # ------------------------------------------------------------------ BASELINE.json full sizes, size-independent properties
-@pytest.mark.parametrize("workload,n", [("single", 1_000_000), ("multi", 250_000), ("qv", 250_000)])
+@pytest.mark.parametrize("workload,n", [("single", 1_000_000), ("multi", 1_000_000), ("qv", 1_000_000), ("single", 10_000_000)])
 def test_full_size_properties(eg, ctx, oracle, pk, workload, n):
-    """configs[1] (1M single-choice) at full size, configs[2]/[3] at 250k: ballots generated on the GPU, 1 % tampered.
-    Properties: exactly the tampered ballots are rejected; tally(A ++ B) == tally(A) + tally(B); verdicts and tally of a
-    random sample are bit-exact against the oracle."""
+    """BASELINE.json configs[1] (1M single-choice), configs[3] (1M multi-choice 3-of-16), configs[2] (1M quadratic voting,
+    5 options / 20 credits) and the whole 10M-ballot batch of configs[4] on one GPU (chunked by the engine), all at full
+    size: ballots generated on the GPU, 1 % tampered.  Properties: exactly the tampered ballots are rejected;
+    tally(A ++ B) == tally(A) + tally(B); verdicts and tally of a random sample are bit-exact against the oracle."""
     import torch
 
     if workload == "single":
@@ -815,6 +816,91 @@ def test_tally_checkpoint_and_resume(eg, ctx, oracle, pk):
     with pytest.raises(Exception):
         b.tally_add(b"\xff" * (64 * 5))
     assert b.tally_encode() == whole                         # untouched by the refused import
+
+
+def test_host_form_accumulates_and_reports_its_own_batch(eg, ctx, oracle, pk):
+    """eg_hip.h tally semantics: every verify call (host or device form) adds to the running tally; tally_out of the host
+    form is the tally of that call's batch alone.  A checkpoint restored with tally_add must survive a host verify_batch."""
+    op = oracle.ChoiceParams(pk, 5, True)
+    ballots = bytearray(op.generate_batch(4711, 0, 90, threads=8))
+    sz = len(ballots) // 90
+    ballots[50 * sz + sz - 32] ^= 1
+    ballots = bytes(ballots)
+    want = op.verify_batch(ballots, threads=8)
+    t_all = op.tally(ballots, want)
+    parts = [ballots[: 30 * sz], ballots[30 * sz : 60 * sz], ballots[60 * sz :]]
+    t_parts = [op.tally(b, want[30 * i : 30 * i + 30]) for i, b in enumerate(parts)]
+    p = eg.ChoiceParams.single_choice(ctx, pk, 5)
+    p.tally_reset()
+    p.tally_add(t_parts[0])                                  # restored checkpoint: the first 30 ballots were verified elsewhere
+    st1, own1 = p.verify_batch(parts[1])                     # host form WITH tally_out
+    assert st1 == want[30:60] and own1 == t_parts[1]         # its own batch only ...
+    grp = eg.Ristretto(ctx)
+    assert p.tally_encode() == grp.element_add(t_parts[0], t_parts[1])[0]    # ... and the running tally kept the checkpoint
+    st2, none = p.verify_batch(parts[2], with_tally=False)   # host form WITHOUT tally_out accumulates as well
+    assert st2 == want[60:] and none is None
+    assert p.tally_encode() == t_all
+    st3, own3 = p.verify_batch(b"")                          # an empty batch: identity tally, running tally untouched
+    assert st3 == [] and own3 == bytes(320) and p.tally_encode() == t_all
+    p.tally_reset()
+    assert p.tally_encode() == bytes(320)
+
+
+def test_points_sum_flags_undecodable_tallies(eg, ctx, oracle, pk):
+    """eg_points_sum_device: an all-gathered tally that does not decode must be reported, not silently dropped."""
+    import torch
+
+    op = oracle.ChoiceParams(pk, 5, True)
+    ballots = op.generate_batch(31, 0, 8)
+    t = op.tally(ballots, [0] * 8)
+    two = torch.frombuffer(bytearray(t + t), dtype=torch.uint8).cuda()
+    out = torch.empty(320, dtype=torch.uint8, device="cuda")
+    bad = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ctx.points_sum_device(2, 10, two.data_ptr(), out.data_ptr(), d_bad=bad.data_ptr())
+    ctx.synchronize()
+    assert int(bad.item()) == 0
+    assert bytes(out.cpu().numpy()) == eg.Ristretto(ctx).element_add(t, t)[0]
+    two[320 + 64 : 320 + 96] = 0xFF                          # rank 1's third point is garbage
+    ctx.points_sum_device(2, 10, two.data_ptr(), out.data_ptr(), d_bad=bad.data_ptr())
+    ctx.synchronize()
+    assert int(bad.item()) == 1
+
+
+# ------------------------------------------------------------------ the RCCL leg and the fixed-total mode of bench.py
+def _run_bench(*args, timeout=600):
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(root / "bench.py"), *args], capture_output=True, text=True, timeout=timeout, env=env,
+                       cwd=str(root))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_bench_rccl_leg_in_a_fresh_process():
+    """The N > 1 code path of bench.py on the one GPU of the box: torch.distributed over RCCL is initialised for a single
+    rank, the tally goes through tally_encode_device -> all_gather_into_tensor -> eg_points_sum_device on the shared stream,
+    and must come out equal to the engine's own tally (examples/voting.rs:199-203 is what the exchange stands in for)."""
+    line = _run_bench("--gpus", "1", "--force-dist", "--ballots", "131072", "--steps", "1", "--warmup", "0", "--no-cpu-baseline")
+    assert line["config"]["tally_exchange_ok"] is True
+    assert line["config"]["accepted"] == 131072 and line["n_gpus"] == 1 and line["scaling"] == "weak"
+    assert line["roofline"]["frac"] > 0 and line["value"] > 1e5
+    assert line["host_inclusive"]["verdicts_match_device_path"] is True
+
+
+def test_bench_fixed_total_mode():
+    """`--total-ballots N` (BASELINE.json configs[4]: a fixed batch sharded over the ranks) with 1 % tampered ballots."""
+    line = _run_bench("--gpus", "1", "--total-ballots", "300000", "--tampered-percent", "1", "--steps", "1", "--warmup", "0",
+                      "--no-cpu-baseline", "--no-host-inclusive")
+    assert line["scaling"] == "strong" and line["config"]["total_ballots"] == 300000
+    assert line["config"]["accepted"] == 300000 - 3000 and line["config"]["tally_exchange_ok"] is True
 
 
 def test_host_buffer_path_matches_device_path(eg, ctx, pk):

@@ -68,12 +68,27 @@ def test_qv_objects(oracle, pk):
     assert tally == oq.tally(accepted, [0] * (len(accepted) // sz))
 
 
-def test_structural_errors_are_deserialisation_errors(oracle, pk):
+def test_structural_errors_fail_their_own_ballot_only(oracle, pk):
+    """A serde failure is per object in the reference: junk from one voter must not abort the batch."""
     op = oracle.ChoiceParams(pk, 2, True)
-    packed = op.generate_batch(13, 0, 1)
-    obj = serde.unpack_encrypted_choice(packed, 2, True)
-    bad = dict(obj, range_proof=dict(obj["range_proof"], ring_responses=obj["range_proof"]["ring_responses"][:1]))
-    with pytest.raises(serde.SerdeError):
-        ingest.verify_choice_objects(OracleParams(op, 2, single=True), OracleGroup(oracle), [bad])
-    with pytest.raises(serde.SerdeError):
-        ingest.verify_choice_objects(OracleParams(op, 2, single=True), OracleGroup(oracle), [dict(obj, sum_proof=None)])
+    packed = op.generate_batch(13, 0, 3)
+    sz = len(packed) // 3
+    objs = [serde.unpack_encrypted_choice(packed[i * sz : (i + 1) * sz], 2, True) for i in range(3)]
+    short = dict(objs[0], range_proof=dict(objs[0]["range_proof"], ring_responses=objs[0]["range_proof"]["ring_responses"][:1]))
+    wrong_kind = dict(objs[1], sum_proof=None)
+    bad_b64 = dict(objs[1], choices=[dict(objs[1]["choices"][0], random_element="not base64!"), objs[1]["choices"][1]])
+    short_b64 = dict(objs[1], choices=[dict(objs[1]["choices"][0], random_element="AAAA"), objs[1]["choices"][1]])
+    missing = {k: v for k, v in objs[1].items() if k != "range_proof"}
+    batch = [short, objs[2], wrong_kind, bad_b64, short_b64, missing, objs[0]]
+    got, tally = ingest.verify_choice_objects(OracleParams(op, 2, single=True), OracleGroup(oracle), batch)
+    m = ingest.status(ingest.ST_MALFORMED)
+    assert got == [m, 0, m, m, m, m, 0]
+    good = packed[2 * sz :] + packed[:sz]
+    assert tally == op.tally(good, [0, 0])
+    oq = oracle.QvParams(pk, 2, 4)
+    qp = oq.generate_batch(14, 0, 2)
+    qsz = len(qp) // 2
+    qobjs = [ingest.unpack_qv_ballot(qp[i * qsz : (i + 1) * qsz], 2, 4) for i in range(2)]
+    junk = dict(qobjs[0], credit_equivalence_proof=dict(qobjs[0]["credit_equivalence_proof"], ciphertext_responses=[]))
+    got, tally = ingest.verify_qv_objects(OracleParams(oq, 2, credits=4), OracleGroup(oracle), [junk, qobjs[1]])
+    assert got == [m, 0] and tally == oq.tally(qp[qsz:], [0])
