@@ -35,12 +35,14 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # VALU model: field operations per building block counted by the host-check build
 # (tests/hostcheck: hc_op_counts) as (fe_mul, fe_sq); one fe_mul = 100 and one fe_sq = 55 v_mad_u64_u32.
 OPS = {"decode": (27, 257), "direct_table": (64, 0), "direct_mul": (1269, 1008), "comb": (119, 0), "encode": (32, 255),
-       "base_table": (994, 860), "base_mul": (470, 168), "enc_batch_each": (23, 10), "enc_batch_inversion": (11, 254)}
+       "base_table": (994, 860), "base_mul": (463, 168), "enc_batch_each": (23, 10), "enc_batch_inversion": (11, 254),
+       "multi_first": (470, 168), "multi_extra": (344, 0)}
 # memory-side traffic per ballot and launch of the profiled kernels comes from profiles/traffic.json, which
 # tools/profile_summary.py writes from the separate rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of tools/profile_round.sh
 TRAFFIC_JSON = ROOT / "profiles" / "traffic.json"
 MAD_PEAK_T = 33.4              # profiles/r01_ubench_valu_rates.txt: v_mad_u64_u32, 8 waves/SIMD, T lane-ops/s chip-wide
 FMUL_PEAK_G = 256.0            # profiles/r01_ubench_fmul_candidates.txt: radix-25.5 field multiply, G/s chip-wide
+DOMINANT_KERNEL = "eg::k_eq_table<false>"   # one table-backed base + fixed-base combs: every ring equation (kernels.cuh)
 
 
 def plan_field_ops(desc: dict):
@@ -52,11 +54,12 @@ def plan_field_ops(desc: dict):
     def mul(x, k):
         return (x[0] * k, x[1] * k)
 
-    direct_terms = desc["var_terms"] - desc["table_terms"]
     return add(mul(OPS["decode"], desc["wire_points"]),
                mul(OPS["base_table"], desc["bases"]),
-               mul(OPS["base_mul"], desc["table_terms"]),
-               mul(add(OPS["direct_table"], OPS["direct_mul"]), direct_terms),
+               mul(OPS["base_mul"], desc["single_table_jobs"] + desc["loose_table_terms"]),
+               mul(OPS["multi_first"], desc["chains"]),                   # several table-backed bases on one doubling chain
+               mul(OPS["multi_extra"], desc["chain_extra_terms"]),
+               mul(add(OPS["direct_table"], OPS["direct_mul"]), desc["direct_terms"]),
                mul(OPS["comb"], desc["combs"]),
                mul(OPS["enc_batch_each"], desc["deferred"]),
                mul(OPS["enc_batch_inversion"], desc["inversion_groups"]),
@@ -228,10 +231,10 @@ def main():
             dist.destroy_process_group()
         return
 
-    # ---- roofline of the dominant kernel (k_msm_jobs), HIP events on the launch stream ------------------------
+    # ---- roofline of the dominant kernel (k_eq_table<false>), HIP events on the launch stream ------------------------
     kind = {"single": "single", "multi": "multi", "qv": "qv"}[args.workload]
     desc = eg.plan_describe(kind, n_opt, args.credits if args.workload == "qv" else 0)
-    n_stages = desc["stages"]   # one k_msm_jobs launch per stage and chunk
+    n_stages = desc["stages"]   # one launch of the dominant kernel per stage and chunk
     launches_per_step = max(1, msm_launches // max(args.steps, 1))
     avg_launch_ms = msm_ms / max(msm_launches, 1)
     n_chunks = max(1, launches_per_step // n_stages)
@@ -244,7 +247,7 @@ def main():
     try:
         tj = json.loads(TRAFFIC_JSON.read_text())
         key = f"{args.workload}-{n_opt}" + (f"-{args.credits}" if args.workload == "qv" else "")
-        ent = tj["workloads"][key]["kernels"]["eg::k_msm_jobs"]
+        ent = tj["workloads"][key]["kernels"][DOMINANT_KERNEL]
         traffic_bpbl = float(ent["bytes_per_ballot_launch"])
         traffic_src = {"file": "profiles/traffic.json", "round": tj.get("round"), "commit": tj.get("commit"),
                        "ballots_per_launch": tj["workloads"][key].get("ballots_per_launch")}
@@ -284,7 +287,7 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "eg::k_msm_jobs",
+            "kernel": DOMINANT_KERNEL,
             "achieved": achieved_gbs,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",

@@ -20,7 +20,7 @@ import os
 from pathlib import Path
 
 __all__ = [
-    "Context", "Ristretto", "ChoiceParams", "QuadraticVotingParams", "PublicKeyVerifier", "DecryptionShareVerifier", "EgError", "library_path", "build",
+    "Context", "Ristretto", "ChoiceParams", "QuadraticVotingParams", "PublicKeyVerifier", "DecryptionShareVerifier", "SumOfSquaresVerifier", "EgError", "library_path", "build",
     "STATUS_NAMES", "status_kind", "status_detail",
 ]
 
@@ -131,6 +131,12 @@ def _load() -> C.CDLL:
         "eg_choice_encrypt_batch": (C.c_int, [vp, C.c_uint64, sz, sz, C.c_int, cp]),
         "eg_choice_encrypt_batch_device": (C.c_int, [vp, C.c_uint64, sz, sz, C.c_int, vp, vp]),
         "eg_qv_encrypt_batch_device": (C.c_int, [vp, C.c_uint64, sz, sz, vp, vp]),
+        "eg_choice_encrypt_selected_batch": (C.c_int, [vp, C.c_uint64, sz, sz, C.c_uint64, vp, cp]),
+        "eg_choice_encrypt_selected_batch_device": (C.c_int, [vp, C.c_uint64, sz, sz, C.c_uint64, vp, vp, vp]),
+        "eg_qv_encrypt_votes_batch": (C.c_int, [vp, C.c_uint64, sz, sz, C.c_uint64, vp, cp]),
+        "eg_qv_encrypt_votes_batch_device": (C.c_int, [vp, C.c_uint64, sz, sz, C.c_uint64, vp, vp, vp]),
+        "eg_sumsq_params_create": (C.c_int, [vp, cp, C.c_int, cp, sz, C.POINTER(vp)]),
+        "eg_merlin_challenge_batch": (C.c_int, [vp, sz, cp, sz, cp, sz, cp, sz, cp, sz, cp, sz]),
         "eg_range_decomposition": (C.c_int, [C.c_uint64, cp, sz]),
         "eg_plan_describe": (C.c_int, [C.c_int, C.c_int, C.c_uint64, cp, sz]),
         "eg_profile_enable": (C.c_int, [vp, C.c_int]),
@@ -138,6 +144,8 @@ def _load() -> C.CDLL:
         "eg_profile_read_tables": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     }
     for name, (res, args) in sig.items():
+        if "EG_LIB" in os.environ and not hasattr(lib, name):
+            continue             # an alternate (older) build selected for an A/B measurement may lack the newest entry points
         fn = getattr(lib, name)  # raises AttributeError if the ABI is incomplete
         fn.restype = res
         fn.argtypes = args
@@ -156,9 +164,9 @@ def plan_describe(kind: str, n_options: int = 0, credits_or_bound: int = 0) -> d
     """Summary of the flattened verification plan (host logic only, no GPU needed)."""
     import json
 
-    kinds = {"single": 0, "multi": 1, "qv": 2, "zero": 3, "bool": 4, "range": 5}
-    b = C.create_string_buffer(2048)
-    _check(_load().eg_plan_describe(kinds[kind], n_options, credits_or_bound, b, 2048))
+    kinds = {"single": 0, "multi": 1, "qv": 2, "zero": 3, "bool": 4, "range": 5, "sumsq": 6}
+    b = C.create_string_buffer(4096)
+    _check(_load().eg_plan_describe(kinds[kind], n_options, credits_or_bound, b, 4096))
     return json.loads(b.value.decode())
 
 
@@ -208,6 +216,19 @@ class Context:
         """d_out[k] = sum over ranks of d_in[r][k] (32-byte encodings): merge of all-gathered per-GPU tallies.
         d_bad: device uint32 counter (zeroed by the caller) of slots that received an undecodable encoding."""
         _check(_load().eg_points_sum_device(self._h, n_ranks, n_points, d_in, d_out, d_bad or None, stream))
+
+    def merlin_challenges(self, proto: bytes, msg_label: bytes, msgs, chal_label: bytes, out_len: int = 64):
+        """``Transcript::new(proto); append_message(msg_label, m); challenge_bytes(chal_label, out_len)`` for every message m
+        (all of one length) on the GPU: the transcript layer of proofs/mod.rs:39-57 as a primitive."""
+        msgs = list(msgs)
+        n = len(msgs)
+        ml = len(msgs[0]) if n else 0
+        if any(len(m) != ml for m in msgs):
+            raise ValueError("messages must have one length")
+        out = C.create_string_buffer(max(n * out_len, 1))
+        _check(_load().eg_merlin_challenge_batch(self._h, n, proto, len(proto), msg_label, len(msg_label), b"".join(msgs), ml,
+                                                 chal_label, len(chal_label), out, out_len))
+        return [out.raw[i * out_len : (i + 1) * out_len] for i in range(n)]
 
     def profile_enable(self, on: bool = True):
         _check(_load().eg_profile_enable(self._h, int(on)))
@@ -389,6 +410,17 @@ class ChoiceParams(_BatchParams):
         """EncryptedChoice::new for n synthetic voters, written packed to device memory."""
         _check(_load().eg_choice_encrypt_batch_device(self._h, base_seed, first, n, n_selected, d_out, stream))
 
+    def encrypt_selected(self, base_seed: int, first: int, selections, rng_skip: int = 0) -> bytes:
+        """``EncryptedChoice::single(params, choice, rng)`` / ``::new(params, &[bool], rng)`` (choice.rs:296-349) on the GPU for the
+        caller's choices: `selections` = one bitmask per ballot (bit k <=> option k chosen); ballot i uses
+        ChaChaRng::seed_from_u64(base_seed + first + i) after `rng_skip` 64-byte draws.  Returns the packed ballots."""
+        sel = list(selections)
+        n = len(sel)
+        arr = (C.c_uint32 * max(n, 1))(*sel)
+        out = C.create_string_buffer(max(n * self.ballot_size, 1))
+        _check(_load().eg_choice_encrypt_selected_batch(self._h, base_seed, first, n, rng_skip, arr, out))
+        return out.raw[: n * self.ballot_size]
+
     def close(self):
         if getattr(self, "_h", None):
             _load().eg_choice_params_destroy(self._h)
@@ -433,6 +465,17 @@ class PublicKeyVerifier:
             pass
 
 
+class SumOfSquaresVerifier(PublicKeyVerifier):
+    """Batched ``SumOfSquaresProof::verify`` (src/proofs/mul.rs:190-260) with ``Transcript::new(label)``.
+    item = n value ciphertexts || sum-of-squares ciphertext || challenge || 2n ciphertext responses || sum response."""
+
+    def __init__(self, ctx: Context, public_key: bytes, n_values: int, label: bytes):
+        self.ctx, self.kind = ctx, 4
+        self._h = C.c_void_p()
+        _check(_load().eg_sumsq_params_create(ctx._h, public_key, n_values, label, len(label), C.byref(self._h)))
+        self.item_size = _load().eg_proof_item_size(self._h)
+
+
 class DecryptionShareVerifier(PublicKeyVerifier):
     """Batched ``PublicKeySet::verify_share`` for one participant (src/sharing/key_set.rs:209-228).
     item = ciphertext.random_element || dh_element || challenge || response."""
@@ -458,6 +501,19 @@ class QuadraticVotingParams(_BatchParams):
     def encrypt_batch_device(self, base_seed: int, first: int, n: int, d_out: int, stream: int = 0):
         """QuadraticVotingBallot::new for n synthetic voters, written packed to device memory."""
         _check(_load().eg_qv_encrypt_batch_device(self._h, base_seed, first, n, d_out, stream))
+
+    def encrypt_votes(self, base_seed: int, first: int, votes, rng_skip: int = 0) -> bytes:
+        """``QuadraticVotingBallot::new(params, votes, rng)`` (quadratic_voting.rs:234-284) on the GPU for the caller's votes
+        (one list of n_options integers per ballot); RNG as in ChoiceParams.encrypt_selected."""
+        votes = [list(v) for v in votes]
+        n = len(votes)
+        if any(len(v) != self.n_options for v in votes):
+            raise ValueError("every ballot needs n_options votes")
+        flat = [x for v in votes for x in v]
+        arr = (C.c_uint32 * max(len(flat), 1))(*flat)
+        out = C.create_string_buffer(max(n * self.ballot_size, 1))
+        _check(_load().eg_qv_encrypt_votes_batch(self._h, base_seed, first, n, rng_skip, arr, out))
+        return out.raw[: n * self.ballot_size]
 
     def close(self):
         if getattr(self, "_h", None):

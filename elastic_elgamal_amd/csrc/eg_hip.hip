@@ -22,12 +22,13 @@
 
 using namespace eg;
 
-void eg_launch_qv_encrypt(int blocks, hipStream_t s, u64 seed0, size_t n, int n_options, u64 credits, const int* vote_range,
+void eg_launch_qv_encrypt(int blocks, hipStream_t s, u64 seed0, size_t n, int n_options, u64 credits, const u32* votes, u64 rng_skip,
+                          const int* vote_range,
                           const int* credit_range, int pre_sumsq, const uint4* tabG, const uint4* tabK, const u32* prefixes,
                           u32* out, u32 stride_words, u32 vote_words, u32 credit_words);
 // defined in eg_gen.hip (separate translation unit so the two compile in parallel)
 void eg_launch_choice_encrypt(int blocks, hipStream_t s, u64 seed0, size_t n, int n_options, int single, int n_selected,
-                              const uint4* tabG, const uint4* tabK, const u32* prefixes, int pre_main, int pre_ring,
+                              const u32* selection, u64 rng_skip, const uint4* tabG, const uint4* tabK, const u32* prefixes, int pre_main, int pre_ring,
                               int pre_logeq, u32* out, u32 stride_words);
 
 static thread_local std::string g_err;
@@ -51,7 +52,7 @@ struct eg_ctx {
   std::string name;
   uint4* tabG = nullptr;     // fixed-base table of the generator
   u32* gen_words = nullptr;  // generator as 40 limbs
-  int msm_blocks = 0;        // persistent grid of k_msm_jobs
+  int msm_blocks = 0;        // persistent grid of the equation kernels
   uint4* ws = nullptr;       // variable-base table workspace (msm_blocks * 80 * NT uint4)
   bool prof = false;
   std::vector<ProfSpan> spans;
@@ -88,7 +89,18 @@ static int upload(T** dptr, const std::vector<T>& v, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-struct StageDev { int job_first, job_count, inst_first, inst_count, defer_first, defer_count; };
+// the equations of a stage, sorted by kernel family (kernels.cuh): FAM_TABLE1 one table-backed base, FAM_TABLEN several
+// table-backed bases on one doubling chain, FAM_GENERIC everything else, FAM_ENCODE plain encodings of point slots
+enum { FAM_TABLE1 = 0, FAM_TABLEN = 1, FAM_GENERIC = 2, FAM_ENCODE = 3, N_FAM = 4 };
+constexpr int EG_MULTI_GROUP = 8;           // terms per shared doubling chain: 8 sign vectors = 72 KiB of LDS per block, two blocks per CU
+static int job_family(const egplan::JobClass& j, const std::vector<egplan::VarTerm>& vterms) {
+  if (!j.defer) return FAM_ENCODE;
+  if (j.term_count == 0) return FAM_GENERIC;
+  for (unsigned t = 0; t < j.term_count; ++t)
+    if (vterms[j.term_first + t].base == 0xffff) return FAM_GENERIC;
+  return j.term_count == 1 ? FAM_TABLE1 : FAM_TABLEN;
+}
+struct StageDev { int fam_first[N_FAM], fam_count[N_FAM], max_terms, inst_first, inst_count, defer_first, defer_count; };
 struct LevelDev { int first, count; };
 
 struct Engine {
@@ -228,8 +240,16 @@ static int engine_create(eg_ctx* ctx, eghost::Plan&& plan, const uint8_t pk[32],
     sd.defer_first = (int)defer_slots.size(); sd.defer_count = (int)st.deferred.size();
     defer_slots.insert(defer_slots.end(), st.deferred.begin(), st.deferred.end());
     e->max_defer = std::max(e->max_defer, std::min(sd.defer_count, 32));
-    sd.job_first = (int)jobs.size(); sd.job_count = (int)st.jobs.size();
-    jobs.insert(jobs.end(), st.jobs.begin(), st.jobs.end());
+    sd.max_terms = 0;
+    for (int f = 0; f < N_FAM; ++f) {
+      sd.fam_first[f] = (int)jobs.size();
+      for (auto& j : st.jobs)
+        if (job_family(j, P.vterms) == f) {
+          jobs.push_back(j);
+          if (f == FAM_TABLEN) sd.max_terms = std::max<int>(sd.max_terms, j.term_count);
+        }
+      sd.fam_count[f] = (int)jobs.size() - sd.fam_first[f];
+    }
     sd.inst_first = (int)insts.size(); sd.inst_count = (int)st.insts.size();
     for (auto& prog : st.insts) {
       insts.push_back({(uint32_t)ops.size(), (uint32_t)prog.size()});
@@ -367,13 +387,25 @@ static int engine_verify_device(Engine* e, size_t n, const void* d_ballots, void
       if ((rc = prof_end(ctx, s, pi))) return rc;
     }
     for (auto& st : e->stages) {
-      if (st.job_count) {
+      if (st.fam_count[FAM_TABLE1]) {
         size_t pi = 0;
         if ((rc = prof_begin(ctx, s, PROF_MSM, &pi))) return rc;
-        hipLaunchKernelGGL(k_msm_jobs, dim3(grid_for((size_t)st.job_count * cn, ctx->msm_blocks)), dim3(NT), 0, s, B, e->d_jobs,
-                           e->d_vterms, st.job_first, st.job_count);
+        hipLaunchKernelGGL(k_eq_table<false>, dim3(grid_for((size_t)st.fam_count[FAM_TABLE1] * cn, ctx->msm_blocks)), dim3(NT), 0, s, B,
+                           e->d_jobs, e->d_vterms, st.fam_first[FAM_TABLE1], st.fam_count[FAM_TABLE1], 1);
         if ((rc = prof_end(ctx, s, pi))) return rc;
       }
+      if (st.fam_count[FAM_TABLEN]) {
+        const int group = std::min(st.max_terms, EG_MULTI_GROUP);
+        hipLaunchKernelGGL(k_eq_table<true>, dim3(grid_for((size_t)st.fam_count[FAM_TABLEN] * cn, ctx->msm_blocks)), dim3(NT),
+                           (size_t)group * 9 * NT * sizeof(u32), s, B, e->d_jobs, e->d_vterms, st.fam_first[FAM_TABLEN],
+                           st.fam_count[FAM_TABLEN], group);
+      }
+      if (st.fam_count[FAM_GENERIC])
+        hipLaunchKernelGGL(k_eq_generic, dim3(grid_for((size_t)st.fam_count[FAM_GENERIC] * cn, ctx->msm_blocks)), dim3(NT), 0, s, B,
+                           e->d_jobs, e->d_vterms, st.fam_first[FAM_GENERIC], st.fam_count[FAM_GENERIC]);
+      if (st.fam_count[FAM_ENCODE])
+        hipLaunchKernelGGL(k_encode_plain, dim3(grid_for((size_t)st.fam_count[FAM_ENCODE] * cn, wide)), dim3(NT), 0, s, B, e->d_jobs,
+                           st.fam_first[FAM_ENCODE], st.fam_count[FAM_ENCODE]);
       for (int d0 = 0; d0 < st.defer_count; d0 += 32)   // one batched inversion per ballot and group of <= 32 commitments
         hipLaunchKernelGGL(k_encode_batch, dim3(grid_for(cn, wide)), dim3(NT), 0, s, B, e->d_defer_slots + st.defer_first + d0,
                            std::min(32, st.defer_count - d0));
@@ -554,7 +586,10 @@ int eg_init(int device, eg_ctx** out) {
   hipLaunchKernelGGL(k_setup_points, dim3(1), dim3(64), 0, c->stream, (const u32*)nullptr, c->gen_words, (u32*)nullptr);
   hipLaunchKernelGGL(k_build_fixed_table, dim3((EG_FIXED_WINDOWS * EG_FIXED_ENTRIES + NT - 1) / NT), dim3(NT), 0, c->stream, c->gen_words, c->tabG);
   int per_cu = 0;
-  HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_msm_jobs, NT, 0));
+  HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_eq_table<false>, NT, 0));
+  // the shared-chain kernel keeps up to EG_MULTI_GROUP sign vectors per lane in dynamic LDS (9 KiB per term and block)
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_eq_table<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             EG_MULTI_GROUP * 9 * NT * (int)sizeof(u32)));
   if (per_cu < 1) per_cu = 1;
   const char* env = getenv("EG_MSM_BLOCKS_PER_CU");
   if (env) per_cu = std::max(1, atoi(env));
@@ -851,7 +886,16 @@ int eg_share_params_create(eg_ctx* c, const uint8_t shared_key[32], uint64_t sha
   if (shares < 1 || threshold < 1 || threshold > shares || index >= shares) return fail(EG_ERR_BAD_ARG, "bad sharing parameters");
   Engine* e = nullptr;
   TRY(engine_create(c, eghost::build_share_plan(shares, threshold, shared_key, index), participant_key, 0, &e));
-  *out = new eg_proof_params{e, 3, 128};
+  *out = new eg_proof_params{e, EG_PROOF_SHARE, 128};
+  return EG_OK;
+}
+int eg_sumsq_params_create(eg_ctx* c, const uint8_t pk[32], int n_values, const char* label, size_t label_len, eg_proof_params** out) { EG_LOCK(c);
+  if (!c || !pk || !out || (!label && label_len)) return fail(EG_ERR_BAD_ARG, "bad argument");
+  if (n_values < 1 || n_values > 1000 || label_len > 255) return fail(EG_ERR_BAD_ARG, "n_values in 1..1000, label up to 255 bytes");
+  Engine* e = nullptr;
+  size_t item = 0;
+  TRY(engine_create(c, eghost::build_sumsq_plan(n_values, std::string(label ? label : "", label_len), &item), pk, 0, &e));
+  *out = new eg_proof_params{e, EG_PROOF_SUMSQ, item};
   return EG_OK;
 }
 void eg_proof_params_destroy(eg_proof_params* p) { params_destroy(p); }
@@ -885,10 +929,12 @@ int eg_plan_describe(int kind, int n_options, uint64_t credits_or_bound, char* b
     case 3: P = eghost::build_zero_plan(); break;
     case 4: P = eghost::build_bool_plan(); break;
     case 5: P = eghost::build_range_plan(credits_or_bound, &item); break;
+    case 6: P = eghost::build_sumsq_plan(n_options, "test", &item); break;
     default: return fail(EG_ERR_BAD_ARG, "unknown plan kind");
   }
   size_t jobs = 0, insts = 0, var_terms = P.vterms.size(), table_terms = 0, derived = 0;
   size_t combs = 0, deferred = 0, plain_encodes = 0, inversion_groups = 0, derive_terms = P.dterms.size();
+  size_t jobs_table1 = 0, chains = 0, chain_extra_terms = 0, loose_table_terms = 0, direct_terms = 0;
   std::string per_stage;
   for (auto& st : P.stages) {
     jobs += st.jobs.size(); insts += st.insts.size();
@@ -896,19 +942,35 @@ int eg_plan_describe(int kind, int n_options, uint64_t credits_or_bound, char* b
     for (auto& j : st.jobs) {
       combs += (j.g.kind != egplan::SRC_NONE) + (j.k.kind != egplan::SRC_NONE);
       if (j.defer) ++deferred; else ++plain_encodes;
+      switch (job_family(j, P.vterms)) {
+        case FAM_TABLE1: ++jobs_table1; break;
+        case FAM_TABLEN:
+          for (int t0 = 0; t0 < (int)j.term_count; t0 += EG_MULTI_GROUP) {
+            ++chains;
+            chain_extra_terms += std::min<int>(EG_MULTI_GROUP, j.term_count - t0) - 1;
+          }
+          break;
+        case FAM_GENERIC:
+          for (unsigned t = 0; t < j.term_count; ++t)
+            if (P.vterms[j.term_first + t].base == 0xffff) ++direct_terms; else ++loose_table_terms;
+          break;
+        default: break;
+      }
     }
     inversion_groups += (st.deferred.size() + 31) / 32;
   }
   for (auto& t : P.vterms) table_terms += t.base != 0xffff;
   for (auto& l : P.derive_levels) derived += l.size();
-  char tmp[1536];
+  char tmp[2048];
   snprintf(tmp, sizeof tmp,
            "{\"stride\": %zu, \"wire_points\": %zu, \"wire_scalars\": %zu, \"derived_points\": %zu, \"derive_terms\": %zu, \"bases\": %zu, "
            "\"stages\": %zu, \"jobs\": %zu, \"jobs_per_stage\": [%s], \"var_terms\": %zu, \"table_terms\": %zu, "
            "\"combs\": %zu, \"deferred\": %zu, \"plain_encodes\": %zu, \"inversion_groups\": %zu, "
+           "\"single_table_jobs\": %zu, \"chains\": %zu, \"chain_extra_terms\": %zu, \"loose_table_terms\": %zu, \"direct_terms\": %zu, "
            "\"hash_programs\": %zu, \"prefixes\": %d, \"flags\": %d, \"rules\": %zu, \"tally_slots\": %zu}",
            P.stride, P.pt_items.size(), P.sc_items.size(), derived, derive_terms, P.base_slots.size(), P.stages.size(), jobs, per_stage.c_str(),
-           var_terms, table_terms, combs, deferred, plain_encodes, inversion_groups, insts, P.n_prefixes, P.n_flag_slots, P.rules.size(),
+           var_terms, table_terms, combs, deferred, plain_encodes, inversion_groups, jobs_table1, chains, chain_extra_terms,
+           loose_table_terms, direct_terms, insts, P.n_prefixes, P.n_flag_slots, P.rules.size(),
            P.tally_slots.size());
   if (strlen(tmp) + 1 > cap) return fail(EG_ERR_BAD_ARG, "buffer too small");
   memcpy(buf, tmp, strlen(tmp) + 1);
@@ -916,20 +978,24 @@ int eg_plan_describe(int kind, int n_options, uint64_t credits_or_bound, char* b
 }
 
 // ---- synthetic ballots ---------------------------------------------------------------------------------------------------------
-int eg_choice_encrypt_batch_device(eg_choice_params* p, uint64_t base_seed, size_t first, size_t n, int n_selected, void* d_out,
-                                   void* stream) { EG_LOCK_P(p);
-  if (!p || (n && !d_out)) return fail(EG_ERR_BAD_ARG, "bad argument");
+static int choice_encrypt_device(eg_choice_params* p, uint64_t base_seed, size_t first, size_t n, int n_selected,
+                                 const void* d_selection, uint64_t rng_skip, void* d_out, hipStream_t s) {
   Engine* e = p->eng;
   HIPCHK(hipSetDevice(e->ctx->device));
-  hipStream_t s = (hipStream_t)stream;
-  if (!p->single && (n_selected < 0 || n_selected > p->n_options)) return fail(EG_ERR_BAD_ARG, "n_selected out of range");
+  if (!d_selection && !p->single && (n_selected < 0 || n_selected > p->n_options)) return fail(EG_ERR_BAD_ARG, "n_selected out of range");
   if (n == 0) return EG_OK;
   if (p->n_options > 32) return fail(EG_ERR_BAD_ARG, "the generator supports at most 32 options");
-  eg_launch_choice_encrypt(grid_for(n, e->ctx->cus * 4), s, base_seed + first, n, p->n_options, p->single, n_selected, e->ctx->tabG,
+  eg_launch_choice_encrypt(grid_for(n, e->ctx->cus * 4), s, base_seed + first, n, p->n_options, p->single, n_selected,
+                           reinterpret_cast<const u32*>(d_selection), rng_skip, e->ctx->tabG,
                            e->d_tabK, e->d_prefixes, e->plan.gen_pre_main, e->plan.gen_pre_ring, e->plan.gen_pre_logeq,
                            reinterpret_cast<u32*>(d_out), (u32)(e->plan.stride / 4));
   HIPCHK(hipGetLastError());
   return EG_OK;
+}
+int eg_choice_encrypt_batch_device(eg_choice_params* p, uint64_t base_seed, size_t first, size_t n, int n_selected, void* d_out,
+                                   void* stream) { EG_LOCK_P(p);
+  if (!p || (n && !d_out)) return fail(EG_ERR_BAD_ARG, "bad argument");
+  return choice_encrypt_device(p, base_seed, first, n, n_selected, nullptr, 0, d_out, (hipStream_t)stream);
 }
 int eg_choice_encrypt_batch(eg_choice_params* p, uint64_t base_seed, size_t first, size_t n, int n_selected, uint8_t* out) { EG_LOCK_P(p);
   if (!p || (n && !out)) return fail(EG_ERR_BAD_ARG, "bad argument");
@@ -937,16 +1003,37 @@ int eg_choice_encrypt_batch(eg_choice_params* p, uint64_t base_seed, size_t firs
   HIPCHK(hipSetDevice(e->ctx->device));
   DevBuf d;
   TRY(d.alloc(n * e->plan.stride));
-  TRY(eg_choice_encrypt_batch_device(p, base_seed, first, n, n_selected, d.p, e->ctx->stream));
+  TRY(choice_encrypt_device(p, base_seed, first, n, n_selected, nullptr, 0, d.p, e->ctx->stream));
   TRY(d.get(out, n * e->plan.stride, e->ctx->stream));
   HIPCHK(hipStreamSynchronize(e->ctx->stream));
   return EG_OK;
 }
-int eg_qv_encrypt_batch_device(eg_qv_params* p, uint64_t base_seed, size_t first, size_t n, void* d_out, void* stream) { EG_LOCK_P(p);
-  if (!p || (n && !d_out)) return fail(EG_ERR_BAD_ARG, "bad argument");
+int eg_choice_encrypt_selected_batch_device(eg_choice_params* p, uint64_t base_seed, size_t first, size_t n, uint64_t rng_skip,
+                                            const void* d_selection, void* d_out, void* stream) { EG_LOCK_P(p);
+  if (!p || (n && (!d_out || !d_selection))) return fail(EG_ERR_BAD_ARG, "bad argument");
+  return choice_encrypt_device(p, base_seed, first, n, 0, d_selection, rng_skip, d_out, (hipStream_t)stream);
+}
+int eg_choice_encrypt_selected_batch(eg_choice_params* p, uint64_t base_seed, size_t first, size_t n, uint64_t rng_skip,
+                                     const uint32_t* selection, uint8_t* out) { EG_LOCK_P(p);
+  if (!p || (n && (!out || !selection))) return fail(EG_ERR_BAD_ARG, "bad argument");
   Engine* e = p->eng;
   HIPCHK(hipSetDevice(e->ctx->device));
-  hipStream_t s = (hipStream_t)stream;
+  for (size_t i = 0; i < n; ++i) {      // what EncryptedChoice::single / ::new would refuse or mis-prove
+    if (p->n_options < 32 && (selection[i] >> p->n_options)) return fail(EG_ERR_BAD_ARG, "selection has bits beyond the options");
+    if (p->single && __builtin_popcount(selection[i]) != 1) return fail(EG_ERR_BAD_ARG, "a single-choice ballot selects exactly one option");
+  }
+  DevBuf d, sel;
+  TRY(d.alloc(n * e->plan.stride)); TRY(sel.alloc(n * 4));
+  TRY(sel.put(selection, n * 4, e->ctx->stream));
+  TRY(choice_encrypt_device(p, base_seed, first, n, 0, sel.p, rng_skip, d.p, e->ctx->stream));
+  TRY(d.get(out, n * e->plan.stride, e->ctx->stream));
+  HIPCHK(hipStreamSynchronize(e->ctx->stream));
+  return EG_OK;
+}
+static int qv_encrypt_device(eg_qv_params* p, uint64_t base_seed, size_t first, size_t n, const void* d_votes, uint64_t rng_skip,
+                             void* d_out, hipStream_t s) {
+  Engine* e = p->eng;
+  HIPCHK(hipSetDevice(e->ctx->device));
   const eghost::QvShape& sh = p->shape;
   if (p->n_options > 16 || sh.vote_range.rings.size() > 4 || sh.credit_range.rings.size() > 4)
     return fail(EG_ERR_BAD_ARG, "the generator supports at most 16 options and 4 rings per range");
@@ -960,9 +1047,66 @@ int eg_qv_encrypt_batch_device(eg_qv_params* p, uint64_t base_seed, size_t first
   };
   const std::vector<int> v = pack(sh.vote_range, e->plan.gen_vote_main, e->plan.gen_vote_ring);
   const std::vector<int> c = pack(sh.credit_range, e->plan.gen_credit_main, e->plan.gen_credit_ring);
-  eg_launch_qv_encrypt(grid_for(n, e->ctx->cus * 4), s, base_seed + first, n, p->n_options, p->credits, v.data(), c.data(),
+  eg_launch_qv_encrypt(grid_for(n, e->ctx->cus * 4), s, base_seed + first, n, p->n_options, p->credits,
+                       reinterpret_cast<const u32*>(d_votes), rng_skip, v.data(), c.data(),
                        e->plan.gen_pre_sumsq, e->ctx->tabG, e->d_tabK, e->d_prefixes, reinterpret_cast<u32*>(d_out),
                        (u32)(sh.ballot_size / 4), (u32)(sh.vote_size / 4), (u32)(sh.credit_size / 4));
+  HIPCHK(hipGetLastError());
+  return EG_OK;
+}
+int eg_qv_encrypt_batch_device(eg_qv_params* p, uint64_t base_seed, size_t first, size_t n, void* d_out, void* stream) { EG_LOCK_P(p);
+  if (!p || (n && !d_out)) return fail(EG_ERR_BAD_ARG, "bad argument");
+  return qv_encrypt_device(p, base_seed, first, n, nullptr, 0, d_out, (hipStream_t)stream);
+}
+int eg_qv_encrypt_votes_batch_device(eg_qv_params* p, uint64_t base_seed, size_t first, size_t n, uint64_t rng_skip,
+                                     const void* d_votes, void* d_out, void* stream) { EG_LOCK_P(p);
+  if (!p || (n && (!d_out || !d_votes))) return fail(EG_ERR_BAD_ARG, "bad argument");
+  return qv_encrypt_device(p, base_seed, first, n, d_votes, rng_skip, d_out, (hipStream_t)stream);
+}
+int eg_qv_encrypt_votes_batch(eg_qv_params* p, uint64_t base_seed, size_t first, size_t n, uint64_t rng_skip, const uint32_t* votes,
+                              uint8_t* out) { EG_LOCK_P(p);
+  if (!p || (n && (!out || !votes))) return fail(EG_ERR_BAD_ARG, "bad argument");
+  Engine* e = p->eng;
+  HIPCHK(hipSetDevice(e->ctx->device));
+  const uint64_t max_vote = eghost::isqrt(p->credits);
+  for (size_t i = 0; i < n; ++i) {      // the assertions of QuadraticVotingBallot::new (quadratic_voting.rs:240-253)
+    uint64_t credit = 0;
+    for (int k = 0; k < p->n_options; ++k) {
+      const uint64_t v = votes[i * (size_t)p->n_options + k];
+      if (v > max_vote) return fail(EG_ERR_BAD_ARG, "a vote exceeds isqrt(credits)");
+      credit += v * v;
+    }
+    if (credit > p->credits) return fail(EG_ERR_BAD_ARG, "votes exceed the credit amount");
+  }
+  DevBuf d, vv;
+  TRY(d.alloc(n * e->plan.stride)); TRY(vv.alloc(n * (size_t)p->n_options * 4));
+  TRY(vv.put(votes, n * (size_t)p->n_options * 4, e->ctx->stream));
+  TRY(qv_encrypt_device(p, base_seed, first, n, vv.p, rng_skip, d.p, e->ctx->stream));
+  TRY(d.get(out, n * e->plan.stride, e->ctx->stream));
+  HIPCHK(hipStreamSynchronize(e->ctx->stream));
+  return EG_OK;
+}
+
+// ---- Merlin transcripts as a primitive (merlin 3.0.0 via src/proofs/mod.rs:39-57): known-answer tests on the device ----------
+int eg_merlin_challenge_batch(eg_ctx* c, size_t n, const char* proto, size_t proto_len, const char* msg_label, size_t msg_label_len,
+                              const uint8_t* msgs, size_t msg_len, const char* chal_label, size_t chal_label_len, uint8_t* out,
+                              size_t out_len) { EG_LOCK(c);
+  if (!c || !proto || !msg_label || !chal_label || (n && (!out || (msg_len && !msgs)))) return fail(EG_ERR_BAD_ARG, "bad argument");
+  if (proto_len > 255 || msg_label_len > 255 || chal_label_len > 255 || out_len == 0 || out_len > 1024 || msg_len > (1u << 20))
+    return fail(EG_ERR_BAD_ARG, "labels up to 255 bytes, challenges of 1..1024 bytes, messages up to 1 MiB");
+  if (n == 0) return EG_OK;
+  HIPCHK(hipSetDevice(c->device));
+  std::vector<uint8_t> labels;
+  labels.insert(labels.end(), proto, proto + proto_len);
+  labels.insert(labels.end(), msg_label, msg_label + msg_label_len);
+  labels.insert(labels.end(), chal_label, chal_label + chal_label_len);
+  DevBuf l, m, o;
+  TRY(l.alloc(labels.size())); TRY(m.alloc(n * msg_len)); TRY(o.alloc(n * out_len));
+  TRY(l.put(labels.data(), labels.size(), c->stream)); TRY(m.put(msgs, n * msg_len, c->stream));
+  hipLaunchKernelGGL(k_prim_merlin, dim3(blocks_of(n)), dim3(NT), 0, c->stream, n, (const unsigned char*)l.p, (int)proto_len,
+                     (int)msg_label_len, (int)chal_label_len, (const unsigned char*)m.p, (int)msg_len, (unsigned char*)o.p, (int)out_len);
+  TRY(o.get(out, n * out_len, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(hipGetLastError());
   return EG_OK;
 }

@@ -422,8 +422,8 @@ EG_HD void ge_var_mul(ge& acc, TableIO& io, const u32 digits[8]) {
 #define EG_TEETH_COLS 43
 #define EG_TEETH_ENTRIES 32
 
-// rows[j] = the 43 sign bits of tooth j, left-aligned (bit 63 = column 42)
-EG_HD void sc_recode_teeth(u64 rows[EG_TEETH], const u32 s[8]) {
+// sg = the 258 sign bits of the multiplier (sg bit i <=> s_i = +1): (k_odd >> 1) with bit 257 set, k_odd = k or k + l
+EG_HD void sc_teeth_signs(u32 sg[9], const u32 s[8]) {
   const u32 l[8] = EG_L_WORDS;
   const bool even = (s[0] & 1u) == 0;
   u32 t[8];
@@ -434,11 +434,15 @@ EG_HD void sc_recode_teeth(u64 rows[EG_TEETH], const u32 s[8]) {
     t[i] = (u32)v;
     carry = v >> 32;          // no carry out of word 7: s < 2^254
   }
-  u32 sg[9];                  // sign bits: (k >> 1) with bit 257 set
 #pragma unroll
   for (int i = 0; i < 7; ++i) sg[i] = (t[i] >> 1) | (t[i + 1] << 31);
   sg[7] = t[7] >> 1;
   sg[8] = 2u;
+}
+// rows[j] = the 43 sign bits of tooth j, left-aligned (bit 63 = column 42)
+EG_HD void sc_recode_teeth(u64 rows[EG_TEETH], const u32 s[8]) {
+  u32 sg[9];
+  sc_teeth_signs(sg, s);
 #pragma unroll
   for (int j = 0; j < EG_TEETH; ++j) {
     const int off = EG_TEETH_COLS * j, wi = off >> 5, sh = off & 31;
@@ -446,6 +450,21 @@ EG_HD void sc_recode_teeth(u64 rows[EG_TEETH], const u32 s[8]) {
     if (sh + EG_TEETH_COLS > 64) v |= (u64)sg[wi + 2] << (64 - sh);
     rows[j] = (v & ((1ull << EG_TEETH_COLS) - 1ull)) << (64 - EG_TEETH_COLS);
   }
+}
+// column c of a sign vector read word by word through `word(i)` (the multi-term kernel keeps the vectors in LDS): table entry
+// index and whether the entry is negated.  Bit positions are the same in every lane, so the word index is wave-uniform.
+template <class WordFn>
+EG_HD void sc_teeth_column(WordFn word, int c, int& idx, bool& neg) {
+  u32 m = 0;
+#pragma unroll
+  for (int j = 0; j < EG_TEETH - 1; ++j) {
+    const int q = EG_TEETH_COLS * j + c;
+    m |= ((word(q >> 5) >> (q & 31)) & 1u) << j;
+  }
+  const int qt = EG_TEETH_COLS * (EG_TEETH - 1) + c;
+  const bool top = ((word(qt >> 5) >> (qt & 31)) & 1u) != 0;
+  idx = (int)(top ? m : (m ^ (EG_TEETH_ENTRIES - 1)));
+  neg = !top;
 }
 // pops the next column (from column 42 downwards): table entry index and whether the entry is negated
 EG_HD void sc_teeth_next(u64 rows[EG_TEETH], int& idx, bool& neg) {
@@ -510,20 +529,29 @@ EG_HD void ge_teeth_tables_build(TableIO& io, TmpIO& tmp, const ge& p) {
 
 // acc = [k]P from the teeth table; rows = sc_recode_teeth(k) (consumed).  A column's entry is requested before the doubling and
 // used after it, which hides the load without a second entry buffer (an explicit one-column-ahead prefetch measured -0.4 %).
+// The first column is not added to the identity: +-entry = (Y+X, Y-X, 2Z, ..) IS the point (2X : 2Y : 2Z) in projective
+// coordinates, and the operation that follows is a doubling, which does not read T (saves one 8-multiplication addition).
 template <class TableIO>
 EG_HD void ge_teeth_mul(ge& acc, TableIO& io, u64 rows[EG_TEETH]) {
-  ge_identity(acc);
+  {
+    int idx; bool neg;
+    sc_teeth_next(rows, idx, neg);
+    ge_cached cur;
+    io.load(cur, idx);
+    fe t = cur.YpX; fe_cmov(cur.YpX, cur.YmX, neg); fe_cmov(cur.YmX, t, neg);   // -(x, y) = (-x, y)
+    fe_sub4(acc.X, cur.YpX, cur.YmX); fe_carry(acc.X);    // 2X
+    fe_add(acc.Y, cur.YpX, cur.YmX); fe_carry(acc.Y);     // 2Y
+    acc.Z = cur.Z2;                                       // 2Z [2]
+  }
 #pragma unroll 1
-  for (int c = EG_TEETH_COLS - 1; c >= 0; --c) {
+  for (int c = EG_TEETH_COLS - 2; c >= 0; --c) {
     int idx; bool neg;
     sc_teeth_next(rows, idx, neg);
     ge_cached cur;
     io.load(cur, idx);
     ge_p1p1 t;
-    if (c != EG_TEETH_COLS - 1) {
-      ge_dbl(t, acc.X, acc.Y, acc.Z);
-      ge_dbl_to_p3(acc, t);
-    }
+    ge_dbl(t, acc.X, acc.Y, acc.Z);
+    ge_dbl_to_p3(acc, t);
     ge_cached_cneg(cur, neg);
     ge_add(t, acc, cur);
     if (c > 0) {                          // next operation is a doubling: T is not needed (saves one multiplication)
@@ -531,6 +559,37 @@ EG_HD void ge_teeth_mul(ge& acc, TableIO& io, u64 rows[EG_TEETH]) {
       acc.X = q.X; acc.Y = q.Y; acc.Z = q.Z;
     } else {
       ge_add_to_p3(acc, t);
+    }
+  }
+}
+
+// acc = sum_t [k_t]P_t for bases that all have teeth tables, with ONE chain of 42 doublings shared by every term (Straus /
+// interleaved evaluation, the structure dalek uses for vartime_multi_mul, ristretto.rs:139-145): per column one doubling and
+// one addition per term.  column(t, c, idx, neg) yields term t's entry for column c; load(t, idx, entry) fetches it.
+template <class ColumnFn, class LoadFn>
+EG_HD void ge_teeth_mul_multi(ge& acc, int n_terms, ColumnFn column, LoadFn load) {
+  ge_identity(acc);
+#pragma unroll 1
+  for (int c = EG_TEETH_COLS - 1; c >= 0; --c) {
+    ge_p1p1 t;
+    if (c != EG_TEETH_COLS - 1) {
+      ge_dbl(t, acc.X, acc.Y, acc.Z);
+      ge_dbl_to_p3(acc, t);
+    }
+#pragma unroll 1
+    for (int k = 0; k < n_terms; ++k) {
+      int idx; bool neg;
+      column(k, c, idx, neg);
+      ge_cached cur;
+      load(k, idx, cur);
+      ge_cached_cneg(cur, neg);
+      ge_add(t, acc, cur);
+      if (k + 1 == n_terms && c > 0) {    // a doubling follows: T is not needed
+        ge_p2 q; ge_add_to_p2(q, t);
+        acc.X = q.X; acc.Y = q.Y; acc.Z = q.Z;
+      } else {
+        ge_add_to_p3(acc, t);
+      }
     }
   }
 }

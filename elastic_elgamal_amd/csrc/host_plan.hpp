@@ -188,10 +188,17 @@ struct Plan {
   }
 };
 
+// [a](P_1 + .. + P_m) as m table-backed terms with the same multiplier: the equation kernels evaluate all table-backed terms of
+// an equation on ONE doubling chain (k_eq_table<true>), so a term costs 43 additions, against 252 doublings + 71 additions for a
+// ladder over the sum itself.  Used where the reference multiplies a ciphertext that is, component-wise, the sum of ring
+// ciphertexts (mul.rs:207-247 on the vote / credit ciphertexts of a range proof).
+inline void push_sum_terms(Plan& P, std::vector<VarTerm>& out, const std::vector<uint16_t>& slots, ScalarSrc sc) {
+  for (uint16_t s : slots) out.push_back(P.bterm(s, sc));
+}
+
 inline ScalarSrc wire_src(uint16_t item, bool neg = false) { return ScalarSrc{SRC_WIRE, (uint8_t)neg, item, 0}; }
 inline ScalarSrc chal_src(uint16_t slot, bool neg = false) { return ScalarSrc{SRC_CHAL, (uint8_t)neg, slot, 0}; }
 inline ScalarSrc no_src() { return ScalarSrc{SRC_NONE, 0, 0, 0}; }
-inline ScalarSrc times(ScalarSrc s, uint64_t m) { s.mul = (uint32_t)m; return s; }
 
 // one ring of a RingProof
 struct RingIn {
@@ -237,13 +244,16 @@ inline uint16_t add_ring_proof(Plan& P, const std::vector<HashOp>& setup, const 
     for (size_t j = 0; j < s; ++j) {
       // R_G = [s]G - [e]R ;  R_K = [s]K - [e](B - x_j) = [s]K + [e m_j]G - [e]B  with x_j = [m_j]G   (ring.rs:338-350).
       // Folding x_j into the generator term keeps B itself as the only variable base of the ring's K side, so the
-      // comb tables of R and B are shared by all equations of the ring.
+      // comb tables of R and B are shared by all equations of the ring.  x_0 = O, so the folded multiplier e m_j is only ever
+      // needed for a DERIVED challenge: the transcript kernel stores it next to the challenge (OP_CHALLENGE, slot + 1).
       const ScalarSrc e_pos = j == 0 ? wire_src(challenge_item) : chal_src(chal);
       ScalarSrc e = e_pos;
       e.neg = 1;
       const ScalarSrc resp = wire_src((uint16_t)(r.resp_item + j));
       const uint16_t cg = P.job(first_stage + j, {P.bterm(r.ptR, e)}, resp, no_src());
-      const ScalarSrc fold = r.admissible[j] != 0 ? times(e_pos, r.admissible[j]) : no_src();
+      ScalarSrc fold = no_src();
+      if (r.admissible[j] == 1) fold = e_pos;
+      else if (r.admissible[j] > 1) fold = chal_src((uint16_t)(chal + 1));      // j >= 1 here: admissible[0] == 0
       const uint16_t ck = P.job(first_stage + j, {P.bterm(r.ptB, e)}, fold, resp);
       if (j + 1 < s) {   // ring.rs:354-360
         std::vector<HashOp> ops;
@@ -260,7 +270,9 @@ inline uint16_t add_ring_proof(Plan& P, const std::vector<HashOp>& setup, const 
         ops.push_back({OP_APPEND_CMP, P.ref("R_G"), cg, 0xffff});
         ops.push_back({OP_APPEND_CMP, P.ref("R_K"), ck, 0xffff});
         chal = P.new_chal();
-        ops.push_back({OP_CHALLENGE, P.ref("c"), chal, 0});
+        const uint64_t m_next = r.admissible[j + 1];
+        if (m_next > 1) (void)P.new_chal();                       // slot chal + 1 receives m_next * challenge
+        ops.push_back({OP_CHALLENGE, P.ref("c"), chal, (uint32_t)(m_next > 1 ? m_next : 0)});
         P.stage(first_stage + j).insts.push_back(ops);
       } else {
         terminal[ri] = {cg, ck};
@@ -309,8 +321,19 @@ inline Plan build_choice_plan(int n, bool single) {
                                  {OP_SAVE_PREFIX, 0, pre, 0}});
     // LogEqualityProof::verify (log_equality.rs:153-180)
     const ScalarSrc c = wire_src(sum_items, true), s = wire_src((uint16_t)(sum_items + 1));
-    const uint16_t xg = P.job(0, {P.term(p0, c)}, s, no_src());
-    const uint16_t xk = P.job(0, {P.term(p1, c)}, no_src(), s);
+    uint16_t xg, xk;
+    if (n <= 4) {
+      // few options: [-c](sum R_k) and [-c](sum B_k - G) = sum [-c]B_k + [c]G over the comb tables the rings need anyway,
+      // all terms on one doubling chain (42 doublings + 43 n additions, against 252 + 71 for a ladder over the sum)
+      std::vector<VarTerm> tg, tk;
+      push_sum_terms(P, tg, R, c);
+      push_sum_terms(P, tk, B, c);
+      xg = P.job(0, tg, s, no_src());
+      xk = P.job(0, tk, wire_src(sum_items), s);
+    } else {
+      xg = P.job(0, {P.term(p0, c)}, s, no_src());
+      xk = P.job(0, {P.term(p1, c)}, no_src(), s);
+    }
     const uint16_t e0 = P.encode_job(0, p0), e1 = P.encode_job(0, p1);
     sum_flag = P.new_flag();
     P.stage(0).insts.push_back({{OP_LOAD_PREFIX, 0, pre, 0},
@@ -336,7 +359,12 @@ inline Plan build_choice_plan(int n, bool single) {
 }
 
 // ---- RangeProof::verify (range.rs:547-577) on items [first_item ...): ct(2) partials(2(r-1)) e0 responses ------------------
-struct RangeOut { uint16_t flag; uint16_t ctR, ctB; uint16_t n_items; int pre_main, pre_ring; };
+struct RangeOut {
+  uint16_t flag; uint16_t ctR, ctB; uint16_t n_items; int pre_main, pre_ring;
+  // the ring ciphertexts (partials, then last = ct - sum(partials), range.rs:564-572): ct = sum of them, component-wise, and
+  // every one of them is a ring base with a comb table
+  std::vector<uint16_t> ringR, ringB;
+};
 inline RangeOut add_range_proof(Plan& P, const RangeDecomposition& d, const std::string& label, uint16_t first_item) {
   const int nr = (int)d.rings.size();
   RangeOut out;
@@ -377,6 +405,7 @@ inline RangeOut add_range_proof(Plan& P, const RangeDecomposition& d, const std:
                                      {OP_APPEND_BLOB, P.ref("dom-sep"), P.ref("encryption_range_proof"), 0},
                                      {OP_APPEND_BLOB, P.ref("range"), P.ref(d.to_string()), 0}};   // range.rs:561-562
   out.flag = add_ring_proof(P, setup, rings, chal_item, 0, &out.pre_main, &out.pre_ring);
+  out.ringR = pR; out.ringB = pB;
   return out;
 }
 
@@ -429,18 +458,21 @@ inline Plan build_qv_plan(int n, uint64_t credits) {
   uint16_t vitem = 0;
   for (int i = 0; i < n; ++i) {
     const ScalarSrc s_r = wire_src((uint16_t)(c_item + 1 + 2 * i)), s_x = wire_src((uint16_t)(c_item + 2 + 2 * i));
-    const uint16_t er = P.job(0, {P.term(votes[i].ctR, neg_c)}, s_r, no_src());                 // mul.rs:213-217
-    const uint16_t ex = P.job(0, {P.term(votes[i].ctB, neg_c)}, s_x, s_r);                      // mul.rs:219-226
+    std::vector<VarTerm> tr, tx;
+    push_sum_terms(P, tr, votes[i].ringR, neg_c);
+    push_sum_terms(P, tx, votes[i].ringB, neg_c);
+    const uint16_t er = P.job(0, tr, s_r, no_src());                                            // mul.rs:213-217
+    const uint16_t ex = P.job(0, tx, s_x, s_r);                                                 // mul.rs:219-226
     ops.push_back({OP_APPEND_WIRE, P.ref("R_x"), vitem, 1});
     ops.push_back({OP_APPEND_WIRE, P.ref("X"), (uint32_t)(vitem + 1), 1});
     ops.push_back({OP_APPEND_CMP, P.ref("[e_r]G"), er, 0xffff});
     ops.push_back({OP_APPEND_CMP, P.ref("[e_x]G + [e_r]K"), ex, 0xffff});
-    trz.push_back(P.term(votes[i].ctR, s_x));
-    tz.push_back(P.term(votes[i].ctB, s_x));
+    push_sum_terms(P, trz, votes[i].ringR, s_x);
+    push_sum_terms(P, tz, votes[i].ringB, s_x);
     vitem = (uint16_t)(vitem + votes[i].n_items);
   }
-  trz.push_back(P.term(credit.ctR, neg_c));
-  tz.push_back(P.term(credit.ctB, neg_c));
+  push_sum_terms(P, trz, credit.ringR, neg_c);
+  push_sum_terms(P, tz, credit.ringB, neg_c);
   const uint16_t erz = P.job(0, trz, wire_src(sz_item), no_src());   // mul.rs:232-240
   const uint16_t ez = P.job(0, tz, no_src(), wire_src(sz_item));     // mul.rs:241-247
   ops.push_back({OP_APPEND_WIRE, P.ref("R_z"), vitem, 1});
@@ -496,6 +528,53 @@ inline Plan build_range_plan(uint64_t upper_bound, size_t* item_size) {   // ct 
   P.stride = (size_t)r.n_items * 32;
   if (item_size) *item_size = P.stride;
   P.rules.push_back({r.flag, 6});
+  return P;
+}
+
+// ---- SumOfSquaresProof::verify (mul.rs:190-260) on its own, with the caller's transcript label --------------------------------
+// item = n value ciphertexts (64 each) || sum-of-squares ciphertext (64) || challenge || 2n ciphertext responses || sum response.
+// Every ciphertext element is multiplied twice (once per-ciphertext, once in the (n+2)-term equations), so all of them get comb
+// tables and the two long equations run on one doubling chain each.
+inline Plan build_sumsq_plan(int n, const std::string& label, size_t* item_size) {
+  Plan P;
+  P.stride = (size_t)64 * (n + 1) + 32 * (size_t)(2 * n + 2);
+  if (item_size) *item_size = P.stride;
+  std::vector<uint16_t> R(n + 1), X(n + 1);
+  for (int i = 0; i <= n; ++i) { R[i] = P.wire_point((uint16_t)(2 * i)); X[i] = P.wire_point((uint16_t)(2 * i + 1)); }
+  const uint16_t c_item = (uint16_t)(2 * (n + 1));
+  for (int i = 0; i < 2 * n + 2; ++i) P.wire_scalar((uint16_t)(c_item + i));
+  const uint16_t sz_item = (uint16_t)(c_item + 1 + 2 * n);
+  const uint32_t pre = P.new_prefix();
+  P.prefix_programs.push_back({{OP_NEW, P.ref(label), 0, 0},
+                               {OP_APPEND_BLOB, P.ref("dom-sep"), P.ref("sum_of_squares"), 0},
+                               {OP_APPEND_BLOB, P.ref("K"), P.pk_ref(), 0},
+                               {OP_SAVE_PREFIX, 0, pre, 0}});
+  std::vector<HashOp> ops{{OP_LOAD_PREFIX, 0, pre, 0}};
+  const ScalarSrc neg_c = wire_src(c_item, true);
+  std::vector<VarTerm> trz, tz;
+  for (int i = 0; i < n; ++i) {
+    const ScalarSrc s_r = wire_src((uint16_t)(c_item + 1 + 2 * i)), s_x = wire_src((uint16_t)(c_item + 2 + 2 * i));
+    const uint16_t er = P.job(0, {P.bterm(R[i], neg_c)}, s_r, no_src());      // mul.rs:213-217
+    const uint16_t ex = P.job(0, {P.bterm(X[i], neg_c)}, s_x, s_r);           // mul.rs:219-226
+    ops.push_back({OP_APPEND_WIRE, P.ref("R_x"), (uint32_t)(2 * i), 1});
+    ops.push_back({OP_APPEND_WIRE, P.ref("X"), (uint32_t)(2 * i + 1), 1});
+    ops.push_back({OP_APPEND_CMP, P.ref("[e_r]G"), er, 0xffff});
+    ops.push_back({OP_APPEND_CMP, P.ref("[e_x]G + [e_r]K"), ex, 0xffff});
+    trz.push_back(P.bterm(R[i], s_x));
+    tz.push_back(P.bterm(X[i], s_x));
+  }
+  trz.push_back(P.bterm(R[n], neg_c));
+  tz.push_back(P.bterm(X[n], neg_c));
+  const uint16_t erz = P.job(0, trz, wire_src(sz_item), no_src());   // mul.rs:232-240
+  const uint16_t ez = P.job(0, tz, no_src(), wire_src(sz_item));     // mul.rs:241-247
+  ops.push_back({OP_APPEND_WIRE, P.ref("R_z"), (uint32_t)(2 * n), 1});
+  ops.push_back({OP_APPEND_WIRE, P.ref("Z"), (uint32_t)(2 * n + 1), 1});
+  ops.push_back({OP_APPEND_CMP, P.ref("[e_x]R_x + [e_z]G"), erz, 0xffff});
+  ops.push_back({OP_APPEND_CMP, P.ref("[e_x]X + [e_z]K"), ez, 0xffff});
+  const uint16_t flag = P.new_flag();
+  ops.push_back({OP_CHALLENGE_CHECK, P.ref("c"), c_item, flag});
+  P.stage(0).insts.push_back(ops);
+  P.rules.push_back({flag, 12 /* EG_ST_QV_CREDIT_EQUIV_CHALLENGE: ChallengeMismatch of the sum-of-squares proof */});
   return P;
 }
 

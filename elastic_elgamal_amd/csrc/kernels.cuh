@@ -12,7 +12,7 @@
 //
 // Kernels and what bounds them (DESIGN.md has the numbers):
 //   k_decode_points / k_check_scalars / k_derive_points   VALU (1 inverse square root per point)
-//   k_msm_jobs     VALU-bound integer multiply-add: the dominant kernel (>90 % of the time)
+//   k_base_tables / k_eq_table / k_eq_generic   VALU-bound integer multiply-add: >90 % of the time
 //   k_hash         LDS + VALU (Keccak-f[1600])
 //   k_status, k_tally_*   trivial
 #pragma once
@@ -28,14 +28,6 @@ __device__ __forceinline__ void load_scalar(u32 s[8], const EngineBufs& B, u32 b
   if (src.neg) { u32 t[8]; sc_neg(t, s);
 #pragma unroll
     for (int i = 0; i < 8; ++i) s[i] = t[i]; }
-  if (src.mul > 1u) {
-    u32 m[8], t[8];
-    const u32 z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    sc_from_u64(m, (u64)src.mul);
-    sc_muladd(t, s, m, z);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) s[i] = t[i];
-  }
   if (halve) { u32 t[8]; sc_halve(t, s);
 #pragma unroll
     for (int i = 0; i < 8; ++i) s[i] = t[i]; }
@@ -108,31 +100,95 @@ __global__ void __launch_bounds__(NT, 2) k_base_tables(EngineBufs B, const unsig
   }
 }
 
-// ---- k_msm_jobs: out = encode( sum_i [a_i]P_i + [g]G + [k]K ) -----------------------------------------------------------------
-// One lane = one group equation of one ballot: vartime_double_mul_generator / vartime_multi_mul followed by
-// serialize_element (ring.rs:342-350, log_equality.rs:160-164, mul.rs:213-247 + proofs/mod.rs:48-52).
-// Persistent blocks stride over (class, ballot); lanes of a wave share the class, so control flow is uniform.
-__global__ void __launch_bounds__(NT, 2) k_msm_jobs(EngineBufs B, const egplan::JobClass* classes,
-                                                    const egplan::VarTerm* terms, int class_first, int n_classes) {
-  const size_t total = (size_t)n_classes * B.n;
-  WsTable tab;
-  tab.init(B.ws);
+// ---- group equations: P = sum_i [a_i]P_i + [g]G + [k]K (halved scalars; k_encode_batch then emits encode(2P)) ------------------
+// One lane = one group equation of one ballot: vartime_double_mul_generator / vartime_multi_mul (ring.rs:342-350,
+// log_equality.rs:160-164, mul.rs:213-247).  Persistent blocks stride over (class, ballot); lanes of a wave share the class, so
+// control flow is uniform.  The equations are split by shape into kernels whose live registers fit the file without scratch
+// (one kernel carrying every shape spilled 159 VGPRs):
+//   k_eq_table<false>  one variable base with a comb table (every ring equation) + the fixed-base combs   -- the dominant kernel
+//   k_eq_table<true>   several table-backed bases evaluated on ONE doubling chain (Straus); sign vectors of the scalars in LDS
+//   k_eq_generic       anything else: bases without a table (radix-16 ladder over a per-lane workspace table), any mix of terms
+//   k_encode_plain     serialize_element of points that are not produced by an equation (derived ciphertexts)
+__device__ __forceinline__ void eq_fixed_terms(ge& acc, const EngineBufs& B, u32 b, const egplan::JobClass& jc) {
   const FixedTable tg{B.tabG}, tk{B.tabK};
+  if (jc.g.kind != egplan::SRC_NONE) {
+    u32 s[8], dg[EG_COMB_WORDS];
+    load_scalar(s, B, b, jc.g, true);
+    sc_recode_comb(dg, s);
+    ge_fixed_mul_add(acc, tg, dg);
+  }
+  if (jc.k.kind != egplan::SRC_NONE) {
+    u32 s[8], dg[EG_COMB_WORDS];
+    load_scalar(s, B, b, jc.k, true);
+    sc_recode_comb(dg, s);
+    ge_fixed_mul_add(acc, tk, dg);
+  }
+}
+
+template <bool MULTI>
+__global__ void __launch_bounds__(NT, 2) k_eq_table(EngineBufs B, const egplan::JobClass* classes, const egplan::VarTerm* terms,
+                                                    int class_first, int n_classes, int group) {
+  extern __shared__ u32 eq_signs[];          // MULTI: [group][9][NT] sign vectors of the multipliers (sc_teeth_signs)
+  const size_t total = (size_t)n_classes * B.n;
   for (size_t j = (size_t)blockIdx.x * NT + threadIdx.x; j < total; j += (size_t)gridDim.x * NT) {
     const u32 c = class_first + (u32)(j / B.n), b = (u32)(j % B.n);
     const egplan::JobClass jc = classes[c];
     ge acc;
-    if (jc.term_count == 0) {
-      if (jc.enc_slot != 0xffffu) load_pt(acc, B.pts, B.cap, jc.enc_slot, b);
-      else ge_identity(acc);
+    if (!MULTI) {
+      const egplan::VarTerm vt = terms[jc.term_first];
+      u32 s[8];
+      load_scalar(s, B, b, vt.s, true);
+      u64 rows[EG_TEETH];
+      sc_recode_teeth(rows, s);
+      BaseTable bt{B.btab + ((size_t)vt.base * B.cap + b) * BTAB_QUADS};
+      ge_teeth_mul(acc, bt, rows);
+    } else {
+      // groups of up to `group` terms share a doubling chain (the group size is what fits LDS at two blocks per CU)
+      const int nt = (int)jc.term_count;
+#pragma unroll 1
+      for (int t0 = 0; t0 < nt; t0 += group) {
+        const int m = min(group, nt - t0);
+#pragma unroll 1
+        for (int t = 0; t < m; ++t) {
+          u32 s[8], sg[9];
+          load_scalar(s, B, b, terms[jc.term_first + t0 + t].s, true);
+          sc_teeth_signs(sg, s);
+#pragma unroll
+          for (int w = 0; w < 9; ++w) eq_signs[(t * 9 + w) * NT + threadIdx.x] = sg[w];
+        }
+        ge part;
+        ge_teeth_mul_multi(part, m,
+            [&](int t, int col, int& idx, bool& neg) {
+              sc_teeth_column([&](int w) { return eq_signs[(t * 9 + w) * NT + threadIdx.x]; }, col, idx, neg);
+            },
+            [&](int t, int idx, ge_cached& e) {
+              const BaseTable bt{B.btab + ((size_t)terms[jc.term_first + t0 + t].base * B.cap + b) * BTAB_QUADS};
+              bt.load(e, idx);
+            });
+        if (t0 == 0) acc = part;
+        else { ge sum; ge_add_full(sum, acc, part); acc = sum; }
+      }
     }
+    eq_fixed_terms(acc, B, b, jc);
+    store_pt(B.dpt, B.cap, jc.out_slot, b, acc);       // encoded (as 2 * acc) by k_encode_batch
+  }
+}
+
+__global__ void __launch_bounds__(NT, 2) k_eq_generic(EngineBufs B, const egplan::JobClass* classes,
+                                                      const egplan::VarTerm* terms, int class_first, int n_classes) {
+  const size_t total = (size_t)n_classes * B.n;
+  WsTable tab;
+  tab.init(B.ws);
+  for (size_t j = (size_t)blockIdx.x * NT + threadIdx.x; j < total; j += (size_t)gridDim.x * NT) {
+    const u32 c = class_first + (u32)(j / B.n), b = (u32)(j % B.n);
+    const egplan::JobClass jc = classes[c];
+    ge acc;
+    if (jc.term_count == 0) ge_identity(acc);
 #pragma unroll 1
     for (u32 t = 0; t < jc.term_count; ++t) {
       const egplan::VarTerm vt = terms[jc.term_first + t];
-      ge p;
-      if (vt.base == 0xffffu) load_pt(p, B.pts, B.cap, vt.slot, b);
       u32 s[8];
-      load_scalar(s, B, b, vt.s, jc.defer != 0);
+      load_scalar(s, B, b, vt.s, true);
       ge part;
       if (vt.base != 0xffffu) {
         BaseTable bt{B.btab + ((size_t)vt.base * B.cap + b) * BTAB_QUADS};
@@ -140,6 +196,8 @@ __global__ void __launch_bounds__(NT, 2) k_msm_jobs(EngineBufs B, const egplan::
         sc_recode_teeth(rows, s);
         ge_teeth_mul(part, bt, rows);
       } else {
+        ge p;
+        load_pt(p, B.pts, B.cap, vt.slot, b);
         u32 dg[8];
         sc_recode_radix16(dg, s);
         ge_var_table_build(tab, p);
@@ -148,25 +206,23 @@ __global__ void __launch_bounds__(NT, 2) k_msm_jobs(EngineBufs B, const egplan::
       if (t == 0) acc = part;
       else { ge sum; ge_add_full(sum, acc, part); acc = sum; }
     }
-    if (jc.g.kind != egplan::SRC_NONE) {
-      u32 s[8], dg[EG_COMB_WORDS];
-      load_scalar(s, B, b, jc.g, jc.defer != 0);
-      sc_recode_comb(dg, s);
-      ge_fixed_mul_add(acc, tg, dg);
-    }
-    if (jc.k.kind != egplan::SRC_NONE) {
-      u32 s[8], dg[EG_COMB_WORDS];
-      load_scalar(s, B, b, jc.k, jc.defer != 0);
-      sc_recode_comb(dg, s);
-      ge_fixed_mul_add(acc, tk, dg);
-    }
-    if (jc.defer) {
-      store_pt(B.dpt, B.cap, jc.out_slot, b, acc);     // encoded (as 2 * acc) by k_encode_batch
-    } else {
-      u32 out[8];
-      ristretto_encode(out, acc);
-      store32(B.cmp, B.cap, jc.out_slot, b, out);
-    }
+    eq_fixed_terms(acc, B, b, jc);
+    store_pt(B.dpt, B.cap, jc.out_slot, b, acc);
+  }
+}
+
+// serialize_element (ristretto.rs:88-90) of point slots: the "enc" bytes of derived ciphertexts (range.rs:572), the sum of the
+// choices (choice.rs:83-86).  class: enc_slot -> out_slot.
+__global__ void __launch_bounds__(NT) k_encode_plain(EngineBufs B, const egplan::JobClass* classes, int class_first, int n_classes) {
+  const size_t total = (size_t)n_classes * B.n;
+  for (size_t j = (size_t)blockIdx.x * NT + threadIdx.x; j < total; j += (size_t)gridDim.x * NT) {
+    const u32 c = class_first + (u32)(j / B.n), b = (u32)(j % B.n);
+    const egplan::JobClass jc = classes[c];
+    ge p;
+    load_pt(p, B.pts, B.cap, jc.enc_slot, b);
+    u32 out[8];
+    ristretto_encode(out, p);
+    store32(B.cmp, B.cap, jc.out_slot, b, out);
   }
 }
 
@@ -265,6 +321,13 @@ __global__ void __launch_bounds__(NT) k_hash(EngineBufs B, const egplan::HashIns
         merlin_challenge64(t, label, label_len, wide);
         sc_from_wide(e, wide);
         store32(B.chal, B.cap, op.b, b, e);
+        if (op.c > 1u) {            // m * e for the folded admissible value of the next equation (ring.rs:338)
+          u32 m[8], t[8];
+          const u32 z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+          sc_from_u64(m, (u64)op.c);
+          sc_muladd(t, e, m, z);
+          store32(B.chal, B.cap, op.b + 1u, b, t);
+        }
         break;
       }
       case egplan::OP_CHALLENGE_CHECK: {
@@ -586,6 +649,25 @@ __global__ void __launch_bounds__(NT) k_prim_point_add(size_t n, const u32* a, c
   st8(out + i * 8, o);
   ok[i] = okk ? 1 : 0;
 }
+// Transcript::new(proto); append_message(msg_label, msg_i); challenge_bytes(chal_label, out_len) for n independent messages:
+// the Merlin framing of proofs/mod.rs:39-57 as a primitive, so that known-answer vectors (the upstream merlin KAT) run on the GPU
+__global__ void __launch_bounds__(NT) k_prim_merlin(size_t n, const unsigned char* labels, int proto_len, int msg_label_len,
+                                                    int chal_label_len, const unsigned char* msgs, int msg_len, unsigned char* out,
+                                                    int out_len) {
+  __shared__ u32 lds[50 * NT];
+  const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+  if (i >= n) return;
+  Transcript<LdsState> t;
+  t.st.base = lds + threadIdx.x;
+  const char* l = reinterpret_cast<const char*>(labels);
+  merlin_init(t, l, proto_len);
+  merlin_append_bytes(t, l + proto_len, msg_label_len, reinterpret_cast<const char*>(msgs) + i * (size_t)msg_len, msg_len);
+  merlin_frame(t, l + proto_len + msg_label_len, chal_label_len, (u32)out_len);
+  strobe_begin_op(t, EG_FLAG_PRF);
+#pragma unroll 1
+  for (int k = 0; k < out_len; ++k) out[i * (size_t)out_len + k] = (unsigned char)strobe_squeeze_byte(t);
+}
+
 // out = enc( sum_t [k_t]P_t + [r]G ); terms may be 0 (then r must be given).  Group::mul_generator,
 // vartime_double_mul_generator and vartime_multi_mul all map onto this kernel.
 __global__ void __launch_bounds__(NT) k_prim_msm(size_t n, int terms, const u32* scalars, const u32* points, const u32* r,

@@ -23,7 +23,7 @@ struct ScalarSrc {
   uint8_t kind;   // SRC_*
   uint8_t neg;    // use -scalar (ring.rs:339, log_equality.rs:160, mul.rs:205)
   uint16_t idx;   // wire item index or challenge slot
-  uint32_t mul;   // > 1: multiply by this small integer (the [e * x_j] G term of B - x_j, ring.rs:338)
+  uint32_t pad;
 };
 
 struct VarTerm {
@@ -58,7 +58,8 @@ enum : uint32_t {
   OP_APPEND_WIRE,      // a = label, b = first item, c = item count
   OP_APPEND_CMP,       // a = label, b = slot, c = second slot or 0xffff
   OP_APPEND_U64,       // a = label, b = value
-  OP_CHALLENGE,        // a = label, b = challenge slot         challenge_scalar -> slot
+  OP_CHALLENGE,        // a = label, b = challenge slot, c = m  challenge_scalar -> slot; if m > 1 also m * challenge -> slot + 1
+                       //                                       (the [e * m_j]G term of B - x_j, x_j = [m_j]G, ring.rs:338)
   OP_CHALLENGE_CHECK,  // a = label, b = wire item, c = flag    flag = (challenge_scalar == wire scalar)
   OP_LOAD_PREFIX,      // b = prefix index
   OP_SAVE_PREFIX,      // b = prefix index

@@ -89,7 +89,11 @@ __device__ __noinline__ void gen_muladd(u32 out[8], const u32* a, const u32* b, 
 constexpr int EG_GEN_MAX_OPTIONS = 32;
 
 // One lane = one voter.  out: packed ballot (choice wire layout of eg_hip.h).
+// selection: null = the voter's choice comes from the second stream; else one bitmask word per voter (bit k = option k chosen,
+// EncryptedChoice::single(params, choice, rng) / ::new(params, &[bool], rng)).  rng_skip = 64-byte draws the voter's RNG has
+// served before the ballot (tests/snapshots.rs:107-131 draws the keypair first: 1).
 __global__ void __launch_bounds__(NT) k_choice_encrypt(u64 seed0, size_t n, int n_options, int single, int n_selected,
+                                                       const u32* selection, u64 rng_skip,
                                                        const uint4* tabG, const uint4* tabK, const u32* prefixes,
                                                        int pre_main, int pre_ring, int pre_logeq, u32* out, u32 stride_words) {
   __shared__ u32 lds[50 * NT];
@@ -98,10 +102,13 @@ __global__ void __launch_bounds__(NT) k_choice_encrypt(u64 seed0, size_t n, int 
     const u64 seed = seed0 + i;
     ChaChaRng rng;
     chacha_seed_from_u64(rng, seed);
+    rng.counter = rng_skip;
     u32* ob = out + i * stride_words;
-    // ---- voter selection (second stream) ----
+    // ---- voter selection (given, or drawn from a second stream) ----
     u32 flags = 0;   // bit k set <=> option k selected
-    {
+    if (selection) {
+      flags = selection[i];
+    } else {
       ChaChaRng sel;
       chacha_seed_from_u64(sel, ~seed);
       u32 buf[16];
@@ -416,7 +423,10 @@ __device__ __noinline__ void gen_range_proof(Transcript<LdsState>& t, ChaChaRng&
 
 constexpr int EG_GEN_QV_MAX_OPTIONS = 16;
 
-__global__ void __launch_bounds__(NT) k_qv_encrypt(u64 seed0, size_t n, int n_options, u64 credits, GenRange vote_range,
+// votes_in: null = votes drawn from the second stream; else n_options words per voter (QuadraticVotingBallot::new(params, votes,
+// rng), quadratic_voting.rs:234-284; the caller keeps sum(v^2) <= credits and v <= isqrt(credits), as the reference asserts)
+__global__ void __launch_bounds__(NT) k_qv_encrypt(u64 seed0, size_t n, int n_options, u64 credits, const u32* votes_in, u64 rng_skip,
+                                                   GenRange vote_range,
                                                    GenRange credit_range, int pre_sumsq, const uint4* tabG, const uint4* tabK,
                                                    const u32* prefixes, u32* out, u32 stride_words, u32 vote_words,
                                                    u32 credit_words) {
@@ -426,11 +436,12 @@ __global__ void __launch_bounds__(NT) k_qv_encrypt(u64 seed0, size_t n, int n_op
     const u64 seed = seed0 + i;
     ChaChaRng rng;
     chacha_seed_from_u64(rng, seed);
+    rng.counter = rng_skip;
     u32* ob = out + i * stride_words;
-    // votes as in tests/integration/sharing.rs:135-147 (geometric, p = 0.8), second stream
+    // votes: given, or as in tests/integration/sharing.rs:135-147 (geometric, p = 0.8) from a second stream
     u64 votes[EG_GEN_QV_MAX_OPTIONS];
-    for (int k = 0; k < n_options; ++k) votes[k] = 0;
-    {
+    for (int k = 0; k < n_options; ++k) votes[k] = votes_in ? (u64)votes_in[i * (size_t)n_options + k] : 0;
+    if (!votes_in) {
       ChaChaRng sel;
       chacha_seed_from_u64(sel, ~seed);
       u32 buf[16];

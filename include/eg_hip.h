@@ -99,6 +99,12 @@ int eg_point_is_identity_batch(eg_ctx*, size_t n, const uint8_t* in /*32n*/, uin
 /* Element Add / Sub (ristretto.rs:76-86 via RistrettoPoint ops); ok[i]=0 if an input fails to decode.
  * Element Neg is `subtract` with a = identity (32 zero bytes). */
 int eg_point_add_batch(eg_ctx*, size_t n, const uint8_t* a, const uint8_t* b, int subtract, uint8_t* out, uint8_t* ok);
+/* TranscriptForGroup's framing (proofs/mod.rs:39-57 over merlin 3.0.0): for each of n messages,
+ * Transcript::new(proto); append_message(msg_label, msg_i); challenge_bytes(chal_label, out_len) -> out_i.  Lets known-answer
+ * vectors of the transcript layer (the upstream merlin test vector) be checked on the device itself. */
+int eg_merlin_challenge_batch(eg_ctx*, size_t n, const char* proto, size_t proto_len, const char* msg_label, size_t msg_label_len,
+                              const uint8_t* msgs /* n x msg_len */, size_t msg_len, const char* chal_label, size_t chal_label_len,
+                              uint8_t* out /* n x out_len */, size_t out_len);
 /* Group::mul_generator / vartime_mul_generator (ristretto.rs:105-121) */
 int eg_mul_generator_batch(eg_ctx*, size_t n, const uint8_t* k /*32n*/, uint8_t* out /*32n*/);
 /* Group::vartime_double_mul_generator(k, P, r) = [k]P + [r]G (ristretto.rs:131-137) */
@@ -166,13 +172,19 @@ int eg_qv_tally_encode_device(eg_qv_params*, void* d_out, void* stream);
  *   with RangeDecomposition::optimal(upper_bound) (range.rs:148-153); eg_proof_item_size gives the stride.
  * status: EG_ST_OK, EG_ST_BAD_*, EG_ST_SUM_CHALLENGE (zero: ChallengeMismatch) or EG_ST_RANGE_CHALLENGE (bool/range). */
 typedef struct eg_proof_params eg_proof_params;
-enum { EG_PROOF_ZERO = 0, EG_PROOF_BOOL = 1, EG_PROOF_RANGE = 2 };
+enum { EG_PROOF_ZERO = 0, EG_PROOF_BOOL = 1, EG_PROOF_RANGE = 2, EG_PROOF_SHARE = 3, EG_PROOF_SUMSQ = 4 };
 int eg_proof_params_create(eg_ctx*, const uint8_t pk[32], int kind, uint64_t upper_bound, eg_proof_params** out);
 /* PublicKeySet::verify_share (sharing/key_set.rs:209-228) for one participant: item = the ciphertext's
  * random element R(32) || decryption share dh(32) || challenge || response; status EG_ST_SUM_CHALLENGE on ChallengeMismatch.
  * Verify with eg_verify_proof_batch. */
 int eg_share_params_create(eg_ctx*, const uint8_t shared_key[32], uint64_t shares, uint64_t threshold, uint64_t index,
                            const uint8_t participant_key[32], eg_proof_params** out);
+/* SumOfSquaresProof::verify(ciphertexts, sum_of_squares_ciphertext, receiver, transcript) (mul.rs:190-260) with
+ * transcript = Transcript::new(label) (tests/snapshots.rs:133-153 uses b"test"): item = n_values value ciphertexts (64 B each) ||
+ * sum-of-squares ciphertext (64) || challenge || ciphertext_responses (2 n_values x 32) || sum_response; status EG_ST_OK,
+ * EG_ST_BAD_* or EG_ST_QV_CREDIT_EQUIV_CHALLENGE (ChallengeMismatch).  A wrong number of responses (LenMismatch, mul.rs:197-202)
+ * cannot be expressed in a packed item.  Verify with eg_verify_proof_batch. */
+int eg_sumsq_params_create(eg_ctx*, const uint8_t pk[32], int n_values, const char* label, size_t label_len, eg_proof_params** out);
 void eg_proof_params_destroy(eg_proof_params*);
 size_t eg_proof_item_size(const eg_proof_params*);
 int eg_verify_proof_batch(eg_proof_params*, size_t n, const uint8_t* items, uint32_t* status);
@@ -190,16 +202,31 @@ int eg_choice_encrypt_batch_device(eg_choice_params*, uint64_t base_seed, size_t
 int eg_choice_encrypt_batch(eg_choice_params*, uint64_t base_seed, size_t first, size_t n, int n_selected,
                             uint8_t* out /* host, n * eg_choice_ballot_size */);
 int eg_qv_encrypt_batch_device(eg_qv_params*, uint64_t base_seed, size_t first, size_t n, void* d_out, void* stream);
+/* The same provers with the CALLER's choices: EncryptedChoice::single(params, choice, rng) / ::new(params, &[bool], rng)
+ * (choice.rs:296-349) and QuadraticVotingBallot::new(params, votes, rng) (quadratic_voting.rs:234-284).  selection: one uint32 per
+ * ballot, bit k set <=> option k chosen (single-choice: exactly one bit); votes: n_options uint32 per ballot with
+ * sum(v^2) <= credits.  rng_skip = number of 64-byte draws the ballot's RNG, ChaChaRng::seed_from_u64(base_seed + first + i), has
+ * already served: tests/snapshots.rs:107-161 draw the keypair first, so (12345, rng_skip = 1) reproduces the reference's
+ * `encrypted-choice`, `encrypted-multi-choice` and `qv-ballot` snapshots byte for byte.  The host forms validate the choices
+ * (EG_ERR_BAD_ARG); the device forms trust them, as the reference trusts its caller's assertions. */
+int eg_choice_encrypt_selected_batch(eg_choice_params*, uint64_t base_seed, size_t first, size_t n, uint64_t rng_skip,
+                                     const uint32_t* selection /* n */, uint8_t* out);
+int eg_choice_encrypt_selected_batch_device(eg_choice_params*, uint64_t base_seed, size_t first, size_t n, uint64_t rng_skip,
+                                            const void* d_selection, void* d_out, void* stream);
+int eg_qv_encrypt_votes_batch(eg_qv_params*, uint64_t base_seed, size_t first, size_t n, uint64_t rng_skip,
+                              const uint32_t* votes /* n x n_options */, uint8_t* out);
+int eg_qv_encrypt_votes_batch_device(eg_qv_params*, uint64_t base_seed, size_t first, size_t n, uint64_t rng_skip,
+                                     const void* d_votes, void* d_out, void* stream);
 
 /* ---- host-only introspection (no GPU needed; used by the CPU-side tests of the host logic) -------------------------------------
  * RangeDecomposition::optimal(upper_bound).to_string() (range.rs:110-124,148-305): the string hashed into the transcript */
 int eg_range_decomposition(uint64_t upper_bound, char* buf, size_t cap);
 /* JSON summary of the verification plan: kind 0 single-choice, 1 multi-choice, 2 quadratic voting (credits), 3 verify_zero,
- * 4 verify_bool, 5 verify_range (upper bound) */
+ * 4 verify_bool, 5 verify_range (upper bound), 6 sum-of-squares proof over n_options values */
 int eg_plan_describe(int kind, int n_options, uint64_t credits_or_bound, char* buf, size_t cap);
 
 /* ---- measurement hooks (bench.py) ------------------------------------------------------------------------------------------
- * Average duration in milliseconds of the dominant kernel (k_msm_jobs) over the launches since the last reset,
+ * Average duration in milliseconds of the dominant kernel (k_eq_table<false>: the ring equations) over the launches since the last reset,
  * measured with HIP events on the stream the kernel was launched on; launches = number of launches averaged. */
 int eg_profile_enable(eg_ctx*, int enable);
 int eg_profile_read(eg_ctx*, double* msm_ms_total, uint64_t* msm_launches, double* all_ms_total);

@@ -91,6 +91,31 @@ int hc_double_mul_generator_teeth(const uint8_t k[32], const uint8_t p_enc[32], 
   return 1;
 }
 
+// out = enc(sum_i [k_i]P_i + [r]G) with every base behind a teeth table and ONE shared doubling chain (ge_teeth_mul_multi, what
+// k_eq_table<true> runs); the sign vectors are read word by word, as the kernel reads them from LDS
+int hc_multi_mul_teeth(int n, const uint8_t* ks, const uint8_t* ps, const uint8_t r[32], uint8_t out[32]) {
+  if (g_base_table.e.empty()) { ge g; ge_generator(g); build_fixed(g_base_table, g); }
+  std::vector<ArrBase> tabs(n);
+  std::vector<u32> sg(9 * (size_t)n);
+  for (int i = 0; i < n; ++i) {
+    u32 kw[8], pw[8];
+    words_from_bytes(kw, ks + 32 * i, 8); words_from_bytes(pw, ps + 32 * i, 8);
+    ge p; if (!ristretto_decode(p, pw)) return 0;
+    ArrTable tmp; ge_teeth_tables_build(tabs[i], tmp, p);
+    sc_teeth_signs(&sg[9 * i], kw);
+  }
+  ge acc;
+  ge_teeth_mul_multi(acc, n,
+      [&](int t, int c, int& idx, bool& neg) { sc_teeth_column([&](int w) { return sg[9 * t + w]; }, c, idx, neg); },
+      [&](int t, int idx, ge_cached& e) { tabs[t].load(e, idx); });
+  u32 rw[8], dr[EG_COMB_WORDS], o[8];
+  words_from_bytes(rw, r, 8); sc_recode_comb(dr, rw);
+  ge_fixed_mul_add(acc, g_base_table, dr);
+  ristretto_encode(o, acc);
+  bytes_from_words(out, o, 8);
+  return 1;
+}
+
 // encode(2P) through the batched-inversion path vs the plain encoder; returns 1 when they agree
 int hc_double_encode(const uint8_t p_enc[32], uint8_t out[32]) {
   u32 pw[8], o[8], ref[8]; words_from_bytes(pw, p_enc, 8);
@@ -166,7 +191,8 @@ int hc_merlin(const char* label, const char* l1, const uint8_t* m1, int m1_len, 
 // field operation counts of the hot-path building blocks: out[2*i], out[2*i+1] = (fe_mul, fe_sq) calls of
 // 0: ristretto_decode  1: direct table build  2: direct variable-base multiply  3: fixed-base comb
 // 4: ristretto_encode  5: comb-table build (per base)  6: comb multiply (per equation)
-void hc_op_counts(unsigned long long out[18]) {
+// 9: shared-chain product of ONE term (ge_teeth_mul_multi)   10: every further term of it
+void hc_op_counts(unsigned long long out[22]) {
   if (g_base_table.e.empty()) { ge g; ge_generator(g); build_fixed(g_base_table, g); }
   u32 gw[8] = {0x0aaef2e2u, 0x714ebc6au, 0x61a984a8u, 0x5f5100c5u, 0x6a0be358u, 0x8ddd82a5u, 0x4559a6b6u, 0x762d8de0u};
   u32 k[8] = {0x12345678u, 0x9abcdef0u, 0x0fedcba9u, 0x87654321u, 0x11111111u, 0x22222222u, 0x33333333u, 0x04444444u};
@@ -200,6 +226,14 @@ void hc_op_counts(unsigned long long out[18]) {
   m0 = g_fe_mul_count; s0 = g_fe_sq_count;
   ge_double_encode_finish(o, acc, inv, zero);
   out[14] += g_fe_mul_count - m0; out[15] += g_fe_sq_count - s0;
+  u32 sg[9]; sc_teeth_signs(sg, k);
+  auto column = [&](int, int c, int& idx, bool& neg) { sc_teeth_column([&](int w) { return sg[w]; }, c, idx, neg); };
+  auto load = [&](int, int idx, ge_cached& e) { st.load(e, idx); };
+  m0 = g_fe_mul_count; s0 = g_fe_sq_count;
+  ge_teeth_mul_multi(acc, 1, column, load); snap(9, m0, s0);
+  m0 = g_fe_mul_count; s0 = g_fe_sq_count;
+  ge_teeth_mul_multi(acc, 2, column, load);
+  out[20] = g_fe_mul_count - m0 - out[18]; out[21] = g_fe_sq_count - s0 - out[19];
 }
 
 void hc_fe_roundtrip(const uint8_t in[32], uint8_t out[32]) {

@@ -307,6 +307,83 @@ def test_snapshot_seed_reproduced_on_gpu(eg, ctx, golden, pk, oracle):
     assert one == op.new_ballot(flags, rng)
 
 
+def test_gpu_prover_reproduces_the_reference_snapshots(eg, ctx, golden, pk):
+    """tests/snapshots.rs:107-131,155-161 directly on the HIP prover: seed 12345, the keypair draw skipped (rng_skip = 1), the
+    snapshot's own choices / votes -> the packed bytes of `encrypted-choice`, `encrypted-multi-choice` and `qv-ballot`."""
+    g = golden["encrypted-choice"]
+    p = eg.ChoiceParams.single_choice(ctx, pk, g["params"]["options"])
+    assert p.encrypt_selected(golden["seed"], 0, [1 << g["params"]["choice"]], rng_skip=1).hex() == g["packed"]
+    g = golden["encrypted-multi-choice"]
+    m = eg.ChoiceParams.multi_choice(ctx, pk, g["params"]["options"])
+    mask = sum(1 << k for k, c in enumerate(g["params"]["choices"]) if c)
+    assert m.encrypt_selected(golden["seed"], 0, [mask], rng_skip=1).hex() == g["packed"]
+    g = golden["qv-ballot"]
+    q = eg.QuadraticVotingParams(ctx, pk, g["params"]["options"], g["params"]["credits"])
+    assert q.encrypt_votes(golden["seed"], 0, [g["params"]["votes"]], rng_skip=1).hex() == g["packed"]
+    # the host forms refuse what EncryptedChoice::single / QuadraticVotingBallot::new would not accept
+    with pytest.raises(eg.EgError):
+        p.encrypt_selected(1, 0, [0b11])
+    with pytest.raises(eg.EgError):
+        p.encrypt_selected(1, 0, [1 << 7])
+    with pytest.raises(eg.EgError):
+        q.encrypt_votes(1, 0, [[3, 3, 0, 0, 0]])              # 18 credits > 15
+    # explicit choices, many ballots: every one verifies and the tally counts the chosen options
+    sel = [1 << (i % 5) for i in range(200)]
+    st, tally = p.verify_batch(p.encrypt_selected(99, 0, sel))
+    assert st == [0] * 200 and len(tally) == 320
+
+
+def test_sum_of_squares_proof_on_its_own(eg, ctx, golden, pk, oracle):
+    """SumOfSquaresProof::verify (mul.rs:190-260) as its own entry: the reference's `sum-sq-proof` snapshot (label b"test",
+    values [1, 3, 3, 7, 5]; the snapshot holds only the proof, its ciphertexts are re-derived from the seed by the pinned oracle
+    prover) is accepted by the HIP path; tampered, reordered and re-labelled variants get the oracle's verdicts."""
+    k = oracle.PublicKey(pk)
+    vals = golden["sum-sq-proof"]["params"]["values"]
+    rng = oracle.keypair_from_seed(golden["seed"])[2]                          # the RNG after the keypair draw
+    cts, proof = k.sumsq_snapshot(vals, rng)                                   # cts = sum ciphertext || value ciphertexts
+    assert proof.hex() == golden["sum-sq-proof"]["packed"]
+    n = len(vals)
+    item = cts[64:] + cts[:64] + proof
+    v = eg.SumOfSquaresVerifier(ctx, pk, n, b"test")
+    assert v.item_size == len(item) == 64 * (n + 1) + 32 * (2 * n + 2)
+    swapped = cts[128:192] + cts[64:128] + cts[192:] + cts[:64] + proof        # reorder two ciphertexts (mul.rs:332-361)
+    bad_resp = bytearray(item); bad_resp[-1] ^= 1
+    bad_pt = bytearray(item); bad_pt[0:32] = b"\xff" * 32
+    batch = [item, swapped, bytes(bad_resp), bytes(bad_pt), item]
+    got = v.verify_batch(b"".join(batch))
+    oracle_verdict = lambda b: k.verify_sumsq(b[: 64 * n], b[64 * n : 64 * n + 64], b[64 * n + 64 :], b"test")
+    assert got[0] == got[4] == 0 == oracle_verdict(item)
+    assert got[1] == eg.QV_CREDIT_EQUIV_CHALLENGE == oracle_verdict(swapped)
+    if int.from_bytes(bad_resp[-32:], "little") < L:                         # flipping the low bit of the top byte keeps it canonical
+        assert got[2] == eg.QV_CREDIT_EQUIV_CHALLENGE == oracle_verdict(bytes(bad_resp))
+    else:
+        assert eg.status_kind(got[2]) == eg.BAD_SCALAR
+    assert eg.status_kind(got[3]) == eg.BAD_POINT and eg.status_detail(got[3]) == 0
+    other = eg.SumOfSquaresVerifier(ctx, pk, n, b"other")
+    assert other.verify_batch(item) == [eg.QV_CREDIT_EQUIV_CHALLENGE] == [k.verify_sumsq(cts[64:], cts[:64], proof, b"other")]
+    # 2 and 9 values, fresh proofs from the oracle prover
+    for m in (2, 9):
+        vv = [(3 * i + 1) % 6 for i in range(m)]
+        c2, p2 = k.sumsq_snapshot(vv, oracle.rng_from_u64(700 + m))
+        it = c2[64:] + c2[:64] + p2
+        assert eg.SumOfSquaresVerifier(ctx, pk, m, b"test").verify_batch(it + it) == [0, 0]
+
+
+def test_merlin_known_answers_on_the_gpu(eg, ctx, oracle):
+    """The transcript layer (merlin 3.0.0 under src/proofs/mod.rs:39-57) checked on the device itself: the upstream merlin test
+    vector and message lengths around the STROBE rate against the oracle's restatement."""
+    got = ctx.merlin_challenges(b"test protocol", b"some label", [b"some data"], b"challenge", 32)
+    assert got[0].hex() == "d5a21972d0d5fe320c0d263fac7fffb8145aa640af6e9bca177c03c7efcf0615"
+    rnd = random.Random(7)
+    for n in (0, 1, 31, 32, 64, 165, 166, 167, 400):
+        msgs = [bytes(rnd.getrandbits(8) for _ in range(n)) for _ in range(70)]
+        for out_len in (64, 200):
+            got = ctx.merlin_challenges(b"encrypted_choice_ranges", b"enc", msgs, b"c", out_len)
+            for m, g in zip(msgs, got):
+                t = oracle.Merlin(b"encrypted_choice_ranges"); t.append(b"enc", m)
+                assert g == t.challenge(b"c", out_len), (n, out_len)
+
+
 # ------------------------------------------------------------------ PublicKey::verify_zero / verify_bool / verify_range
 def test_golden_single_ciphertext_proofs(eg, ctx, golden, pk, oracle):
     z = eg.PublicKeyVerifier(ctx, pk, eg.PublicKeyVerifier.ZERO)

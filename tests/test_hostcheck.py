@@ -132,6 +132,23 @@ def test_double_mul_generator(hc, oracle):
         assert out.raw == oracle.point_double_mul_generator(kb, p, rb), (k, r)
 
 
+def test_shared_chain_multi_mul(hc, oracle):
+    """ge_teeth_mul_multi (Straus over teeth tables, one doubling chain for all terms) against the oracle's multi_mul."""
+    rnd = random.Random(44)
+    pts = [oracle.point_mul_generator(rnd.randrange(L).to_bytes(32, "little")) for _ in range(9)] + [b"\x00" * 32]
+    edge = [0, 1, 2, L - 1, L - 2, 2**252, 2**252 + 2**251 + 12345, 8]      # incl. halved odd scalars (> l) and even ones
+    for n in (1, 2, 3, 7):
+        for trial in range(6):
+            ks = [edge[(trial + i) % len(edge)] if trial < 3 else rnd.randrange(L) for i in range(n)]
+            ps = [pts[(trial * 3 + i) % len(pts)] for i in range(n)]
+            r = rnd.randrange(L)
+            out = _b()
+            kb = b"".join(k.to_bytes(32, "little") for k in ks)
+            assert hc.hc_multi_mul_teeth(n, kb, b"".join(ps), r.to_bytes(32, "little"), out) == 1
+            want = oracle.point_multi_mul(kb + r.to_bytes(32, "little"), b"".join(ps) + oracle.const_bytes(4))
+            assert out.raw == want, (n, trial)
+
+
 def test_merlin(hc, oracle):
     out = _b(64)
     hc.hc_merlin.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_uint64, C.c_char_p, C.c_char_p]
@@ -162,9 +179,10 @@ def test_doubled_encoder(hc, oracle):
 def test_bench_work_model_matches_the_code(hc):
     """bench.py prices a ballot with per-building-block (fe_mul, fe_sq) counts; they must be the counts of the shipped code."""
     import ast
-    out = (C.c_ulonglong * 18)()
+    out = (C.c_ulonglong * 22)()
     hc.hc_op_counts(out)
-    names = ["decode", "direct_table", "direct_mul", "comb", "encode", "base_table", "base_mul", "enc_batch_each", "enc_batch_inversion"]
+    names = ["decode", "direct_table", "direct_mul", "comb", "encode", "base_table", "base_mul", "enc_batch_each", "enc_batch_inversion",
+             "multi_first", "multi_extra"]
     got = {n: (out[2 * i], out[2 * i + 1]) for i, n in enumerate(names)}
     src = (HERE.parent.parent / "bench.py").read_text()
     tree = ast.parse(src)

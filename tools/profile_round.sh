@@ -1,15 +1,34 @@
+#!/bin/bash
+# Runs on the GPU box (through gpurun): bench lines and rocprofv3 passes of one round, written under gpurun_out/.
+#   usage: tools/profile_round.sh [pmc]      (without "pmc": bench lines + kernel-trace stats only)
+# Counters are collected in their own passes (--pmc never combined with tracing), the program after `--` is python3 itself.
+# tools/profile_summary.py <round> then turns the outputs into profiles/<round>_*.txt and profiles/traffic.json.
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-cd $R
-python -m pytest tests -q -x -m gpu 2>&1 | tail -2
-python bench.py --steps 5 --warmup 1 > gpurun_out/bench_single.json 2> gpurun_out/bench_single.err; tail -c 600 gpurun_out/bench_single.json
-python bench.py --steps 3 --warmup 1 --workload multi --ballots 250000 > gpurun_out/bench_multi.json 2>/dev/null
-python bench.py --steps 3 --warmup 1 --workload qv --ballots 250000 > gpurun_out/bench_qv.json 2>/dev/null
-rm -rf gpurun_out/prof_stats gpurun_out/pmc_*
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_stats -o stats --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/prof_stats.log 2>&1
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c -d gpurun_out/pmc_$c -o pmc --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --ballots 262144 > gpurun_out/pmc_$c.log 2>&1
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out
+PMC_BALLOTS=262144
+for w in single multi qv; do
+  timeout -k 10 300 python3 bench.py --steps 5 --warmup 1 --workload $w > gpurun_out/bench_$w.json 2> gpurun_out/bench_$w.err || exit 1
+  tail -c 300 gpurun_out/bench_$w.json; echo
 done
-rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES -d gpurun_out/pmc_SQ1 -o pmc --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --ballots 262144 > gpurun_out/pmc_SQ1.log 2>&1
-rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_WAVES -d gpurun_out/pmc_SQ2 -o pmc --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --ballots 262144 > gpurun_out/pmc_SQ2.log 2>&1
-find gpurun_out -name "*.csv" | head -30
+timeout -k 10 300 python3 bench.py --steps 3 --warmup 1 --total-ballots 10000000 > gpurun_out/bench_10M.json 2> gpurun_out/bench_10M.err || exit 1
+timeout -k 10 300 python3 bench.py --steps 5 --warmup 1 --tampered-percent 1 > gpurun_out/bench_tampered1pct.json 2> gpurun_out/bench_tampered.err || exit 1
+for w in single multi qv; do
+  rm -rf gpurun_out/prof_stats_$w
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_stats_$w -o stats --output-format csv -- \
+    python3 bench.py --steps 3 --warmup 1 --workload $w --no-cpu-baseline --no-host-inclusive > gpurun_out/prof_stats_$w.log 2>&1 || exit 1
+done
+[ "$1" = "pmc" ] || exit 0
+for w in single multi qv; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf gpurun_out/pmc_${c}_$w
+    timeout -k 10 300 rocprofv3 --pmc $c -d gpurun_out/pmc_${c}_$w -o pmc --output-format csv -- \
+      python3 bench.py --steps 1 --warmup 0 --workload $w --no-cpu-baseline --no-host-inclusive --ballots $PMC_BALLOTS > gpurun_out/pmc_${c}_$w.log 2>&1 || exit 1
+  done
+done
+rm -rf gpurun_out/pmc_SQ1_single gpurun_out/pmc_SQ2_single
+timeout -k 10 300 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES -d gpurun_out/pmc_SQ1_single -o pmc --output-format csv -- \
+  python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-host-inclusive --ballots $PMC_BALLOTS > gpurun_out/pmc_SQ1.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_WAVES -d gpurun_out/pmc_SQ2_single -o pmc --output-format csv -- \
+  python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-host-inclusive --ballots $PMC_BALLOTS > gpurun_out/pmc_SQ2.log 2>&1 || exit 1
+echo "profile round done"

@@ -1,57 +1,104 @@
 #!/usr/bin/env python3
-"""Turns the rocprofv3 outputs written by tools/profile_round.sh (under gpurun_out/) into the text summaries kept
-under profiles/.   usage: profile_summary.py <round-tag, e.g. r01>"""
-import csv, sys, collections
+"""Turns the outputs of tools/profile_round.sh (under gpurun_out/) into the summaries kept under profiles/:
+   <round>_bench_line*.json, <round>_kernel_stats_<workload>.txt, <round>_pmc_counters.txt and traffic.json (the memory-side
+   bytes per ballot and launch of every profiled kernel, which bench.py reads for `roofline.traffic`).
+   usage: profile_summary.py <round-tag, e.g. r02>"""
+import collections
+import csv
+import json
+import shutil
+import subprocess
+import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 OUT = ROOT / "gpurun_out"
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+PROF = ROOT / "profiles"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+PMC_BALLOTS = 262144
+WORKLOADS = {"single": "single-5", "multi": "multi-16", "qv": "qv-5-20"}
+DESCR = {"single": "1M single-choice 5-option ballots (BASELINE configs[1])", "multi": "1M multi-choice 3-of-16 ballots (configs[3])",
+         "qv": "1M quadratic-voting ballots, 5 options / 20 credits (configs[2])"}
 
 
-def short(name):
-    return name if len(name) <= 64 else name[:64]
+def kname(name):
+    name = name.split("(")[0].strip()
+    return name[5:] if name.startswith("void ") else name
 
 
-# ---- kernel stats ------------------------------------------------------------------------------------------------
-rows = list(csv.DictReader(open(OUT / "prof_stats" / "stats_kernel_stats.csv")))
-lines = ["# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline   (MI355X)",
-         "# 1 warm-up + 3 timed steps of 1M single-choice 5-option ballots (one chunk: one k_base_tables and two k_msm_jobs launches per step), plus the untimed generator launch",
-         f"{'kernel':64s} {'calls':>6s} {'total_ms':>12s} {'avg_ms':>11s} {'min_ms':>9s} {'max_ms':>9s} {'pct':>8s}"]
-for r in rows:
-    lines.append(f"{short(r['Name']):64s} {int(r['Calls']):6d} {int(r['TotalDurationNs'])/1e6:12.3f} {float(r['AverageNs'])/1e6:11.4f} "
-                 f"{int(r['MinNs'])/1e6:9.3f} {int(r['MaxNs'])/1e6:9.3f} {float(r['Percentage']):8.4g}")
-(ROOT / "profiles" / f"{tag}_bench_kernel_stats.txt").write_text("\n".join(lines) + "\n")
+# ---- bench lines ---------------------------------------------------------------------------------------------------
+for src, dst in (("bench_single.json", "bench_line.json"), ("bench_multi.json", "bench_line_multi16.json"), ("bench_qv.json", "bench_line_qv.json"),
+                 ("bench_10M.json", "bench_line_10M.json"), ("bench_tampered1pct.json", "bench_line_tampered1pct.json")):
+    f = OUT / src
+    if f.exists() and f.read_text().strip():
+        line = f.read_text().strip().splitlines()[-1]
+        json.loads(line)
+        (PROF / f"{tag}_{dst}").write_text(line + "\n")
 
-# ---- PMC passes ----------------------------------------------------------------------------------------------------
-acc = collections.defaultdict(lambda: collections.defaultdict(float))
-launches = collections.defaultdict(set)
-for d in ("pmc_FETCH_SIZE", "pmc_WRITE_SIZE", "pmc_SQ1", "pmc_SQ2"):
-    f = OUT / d / "pmc_counter_collection.csv"
+# ---- kernel stats --------------------------------------------------------------------------------------------------
+for w in WORKLOADS:
+    f = OUT / f"prof_stats_{w}" / "stats_kernel_stats.csv"
     if not f.exists():
         continue
-    for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0]
-        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
-        if r["Counter_Name"] == "FETCH_SIZE":
-            launches[k].add(r["Dispatch_Id"])
-want = ["eg::k_msm_jobs", "eg::k_base_tables", "eg::k_encode_batch", "eg::k_decode_points", "eg::k_hash"]
-lines = ["# rocprofv3 --pmc <counters> -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --ballots 262144   (MI355X)",
-         "# separate passes for FETCH_SIZE, WRITE_SIZE and two groups of SQ counters; values summed over the launches of one step",
-         "# (1 chunk of 262144 ballots).  FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE under-reports 16-B/lane reads by 2x",
-         "# (MI355X_MICROARCH.md, HBM section), hence the x2.", ""]
-for k in want:
-    c = acc.get(k)
-    if not c:
+    rows = list(csv.DictReader(open(f)))
+    lines = [f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --workload {w} --no-cpu-baseline --no-host-inclusive   (MI355X)",
+             f"# 1 warm-up + 3 timed steps of {DESCR[w]}, plus the untimed generator launch",
+             f"{'kernel':64s} {'calls':>6s} {'total_ms':>12s} {'avg_ms':>11s} {'min_ms':>9s} {'max_ms':>9s} {'pct':>8s}"]
+    for r in rows:
+        lines.append(f"{kname(r['Name'])[:64]:64s} {int(r['Calls']):6d} {int(r['TotalDurationNs'])/1e6:12.3f} {float(r['AverageNs'])/1e6:11.4f} "
+                     f"{int(r['MinNs'])/1e6:9.3f} {int(r['MaxNs'])/1e6:9.3f} {float(r['Percentage']):8.4g}")
+    (PROF / f"{tag}_kernel_stats_{w}.txt").write_text("\n".join(lines) + "\n")
+
+# ---- PMC passes ----------------------------------------------------------------------------------------------------
+want = ["eg::k_eq_table<false>", "eg::k_eq_table<true>", "eg::k_eq_generic", "eg::k_base_tables", "eg::k_encode_batch", "eg::k_decode_points", "eg::k_hash"]
+text = [f"# rocprofv3 --pmc <counter> -- python3 bench.py --steps 1 --warmup 0 --workload W --no-cpu-baseline --no-host-inclusive --ballots {PMC_BALLOTS}   (MI355X)",
+        "# separate passes per counter (FETCH_SIZE, WRITE_SIZE; for the single-choice workload also two groups of SQ counters); values are",
+        "# summed over the launches of the one step (1 chunk).  FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the",
+        "# bytes of 16-B-per-lane reads (MI355X_MICROARCH.md, HBM section; calibrated for this access shape in <round>_fetch_calibration.txt),",
+        "# hence the x2.", ""]
+traffic = {"round": tag, "ballots_per_launch_measured": PMC_BALLOTS, "workloads": {}}
+try:
+    traffic["commit"] = subprocess.check_output(["git", "-C", str(ROOT), "rev-parse", "--short", "HEAD"], text=True).strip()
+except Exception:
+    traffic["commit"] = None
+for w, key in WORKLOADS.items():
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    launches = collections.defaultdict(set)
+    dirs = [f"pmc_FETCH_SIZE_{w}", f"pmc_WRITE_SIZE_{w}"] + ([f"pmc_SQ1_{w}", f"pmc_SQ2_{w}"] if w == "single" else [])
+    found = False
+    for d in dirs:
+        f = OUT / d / "pmc_counter_collection.csv"
+        if not f.exists():
+            continue
+        found = True
+        for r in csv.DictReader(open(f)):
+            k = kname(r["Kernel_Name"])
+            acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            if r["Counter_Name"] == "FETCH_SIZE":
+                launches[k].add(r["Dispatch_Id"])
+    if not found:
         continue
-    n = max(len(launches[k]), 1)
-    per_launch = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024 / n / 1e9
-    lines.append(f"{k}: launches={n}  FETCH_SIZE={c['FETCH_SIZE']:.0f} KiB  WRITE_SIZE={c['WRITE_SIZE']:.0f} KiB  "
-                 f"-> per launch (FETCH x2 corrected + WRITE) = {per_launch:.2f} GB")
-    sq = "  ".join(f"{n_}={c[n_]:.3e}" for n_ in sorted(c) if n_.startswith("SQ_"))
-    lines.append("    " + sq)
-    if c.get("SQ_WAVE_CYCLES"):
-        lines.append(f"    VALU-active share of wave cycles = {c['SQ_ACTIVE_INST_VALU'] / c['SQ_WAVE_CYCLES']:.3f}   "
-                     f"issue-stall share = {c['SQ_WAIT_INST_ANY'] / c['SQ_WAVE_CYCLES']:.3f}")
-(ROOT / "profiles" / f"{tag}_bench_pmc_counters.txt").write_text("\n".join(lines) + "\n")
-print((ROOT / "profiles" / f"{tag}_bench_pmc_counters.txt").read_text())
+    text.append(f"== workload {w}: {DESCR[w].replace('1M', str(PMC_BALLOTS))}")
+    ent = {"ballots_per_launch": PMC_BALLOTS, "kernels": {}}
+    for k in want:
+        c = acc.get(k)
+        if not c:
+            continue
+        n = max(len(launches[k]), 1)
+        per_launch = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024 / n
+        ent["kernels"][k] = {"launches": n, "fetch_kib": c["FETCH_SIZE"], "write_kib": c["WRITE_SIZE"],
+                             "bytes_per_launch": per_launch, "bytes_per_ballot_launch": per_launch / PMC_BALLOTS}
+        text.append(f"{k}: launches={n}  FETCH_SIZE={c['FETCH_SIZE']:.0f} KiB  WRITE_SIZE={c['WRITE_SIZE']:.0f} KiB  "
+                    f"-> per launch (FETCH x2 + WRITE) = {per_launch/1e9:.2f} GB = {per_launch/PMC_BALLOTS/1e3:.1f} KB per ballot")
+        sq = "  ".join(f"{n_}={c[n_]:.3e}" for n_ in sorted(c) if n_.startswith("SQ_"))
+        if sq:
+            text.append("    " + sq)
+        if c.get("SQ_WAVE_CYCLES"):
+            text.append(f"    VALU-active share of wave cycles = {c['SQ_ACTIVE_INST_VALU'] / c['SQ_WAVE_CYCLES']:.3f}   "
+                        f"issue-stall share = {c['SQ_WAIT_INST_ANY'] / c['SQ_WAVE_CYCLES']:.3f}")
+    traffic["workloads"][key] = ent
+    text.append("")
+if traffic["workloads"]:
+    (PROF / f"{tag}_pmc_counters.txt").write_text("\n".join(text) + "\n")
+    (PROF / "traffic.json").write_text(json.dumps(traffic, indent=1) + "\n")
+    print("\n".join(text))
