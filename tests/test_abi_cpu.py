@@ -149,3 +149,27 @@ def test_bench_static_sanity():
     mm, ms = mod.plan_field_ops(eg.plan_describe("multi", 16))          # 32 ring bases instead of 10, no sum proof
     assert 2.5 * fm < mm < 3.5 * fm
     assert mod.effective_cores() >= 1
+
+
+def test_integration_ffi_block_matches_header():
+    """INTEGRATION.md shows the binding a maintainer of the reference would write (`extern "C"` in Rust).  It must declare every
+    function of include/eg_hip.h with the same number of arguments, and equal what tools/gen_ffi.py generates from the header."""
+    import importlib.util
+    import re
+
+    spec = importlib.util.spec_from_file_location("gen_ffi", ROOT / "tools" / "gen_ffi.py")
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    header = {name: len(params) for _, name, params in gen.prototypes((ROOT / "include" / "eg_hip.h").read_text())}
+    assert len(header) >= 55 and "eg_verify_choice_batch_device" in header and "eg_points_sum_device" in header
+    doc = (ROOT / "INTEGRATION.md").read_text()
+    block = doc[doc.index(gen.BEGIN) : doc.index(gen.END)]
+    declared = {}
+    for m in re.finditer(r"pub fn (eg_[a-z0-9_]+)\(([^)]*)\)", block):
+        args = [a for a in m.group(2).split(",") if a.strip()]
+        declared[m.group(1)] = len(args)
+    assert declared == header
+    assert gen.rust_block() in block                      # regenerate with `python tools/gen_ffi.py --update`
+    import elastic_elgamal_amd as eg
+
+    assert set(eg.exported_symbols()) == set(header)      # the two header parsers agree
