@@ -21,7 +21,7 @@ from pathlib import Path
 
 __all__ = [
     "Context", "Ristretto", "ChoiceParams", "QuadraticVotingParams", "PublicKeyVerifier", "DecryptionShareVerifier", "SumOfSquaresVerifier", "EgError", "library_path", "build",
-    "STATUS_NAMES", "status_kind", "status_detail",
+    "STATUS_NAMES", "status_kind", "status_detail", "pack_json", "PACK_RESHAPE",
 ]
 
 _PKG = Path(__file__).resolve().parent
@@ -137,6 +137,9 @@ def _load() -> C.CDLL:
         "eg_qv_encrypt_votes_batch_device": (C.c_int, [vp, C.c_uint64, sz, sz, C.c_uint64, vp, vp, vp]),
         "eg_sumsq_params_create": (C.c_int, [vp, cp, C.c_int, cp, sz, C.POINTER(vp)]),
         "eg_merlin_challenge_batch": (C.c_int, [vp, sz, cp, sz, cp, sz, cp, sz, cp, sz, cp, sz]),
+        "eg_choice_pack_json": (C.c_int, [C.c_int, C.c_int, cp, sz, C.c_int, sz, vp, vp, C.POINTER(sz)]),
+        "eg_qv_pack_json": (C.c_int, [C.c_int, C.c_uint64, cp, sz, C.c_int, sz, vp, vp, C.POINTER(sz)]),
+        "eg_qv_ballot_size_for": (sz, [C.c_int, C.c_uint64]),
         "eg_range_decomposition": (C.c_int, [C.c_uint64, cp, sz]),
         "eg_plan_describe": (C.c_int, [C.c_int, C.c_int, C.c_uint64, cp, sz]),
         "eg_profile_enable": (C.c_int, [vp, C.c_int]),
@@ -151,6 +154,36 @@ def _load() -> C.CDLL:
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+PACK_RESHAPE = 0xFFFFFFFE
+
+
+def pack_json(text, n_options: int, single: bool | None = None, credits: int | None = None, threads: int = 0, max_objects: int = 0):
+    """Native wire ingest (csrc/wire_json.hpp; no GPU needed): ballots in serde's JSON layout (one array, or objects back to
+    back) -> (packed bytes of ALL objects, status words).  Object k occupies packed[k*size:(k+1)*size] and is valid iff
+    status[k] == 0; MALFORMED = does not deserialise, PACK_RESHAPE = wrong number of choices / responses (object path).
+    `credits` selects QuadraticVotingBallot, otherwise EncryptedChoice with `single`."""
+    lib = _load()
+    data = text.encode() if isinstance(text, str) else bytes(text)
+    if not threads:
+        threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    if not max_objects:
+        max_objects = data.count(b'"range_proof"') + 1 if credits is None else data.count(b'"credit_equivalence_proof"') + 1
+    size = lib.eg_qv_ballot_size_for(n_options, credits) if credits is not None else lib.eg_choice_ballot_size(n_options, int(bool(single)))
+    if not size:
+        raise EgError("bad election parameters")
+    packed = C.create_string_buffer(max(max_objects * size, 1))
+    status = (C.c_uint32 * max(max_objects, 1))()
+    n = sz_t(0)
+    if credits is not None:
+        _check(lib.eg_qv_pack_json(n_options, credits, data, len(data), threads, max_objects, packed, status, C.byref(n)))
+    else:
+        _check(lib.eg_choice_pack_json(n_options, int(bool(single)), data, len(data), threads, max_objects, packed, status, C.byref(n)))
+    return packed.raw[: n.value * size], list(status[: n.value])
+
+
+sz_t = C.c_size_t
 
 
 def range_decomposition(upper_bound: int) -> str:

@@ -1,0 +1,353 @@
+// wire_json.hpp -- native wire ingest: the JSON that the reference's serde derives produce in human-readable formats
+// (what examples/voting.rs:195-198 prints with serde_json) -> the packed binary layout of include/eg_hip.h.  Host-only C++.
+//
+// Mirrors, for the ballot types of the hot path:
+//   deserialize_bytes / Base64UrlUnpadded (src/serde.rs:29-80): strings are base64url WITHOUT padding; the alphabet, padding and
+//     non-zero trailing bits are errors (base64ct is strict), then the byte length must be 32 (ScalarHelper :191-206,
+//     ElementHelper :254-269)
+//   VecHelper<_, MIN> (:303-355): `ring_responses` and `ciphertext_responses` need at least 2 entries
+//   the serde derives of EncryptedChoice (src/app/choice.rs:276-280: choices, range_proof, sum_proof), RingProof
+//     (src/proofs/ring.rs:282-287: common_challenge, ring_responses), LogEqualityProof (src/proofs/log_equality.rs:96-101:
+//     challenge, response), QuadraticVotingBallot (src/app/quadratic_voting.rs:205-217: votes, credit, credit_equivalence_proof),
+//     CiphertextWithRangeProof (ciphertext, range_proof), RangeProof (src/proofs/range.rs:446-450: partial_ciphertexts + flattened
+//     RingProof), SumOfSquaresProof (src/proofs/mul.rs:86-93: challenge, ciphertext_responses, sum_response), Ciphertext
+//     (src/encryption.rs:96-101: random_element, blinded_element): unknown fields are skipped, missing and duplicate fields fail.
+// Canonicity of scalars and validity of group elements are NOT decided here: they need group arithmetic, which only runs on the
+// GPU (the verifier reports BadScalar / BadPoint with the item index, where serde would have failed).
+//
+// Verdict per object: EG_ST_OK (packed), EG_ST_MALFORMED (does not deserialise) or EG_PACK_RESHAPE (deserialises, but the number
+// of choices / responses / partial ciphertexts differs from the election's: OptionsLenMismatch / LenMismatch territory, decided
+// by the object path in the reference's order of checks).
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace egwire {
+
+struct Cursor {
+  const char* p;
+  const char* end;
+  bool fail = false;
+  void ws() { while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) ++p; }
+  bool eat(char c) { ws(); if (p < end && *p == c) { ++p; return true; } return false; }
+  bool peek(char c) { ws(); return p < end && *p == c; }
+};
+
+struct B64Table {
+  uint8_t v[256];
+  constexpr B64Table() : v() {
+    for (int i = 0; i < 256; ++i) v[i] = 0x80;
+    for (int i = 0; i < 26; ++i) { v['A' + i] = (uint8_t)i; v['a' + i] = (uint8_t)(26 + i); }
+    for (int i = 0; i < 10; ++i) v['0' + i] = (uint8_t)(52 + i);
+    v[(unsigned char)'-'] = 62; v[(unsigned char)'_'] = 63;
+  }
+};
+static constexpr B64Table kB64{};
+
+// a JSON string holding exactly 32 bytes of unpadded base64url (43 characters, the 2 trailing bits zero) -> out.
+// Anything else in the string - another alphabet, padding, a backslash escape, another length - fails.
+inline bool parse_b64_32(Cursor& c, uint8_t out[32]) {
+  if (!c.eat('"')) return false;
+  if (c.end - c.p < 44) return false;
+  const unsigned char* s = reinterpret_cast<const unsigned char*>(c.p);
+  uint32_t bad = 0;
+  for (int g = 0; g < 10; ++g) {                       // 40 characters -> 30 bytes
+    const uint32_t a = kB64.v[s[4 * g]], b = kB64.v[s[4 * g + 1]], d = kB64.v[s[4 * g + 2]], e = kB64.v[s[4 * g + 3]];
+    bad |= a | b | d | e;
+    const uint32_t w = (a << 18) | (b << 12) | (d << 6) | e;
+    out[3 * g] = (uint8_t)(w >> 16); out[3 * g + 1] = (uint8_t)(w >> 8); out[3 * g + 2] = (uint8_t)w;
+  }
+  const uint32_t a = kB64.v[s[40]], b = kB64.v[s[41]], d = kB64.v[s[42]];   // 3 characters -> 2 bytes + 2 bits that must be zero
+  bad |= a | b | d;
+  const uint32_t w = (a << 12) | (b << 6) | d;
+  out[30] = (uint8_t)(w >> 10); out[31] = (uint8_t)(w >> 2);
+  if ((bad & 0x80u) || (w & 3u) || s[43] != '"') return false;
+  c.p += 44;
+  return true;
+}
+
+// skips any JSON value (for unknown fields); strings honour backslash escapes
+inline bool skip_string(Cursor& c) {
+  if (!c.eat('"')) return false;
+  while (c.p < c.end) {
+    const char ch = *c.p++;
+    if (ch == '"') return true;
+    if (ch == '\\') { if (c.p >= c.end) return false; ++c.p; }
+  }
+  return false;
+}
+inline bool skip_value(Cursor& c, int depth = 0) {
+  if (depth > 32) return false;
+  c.ws();
+  if (c.p >= c.end) return false;
+  if (*c.p == '"') return skip_string(c);
+  if (*c.p == '{' || *c.p == '[') {
+    const char close = *c.p == '{' ? '}' : ']';
+    const bool obj = *c.p == '{';
+    ++c.p;
+    if (c.eat(close)) return true;
+    for (;;) {
+      if (obj) { if (!skip_string(c) || !c.eat(':')) return false; }
+      if (!skip_value(c, depth + 1)) return false;
+      if (c.eat(',')) continue;
+      return c.eat(close);
+    }
+  }
+  const char* s = c.p;
+  while (c.p < c.end && *c.p != ',' && *c.p != '}' && *c.p != ']' && *c.p != ' ' && *c.p != '\n' && *c.p != '\t' && *c.p != '\r') ++c.p;
+  return c.p > s;
+}
+
+// field name of an object member, without escapes (every name of the wire format is plain ASCII); longer names are unknown fields
+inline bool parse_key(Cursor& c, char name[32]) {
+  c.ws();
+  if (c.p >= c.end || *c.p != '"') return false;
+  const char* s = c.p + 1;
+  const char* q = s;
+  bool escaped = false;
+  while (q < c.end && *q != '"') { if (*q == '\\') { escaped = true; ++q; if (q >= c.end) return false; } ++q; }
+  if (q >= c.end) return false;
+  const size_t len = (size_t)(q - s);
+  if (escaped || len > 31) name[0] = '\0';
+  else { memcpy(name, s, len); name[len] = '\0'; }
+  c.p = q + 1;
+  return c.eat(':');
+}
+
+// generic object walker: fields[i] names; handler(i) parses the value of field i.  Every field is required exactly once.
+template <class Handler>
+inline bool parse_object(Cursor& c, const char* const* fields, int n_fields, Handler handler) {
+  if (!c.eat('{')) return false;
+  uint32_t seen = 0;
+  if (!c.peek('}')) {
+    for (;;) {
+      char name[32];
+      if (!parse_key(c, name)) return false;
+      int idx = -1;
+      for (int i = 0; i < n_fields; ++i) if (strcmp(name, fields[i]) == 0) { idx = i; break; }
+      if (idx < 0) { if (!skip_value(c)) return false; }
+      else {
+        if (seen & (1u << idx)) return false;          // duplicate field
+        seen |= 1u << idx;
+        if (!handler(idx)) return false;
+      }
+      if (c.eat(',')) continue;
+      break;
+    }
+  }
+  if (!c.eat('}')) return false;
+  return seen == (1u << n_fields) - 1u;                // missing field
+}
+
+using Bytes = std::vector<uint8_t>;
+
+inline bool parse_item(Cursor& c, Bytes& out) {
+  uint8_t b[32];
+  if (!parse_b64_32(c, b)) return false;
+  out.insert(out.end(), b, b + 32);
+  return true;
+}
+// [ "..", ".." ] of 32-byte items; returns the count
+inline bool parse_items(Cursor& c, Bytes& out, size_t& count, size_t minimum) {
+  count = 0;
+  if (!c.eat('[')) return false;
+  if (!c.peek(']')) {
+    for (;;) {
+      if (!parse_item(c, out)) return false;
+      ++count;
+      if (c.eat(',')) continue;
+      break;
+    }
+  }
+  return c.eat(']') && count >= minimum;
+}
+inline bool parse_ciphertext(Cursor& c, Bytes& out) {
+  static const char* const F[] = {"random_element", "blinded_element"};
+  uint8_t r[32], b[32];
+  if (!parse_object(c, F, 2, [&](int i) { return parse_b64_32(c, i == 0 ? r : b); })) return false;
+  out.insert(out.end(), r, r + 32);
+  out.insert(out.end(), b, b + 32);
+  return true;
+}
+inline bool parse_ciphertexts(Cursor& c, Bytes& out, size_t& count) {
+  count = 0;
+  if (!c.eat('[')) return false;
+  if (!c.peek(']')) {
+    for (;;) {
+      if (!parse_ciphertext(c, out)) return false;
+      ++count;
+      if (c.eat(',')) continue;
+      break;
+    }
+  }
+  return c.eat(']');
+}
+
+enum : uint32_t { ST_OK = 0, ST_MALFORMED = 13, PACK_RESHAPE = 0xfffffffeu };
+
+// EncryptedChoice -> choices || e0 || responses [|| c || s]; returns the verdict
+inline uint32_t pack_choice(Cursor& c, int n_options, bool single, uint8_t* dst) {
+  static const char* const F[] = {"choices", "range_proof", "sum_proof"};
+  static const char* const RING[] = {"common_challenge", "ring_responses"};
+  static const char* const LOGEQ[] = {"challenge", "response"};
+  static thread_local Bytes choices, ring_c, ring_r, sum;      // reused across objects: no allocation per ballot
+  choices.clear(); ring_c.clear(); ring_r.clear(); sum.clear();
+  size_t n_choices = 0, n_resp = 0;
+  bool sum_null = false;
+  const bool ok = parse_object(c, F, 3, [&](int i) {
+    if (i == 0) return parse_ciphertexts(c, choices, n_choices);
+    if (i == 1) return parse_object(c, RING, 2, [&](int k) { return k == 0 ? parse_item(c, ring_c) : parse_items(c, ring_r, n_resp, 2); });
+    c.ws();
+    if (c.end - c.p >= 4 && memcmp(c.p, "null", 4) == 0) { c.p += 4; sum_null = true; return true; }
+    uint8_t ch[32], rs[32];
+    if (!parse_object(c, LOGEQ, 2, [&](int k) { return parse_b64_32(c, k == 0 ? ch : rs); })) return false;
+    sum.assign(ch, ch + 32); sum.insert(sum.end(), rs, rs + 32);
+    return true;
+  });
+  if (!ok || sum_null == single) return ST_MALFORMED;       // S::Proof is `()` for MultiChoice, a LogEqualityProof for SingleChoice
+  if (n_choices != (size_t)n_options || n_resp != 2 * (size_t)n_options) return PACK_RESHAPE;
+  uint8_t* d = dst;
+  memcpy(d, choices.data(), choices.size()); d += choices.size();
+  memcpy(d, ring_c.data(), 32); d += 32;
+  memcpy(d, ring_r.data(), ring_r.size()); d += ring_r.size();
+  if (single) memcpy(d, sum.data(), 64);
+  return ST_OK;
+}
+
+struct RangeShape { size_t rings, responses; };   // number of rings and total ring size of a RangeDecomposition
+
+// { "ciphertext": .., "range_proof": { partial_ciphertexts, common_challenge, ring_responses } } -> ct || partials || e0 || responses
+inline bool parse_ct_with_range(Cursor& c, Bytes& out, const RangeShape& shape, bool& shape_ok) {
+  static const char* const F[] = {"ciphertext", "range_proof"};
+  static const char* const RP[] = {"partial_ciphertexts", "common_challenge", "ring_responses"};
+  static thread_local Bytes ct, partials, e0, resp;
+  ct.clear(); partials.clear(); e0.clear(); resp.clear();
+  size_t n_partials = 0, n_resp = 0;
+  if (!parse_object(c, F, 2, [&](int i) {
+        if (i == 0) return parse_ciphertext(c, ct);
+        return parse_object(c, RP, 3, [&](int k) {
+          if (k == 0) return parse_ciphertexts(c, partials, n_partials);
+          if (k == 1) return parse_item(c, e0);
+          return parse_items(c, resp, n_resp, 2);
+        });
+      }))
+    return false;
+  if (n_partials != shape.rings - 1 || n_resp != shape.responses) shape_ok = false;
+  out.insert(out.end(), ct.begin(), ct.end());
+  out.insert(out.end(), partials.begin(), partials.end());
+  out.insert(out.end(), e0.begin(), e0.end());
+  out.insert(out.end(), resp.begin(), resp.end());
+  return true;
+}
+
+inline uint32_t pack_qv(Cursor& c, int n_options, const RangeShape& vote, const RangeShape& credit, size_t ballot_size, uint8_t* dst) {
+  static const char* const F[] = {"votes", "credit", "credit_equivalence_proof"};
+  static const char* const SQ[] = {"challenge", "ciphertext_responses", "sum_response"};
+  static thread_local Bytes votes, cred, proof_c, proof_r, proof_s;
+  votes.clear(); cred.clear(); proof_c.clear(); proof_r.clear(); proof_s.clear();
+  size_t n_votes = 0, n_resp = 0;
+  bool shape_ok = true;
+  const bool ok = parse_object(c, F, 3, [&](int i) {
+    if (i == 0) {
+      if (!c.eat('[')) return false;
+      if (!c.peek(']')) {
+        for (;;) {
+          if (!parse_ct_with_range(c, votes, vote, shape_ok)) return false;
+          ++n_votes;
+          if (c.eat(',')) continue;
+          break;
+        }
+      }
+      return c.eat(']');
+    }
+    if (i == 1) return parse_ct_with_range(c, cred, credit, shape_ok);
+    return parse_object(c, SQ, 3, [&](int k) {
+      if (k == 0) return parse_item(c, proof_c);
+      if (k == 1) return parse_items(c, proof_r, n_resp, 2);
+      return parse_item(c, proof_s);
+    });
+  });
+  if (!ok) return ST_MALFORMED;
+  if (!shape_ok || n_votes != (size_t)n_options || n_resp != 2 * (size_t)n_options) return PACK_RESHAPE;
+  if (votes.size() + cred.size() + 32 + proof_r.size() + 32 != ballot_size) return PACK_RESHAPE;
+  uint8_t* d = dst;
+  memcpy(d, votes.data(), votes.size()); d += votes.size();
+  memcpy(d, cred.data(), cred.size()); d += cred.size();
+  memcpy(d, proof_c.data(), 32); d += 32;
+  memcpy(d, proof_r.data(), proof_r.size()); d += proof_r.size();
+  memcpy(d, proof_s.data(), 32);
+  return ST_OK;
+}
+
+// Start offsets of the top-level values of a stream: either one JSON array of objects, or objects back to back / one per line.
+// Returns false for text that is neither.  Only brace depth and strings are tracked here; the per-object parser does the rest.
+inline bool split_objects(const char* s, size_t len, std::vector<std::pair<size_t, size_t>>& spans) {
+  size_t i = 0;
+  auto ws = [&]() { while (i < len && (s[i] == ' ' || s[i] == '\n' || s[i] == '\t' || s[i] == '\r')) ++i; };
+  ws();
+  const bool array = i < len && s[i] == '[';
+  if (array) ++i;
+  for (;;) {
+    ws();
+    if (i >= len) return !array;
+    if (array && s[i] == ']') { ++i; ws(); return i == len; }
+    if (s[i] != '{') return false;
+    const size_t start = i;
+    int depth = 0;
+    while (i < len) {
+      const char ch = s[i];
+      if (ch == '"') {                                  // skip the string at memchr speed; a quote after a backslash is escaped
+        size_t q = i + 1;
+        for (;;) {
+          const void* hit = memchr(s + q, '"', len - q);
+          if (!hit) return false;
+          q = (size_t)((const char*)hit - s);
+          size_t bs = 0;
+          while (q - 1 - bs > i && s[q - 1 - bs] == '\\') ++bs;
+          if ((bs & 1) == 0) break;
+          ++q;
+        }
+        i = q + 1;
+        continue;
+      }
+      ++i;
+      if (ch == '{' || ch == '[') ++depth;
+      else if (ch == '}' || ch == ']') { if (--depth == 0) break; }
+    }
+    if (depth != 0) return false;
+    spans.push_back({start, i - start});
+    ws();
+    if (array) {
+      if (i < len && s[i] == ',') { ++i; continue; }
+      if (i < len && s[i] == ']') continue;
+      return false;
+    }
+  }
+}
+
+template <class PackOne>
+inline void pack_parallel(const char* json, const std::vector<std::pair<size_t, size_t>>& spans, size_t stride, int threads,
+                          uint8_t* packed, uint32_t* status, PackOne pack_one) {
+  const size_t n = spans.size();
+  if (threads < 1) threads = 1;
+  if ((size_t)threads > n) threads = (int)std::max<size_t>(n, 1);
+  auto work = [&](size_t lo, size_t hi) {
+    for (size_t k = lo; k < hi; ++k) {
+      Cursor c{json + spans[k].first, json + spans[k].first + spans[k].second};
+      uint8_t* dst = packed + k * stride;
+      uint32_t st = pack_one(c, dst);
+      if (st == ST_OK) { c.ws(); if (c.p != c.end) st = ST_MALFORMED; }     // trailing characters after the object
+      if (st != ST_OK) memset(dst, 0, stride);
+      status[k] = st;
+    }
+  };
+  if (threads == 1) { work(0, n); return; }
+  std::vector<std::thread> pool;
+  for (int t = 0; t < threads; ++t) pool.emplace_back(work, n * t / threads, n * (t + 1) / threads);
+  for (auto& th : pool) th.join();
+}
+
+}  // namespace egwire

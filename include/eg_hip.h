@@ -218,6 +218,29 @@ int eg_qv_encrypt_votes_batch(eg_qv_params*, uint64_t base_seed, size_t first, s
 int eg_qv_encrypt_votes_batch_device(eg_qv_params*, uint64_t base_seed, size_t first, size_t n, uint64_t rng_skip,
                                      const void* d_votes, void* d_out, void* stream);
 
+/* ---- wire ingest (host only, no GPU needed) ------------------------------------------------------------
+ * The reference's serde layout in human-readable formats (src/serde.rs:19-80,179-355: every scalar / element an unpadded base64url
+ * string; structures as derived on EncryptedChoice, RingProof, LogEqualityProof, QuadraticVotingBallot, RangeProof,
+ * SumOfSquaresProof, Ciphertext) -> packed ballots.  `json` holds the ballots as ONE JSON array of objects or as objects back to
+ * back / one per line (what examples/voting.rs:195-198 prints); object k is written to packed + k * ballot_size (zeroed unless
+ * status[k] == EG_ST_OK) and gets status[k] =
+ *   EG_ST_OK         packed;
+ *   EG_ST_MALFORMED  does not deserialise: bad alphabet / padding / non-zero trailing bits / byte length != 32
+ *                    (serde.rs:29-47,197,260), fewer than 2 ring_responses or ciphertext_responses (VecHelper<_, 2>, :303-355),
+ *                    missing or duplicate field, sum_proof of the wrong kind;
+ *   EG_PACK_RESHAPE  deserialises, but the number of choices / responses / partial ciphertexts is not the election's
+ *                    (OptionsLenMismatch / LenMismatch, choice.rs:149-158, proofs/mod.rs:73-99): such objects go through the object
+ *                    path (elastic_elgamal_amd/ingest.py), which applies the reference's order of checks.
+ * Canonicity of scalars and validity of elements are decided later, by the GPU verifier (EG_ST_BAD_SCALAR / EG_ST_BAD_POINT with
+ * the item index).  `threads` host threads parse in parallel.  *n_objects = number of objects found; EG_ERR_BAD_ARG if the text is
+ * not a sequence of objects or holds more than max_objects of them. */
+#define EG_PACK_RESHAPE 0xfffffffeu
+int eg_choice_pack_json(int n_options, int single, const char* json, size_t json_len, int threads, size_t max_objects,
+                        uint8_t* packed, uint32_t* status, size_t* n_objects);
+int eg_qv_pack_json(int n_options, uint64_t credits, const char* json, size_t json_len, int threads, size_t max_objects,
+                    uint8_t* packed, uint32_t* status, size_t* n_objects);
+size_t eg_qv_ballot_size_for(int n_options, uint64_t credits);   /* eg_qv_ballot_size without a params object (host only) */
+
 /* ---- host-only introspection (no GPU needed; used by the CPU-side tests of the host logic) -------------------------------------
  * RangeDecomposition::optimal(upper_bound).to_string() (range.rs:110-124,148-305): the string hashed into the transcript */
 int eg_range_decomposition(uint64_t upper_bound, char* buf, size_t cap);
