@@ -814,6 +814,42 @@ def test_object_ingest_length_mismatches(eg, ctx, oracle, pk, kind):
     assert tally == op.tally(accepted, [0] * (len(accepted) // sz))
 
 
+@pytest.mark.parametrize("kind", ["single", "qv"])
+def test_json_text_ingest_matches_object_path(eg, ctx, oracle, pk, kind):
+    """Ballots as JSON text (serde's layout): native packer + one GPU batch for the well-shaped ones, the object path for the
+    rest; verdicts and tally must equal those of the object path on the parsed objects (which the oracle-backed CPU tests pin)."""
+    import json
+    from elastic_elgamal_amd import ingest, serde
+    from ingest_cases import choice_cases, qv_cases
+
+    grp = eg.Ristretto(ctx)
+    if kind == "qv":
+        n, credits = 3, 9
+        op = oracle.QvParams(pk, n, credits)
+        p = eg.QuadraticVotingParams(ctx, pk, n, credits)
+        packed = op.generate_batch(21, 0, 200, threads=8)
+        sz = len(packed) // 200
+        objs = [ingest.unpack_qv_ballot(packed[i * sz : (i + 1) * sz], n, credits) for i in range(200)]
+        cases = [c[1] for c in qv_cases(objs[:8])]
+        verify_objects, verify_json = ingest.verify_qv_objects, ingest.verify_qv_json
+    else:
+        n = 3
+        op = oracle.ChoiceParams(pk, n, True)
+        p = eg.ChoiceParams(ctx, pk, n, True)
+        packed = op.generate_batch(22, 0, 200, threads=8)
+        sz = len(packed) // 200
+        objs = [serde.unpack_encrypted_choice(packed[i * sz : (i + 1) * sz], n, True) for i in range(200)]
+        cases = [c[1] for c in choice_cases(objs[:8], True)]
+        verify_objects, verify_json = ingest.verify_choice_objects, ingest.verify_choice_json
+    batch = objs[8:100] + cases + objs[100:]
+    batch[5] = dict(batch[5]); batch[5].pop(next(iter(batch[5])))                    # a missing field: Malformed
+    want, want_tally = verify_objects(p, grp, batch)
+    for text in (json.dumps(batch), "\n".join(json.dumps(o, indent=1) for o in batch)):
+        got, tally = verify_json(p, grp, text)
+        assert got == want and tally == want_tally
+    assert want.count(0) >= 190 and eg.MALFORMED in want and len({w & 0xFF for w in want}) >= 4
+
+
 @pytest.mark.parametrize("upper_bound", [12, 15, 20, 50])
 def test_range_proof_negative_cases(eg, ctx, oracle, pk, upper_bound):
     """range.rs:708-795 (range_proof_basics): a proof must not verify for another receiver, another ciphertext, a mangled

@@ -25,6 +25,7 @@ class OracleParams:
 
     def __init__(self, op, n_options, single=None, credits=None):
         self.op, self.n_options, self.single, self.credits = op, n_options, single, credits
+        self.ballot_size = op.ballot_size
 
     def verify_batch(self, ballots: bytes, with_tally: bool = True):
         st = self.op.verify_batch(ballots) if ballots else []
@@ -92,3 +93,33 @@ def test_structural_errors_fail_their_own_ballot_only(oracle, pk):
     junk = dict(qobjs[0], credit_equivalence_proof=dict(qobjs[0]["credit_equivalence_proof"], ciphertext_responses=[]))
     got, tally = ingest.verify_qv_objects(OracleParams(oq, 2, credits=4), OracleGroup(oracle), [junk, qobjs[1]])
     assert got == [m, 0] and tally == oq.tally(qp[qsz:], [0])
+
+
+@pytest.mark.parametrize("kind", ["single", "multi", "qv"])
+def test_json_text_path_equals_object_path(oracle, pk, kind):
+    """ingest.verify_*_json = native packer (libeg_hip.so, host-only code) + batch verify + object path for the odd ones: same
+    verdicts and tally as the object path on the parsed objects, here with the verify calls answered by the oracle."""
+    import json
+
+    if kind == "qv":
+        n, credits = 3, 9
+        op = oracle.QvParams(pk, n, credits)
+        packed = op.generate_batch(12, 0, 12)
+        sz = len(packed) // 12
+        objs = [ingest.unpack_qv_ballot(packed[i * sz : (i + 1) * sz], n, credits) for i in range(12)]
+        batch = [c[1] for c in qv_cases(objs[:8])] + objs[8:]
+        params, fn_obj, fn_json = OracleParams(op, n, credits=credits), ingest.verify_qv_objects, ingest.verify_qv_json
+    else:
+        n, single = 3, kind == "single"
+        op = oracle.ChoiceParams(pk, n, single)
+        packed = op.generate_batch(11, 0, 12, n_selected=0 if single else 2)
+        sz = len(packed) // 12
+        objs = [serde.unpack_encrypted_choice(packed[i * sz : (i + 1) * sz], n, single) for i in range(12)]
+        batch = [c[1] for c in choice_cases(objs[:8], single)] + objs[8:]
+        params, fn_obj, fn_json = OracleParams(op, n, single=single), ingest.verify_choice_objects, ingest.verify_choice_json
+    batch.insert(3, {"choices": "junk"})
+    want, want_tally = fn_obj(params, OracleGroup(oracle), batch)
+    got, tally = fn_json(params, OracleGroup(oracle), json.dumps(batch))
+    assert got == want and tally == want_tally and want[3] == ingest.status(ingest.ST_MALFORMED)
+    got, tally = fn_json(params, OracleGroup(oracle), "\n".join(json.dumps(o) for o in batch))
+    assert got == want and tally == want_tally
