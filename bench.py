@@ -86,6 +86,8 @@ def parse():
                     help="flip one response bit in this share of the ballots before timing (SURVEY 8d: verdict parity and tally "
                          "exclusion with invalid ballots in the batch); the headline line uses 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-wire-ingest", action="store_true",
+                    help="skip the wire-ingest leg (JSON text of the same ballots through the native packer on the host cores)")
     ap.add_argument("--no-host-inclusive", action="store_true",
                     help="skip the PCIe-inclusive leg (host buffers through eg_verify_*_batch) that follows the timed loop at N = 1")
     ap.add_argument("--force-dist", action="store_true",
@@ -346,6 +348,39 @@ def main():
                                  "bytes_h2d": B * params.ballot_size, "bytes_d2h": 4 * B,
                                  "verdicts_match_device_path": bool(torch.equal(host_status, status.cpu())),
                                  "vs_value": B / hs / value}
+
+    # ---- wire ingest: the same ballots as JSON text in serde's layout through the native packer -------------
+    if not args.no_wire_ingest and world == 1:
+        from elastic_elgamal_amd import ingest as eging, serde as egserde
+
+        distinct = min(B, 1000)
+        raw = bytes(ballots[: distinct * params.ballot_size].cpu().numpy())
+        if args.workload == "qv":
+            objs = [eging.unpack_qv_ballot(raw[i * params.ballot_size : (i + 1) * params.ballot_size], n_opt, args.credits) for i in range(distinct)]
+        else:
+            objs = [egserde.unpack_encrypted_choice(raw[i * params.ballot_size : (i + 1) * params.ballot_size], n_opt, args.workload == "single")
+                    for i in range(distinct)]
+        one = [json.dumps(o) for o in objs]
+        reps = max(1, min(100, B // distinct))
+        text = ("[" + ",".join(one * reps) + "]").encode()
+        n_obj = distinct * reps
+        cores = effective_cores()
+        kw = {"credits": args.credits} if args.workload == "qv" else {"single": args.workload == "single"}
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            packed, st = eg.pack_json(text, n_opt, threads=cores, max_objects=n_obj, **kw)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        t0 = time.perf_counter()
+        packer = egserde.pack_qv_ballot if args.workload == "qv" else egserde.pack_encrypted_choice
+        ref = b"".join(packer(o) for o in json.loads(text[: 1 + sum(len(x) + 1 for x in one) - 1].decode() + "]"))
+        py_s = time.perf_counter() - t0
+        out["wire_ingest"] = {"value": n_obj / best, "unit": "ballots/s", "threads": cores, "json_bytes": len(text), "objects": n_obj,
+                              "json_mb_per_s": len(text) / best / 1e6, "all_packed": st.count(0) == n_obj,
+                              "equals_device_ballots": packed[: distinct * params.ballot_size] == raw == ref,
+                              "python_mirror_value": distinct / py_s,
+                              "note": "JSON text (serde layout, base64url) -> packed bytes on the host, before the PCIe-inclusive path above"}
 
     # ---- CPU baseline: the oracle ("port": CPU restatement, not curve25519-dalek) on a bounded sample --------------
     if not args.no_cpu_baseline and world == 1:

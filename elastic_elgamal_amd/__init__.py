@@ -449,7 +449,9 @@ class ChoiceParams(_BatchParams):
         ChaChaRng::seed_from_u64(base_seed + first + i) after `rng_skip` 64-byte draws.  Returns the packed ballots."""
         sel = list(selections)
         n = len(sel)
-        arr = (C.c_uint32 * max(n, 1))(*sel)
+        sw = (self.n_options + 31) // 32                       # bitmask words per ballot
+        words = [(int(m) >> (32 * w)) & 0xFFFFFFFF for m in sel for w in range(sw)]
+        arr = (C.c_uint32 * max(len(words), 1))(*words)
         out = C.create_string_buffer(max(n * self.ballot_size, 1))
         _check(_load().eg_choice_encrypt_selected_batch(self._h, base_seed, first, n, rng_skip, arr, out))
         return out.raw[: n * self.ballot_size]

@@ -23,14 +23,16 @@
 
 using namespace eg;
 
-void eg_launch_qv_encrypt(int blocks, hipStream_t s, u64 seed0, size_t n, int n_options, u64 credits, const u32* votes, u64 rng_skip,
-                          const int* vote_range,
-                          const int* credit_range, int pre_sumsq, const uint4* tabG, const uint4* tabK, const u32* prefixes,
-                          u32* out, u32 stride_words, u32 vote_words, u32 credit_words);
 // defined in eg_gen.hip (separate translation unit so the two compile in parallel)
+void eg_launch_qv_encrypt(int blocks, hipStream_t s, u64 seed0, size_t n, int n_options, u64 credits, const u32* votes, u64 rng_skip,
+                          int vote_rings, int vote_main, int vote_ring, const u32* d_vote_desc, int credit_rings, int credit_main,
+                          int credit_ring, const u32* d_credit_desc, int pre_sumsq, const uint4* tabG, const uint4* tabK,
+                          const u32* prefixes, u32* out, u32 stride_words, u32 vote_words, u32 credit_words, u32* gws);
 void eg_launch_choice_encrypt(int blocks, hipStream_t s, u64 seed0, size_t n, int n_options, int single, int n_selected,
                               const u32* selection, u64 rng_skip, const uint4* tabG, const uint4* tabK, const u32* prefixes, int pre_main, int pre_ring,
-                              int pre_logeq, u32* out, u32 stride_words);
+                              int pre_logeq, u32* out, u32 stride_words, u32* gws);
+unsigned eg_gen_choice_ws_words(int n_options);
+unsigned eg_gen_qv_ws_words(int n_options, unsigned max_rings, unsigned max_responses);
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
@@ -90,19 +92,9 @@ static int upload(T** dptr, const std::vector<T>& v, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// the equations of a stage, sorted by kernel family (kernels.cuh): FAM_TABLE1 one table-backed base, FAM_TABLEN several
-// table-backed bases on one doubling chain, FAM_GENERIC everything else, FAM_ENCODE plain encodings of point slots
-enum { FAM_TABLE1 = 0, FAM_TABLEN = 1, FAM_GENERIC = 2, FAM_ENCODE = 3, N_FAM = 4 };
-constexpr int EG_MULTI_GROUP = 8;           // terms per shared doubling chain: 8 sign vectors = 72 KiB of LDS per block, two blocks per CU
-static int job_family(const egplan::JobClass& j, const std::vector<egplan::VarTerm>& vterms) {
-  if (!j.defer) return FAM_ENCODE;
-  if (j.term_count == 0) return FAM_GENERIC;
-  for (unsigned t = 0; t < j.term_count; ++t)
-    if (vterms[j.term_first + t].base == 0xffff) return FAM_GENERIC;
-  return j.term_count == 1 ? FAM_TABLE1 : FAM_TABLEN;
-}
-struct StageDev { int fam_first[N_FAM], fam_count[N_FAM], max_terms, inst_first, inst_count, defer_first, defer_count; };
-struct LevelDev { int first, count; };
+using eghost::StageDev; using eghost::LevelDev;
+using eghost::FAM_TABLE1; using eghost::FAM_TABLEN; using eghost::FAM_GENERIC; using eghost::FAM_ENCODE; using eghost::N_FAM;
+using eghost::EG_MULTI_GROUP; using eghost::job_family;
 
 struct Engine {
   eg_ctx* ctx = nullptr;
@@ -144,13 +136,36 @@ struct Engine {
   unsigned char* d_wire = nullptr;
   u32* d_status = nullptr;
   size_t staging_ballots = 0;
+  // generators: per-lane workspace (grown on demand) and the ring shapes of the two range proofs of a QV ballot
+  u32* gen_ws = nullptr;
+  size_t gen_ws_bytes = 0;
+  u32* d_gen_desc = nullptr;
 };
+
+static int grid_for(size_t lanes, int cap_blocks);
+// blocks of a generator launch and its per-lane workspace: at most ~2 GiB of scratch, whatever the election's size
+static int gen_workspace(Engine* e, size_t n, unsigned words, int* blocks_out) {
+  const size_t budget = (size_t)2 << 30;
+  int blocks = grid_for(n, e->ctx->cus * 4);
+  const size_t per_block = (size_t)NT * words * sizeof(u32);
+  if ((size_t)blocks * per_block > budget) blocks = (int)std::max<size_t>(1, budget / per_block);
+  const size_t need = (size_t)blocks * per_block;
+  if (need > e->gen_ws_bytes) {
+    HIPCHK(hipDeviceSynchronize());     // an earlier generator launch may still use the old slice
+    if (e->gen_ws) (void)hipFree(e->gen_ws);
+    e->gen_ws = nullptr; e->gen_ws_bytes = 0;
+    HIPCHK(hipMalloc((void**)&e->gen_ws, need));
+    e->gen_ws_bytes = need;
+  }
+  *blocks_out = blocks;
+  return EG_OK;
+}
 
 static void engine_free(Engine* e) {
   if (!e) return;
   void* ptrs[] = {e->d_pt_items, e->d_sc_items, e->d_dclasses, e->d_dterms, e->d_jobs, e->d_vterms, e->d_insts, e->d_ops,
                   e->d_rules, e->d_tally_slots, e->d_base_slots, e->d_defer_slots, e->btab, e->dpt, e->encw, e->d_blob, e->d_tabK, e->d_cpts, e->d_prefixes, e->d_key_words, e->pts, e->cmp,
-                  e->chal, e->states, e->flags, e->bad_item, e->partial, e->tally, e->tally_saved, e->d_wire, e->d_status};
+                  e->chal, e->states, e->flags, e->bad_item, e->partial, e->tally, e->tally_saved, e->d_wire, e->d_status, e->gen_ws, e->d_gen_desc};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
   delete e;
@@ -231,44 +246,22 @@ static int engine_create(eg_ctx* ctx, eghost::Plan&& plan, const uint8_t pk[32],
   HIPCHK(hipSetDevice(ctx->device));
   if (P.pk_off >= 0) memcpy(P.blob.data() + P.pk_off, pk, 32);
 
-  // flatten stages / levels / programs
-  std::vector<egplan::JobClass> jobs;
-  std::vector<egplan::HashInst> insts;
-  std::vector<egplan::HashOp> ops;
-  std::vector<uint16_t> defer_slots;
-  for (auto& st : P.stages) {
-    StageDev sd;
-    sd.defer_first = (int)defer_slots.size(); sd.defer_count = (int)st.deferred.size();
-    defer_slots.insert(defer_slots.end(), st.deferred.begin(), st.deferred.end());
-    e->max_defer = std::max(e->max_defer, std::min(sd.defer_count, 32));
-    sd.max_terms = 0;
-    for (int f = 0; f < N_FAM; ++f) {
-      sd.fam_first[f] = (int)jobs.size();
-      for (auto& j : st.jobs)
-        if (job_family(j, P.vterms) == f) {
-          jobs.push_back(j);
-          if (f == FAM_TABLEN) sd.max_terms = std::max<int>(sd.max_terms, j.term_count);
-        }
-      sd.fam_count[f] = (int)jobs.size() - sd.fam_first[f];
-    }
-    sd.inst_first = (int)insts.size(); sd.inst_count = (int)st.insts.size();
-    for (auto& prog : st.insts) {
-      insts.push_back({(uint32_t)ops.size(), (uint32_t)prog.size()});
-      ops.insert(ops.end(), prog.begin(), prog.end());
-    }
-    e->stages.push_back(sd);
+  // flatten stages / levels / programs (pure host logic: host_plan.hpp)
+  const eghost::FlatPlan F = eghost::flatten_plan(P);
+  {
+    const std::string why = eghost::check_flat_plan(P, F);
+    if (!why.empty()) return fail(EG_ERR_BAD_ARG, "internal: inconsistent verification plan: " + why);
   }
-  e->prefix_inst_first = (int)insts.size();
-  e->prefix_inst_count = (int)P.prefix_programs.size();
-  for (auto& prog : P.prefix_programs) {
-    insts.push_back({(uint32_t)ops.size(), (uint32_t)prog.size()});
-    ops.insert(ops.end(), prog.begin(), prog.end());
-  }
-  std::vector<egplan::DeriveClass> dclasses;
-  for (auto& lvl : P.derive_levels) {
-    e->levels.push_back({(int)dclasses.size(), (int)lvl.size()});
-    dclasses.insert(dclasses.end(), lvl.begin(), lvl.end());
-  }
+  e->stages = F.stages;
+  e->levels = F.levels;
+  e->max_defer = F.max_defer;
+  e->prefix_inst_first = F.prefix_inst_first;
+  e->prefix_inst_count = F.prefix_inst_count;
+  const std::vector<egplan::JobClass>& jobs = F.jobs;
+  const std::vector<egplan::HashInst>& insts = F.insts;
+  const std::vector<egplan::HashOp>& ops = F.ops;
+  const std::vector<uint16_t>& defer_slots = F.defer_slots;
+  const std::vector<egplan::DeriveClass>& dclasses = F.dclasses;
   int rc;
   if ((rc = upload(&e->d_pt_items, P.pt_items, s))) return rc;
   if ((rc = upload(&e->d_sc_items, P.sc_items, s))) return rc;
@@ -1025,11 +1018,12 @@ static int choice_encrypt_device(eg_choice_params* p, uint64_t base_seed, size_t
   HIPCHK(hipSetDevice(e->ctx->device));
   if (!d_selection && !p->single && (n_selected < 0 || n_selected > p->n_options)) return fail(EG_ERR_BAD_ARG, "n_selected out of range");
   if (n == 0) return EG_OK;
-  if (p->n_options > 32) return fail(EG_ERR_BAD_ARG, "the generator supports at most 32 options");
-  eg_launch_choice_encrypt(grid_for(n, e->ctx->cus * 4), s, base_seed + first, n, p->n_options, p->single, n_selected,
+  int blocks = 0;
+  TRY(gen_workspace(e, n, eg_gen_choice_ws_words(p->n_options), &blocks));
+  eg_launch_choice_encrypt(blocks, s, base_seed + first, n, p->n_options, p->single, n_selected,
                            reinterpret_cast<const u32*>(d_selection), rng_skip, e->ctx->tabG,
                            e->d_tabK, e->d_prefixes, e->plan.gen_pre_main, e->plan.gen_pre_ring, e->plan.gen_pre_logeq,
-                           reinterpret_cast<u32*>(d_out), (u32)(e->plan.stride / 4));
+                           reinterpret_cast<u32*>(d_out), (u32)(e->plan.stride / 4), e->gen_ws);
   HIPCHK(hipGetLastError());
   return EG_OK;
 }
@@ -1059,13 +1053,20 @@ int eg_choice_encrypt_selected_batch(eg_choice_params* p, uint64_t base_seed, si
   if (!p || (n && (!out || !selection))) return fail(EG_ERR_BAD_ARG, "bad argument");
   Engine* e = p->eng;
   HIPCHK(hipSetDevice(e->ctx->device));
+  const size_t sw = ((size_t)p->n_options + 31) / 32;
   for (size_t i = 0; i < n; ++i) {      // what EncryptedChoice::single / ::new would refuse or mis-prove
-    if (p->n_options < 32 && (selection[i] >> p->n_options)) return fail(EG_ERR_BAD_ARG, "selection has bits beyond the options");
-    if (p->single && __builtin_popcount(selection[i]) != 1) return fail(EG_ERR_BAD_ARG, "a single-choice ballot selects exactly one option");
+    int chosen = 0;
+    for (size_t w = 0; w < sw; ++w) {
+      const uint32_t word = selection[i * sw + w];
+      const int valid_bits = (int)std::min<size_t>(32, (size_t)p->n_options - 32 * w);
+      if (valid_bits < 32 && (word >> valid_bits)) return fail(EG_ERR_BAD_ARG, "selection has bits beyond the options");
+      chosen += __builtin_popcount(word);
+    }
+    if (p->single && chosen != 1) return fail(EG_ERR_BAD_ARG, "a single-choice ballot selects exactly one option");
   }
   DevBuf d, sel;
-  TRY(d.alloc(n * e->plan.stride)); TRY(sel.alloc(n * 4));
-  TRY(sel.put(selection, n * 4, e->ctx->stream));
+  TRY(d.alloc(n * e->plan.stride)); TRY(sel.alloc(n * sw * 4));
+  TRY(sel.put(selection, n * sw * 4, e->ctx->stream));
   TRY(choice_encrypt_device(p, base_seed, first, n, 0, sel.p, rng_skip, d.p, e->ctx->stream));
   TRY(d.get(out, n * e->plan.stride, e->ctx->stream));
   HIPCHK(hipStreamSynchronize(e->ctx->stream));
@@ -1076,22 +1077,24 @@ static int qv_encrypt_device(eg_qv_params* p, uint64_t base_seed, size_t first, 
   Engine* e = p->eng;
   HIPCHK(hipSetDevice(e->ctx->device));
   const eghost::QvShape& sh = p->shape;
-  if (p->n_options > 16 || sh.vote_range.rings.size() > 4 || sh.credit_range.rings.size() > 4)
-    return fail(EG_ERR_BAD_ARG, "the generator supports at most 16 options and 4 rings per range");
-  for (auto* d : {&sh.vote_range, &sh.credit_range})
-    for (auto& r : d->rings) if (r.size > 16) return fail(EG_ERR_BAD_ARG, "the generator supports ring sizes up to 16");
   if (n == 0) return EG_OK;
-  auto pack = [](const eghost::RangeDecomposition& d, int pre_main, int pre_ring) {
-    std::vector<int> a{(int)d.rings.size(), pre_main, pre_ring};
-    for (auto& r : d.rings) { a.push_back((int)r.size); a.push_back((int)r.step); }
-    return a;
-  };
-  const std::vector<int> v = pack(sh.vote_range, e->plan.gen_vote_main, e->plan.gen_vote_ring);
-  const std::vector<int> c = pack(sh.credit_range, e->plan.gen_credit_main, e->plan.gen_credit_ring);
-  eg_launch_qv_encrypt(grid_for(n, e->ctx->cus * 4), s, base_seed + first, n, p->n_options, p->credits,
-                       reinterpret_cast<const u32*>(d_votes), rng_skip, v.data(), c.data(),
-                       e->plan.gen_pre_sumsq, e->ctx->tabG, e->d_tabK, e->d_prefixes, reinterpret_cast<u32*>(d_out),
-                       (u32)(sh.ballot_size / 4), (u32)(sh.vote_size / 4), (u32)(sh.credit_size / 4));
+  const size_t vr = sh.vote_range.rings.size(), cr = sh.credit_range.rings.size();
+  if (!e->d_gen_desc) {     // ring shapes (size, step) of the vote range, then of the credit range
+    std::vector<u32> desc;
+    for (auto* d : {&sh.vote_range, &sh.credit_range})
+      for (auto& r : d->rings) { desc.push_back((u32)r.size); desc.push_back((u32)r.step); }
+    HIPCHK(hipMalloc((void**)&e->d_gen_desc, desc.size() * sizeof(u32)));
+    HIPCHK(hipMemcpy(e->d_gen_desc, desc.data(), desc.size() * sizeof(u32), hipMemcpyHostToDevice));
+  }
+  int blocks = 0;
+  const unsigned words = eg_gen_qv_ws_words(p->n_options, (unsigned)std::max(vr, cr),
+                                            (unsigned)std::max(sh.vote_range.rings_size(), sh.credit_range.rings_size()));
+  TRY(gen_workspace(e, n, words, &blocks));
+  eg_launch_qv_encrypt(blocks, s, base_seed + first, n, p->n_options, p->credits, reinterpret_cast<const u32*>(d_votes), rng_skip,
+                       (int)vr, e->plan.gen_vote_main, e->plan.gen_vote_ring, e->d_gen_desc, (int)cr, e->plan.gen_credit_main,
+                       e->plan.gen_credit_ring, e->d_gen_desc + 2 * vr, e->plan.gen_pre_sumsq, e->ctx->tabG, e->d_tabK,
+                       e->d_prefixes, reinterpret_cast<u32*>(d_out), (u32)(sh.ballot_size / 4), (u32)(sh.vote_size / 4),
+                       (u32)(sh.credit_size / 4), e->gen_ws);
   HIPCHK(hipGetLastError());
   return EG_OK;
 }

@@ -7,6 +7,7 @@
 // (quadratic_voting.rs:63-76,127-143), and the transcript label schedules of ring.rs:290-293,317-368,
 // log_equality.rs:167-173, range.rs:561-562, mul.rs:96-99,204-253.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -608,6 +609,138 @@ inline Plan build_share_plan(uint64_t shares, uint64_t threshold, const uint8_t 
                               {OP_CHALLENGE_CHECK, P.ref("c"), 2, flag}});
   P.rules.push_back({flag, 4});
   return P;
+}
+
+// ---- flattening of a plan into the arrays the kernels index (pure host logic, sanitizer-tested in tests/hostcheck) ------------
+// the equations of a stage, sorted by kernel family (kernels.cuh): FAM_TABLE1 one table-backed base, FAM_TABLEN several
+// table-backed bases on shared doubling chains, FAM_GENERIC everything else, FAM_ENCODE plain encodings of point slots
+enum { FAM_TABLE1 = 0, FAM_TABLEN = 1, FAM_GENERIC = 2, FAM_ENCODE = 3, N_FAM = 4 };
+constexpr int EG_MULTI_GROUP = 8;           // terms per shared doubling chain: 8 sign vectors = 72 KiB of LDS per block, two blocks per CU
+inline int job_family(const JobClass& j, const std::vector<VarTerm>& vterms) {
+  if (!j.defer) return FAM_ENCODE;
+  if (j.term_count == 0) return FAM_GENERIC;
+  for (unsigned t = 0; t < j.term_count; ++t)
+    if (vterms[j.term_first + t].base == 0xffff) return FAM_GENERIC;
+  return j.term_count == 1 ? FAM_TABLE1 : FAM_TABLEN;
+}
+struct StageDev { int fam_first[N_FAM], fam_count[N_FAM], max_terms, inst_first, inst_count, defer_first, defer_count; };
+struct LevelDev { int first, count; };
+struct FlatPlan {
+  std::vector<JobClass> jobs;
+  std::vector<HashInst> insts;
+  std::vector<HashOp> ops;
+  std::vector<uint16_t> defer_slots;
+  std::vector<DeriveClass> dclasses;
+  std::vector<StageDev> stages;
+  std::vector<LevelDev> levels;
+  int max_defer = 0, prefix_inst_first = 0, prefix_inst_count = 0;
+};
+inline FlatPlan flatten_plan(const Plan& P) {
+  FlatPlan F;
+  for (auto& st : P.stages) {
+    StageDev sd;
+    sd.defer_first = (int)F.defer_slots.size(); sd.defer_count = (int)st.deferred.size();
+    F.defer_slots.insert(F.defer_slots.end(), st.deferred.begin(), st.deferred.end());
+    F.max_defer = std::max(F.max_defer, std::min(sd.defer_count, 32));
+    sd.max_terms = 0;
+    for (int f = 0; f < N_FAM; ++f) {
+      sd.fam_first[f] = (int)F.jobs.size();
+      for (auto& j : st.jobs)
+        if (job_family(j, P.vterms) == f) {
+          F.jobs.push_back(j);
+          if (f == FAM_TABLEN) sd.max_terms = std::max<int>(sd.max_terms, j.term_count);
+        }
+      sd.fam_count[f] = (int)F.jobs.size() - sd.fam_first[f];
+    }
+    sd.inst_first = (int)F.insts.size(); sd.inst_count = (int)st.insts.size();
+    for (auto& prog : st.insts) {
+      F.insts.push_back({(uint32_t)F.ops.size(), (uint32_t)prog.size()});
+      F.ops.insert(F.ops.end(), prog.begin(), prog.end());
+    }
+    F.stages.push_back(sd);
+  }
+  F.prefix_inst_first = (int)F.insts.size();
+  F.prefix_inst_count = (int)P.prefix_programs.size();
+  for (auto& prog : P.prefix_programs) {
+    F.insts.push_back({(uint32_t)F.ops.size(), (uint32_t)prog.size()});
+    F.ops.insert(F.ops.end(), prog.begin(), prog.end());
+  }
+  for (auto& lvl : P.derive_levels) {
+    F.levels.push_back({(int)F.dclasses.size(), (int)lvl.size()});
+    F.dclasses.insert(F.dclasses.end(), lvl.begin(), lvl.end());
+  }
+  return F;
+}
+
+// Every index the kernels will dereference, checked against the sizes the engine allocates (a fault on the device can take
+// the whole node down, so an inconsistent plan is refused on the host).  Returns "" when consistent.
+inline std::string check_flat_plan(const Plan& P, const FlatPlan& F) {
+  const size_t items = P.stride / 32;
+  auto scalar_ok = [&](const ScalarSrc& s) {
+    if (s.kind == SRC_NONE) return true;
+    if (s.kind == SRC_WIRE) return (size_t)s.idx < items;
+    return s.kind == SRC_CHAL && (int)s.idx < P.n_chal_slots;
+  };
+  if (P.stride % 32) return "stride is not a multiple of 32";
+  for (auto& w : P.pt_items) if (w.item >= items || (int)w.slot >= P.n_pt_slots) return "wire point out of range";
+  for (auto& w : P.sc_items) if (w.item >= items) return "wire scalar out of range";
+  for (auto& d : F.dclasses) {
+    if ((size_t)d.term_first + d.term_count > P.dterms.size() || (int)d.out_slot >= P.n_pt_slots) return "derive class out of range";
+    for (unsigned t = 0; t < d.term_count; ++t) {
+      const DeriveTerm& dt = P.dterms[d.term_first + t];
+      if (dt.is_const ? dt.slot >= P.const_mults.size() : (int)dt.slot >= P.n_pt_slots) return "derive term out of range";
+    }
+  }
+  for (uint16_t b : P.base_slots) if ((int)b >= P.n_pt_slots) return "base slot out of range";
+  size_t counted = 0;
+  for (auto& sd : F.stages) {
+    for (int f = 0; f < N_FAM; ++f) {
+      if (sd.fam_first[f] < 0 || (size_t)sd.fam_first[f] + sd.fam_count[f] > F.jobs.size()) return "family range out of range";
+      counted += sd.fam_count[f];
+      for (int k = 0; k < sd.fam_count[f]; ++k) {
+        const JobClass& j = F.jobs[sd.fam_first[f] + k];
+        if (job_family(j, P.vterms) != f) return "job in the wrong family";
+        if ((size_t)j.term_first + j.term_count > P.vterms.size()) return "job terms out of range";
+        if ((int)j.out_slot >= P.n_cmp_slots) return "job output out of range";
+        if (!j.defer && (int)j.enc_slot >= P.n_pt_slots) return "encode job source out of range";
+        if (!scalar_ok(j.g) || !scalar_ok(j.k)) return "job scalar out of range";
+        for (unsigned t = 0; t < j.term_count; ++t) {
+          const VarTerm& v = P.vterms[j.term_first + t];
+          if (!scalar_ok(v.s) || v.s.kind == SRC_NONE) return "term scalar out of range";
+          if (v.base == 0xffff ? (int)v.slot >= P.n_pt_slots : v.base >= P.base_slots.size()) return "term base out of range";
+        }
+      }
+    }
+    if ((size_t)sd.defer_first + sd.defer_count > F.defer_slots.size()) return "deferred range out of range";
+    if ((size_t)sd.inst_first + sd.inst_count > F.insts.size()) return "program range out of range";
+  }
+  if (counted != F.jobs.size()) return "jobs lost in the family sort";
+  for (uint16_t d : F.defer_slots) if ((int)d >= P.n_cmp_slots) return "deferred slot out of range";
+  for (auto& in : F.insts) {
+    if ((size_t)in.op_first + in.op_count > F.ops.size()) return "program ops out of range";
+    for (uint32_t o = 0; o < in.op_count; ++o) {
+      const HashOp& op = F.ops[in.op_first + o];
+      auto blob_ok = [&](uint32_t ref) { return (size_t)(ref >> 12) + (ref & 0xfffu) <= P.blob.size(); };
+      switch (op.op) {
+        case OP_NEW: case OP_APPEND_U64: if (!blob_ok(op.a)) return "label out of range"; break;
+        case OP_APPEND_BLOB: if (!blob_ok(op.a) || !blob_ok(op.b)) return "blob out of range"; break;
+        case OP_APPEND_WIRE: if (!blob_ok(op.a) || (size_t)op.b + op.c > items) return "wire append out of range"; break;
+        case OP_APPEND_CMP:
+          if (!blob_ok(op.a) || (int)op.b >= P.n_cmp_slots || (op.c != 0xffffu && (int)op.c >= P.n_cmp_slots)) return "cmp append out of range";
+          break;
+        case OP_CHALLENGE:
+          if (!blob_ok(op.a) || (int)op.b + (op.c > 1 ? 1 : 0) >= P.n_chal_slots) return "challenge slot out of range";
+          break;
+        case OP_CHALLENGE_CHECK: if (!blob_ok(op.a) || op.b >= items || (int)op.c >= P.n_flag_slots) return "challenge check out of range"; break;
+        case OP_LOAD_PREFIX: case OP_SAVE_PREFIX: if ((int)op.b >= P.n_prefixes) return "prefix out of range"; break;
+        case OP_LOAD_STATE: case OP_SAVE_STATE: if ((int)op.b >= P.n_state_slots) return "state slot out of range"; break;
+        default: return "unknown transcript op";
+      }
+    }
+  }
+  for (auto& r : P.rules) if ((int)r.flag_slot >= P.n_flag_slots) return "rule flag out of range";
+  for (uint32_t t : P.tally_slots) if ((int)t >= P.n_pt_slots) return "tally slot out of range";
+  return "";
 }
 
 }  // namespace eghost

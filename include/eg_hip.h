@@ -194,23 +194,23 @@ int eg_verify_proof_batch_device(eg_proof_params*, size_t n, const void* d_items
  * Ballot i of the call is produced from ChaChaRng::seed_from_u64(base_seed + first + i) with the reference's
  * RNG draw order (choice.rs:313-349, ring.rs:54-194, log_equality.rs:114-139, range.rs:462-534, mul.rs:107-181);
  * the voter's selection comes from a second stream seeded with the complemented seed.  n_selected is only
- * used for multi-choice params.  The generators keep a ballot's secrets in registers / scratch and therefore cap the
- * election shape (EG_ERR_BAD_ARG beyond it): choice ballots up to 32 options; quadratic voting up to 16 options, 4 rings
- * per range proof and ring sizes up to 16.  The verifiers have no such caps (n_options up to 4000 / 256). */
+ * used for multi-choice params.  A ballot's secrets live in a per-lane workspace in device memory sized from the election's
+ * shape, so the generators accept every election the verifiers accept (n_options up to 4000 / 256). */
 int eg_choice_encrypt_batch_device(eg_choice_params*, uint64_t base_seed, size_t first, size_t n, int n_selected,
                                    void* d_out, void* stream);
 int eg_choice_encrypt_batch(eg_choice_params*, uint64_t base_seed, size_t first, size_t n, int n_selected,
                             uint8_t* out /* host, n * eg_choice_ballot_size */);
 int eg_qv_encrypt_batch_device(eg_qv_params*, uint64_t base_seed, size_t first, size_t n, void* d_out, void* stream);
 /* The same provers with the CALLER's choices: EncryptedChoice::single(params, choice, rng) / ::new(params, &[bool], rng)
- * (choice.rs:296-349) and QuadraticVotingBallot::new(params, votes, rng) (quadratic_voting.rs:234-284).  selection: one uint32 per
- * ballot, bit k set <=> option k chosen (single-choice: exactly one bit); votes: n_options uint32 per ballot with
+ * (choice.rs:296-349) and QuadraticVotingBallot::new(params, votes, rng) (quadratic_voting.rs:234-284).  selection:
+ * ceil(n_options / 32) uint32 per ballot, bit k of the bitmask set <=> option k chosen (single-choice: exactly one bit); votes:
+ * n_options uint32 per ballot with
  * sum(v^2) <= credits.  rng_skip = number of 64-byte draws the ballot's RNG, ChaChaRng::seed_from_u64(base_seed + first + i), has
  * already served: tests/snapshots.rs:107-161 draw the keypair first, so (12345, rng_skip = 1) reproduces the reference's
  * `encrypted-choice`, `encrypted-multi-choice` and `qv-ballot` snapshots byte for byte.  The host forms validate the choices
  * (EG_ERR_BAD_ARG); the device forms trust them, as the reference trusts its caller's assertions. */
 int eg_choice_encrypt_selected_batch(eg_choice_params*, uint64_t base_seed, size_t first, size_t n, uint64_t rng_skip,
-                                     const uint32_t* selection /* n */, uint8_t* out);
+                                     const uint32_t* selection /* n x ceil(n_options / 32) */, uint8_t* out);
 int eg_choice_encrypt_selected_batch_device(eg_choice_params*, uint64_t base_seed, size_t first, size_t n, uint64_t rng_skip,
                                             const void* d_selection, void* d_out, void* stream);
 int eg_qv_encrypt_votes_batch(eg_qv_params*, uint64_t base_seed, size_t first, size_t n, uint64_t rng_skip,

@@ -295,6 +295,19 @@ def test_generator_matches_oracle_prover(eg, ctx, oracle, pk):
         q = eg.ChoiceParams(ctx, pk, n, True)
         oq = oracle.ChoiceParams(pk, n, True)
         assert _gen_on_gpu(eg, q, 9000 + n, 0, 20) == oq.generate_batch(9000 + n, 0, 20)
+    # elections beyond 32 options: a ballot's secrets live in the generator's device workspace, nothing caps the shape
+    for n, single, sel in ((33, True, 0), (40, False, 7), (150, False, 4)):
+        q = eg.ChoiceParams(ctx, pk, n, single)
+        oq = oracle.ChoiceParams(pk, n, single)
+        assert _gen_on_gpu(eg, q, 7000 + n, 3, 12, n_selected=sel) == oq.generate_batch(7000 + n, 3, 12, n_selected=sel, threads=8)
+    # explicit choices with a two-word bitmask (40 options), against the oracle prover given the same flags
+    q = eg.ChoiceParams(ctx, pk, 40, False)
+    oq = oracle.ChoiceParams(pk, 40, False)
+    mask = (1 << 39) | (1 << 32) | (1 << 31) | 1
+    got = q.encrypt_selected(4321, 0, [mask, 1 << 35])
+    for i, m in enumerate((mask, 1 << 35)):
+        flags = [(m >> k) & 1 for k in range(40)]
+        assert got[i * q.ballot_size : (i + 1) * q.ballot_size] == oq.new_ballot(flags, oracle.rng_from_u64(4321 + i))
 
 
 def test_snapshot_seed_reproduced_on_gpu(eg, ctx, golden, pk, oracle):
@@ -446,14 +459,14 @@ def test_cpp_voting_example(tmp_path):
 def test_qv_generator_matches_oracle_prover(eg, ctx, oracle, pk):
     import torch
 
-    for credits, n in ((20, 96), (15, 24), (100, 8)):
-        q = eg.QuadraticVotingParams(ctx, pk, 5, credits)
-        oq = oracle.QvParams(pk, 5, credits)
+    for options, credits, n in ((5, 20, 96), (5, 15, 24), (5, 100, 8), (12, 200, 6), (20, 1000, 4), (3, 10000, 4), (1, 1, 5)):
+        q = eg.QuadraticVotingParams(ctx, pk, options, credits)
+        oq = oracle.QvParams(pk, options, credits)
         out = torch.zeros(n * q.ballot_size, dtype=torch.uint8, device="cuda")
         q.encrypt_batch_device(31, 5, n, out.data_ptr())
         ctx.synchronize()
         got = bytes(out.cpu().numpy())
-        assert got == oq.generate_batch(31, 5, n), credits
+        assert got == oq.generate_batch(31, 5, n, threads=8), (options, credits)
         st, _ = q.verify_batch(got)
         assert st == [0] * n
 
@@ -663,42 +676,51 @@ def test_concurrent_host_calls_are_serialised(eg, ctx, oracle, pk):
 
 def test_large_election_chunks_follow_device_memory(eg, ctx, oracle, pk):
     """150 options: ~1.6 MB of comb tables per ballot, so the engine must shrink its chunks below EG_CHUNK to fit the
-    device.  48 oracle-made ballots are tiled to ~98k; verdicts, tampering and the tally stay exact."""
+    device.  ~98k INDEPENDENT ballots made by the GPU prover (4 of 150 options each); verdicts of a sample and of the
+    tampered ballots are the oracle's, and the tally is linear over a split of the batch."""
     import torch
 
-    n_opt, tile, reps = 150, 48, 2048
-    n = tile * reps
+    n_opt, n = 150, 98304
     p = eg.ChoiceParams(ctx, pk, n_opt, False)
     op = oracle.ChoiceParams(pk, n_opt, False)
     sz = p.ballot_size
-    base = op.generate_batch(909, 0, tile, n_selected=4, threads=8)
-    want = op.verify_batch(base, threads=8)
-    assert want == [0] * tile
-    got_st, got_tally = p.verify_batch(base)
-    assert got_st == want and got_tally == op.tally(base, want)
-    d = torch.frombuffer(bytearray(base), dtype=torch.uint8).cuda().repeat(reps)
+    d = torch.empty(n * sz, dtype=torch.uint8, device="cuda")
+    p.encrypt_batch_device(909, 0, n, d.data_ptr(), n_selected=4)
+    ctx.synchronize()
+    view = d.view(n, sz)
+    head = bytes(view[:24].cpu().numpy())
+    assert head == op.generate_batch(909, 0, 24, n_selected=4, threads=8)          # the prover itself, on this shape
+    bad = torch.tensor([0, 7, n // 2, n - 1], device="cuda")
+    view[bad, sz - 32] ^= 1
     st = torch.empty(n, dtype=torch.int32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
     p.tally_reset()
     p.verify_batch_device(n, d.data_ptr(), st.data_ptr(), stream)
     torch.cuda.synchronize()
-    assert int((st != 0).sum()) == 0
-    whole = p.tally_encode()
-    grp = eg.Ristretto(ctx)
-    m = reps.to_bytes(32, "little")
-    scaled, ok = grp.vartime_multi_mul(1, m * (2 * n_opt), got_tally)       # [reps] * tally(tile), element by element
-    assert set(ok) == {1} and scaled == whole
-    view = d.view(n, sz)
-    bad = torch.tensor([0, 7, n // 2, n - 1], device="cuda")
-    view[bad, sz - 32] ^= 1
-    p.verify_batch_device(n, d.data_ptr(), st.data_ptr(), stream)
-    torch.cuda.synchronize()
     assert torch.nonzero(st != 0).flatten().tolist() == sorted(bad.tolist())
+    whole = p.tally_encode()
+    half = n // 2
+    p.tally_reset()
+    p.verify_batch_device(half, d.data_ptr(), st.data_ptr(), stream)
+    torch.cuda.synchronize()
+    ta = p.tally_encode()
+    p.tally_reset()
+    p.verify_batch_device(n - half, d.data_ptr() + half * sz, st.data_ptr() + 4 * half, stream)
+    torch.cuda.synchronize()
+    tb = p.tally_encode()
+    grp = eg.Ristretto(ctx)
+    assert grp.element_add(ta, tb)[0] == whole
+    idx = [0, 7, 8, 100, n // 2, n // 2 + 1, n - 2, n - 1]
+    sample = b"".join(bytes(view[i].cpu().numpy()) for i in idx)
+    got, gt = p.verify_batch(sample)
+    want = op.verify_batch(sample, threads=8)
+    assert got == want and gt == op.tally(sample, want) and want.count(0) == 4
 
 
 @pytest.mark.parametrize("options,credits", [(12, 200), (20, 1000), (3, 10000)])
 def test_qv_large_parameters_oracle_ballots(eg, ctx, oracle, pk, options, credits):
-    """Beyond the GPU generator's limits (16 options): ballots from the oracle prover, tampered in every section."""
+    """Large quadratic-voting shapes (multi-ring vote ranges, long rings): ballots from the oracle prover, tampered in every
+    section."""
     oq = oracle.QvParams(pk, options, credits)
     q = eg.QuadraticVotingParams(ctx, pk, options, credits)
     n = 24

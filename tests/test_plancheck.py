@@ -1,0 +1,97 @@
+"""The product's pure-host C++ (plan builders + flattening + index check of csrc/host_plan.hpp, native wire ingest of
+csrc/wire_json.hpp) compiled with -fsanitize=address,undefined and driven through every plan shape and through fuzzed JSON.
+The sanitizer build runs in a child process (ASan must be loaded first), so a finding shows up as a non-zero exit code."""
+import subprocess
+import sys
+import textwrap
+from pathlib import Path
+
+import pytest
+
+HERE = Path(__file__).resolve().parent / "hostcheck"
+ROOT = HERE.parent.parent
+
+
+@pytest.fixture(scope="module")
+def lib():
+    so = HERE / "libplancheck.so"
+    srcs = [HERE / "plancheck.cpp", ROOT / "elastic_elgamal_amd" / "csrc" / "host_plan.hpp", ROOT / "elastic_elgamal_amd" / "csrc" / "wire_json.hpp",
+            ROOT / "elastic_elgamal_amd" / "csrc" / "plan.h"]
+    if not so.exists() or any(s.stat().st_mtime > so.stat().st_mtime for s in srcs):
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", "-fsanitize=address,undefined",
+                               "-fno-sanitize-recover=all", "-o", str(so), str(HERE / "plancheck.cpp")])
+    return so
+
+
+def _run(lib, body: str):
+    asan = subprocess.check_output(["g++", "-print-file-name=libasan.so"], text=True).strip()
+    code = textwrap.dedent(f"""
+        import ctypes as C, json, random, sys
+        sys.path.insert(0, {str(ROOT)!r})
+        L = C.CDLL({str(lib)!r})
+        L.pc_qv_size.restype = C.c_ulonglong
+    """) + textwrap.dedent(body)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                       env={"LD_PRELOAD": asan, "ASAN_OPTIONS": "detect_leaks=0:abort_on_error=0:exitcode=99", "PATH": "/usr/bin:/bin"})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-6000:]
+    return r.stdout
+
+
+def test_every_plan_shape_builds_flattens_and_checks(lib):
+    out = _run(lib, """
+        total = 0
+        for n in list(range(1, 41)) + [64, 150, 1000, 4000]:
+            for kind in (0, 1):
+                j = L.pc_plan(kind, n, C.c_ulonglong(0)); assert j == 4 * n + (4 if kind == 0 else 0), (kind, n, j); total += 1
+        for n, credits in [(1, 1), (2, 4), (3, 9), (5, 15), (5, 20), (5, 25), (4, 100), (8, 36), (12, 200), (16, 64), (20, 1000), (3, 10000), (256, 100000)]:
+            assert L.pc_plan(2, n, C.c_ulonglong(credits)) > 0, (n, credits); total += 1
+        for ub in list(range(2, 300)) + [1000, 65536, 777777, 1000000]:
+            assert L.pc_plan(5, 0, C.c_ulonglong(ub)) > 0, ub; total += 1
+        for n in (1, 2, 5, 9, 40, 1000):
+            assert L.pc_plan(6, n, C.c_ulonglong(0)) == 2 * n + 2; total += 1
+        assert L.pc_plan(3, 0, C.c_ulonglong(0)) == 2 and L.pc_plan(4, 0, C.c_ulonglong(0)) == 4 and L.pc_plan(7, 3, C.c_ulonglong(0)) == 2
+        buf = C.create_string_buffer(256)
+        for ub, want in ((5, "0..5"), (21, "3 * 0..7 + 0..3"), (100, "20 * 0..5 + 4 * 0..5 + 0..4"), (12345678, None)):
+            assert L.pc_range(C.c_ulonglong(ub), buf, 256) > 0
+            if want: assert buf.value.decode() == want, buf.value
+        print("plans", total)
+    """)
+    assert "plans" in out
+
+
+def test_wire_packer_survives_fuzzed_json(lib):
+    out = _run(lib, """
+        from elastic_elgamal_amd import serde, ingest
+        gold = json.load(open({0!r}))
+        c, q = gold["encrypted-choice"], gold["qv-ballot"]
+        rnd = random.Random(5)
+        texts = []
+        base = json.dumps([c, c, c])
+        qbase = json.dumps(q, indent=1)
+        for t, src in ((0, base), (1, qbase)):
+            for _ in range(1500):
+                b = bytearray(src.encode())
+                for _ in range(rnd.randrange(1, 6)):
+                    if len(b) < 2: break
+                    op = rnd.randrange(4)
+                    i = rnd.randrange(len(b))
+                    if op == 0: b[i] = rnd.randrange(256)
+                    elif op == 1: del b[i : i + rnd.randrange(1, 60)]
+                    elif op == 2: b[i:i] = bytes(rnd.choice(b'{{}}[]",:\\\\ =') for _ in range(rnd.randrange(1, 5)))
+                    else: b = b[: rnd.randrange(len(b))]
+                texts.append((t, bytes(b)))
+        ok = bad = 0
+        qsize = L.pc_qv_size(5, C.c_ulonglong(15))
+        for t, b in texts:
+            packed = C.create_string_buffer(16 * max(736, qsize)); st = (C.c_uint32 * 16)()
+            if t == 0: n = L.pc_pack_choice(5, 1, b, C.c_size_t(len(b)), 2, packed, st, C.c_size_t(16))
+            else: n = L.pc_pack_qv(5, C.c_ulonglong(15), b, C.c_size_t(len(b)), 2, packed, st, C.c_size_t(16))
+            if n < 0: bad += 1
+            else: ok += sum(1 for k in range(n) if st[k] == 0)
+        print("fuzzed", len(texts), "unsplittable", bad, "objects still accepted", ok)
+        # and the untouched texts pack to the golden bytes under the sanitizers too
+        packed = C.create_string_buffer(3 * 736); st = (C.c_uint32 * 3)()
+        assert L.pc_pack_choice(5, 1, base.encode(), C.c_size_t(len(base)), 3, packed, st, C.c_size_t(3)) == 3 and list(st) == [0, 0, 0]
+        assert packed.raw[:736] == serde.pack_encrypted_choice(c)
+    """.format(str(ROOT / "tests" / "golden" / "snapshots_serde.json")))
+    assert "fuzzed 3000" in out
