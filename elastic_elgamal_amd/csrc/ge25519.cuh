@@ -595,8 +595,8 @@ EG_HD void ge_teeth_mul_multi(ge& acc, int n_terms, ColumnFn column, LoadFn load
 }
 
 // ---- fixed-base scalar multiplication -----------------------------------------------------------------------------
-// Signed radix-2^B comb (B = EG_COMB_BITS, default 15: 17 windows x 16384 affine-Niels entries per base, 34 MiB, Infinity-Cache
-// resident; measured 8 -> 13 bits: +3 %, 13 -> 15: +0.9 %, 16 the same as 15), built once per base on the device
+// Signed radix-2^B comb (B = EG_COMB_BITS: ceil(254 / B) windows x 2^(B-1) affine-Niels entries of 128 B per base; 15 bits =
+// 17 windows, 34 MiB, Infinity-Cache resident; measured 8 -> 13 bits: +3 %, 13 -> 15: +0.9 %), built once per base on the device
 // (k_build_fixed_table).  Table index = window * 2^(B-1) + (|digit| - 1).
 // acc += [k]Base with one mixed addition (7M) per window and no doublings.
 #ifndef EG_COMB_BITS
@@ -604,47 +604,43 @@ EG_HD void ge_teeth_mul_multi(ge& acc, int n_terms, ColumnFn column, LoadFn load
 #endif
 #define EG_FIXED_WINDOWS ((254 + EG_COMB_BITS - 1) / EG_COMB_BITS)     // scalars (also halved ones) are < 2^254
 #define EG_FIXED_ENTRIES (1 << (EG_COMB_BITS - 1))
-#define EG_COMB_STORE (EG_COMB_BITS <= 8 ? 8 : 16)                      // bits per stored digit
-#define EG_COMB_WORDS ((EG_FIXED_WINDOWS * EG_COMB_STORE + 31) / 32)
-// 256-bit scalar (< 2^254) -> EG_FIXED_WINDOWS signed digits in [-2^(B-1), 2^(B-1)), two's complement, packed
+#define EG_COMB_WORDS 8
+// The signed digits are cut from the scalar on the fly, lowest window first (a comb has no doublings, so its windows can be
+// summed in any order): no digit array, only a running carry.  sc_recode_comb is kept as the (now trivial) hand-over of the scalar.
 EG_HD void sc_recode_comb(u32 out[EG_COMB_WORDS], const u32 k[8]) {
 #pragma unroll
-  for (int w = 0; w < EG_COMB_WORDS; ++w) out[w] = 0;
-  u32 carry = 0;
-#pragma unroll
-  for (int i = 0; i < EG_FIXED_WINDOWS; ++i) {
-    const int off = i * EG_COMB_BITS, wi = off >> 5, sh = off & 31;
-    u64 v = wi < 8 ? k[wi] : 0u;
-    if (wi + 1 < 8) v |= (u64)k[wi + 1] << 32;
-    const u32 dgt = ((u32)(v >> sh) & ((1u << EG_COMB_BITS) - 1u)) + carry;   // 0 .. 2^B
-    carry = (dgt + (1u << (EG_COMB_BITS - 1))) >> EG_COMB_BITS;
-    const u32 stored = (dgt - (carry << EG_COMB_BITS)) & ((1u << EG_COMB_STORE) - 1u);
-    out[(i * EG_COMB_STORE) >> 5] |= stored << ((i * EG_COMB_STORE) & 31);
-  }
+  for (int w = 0; w < 8; ++w) out[w] = k[w];
 }
-EG_HD int sc_digit_comb(const u32 d[EG_COMB_WORDS], int i) {
-  const int pos = i * EG_COMB_STORE;
-  u32 w = d[0];
+// signed digit in [-2^(B-1), 2^(B-1)) of window i of a scalar < 2^254, given the carry of window i - 1
+EG_HD int sc_comb_digit(const u32 k[8], int i, u32& carry) {
+  const int off = i * EG_COMB_BITS, wi = off >> 5, sh = off & 31;
+  u32 lo = 0, hi = 0;
 #pragma unroll
-  for (int j = 1; j < EG_COMB_WORDS; ++j) w = ((pos >> 5) == j) ? d[j] : w;
-  const int v = (int)((w >> (pos & 31)) & ((1u << EG_COMB_STORE) - 1u));
-  return v >= (1 << (EG_COMB_STORE - 1)) ? v - (1 << EG_COMB_STORE) : v;
+  for (int j = 0; j < 8; ++j) { lo = (wi == j) ? k[j] : lo; hi = (wi + 1 == j) ? k[j] : hi; }
+  const u64 v = (u64)lo | ((u64)hi << 32);
+  const u32 raw = ((u32)(v >> sh) & ((1u << EG_COMB_BITS) - 1u)) + carry;      // 0 .. 2^B
+  carry = (raw + (1u << (EG_COMB_BITS - 1))) >> EG_COMB_BITS;
+  return (int)raw - (int)(carry << EG_COMB_BITS);
 }
-EG_HD int ge_fixed_index(const u32 digits[EG_COMB_WORDS], int i) {
-  const int d = sc_digit_comb(digits, i);
+EG_HD int ge_fixed_index(int i, int d) {
   const int ad = d < 0 ? -d : d;
   return i * EG_FIXED_ENTRIES + (ad == 0 ? 0 : ad - 1);
 }
 template <class NielsIO>
-EG_HD void ge_fixed_mul_add(ge& acc, NielsIO& io, const u32 digits[EG_COMB_WORDS]) {
+EG_HD void ge_fixed_mul_add(ge& acc, NielsIO& io, const u32 k[EG_COMB_WORDS]) {
   ge_niels ident; ge_niels_identity(ident);
   ge_niels nxt;
-  io.load(nxt, ge_fixed_index(digits, 0));
+  u32 carry = 0;
+  int d_nxt = sc_comb_digit(k, 0, carry);
+  io.load(nxt, ge_fixed_index(0, d_nxt));
 #pragma unroll 1
   for (int i = 0; i < EG_FIXED_WINDOWS; ++i) {
     ge_niels c = nxt;
-    if (i + 1 < EG_FIXED_WINDOWS) io.load(nxt, ge_fixed_index(digits, i + 1));   // one addition ahead of its use
-    const int d = sc_digit_comb(digits, i);
+    const int d = d_nxt;
+    if (i + 1 < EG_FIXED_WINDOWS) {                     // one addition ahead of its use
+      d_nxt = sc_comb_digit(k, i + 1, carry);
+      io.load(nxt, ge_fixed_index(i + 1, d_nxt));
+    }
     fe_cmov(c.ypx, ident.ypx, d == 0); fe_cmov(c.ymx, ident.ymx, d == 0); fe_cmov(c.xy2d, ident.xy2d, d == 0);
     ge_niels_cneg(c, d < 0);
     ge_p1p1 t; ge_madd(t, acc, c);

@@ -19,6 +19,14 @@
 #include <hip/hip_runtime.h>
 #include "device_io.cuh"
 
+// waves per SIMD the register allocation of the two dominant kernels is held to (A/B knobs; 3 would need <= 168 VGPRs)
+#ifndef EG_EQ_WAVES
+#define EG_EQ_WAVES 2        // waves per SIMD the register allocation of the equation kernel is held to
+#endif
+#ifndef EG_TAB_WAVES
+#define EG_TAB_WAVES 2
+#endif
+
 namespace eg {
 
 // ---- scalar operand fetch ---------------------------------------------------------------------------------------
@@ -87,7 +95,7 @@ __global__ void __launch_bounds__(NT) k_derive_points(EngineBufs B, const egplan
 }
 
 // ---- k_base_tables: comb tables of every ring base (once per base and ballot; shared by all equations of the ring) -----------
-__global__ void __launch_bounds__(NT, 2) k_base_tables(EngineBufs B, const unsigned short* base_slots, int n_bases) {
+__global__ void __launch_bounds__(NT, EG_TAB_WAVES) k_base_tables(EngineBufs B, const unsigned short* base_slots, int n_bases) {
   const size_t total = (size_t)n_bases * B.n;
   WsTable tmp;
   tmp.init(B.ws);
@@ -126,7 +134,7 @@ __device__ __forceinline__ void eq_fixed_terms(ge& acc, const EngineBufs& B, u32
 }
 
 template <bool MULTI>
-__global__ void __launch_bounds__(NT, 2) k_eq_table(EngineBufs B, const egplan::JobClass* classes, const egplan::VarTerm* terms,
+__global__ void __launch_bounds__(NT, EG_EQ_WAVES) k_eq_table(EngineBufs B, const egplan::JobClass* classes, const egplan::VarTerm* terms,
                                                     int class_first, int n_classes, int group) {
   extern __shared__ u32 eq_signs[];          // MULTI: [group][9][NT] sign vectors of the multipliers (sc_teeth_signs)
   const size_t total = (size_t)n_classes * B.n;
@@ -140,7 +148,11 @@ __global__ void __launch_bounds__(NT, 2) k_eq_table(EngineBufs B, const egplan::
       load_scalar(s, B, b, vt.s, true);
       u64 rows[EG_TEETH];
       sc_recode_teeth(rows, s);
+#ifdef EG_AB_SHARED_ENTRY   // measurement-only build: every lane reads ballot 0's table (upper bound on what less table traffic can buy)
+      BaseTable bt{B.btab + ((size_t)vt.base * B.cap) * BTAB_QUADS};
+#else
       BaseTable bt{B.btab + ((size_t)vt.base * B.cap + b) * BTAB_QUADS};
+#endif
       ge_teeth_mul(acc, bt, rows);
     } else {
       // groups of up to `group` terms share a doubling chain (the group size is what fits LDS at two blocks per CU)

@@ -80,6 +80,8 @@ def _declare(l: C.CDLL) -> None:
         "or_range_verify": (C.c_uint32, [vp, vp, u8p, u8p]),
         "or_sumsq_verify": (C.c_uint32, [vp, C.c_int, u8p, u8p, u8p, u8p]),
         "or_qv_verify": (C.c_uint32, [vp, u8p]),
+        "or_choice_verify_object": (C.c_uint32, [vp, C.c_int, C.c_int, u8p]),
+        "or_qv_verify_object": (C.c_uint32, [vp, C.POINTER(C.c_int), u8p]),
         "or_verify_zero": (C.c_uint32, [vp, u8p]),
         "or_verify_bool": (C.c_uint32, [vp, u8p]),
         "or_encrypt_u64": (None, [vp, C.c_uint64, C.POINTER(ChaChaRng), u8p]),
@@ -265,6 +267,14 @@ class ChoiceParams:
         assert len(ballot) == self.ballot_size
         return lib().or_choice_verify(self.ptr, ballot)
 
+    def verify_object(self, choices, common_challenge: bytes, responses, sum_proof=None) -> int:
+        """EncryptedChoice::verify on an object of ANY shape (oracle/objects.c): choices = [(R, B) bytes pairs],
+        responses = list of 32-byte scalars, sum_proof = (challenge, response) for single-choice elections."""
+        items = b"".join(r + b for r, b in choices) + common_challenge + b"".join(responses)
+        if self.single:
+            items += sum_proof[0] + sum_proof[1]
+        return lib().or_choice_verify_object(self.ptr, len(choices), len(responses), items)
+
     def generate_batch(self, base_seed: int, first: int, n: int, n_selected: int = 0, threads: int = 0) -> bytes:
         out = _buf(n * self.ballot_size)
         lib().or_choice_generate_batch(self.ptr, base_seed, first, n, n_selected, out, threads or os.cpu_count())
@@ -371,6 +381,18 @@ class QvParams:
     def verify(self, ballot: bytes) -> int:
         assert len(ballot) == self.ballot_size
         return lib().or_qv_verify(self.ptr, ballot)
+
+    def verify_object(self, blocks, sumsq) -> int:
+        """QuadraticVotingBallot::verify on an object of ANY shape (oracle/objects.c).  blocks = votes then credit, each
+        (ciphertext (R, B), [partial (R, B), ..], common_challenge, [responses]); sumsq = (challenge, [responses], sum_response)."""
+        shape, items = [len(blocks) - 1], b""
+        for ct, partials, e0, resp in blocks:
+            shape += [len(partials), len(resp)]
+            items += ct[0] + ct[1] + b"".join(r + b for r, b in partials) + e0 + b"".join(resp)
+        shape.append(len(sumsq[1]))
+        items += sumsq[0] + b"".join(sumsq[1]) + sumsq[2]
+        arr = (C.c_int * len(shape))(*shape)
+        return lib().or_qv_verify_object(self.ptr, arr, items)
 
     def generate_batch(self, base_seed: int, first: int, n: int, threads: int = 0) -> bytes:
         out = _buf(n * self.ballot_size)

@@ -5,7 +5,7 @@ import pytest
 
 from elastic_elgamal_amd import ingest, serde
 
-from ingest_cases import L, choice_cases, qv_cases
+from ingest_cases import BAD_POINT, BAD_SCALAR, L, choice_cases, flip, qv_cases
 
 
 class OracleGroup:
@@ -123,3 +123,104 @@ def test_json_text_path_equals_object_path(oracle, pk, kind):
     assert got == want and tally == want_tally and want[3] == ingest.status(ingest.ST_MALFORMED)
     got, tally = fn_json(params, OracleGroup(oracle), "\n".join(json.dumps(o) for o in batch))
     assert got == want and tally == want_tally
+
+
+# ------------------------------------------------------------------------------------------------ the oracle on objects
+def _choice_object_verdict(op, o):
+    """EncryptedChoice::verify restated on the object (oracle/objects.c), or Malformed if it does not deserialise."""
+    try:
+        d = serde.b64url_decode
+        choices = [(d(c["random_element"]), d(c["blinded_element"])) for c in o["choices"]]
+        rp = o["range_proof"]
+        if len(rp["ring_responses"]) < 2:
+            raise serde.SerdeError("VecHelper<_, 2>")
+        sp = o.get("sum_proof")
+        if op.single != (sp is not None):
+            raise serde.SerdeError("proof kind")
+        sum_proof = (d(sp["challenge"]), d(sp["response"])) if sp else None
+        return op.verify_object(choices, d(rp["common_challenge"]), [d(r) for r in rp["ring_responses"]], sum_proof)
+    except (serde.SerdeError, KeyError, TypeError):
+        return ingest.status(ingest.ST_MALFORMED)
+
+
+def _qv_object_verdict(oq, o):
+    try:
+        d = serde.b64url_decode
+
+        def ct(c):
+            return (d(c["random_element"]), d(c["blinded_element"]))
+
+        def block(v):
+            rp = v["range_proof"]
+            if len(rp["ring_responses"]) < 2:
+                raise serde.SerdeError("VecHelper<_, 2>")
+            return (ct(v["ciphertext"]), [ct(c) for c in rp["partial_ciphertexts"]], d(rp["common_challenge"]), [d(r) for r in rp["ring_responses"]])
+
+        p = o["credit_equivalence_proof"]
+        if len(p["ciphertext_responses"]) < 2:
+            raise serde.SerdeError("VecHelper<_, 2>")
+        blocks = [block(v) for v in o["votes"]] + [block(o["credit"])]
+        return oq.verify_object(blocks, (d(p["challenge"]), [d(r) for r in p["ciphertext_responses"]], d(p["sum_response"])))
+    except (serde.SerdeError, KeyError, TypeError):
+        return ingest.status(ingest.ST_MALFORMED)
+
+
+@pytest.mark.parametrize("kind", ["single", "multi", "qv"])
+def test_length_mismatch_verdicts_are_the_oracles(oracle, pk, kind):
+    """The *_LEN / OptionsLenMismatch expectations of tests/ingest_cases.py are hand-derived; here every case (and a batch of
+    randomly reshaped objects) is also judged by the oracle's restatement of verify() on OBJECTS, which performs the
+    reference's checks in the reference's order (oracle/objects.c).  The product's object path must agree with both."""
+    import copy
+    import random
+
+    rnd = random.Random(7)
+    if kind == "qv":
+        n, credits = 3, 9
+        op = oracle.QvParams(pk, n, credits)
+        packed = op.generate_batch(12, 0, 8)
+        sz = len(packed) // 8
+        objs = [ingest.unpack_qv_ballot(packed[i * sz : (i + 1) * sz], n, credits) for i in range(8)]
+        cases = qv_cases(objs)
+        verdict, params, run = _qv_object_verdict, OracleParams(op, n, credits=credits), ingest.verify_qv_objects
+    else:
+        n, single = 3, kind == "single"
+        op = oracle.ChoiceParams(pk, n, single)
+        packed = op.generate_batch(11, 0, 8, n_selected=0 if single else 2)
+        sz = len(packed) // 8
+        objs = [serde.unpack_encrypted_choice(packed[i * sz : (i + 1) * sz], n, single) for i in range(8)]
+        cases = choice_cases(objs, single)
+        verdict, params, run = _choice_object_verdict, OracleParams(op, n, single=single), ingest.verify_choice_objects
+    for name, o, want in cases:
+        assert verdict(op, o) == want, name
+    # random reshaping / tampering: pop or duplicate list entries anywhere, flip scalars, plant invalid elements
+    fuzzed = []
+    for k in range(60):
+        o = copy.deepcopy(objs[k % 8])
+        for _ in range(rnd.randrange(1, 4)):
+            lists = []
+
+            def walk(x):
+                if isinstance(x, dict):
+                    for v in x.values():
+                        walk(v)
+                elif isinstance(x, list):
+                    lists.append(x)
+                    for v in x:
+                        walk(v)
+
+            walk(o)
+            target = rnd.choice(lists)
+            action = rnd.randrange(4)
+            if action == 0 and target:
+                target.pop(rnd.randrange(len(target)))
+            elif action == 1 and target:
+                target.append(copy.deepcopy(rnd.choice(target)))
+            elif action == 2 and target and isinstance(target[0], str):
+                i = rnd.randrange(len(target)); target[i] = rnd.choice([flip(target[i]), BAD_SCALAR])
+            elif target and isinstance(target[0], dict) and "random_element" in target[0]:
+                rnd.choice(target)["blinded_element"] = BAD_POINT
+        fuzzed.append(o)
+    want = [verdict(op, o) for o in fuzzed]
+    got, _ = run(params, OracleGroup(oracle), fuzzed)
+    assert got == want
+    assert len({w & 0xFF for w in want}) >= 4
