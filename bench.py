@@ -34,7 +34,7 @@ PUBLIC_KEY_HEX = "a6adb6e9c0ae8d54c26e6e56b5ccd7a16bb0e1951abe4d7ee7028e3d4eca85
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # VALU model: field operations per building block counted by the host-check build
 # (tests/hostcheck: hc_op_counts) as (fe_mul, fe_sq); one fe_mul = 100 and one fe_sq = 55 v_mad_u64_u32.
-OPS = {"decode": (27, 257), "direct_table": (64, 0), "direct_mul": (1269, 1008), "comb": (119, 0), "encode": (32, 255),
+OPS = {"decode": (27, 257), "direct_table": (64, 0), "direct_mul": (1269, 1008), "comb": (91, 0), "encode": (32, 255),
        "base_table": (994, 860), "base_mul": (463, 168), "enc_batch_each": (23, 10), "enc_batch_inversion": (11, 254),
        "multi_first": (470, 168), "multi_extra": (344, 0)}
 # memory-side traffic per ballot and launch of the profiled kernels comes from profiles/traffic.json, which

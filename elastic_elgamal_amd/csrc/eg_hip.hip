@@ -972,10 +972,10 @@ int eg_plan_describe(int kind, int n_options, uint64_t credits_or_bound, char* b
 }
 
 // ---- wire ingest: serde's human-readable (JSON, base64url) layout -> packed ballots; host only (wire_json.hpp) --------------------
-static int pack_json_common(const char* json, size_t json_len, size_t max_objects, size_t* n_objects,
+static int pack_json_common(const char* json, size_t json_len, int threads, size_t max_objects, size_t* n_objects,
                             std::vector<std::pair<size_t, size_t>>& spans) {
   if (!json_len) { if (n_objects) *n_objects = 0; return EG_OK; }
-  if (!egwire::split_objects(json, json_len, spans))
+  if (!egwire::split_objects_parallel(json, json_len, threads, spans))
     return fail(EG_ERR_BAD_ARG, "the text is neither a JSON array of objects nor a sequence of JSON objects");
   if (n_objects) *n_objects = spans.size();
   if (spans.size() > max_objects) return fail(EG_ERR_BAD_ARG, "more objects in the text than max_objects (*n_objects says how many)");
@@ -986,7 +986,7 @@ int eg_choice_pack_json(int n_options, int single, const char* json, size_t json
   if (n_options < 1 || n_options > 4000 || (json_len && !json) || (max_objects && (!packed || !status)))
     return fail(EG_ERR_BAD_ARG, "bad argument");
   std::vector<std::pair<size_t, size_t>> spans;
-  TRY(pack_json_common(json, json_len, max_objects, n_objects, spans));
+  TRY(pack_json_common(json, json_len, threads, max_objects, n_objects, spans));
   const size_t stride = eghost::choice_ballot_size(n_options, single != 0);
   egwire::pack_parallel(json, spans, stride, threads, packed, status,
                         [&](egwire::Cursor& c, uint8_t* dst) { return egwire::pack_choice(c, n_options, single != 0, dst); });
@@ -997,7 +997,7 @@ int eg_qv_pack_json(int n_options, uint64_t credits, const char* json, size_t js
   if (n_options < 1 || n_options > 256 || credits < 1 || credits > 100000 || (json_len && !json) || (max_objects && (!packed || !status)))
     return fail(EG_ERR_BAD_ARG, "bad argument");
   std::vector<std::pair<size_t, size_t>> spans;
-  TRY(pack_json_common(json, json_len, max_objects, n_objects, spans));
+  TRY(pack_json_common(json, json_len, threads, max_objects, n_objects, spans));
   const eghost::QvShape sh = eghost::qv_shape(n_options, credits);
   const egwire::RangeShape vote{sh.vote_range.rings.size(), (size_t)sh.vote_range.rings_size()};
   const egwire::RangeShape credit{sh.credit_range.rings.size(), (size_t)sh.credit_range.rings_size()};

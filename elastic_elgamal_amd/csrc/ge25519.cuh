@@ -595,12 +595,13 @@ EG_HD void ge_teeth_mul_multi(ge& acc, int n_terms, ColumnFn column, LoadFn load
 }
 
 // ---- fixed-base scalar multiplication -----------------------------------------------------------------------------
-// Signed radix-2^B comb (B = EG_COMB_BITS: ceil(254 / B) windows x 2^(B-1) affine-Niels entries of 128 B per base; 15 bits =
-// 17 windows, 34 MiB, Infinity-Cache resident; measured 8 -> 13 bits: +3 %, 13 -> 15: +0.9 %), built once per base on the device
-// (k_build_fixed_table).  Table index = window * 2^(B-1) + (|digit| - 1).
+// Signed radix-2^B comb (B = EG_COMB_BITS: ceil(254 / B) windows x 2^(B-1) affine-Niels entries of 128 B per base), built once
+// per base on the device (k_build_fixed_table).  Default 20 bits = 13 windows, 832 MiB per base, read from HBM one addition ahead
+// of its use; measured in one call against 15 bits (17 windows, 34 MiB, Infinity-Cache resident): +1.5 % single-choice, +2.8 %
+// quadratic voting (round 1: 8 -> 13 bits +3 %, 13 -> 15 +0.9 %).  Table index = window * 2^(B-1) + (|digit| - 1).
 // acc += [k]Base with one mixed addition (7M) per window and no doublings.
 #ifndef EG_COMB_BITS
-#define EG_COMB_BITS 15
+#define EG_COMB_BITS 20
 #endif
 #define EG_FIXED_WINDOWS ((254 + EG_COMB_BITS - 1) / EG_COMB_BITS)     // scalars (also halved ones) are < 2^254
 #define EG_FIXED_ENTRIES (1 << (EG_COMB_BITS - 1))

@@ -42,7 +42,8 @@ __device__ __forceinline__ void load_scalar(u32 s[8], const EngineBufs& B, u32 b
 }
 
 // ---- k_decode_points: deserialize_element for every wire point (ristretto.rs:93-95) --------------------------------
-__global__ void __launch_bounds__(NT) k_decode_points(EngineBufs B, const egplan::WireItem* items, int n_items) {
+// (two waves per SIMD: v_mad_u64_u32 reaches its full issue rate only with a second wave to alternate with, profiles/r01_ubench_valu_rates.txt)
+__global__ void __launch_bounds__(NT, 2) k_decode_points(EngineBufs B, const egplan::WireItem* items, int n_items) {
   const size_t total = (size_t)n_items * B.n;
   for (size_t j = (size_t)blockIdx.x * NT + threadIdx.x; j < total; j += (size_t)gridDim.x * NT) {
     const u32 k = (u32)(j / B.n), b = (u32)(j % B.n);
@@ -225,7 +226,7 @@ __global__ void __launch_bounds__(NT, 2) k_eq_generic(EngineBufs B, const egplan
 
 // serialize_element (ristretto.rs:88-90) of point slots: the "enc" bytes of derived ciphertexts (range.rs:572), the sum of the
 // choices (choice.rs:83-86).  class: enc_slot -> out_slot.
-__global__ void __launch_bounds__(NT) k_encode_plain(EngineBufs B, const egplan::JobClass* classes, int class_first, int n_classes) {
+__global__ void __launch_bounds__(NT, 2) k_encode_plain(EngineBufs B, const egplan::JobClass* classes, int class_first, int n_classes) {
   const size_t total = (size_t)n_classes * B.n;
   for (size_t j = (size_t)blockIdx.x * NT + threadIdx.x; j < total; j += (size_t)gridDim.x * NT) {
     const u32 c = class_first + (u32)(j / B.n), b = (u32)(j % B.n);
@@ -248,7 +249,7 @@ __device__ __forceinline__ void encw_load(fe& f, const u32* encw, u32 cap, u32 s
 #pragma unroll
   for (int i = 0; i < 10; ++i) f.v[i] = encw[((size_t)slot * 10 + i) * cap + b];
 }
-__global__ void __launch_bounds__(NT) k_encode_batch(EngineBufs B, const unsigned short* slots, int n_slots) {
+__global__ void __launch_bounds__(NT, 2) k_encode_batch(EngineBufs B, const unsigned short* slots, int n_slots) {
   for (u32 b = blockIdx.x * NT + threadIdx.x; b < B.n; b += gridDim.x * NT) {
     fe prod; fe_1(prod);
     u32 zero_mask = 0;

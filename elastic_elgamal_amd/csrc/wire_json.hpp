@@ -290,10 +290,11 @@ inline bool split_objects(const char* s, size_t len, std::vector<std::pair<size_
   ws();
   const bool array = i < len && s[i] == '[';
   if (array) ++i;
+  bool after_comma = false;
   for (;;) {
     ws();
     if (i >= len) return !array;
-    if (array && s[i] == ']') { ++i; ws(); return i == len; }
+    if (array && s[i] == ']') { if (after_comma) return false; ++i; ws(); return i == len; }
     if (s[i] != '{') return false;
     const size_t start = i;
     int depth = 0;
@@ -316,16 +317,131 @@ inline bool split_objects(const char* s, size_t len, std::vector<std::pair<size_
       ++i;
       if (ch == '{' || ch == '[') ++depth;
       else if (ch == '}' || ch == ']') { if (--depth == 0) break; }
+      else if (ch == '\\') return false;                 // a backslash outside a string is not JSON
     }
     if (depth != 0) return false;
     spans.push_back({start, i - start});
     ws();
+    after_comma = false;
     if (array) {
-      if (i < len && s[i] == ',') { ++i; continue; }
+      if (i < len && s[i] == ',') { ++i; after_comma = true; continue; }
       if (i < len && s[i] == ']') continue;
       return false;
     }
   }
+}
+
+// The same result as split_objects, computed by `threads` workers: (1) every chunk counts its unescaped quotes, which tells the
+// next chunks whether they start inside a string; (2) every chunk computes its change of bracket depth; (3) with the absolute
+// depth known at its start, every chunk emits the starts and ends of the values at the base depth.  Three passes over the text,
+// each split `threads` ways, instead of one sequential pass: the splitter, not the per-object parser, is what limits a many-core
+// host.  Falls back to the sequential splitter for small texts.
+inline bool split_objects_parallel(const char* s, size_t len, int threads, std::vector<std::pair<size_t, size_t>>& spans,
+                                   size_t min_len = (size_t)1 << 20) {
+  if (threads < 2 || len < min_len || len < 4 * (size_t)threads) return split_objects(s, len, spans);
+  const size_t T = (size_t)threads;
+  auto lo = [&](size_t t) { return len * t / T; };
+  // a quote is a delimiter unless an odd run of backslashes precedes it (the run may begin in the previous chunk)
+  auto is_delim = [&](size_t q) { size_t bs = 0; while (q > bs && s[q - 1 - bs] == '\\') ++bs; return (bs & 1) == 0; };
+  std::vector<size_t> quotes(T, 0);
+  auto run = [&](auto fn) {
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < T; ++t) pool.emplace_back(fn, t);
+    fn(0);
+    for (auto& th : pool) th.join();
+  };
+  run([&](size_t t) {
+    size_t n = 0;
+    const char* p = s + lo(t);
+    const char* e = s + lo(t + 1);
+    while (p < e) {
+      const void* hit = memchr(p, '"', (size_t)(e - p));
+      if (!hit) break;
+      p = (const char*)hit;
+      n += is_delim((size_t)(p - s));
+      ++p;
+    }
+    quotes[t] = n;
+  });
+  std::vector<char> in_str(T, 0);
+  for (size_t t = 1; t < T; ++t) in_str[t] = (char)((in_str[t - 1] + quotes[t - 1]) & 1);
+  // scans a chunk outside strings, calling on_open / on_close for brackets
+  auto scan = [&](size_t t, auto on_bracket) {
+    size_t i = lo(t);
+    const size_t e = lo(t + 1);
+    bool str = in_str[t] != 0;
+    while (i < e) {
+      if (str) {
+        const void* hit = memchr(s + i, '"', e - i);
+        if (!hit) return;
+        i = (size_t)((const char*)hit - s);
+        if (is_delim(i)) str = false;
+        ++i;
+        continue;
+      }
+      const char ch = s[i];
+      if (ch == '"') str = true;
+      else if (ch == '{' || ch == '[') on_bracket(i, +1);
+      else if (ch == '}' || ch == ']') on_bracket(i, -1);
+      else if (ch == '\\') on_bracket(i, 0);             // a backslash outside a string is not JSON
+      ++i;
+    }
+  };
+  std::vector<long> delta(T, 0);
+  std::vector<char> bad(T, 0);
+  run([&](size_t t) { long d = 0; scan(t, [&](size_t, int step) { d += step; if (!step) bad[t] = 1; }); delta[t] = d; });
+  for (size_t t = 0; t < T; ++t) if (bad[t]) return false;
+  // base depth: 1 inside a top-level array, 0 for a stream of objects
+  size_t first = 0;
+  while (first < len && (s[first] == ' ' || s[first] == '\n' || s[first] == '\t' || s[first] == '\r')) ++first;
+  if (first >= len) return true;
+  const bool array = s[first] == '[';
+  if (!array && s[first] != '{') return false;
+  const long base = array ? 1 : 0;
+  std::vector<long> depth0(T, 0);
+  for (size_t t = 1; t < T; ++t) depth0[t] = depth0[t - 1] + delta[t - 1];
+  if (depth0[T - 1] + delta[T - 1] != 0) return false;
+  std::vector<std::vector<size_t>> starts(T), ends(T);
+  run([&](size_t t) {
+    long d = depth0[t];
+    scan(t, [&](size_t pos, int step) {
+      if (step == 0) bad[t] = 1;
+      else if (step > 0) { if (d == base) { if (s[pos] != '{') bad[t] = 1; starts[t].push_back(pos); } ++d; }
+      else { --d; if (d == base) ends[t].push_back(pos + 1); if (d < 0) bad[t] = 1; }
+    });
+  });
+  std::vector<size_t> st, en;
+  for (size_t t = 0; t < T; ++t) {
+    if (bad[t]) return false;
+    st.insert(st.end(), starts[t].begin(), starts[t].end());
+    en.insert(en.end(), ends[t].begin(), ends[t].end());
+  }
+  if (array) {           // the array's own brackets are at depth 0 -> 1: its '[' is not an object start; drop nothing, but check
+    if (en.size() != st.size()) return false;
+  } else if (en.size() != st.size()) return false;
+  spans.reserve(st.size());
+  size_t prev_end = array ? first + 1 : 0;
+  for (size_t k = 0; k < st.size(); ++k) {
+    if (en[k] <= st[k]) return false;
+    // between two values only white space (and one comma inside an array) may appear
+    size_t commas = 0;
+    for (size_t i = prev_end; i < st[k]; ++i) {
+      const char ch = s[i];
+      if (ch == ',') ++commas;
+      else if (!(ch == ' ' || ch == '\n' || ch == '\t' || ch == '\r')) return false;
+    }
+    if (array ? commas != (k ? 1u : 0u) : commas != 0) return false;
+    spans.push_back({st[k], en[k] - st[k]});
+    prev_end = en[k];
+  }
+  // tail: white space, and the closing bracket of an array
+  bool closed = !array;
+  for (size_t i = prev_end; i < len; ++i) {
+    const char ch = s[i];
+    if (ch == ']' && !closed) closed = true;
+    else if (!(ch == ' ' || ch == '\n' || ch == '\t' || ch == '\r')) return false;
+  }
+  return closed;
 }
 
 template <class PackOne>

@@ -3,6 +3,7 @@
 // code paths below proves the bound discipline of fe25519.cuh/ge25519.cuh; results are compared with
 // the oracle by tests/test_hostcheck.py.  This library is never loaded by the product.
 #include <string.h>
+#include <map>
 #include <vector>
 #include "../../elastic_elgamal_amd/csrc/ge25519.cuh"
 #include "../../elastic_elgamal_amd/csrc/sc25519.cuh"
@@ -20,9 +21,29 @@ struct ArrBase {
   void store(int i, const ge_cached& c) { e[i] = c; }
   void load(ge_cached& c, int i) const { c = e[i]; }
 };
+// fixed-base comb table with entries computed on demand (the product's table has millions of entries; a comb touches one per window)
 struct ArrNiels {
-  std::vector<ge_niels> e;
-  void load(ge_niels& c, int i) const { c = e[i]; }
+  ge base;
+  bool ready = false;
+  mutable std::map<int, ge_niels> cache;
+  void load(ge_niels& c, int idx) const {
+    auto it = cache.find(idx);
+    if (it == cache.end()) {
+      const unsigned long long m0 = g_fe_mul_count, s0 = g_fe_sq_count;     // table construction is not the comb's work
+      const int w = idx / EG_FIXED_ENTRIES, k = idx % EG_FIXED_ENTRIES + 1;    // entry = [k * 2^(B w)] base
+      ge p = base;
+      for (int i = 0; i < EG_COMB_BITS * w; ++i) { ge d; ge_dbl_full(d, p); p = d; }
+      ge q; ge_identity(q);
+      for (int bit = EG_COMB_BITS - 1; bit >= 0; --bit) {
+        ge d; ge_dbl_full(d, q); q = d;
+        if ((k >> bit) & 1) { ge t; ge_add_full(t, q, p); q = t; }
+      }
+      ge_niels n; ge_to_niels(n, q);
+      it = cache.emplace(idx, n).first;
+      g_fe_mul_count = m0; g_fe_sq_count = s0;
+    }
+    c = it->second;
+  }
 };
 struct ArrState {
   u32 w[50];
@@ -38,18 +59,7 @@ static void bytes_from_words(uint8_t* b, const u32* w, int nwords) {
 }
 
 static ArrNiels g_base_table;
-static void build_fixed(ArrNiels& t, const ge& base) {
-  t.e.resize(EG_FIXED_WINDOWS * EG_FIXED_ENTRIES);
-  ge win = base;
-  for (int w = 0; w < EG_FIXED_WINDOWS; ++w) {
-    ge cur = win;
-    for (int k = 1; k <= EG_FIXED_ENTRIES; ++k) {
-      ge_to_niels(t.e[w * EG_FIXED_ENTRIES + k - 1], cur);
-      ge nxt; ge_add_full(nxt, cur, win); cur = nxt;
-    }
-    for (int d = 0; d < EG_COMB_BITS; ++d) { ge nxt; ge_dbl_full(nxt, win); win = nxt; }
-  }
-}
+static void build_fixed(ArrNiels& t, const ge& base) { t.base = base; t.ready = true; }
 
 extern "C" {
 
@@ -63,7 +73,7 @@ int hc_point_roundtrip(const uint8_t in[32], uint8_t out[32]) {
 
 // out = enc([k]P + [r]G)   (Group::vartime_double_mul_generator)
 int hc_double_mul_generator(const uint8_t k[32], const uint8_t p_enc[32], const uint8_t r[32], uint8_t out[32]) {
-  if (g_base_table.e.empty()) { ge g; ge_generator(g); build_fixed(g_base_table, g); }
+  if (!g_base_table.ready) { ge g; ge_generator(g); build_fixed(g_base_table, g); }
   u32 kw[8], rw[8], pw[8], o[8];
   words_from_bytes(kw, k, 8); words_from_bytes(rw, r, 8); words_from_bytes(pw, p_enc, 8);
   ge p; if (!ristretto_decode(p, pw)) return 0;
@@ -78,7 +88,7 @@ int hc_double_mul_generator(const uint8_t k[32], const uint8_t p_enc[32], const 
 
 // same as hc_double_mul_generator but through the per-base comb table (ge_teeth_tables_build / ge_teeth_mul)
 int hc_double_mul_generator_teeth(const uint8_t k[32], const uint8_t p_enc[32], const uint8_t r[32], uint8_t out[32]) {
-  if (g_base_table.e.empty()) { ge g; ge_generator(g); build_fixed(g_base_table, g); }
+  if (!g_base_table.ready) { ge g; ge_generator(g); build_fixed(g_base_table, g); }
   u32 kw[8], rw[8], pw[8], o[8];
   words_from_bytes(kw, k, 8); words_from_bytes(rw, r, 8); words_from_bytes(pw, p_enc, 8);
   ge p; if (!ristretto_decode(p, pw)) return 0;
@@ -94,7 +104,7 @@ int hc_double_mul_generator_teeth(const uint8_t k[32], const uint8_t p_enc[32], 
 // out = enc(sum_i [k_i]P_i + [r]G) with every base behind a teeth table and ONE shared doubling chain (ge_teeth_mul_multi, what
 // k_eq_table<true> runs); the sign vectors are read word by word, as the kernel reads them from LDS
 int hc_multi_mul_teeth(int n, const uint8_t* ks, const uint8_t* ps, const uint8_t r[32], uint8_t out[32]) {
-  if (g_base_table.e.empty()) { ge g; ge_generator(g); build_fixed(g_base_table, g); }
+  if (!g_base_table.ready) { ge g; ge_generator(g); build_fixed(g_base_table, g); }
   std::vector<ArrBase> tabs(n);
   std::vector<u32> sg(9 * (size_t)n);
   for (int i = 0; i < n; ++i) {
@@ -131,7 +141,7 @@ int hc_double_encode(const uint8_t p_enc[32], uint8_t out[32]) {
 }
 // [k]P + [r]G evaluated as 2 * ([k/2]P + [r/2]G) with the doubled encoder (what k_msm_jobs + k_encode_batch do)
 int hc_double_mul_generator_halved(const uint8_t k[32], const uint8_t p_enc[32], const uint8_t r[32], uint8_t out[32]) {
-  if (g_base_table.e.empty()) { ge g; ge_generator(g); build_fixed(g_base_table, g); }
+  if (!g_base_table.ready) { ge g; ge_generator(g); build_fixed(g_base_table, g); }
   u32 kw[8], rw[8], pw[8], o[8], kh[8], rh[8];
   words_from_bytes(kw, k, 8); words_from_bytes(rw, r, 8); words_from_bytes(pw, p_enc, 8);
   ge p; if (!ristretto_decode(p, pw)) return 0;
@@ -193,7 +203,7 @@ int hc_merlin(const char* label, const char* l1, const uint8_t* m1, int m1_len, 
 // 4: ristretto_encode  5: comb-table build (per base)  6: comb multiply (per equation)
 // 9: shared-chain product of ONE term (ge_teeth_mul_multi)   10: every further term of it
 void hc_op_counts(unsigned long long out[22]) {
-  if (g_base_table.e.empty()) { ge g; ge_generator(g); build_fixed(g_base_table, g); }
+  if (!g_base_table.ready) { ge g; ge_generator(g); build_fixed(g_base_table, g); }
   u32 gw[8] = {0x0aaef2e2u, 0x714ebc6au, 0x61a984a8u, 0x5f5100c5u, 0x6a0be358u, 0x8ddd82a5u, 0x4559a6b6u, 0x762d8de0u};
   u32 k[8] = {0x12345678u, 0x9abcdef0u, 0x0fedcba9u, 0x87654321u, 0x11111111u, 0x22222222u, 0x33333333u, 0x04444444u};
   auto snap = [&](int i, unsigned long long m0, unsigned long long s0) { out[2 * i] = g_fe_mul_count - m0; out[2 * i + 1] = g_fe_sq_count - s0; };

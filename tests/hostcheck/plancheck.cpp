@@ -42,14 +42,19 @@ int pc_range(unsigned long long ub, char* buf, int cap) {
 // the native JSON packer on arbitrary bytes (fuzzed by the test): returns the number of objects or -1
 int pc_pack_choice(int n_options, int single, const char* json, size_t len, int threads, uint8_t* packed, uint32_t* status, size_t max) {
   std::vector<std::pair<size_t, size_t>> spans;
-  if (!egwire::split_objects(json, len, spans) || spans.size() > max) return -1;
+  std::vector<std::pair<size_t, size_t>> seq;
+  const bool ok = egwire::split_objects_parallel(json, len, threads, spans, 0), ok_seq = egwire::split_objects(json, len, seq);
+  if (ok != ok_seq || (ok && spans != seq)) return -7;          // the two splitters must agree on every input
+  if (!ok || spans.size() > max) return -1;
   egwire::pack_parallel(json, spans, choice_ballot_size(n_options, single != 0), threads, packed, status,
                         [&](egwire::Cursor& c, uint8_t* dst) { return egwire::pack_choice(c, n_options, single != 0, dst); });
   return (int)spans.size();
 }
 int pc_pack_qv(int n_options, unsigned long long credits, const char* json, size_t len, int threads, uint8_t* packed, uint32_t* status, size_t max) {
-  std::vector<std::pair<size_t, size_t>> spans;
-  if (!egwire::split_objects(json, len, spans) || spans.size() > max) return -1;
+  std::vector<std::pair<size_t, size_t>> spans, seq;
+  const bool ok = egwire::split_objects_parallel(json, len, threads, spans, 0), ok_seq = egwire::split_objects(json, len, seq);
+  if (ok != ok_seq || (ok && spans != seq)) return -7;
+  if (!ok || spans.size() > max) return -1;
   const QvShape sh = qv_shape(n_options, credits);
   const egwire::RangeShape vote{sh.vote_range.rings.size(), (size_t)sh.vote_range.rings_size()};
   const egwire::RangeShape credit{sh.credit_range.rings.size(), (size_t)sh.credit_range.rings_size()};
