@@ -33,7 +33,12 @@ struct EngineBufs {
   u32* encw;            // k_encode_batch scratch: prefix products and N   [2 * slot][10][cap]
   uint4* btab;          // comb tables of the ring bases [base][cap] x 320 uint4 (32 cached entries, 5 KiB)
 };
-constexpr int BTAB_QUADS = 32 * 10;
+#ifdef EG_AB_ONE_LINE      // measurement-only build: entries at a 256-B stride, lookups read ONE 128-B line (results are wrong)
+constexpr int BTAB_ENTRY_QUADS = 16;
+#else
+constexpr int BTAB_ENTRY_QUADS = 10;
+#endif
+constexpr int BTAB_QUADS = 32 * BTAB_ENTRY_QUADS;
 
 // ---- SoA accessors ------------------------------------------------------------------------------------
 __device__ __forceinline__ void words_to_ge(ge& p, const u32 w[40]) {
@@ -116,15 +121,25 @@ struct BaseTable {
 #pragma unroll
     for (int i = 0; i < 10; ++i) { w[i] = c.YpX.v[i]; w[10 + i] = c.YmX.v[i]; w[20 + i] = c.Z2.v[i]; w[30 + i] = c.T2d.v[i]; }
 #pragma unroll
-    for (int q = 0; q < 10; ++q) base[e * 10 + q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+    for (int q = 0; q < 10; ++q) base[e * BTAB_ENTRY_QUADS + q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
   }
   __device__ __forceinline__ void load(ge_cached& c, int e) const {
     u32 w[40];
+#ifdef EG_AB_ONE_LINE
 #pragma unroll
-    for (int q = 0; q < 10; ++q) {
-      const uint4 v = base[e * 10 + q];
+    for (int q = 0; q < 8; ++q) {
+      const uint4 v = base[e * BTAB_ENTRY_QUADS + q];
       w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
     }
+#pragma unroll
+    for (int i = 32; i < 40; ++i) w[i] = w[i - 32];
+#else
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {
+      const uint4 v = base[e * BTAB_ENTRY_QUADS + q];
+      w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+    }
+#endif
 #pragma unroll
     for (int i = 0; i < 10; ++i) { c.YpX.v[i] = w[i]; c.YmX.v[i] = w[10 + i]; c.Z2.v[i] = w[20 + i]; c.T2d.v[i] = w[30 + i]; }
   }

@@ -528,7 +528,8 @@ EG_HD void ge_teeth_tables_build(TableIO& io, TmpIO& tmp, const ge& p) {
 }
 
 // acc = [k]P from the teeth table; rows = sc_recode_teeth(k) (consumed).  A column's entry is requested before the doubling and
-// used after it, which hides the load without a second entry buffer (an explicit one-column-ahead prefetch measured -0.4 %).
+// used after it, which hides the load without a second entry buffer (requesting it a whole column ahead, in a second register
+// buffer, measured -0.4 % in round 1 and +-0.2 % = nothing in round 2, when the kernel had the 40 registers to spare).
 // The first column is not added to the identity: +-entry = (Y+X, Y-X, 2Z, ..) IS the point (2X : 2Y : 2Z) in projective
 // coordinates, and the operation that follows is a doubling, which does not read T (saves one 8-multiplication addition).
 template <class TableIO>
