@@ -366,19 +366,22 @@ def main():
         n_obj = distinct * reps
         cores = effective_cores()
         kw = {"credits": args.credits} if args.workload == "qv" else {"single": args.workload == "single"}
+        native = eg.JsonPacker(n_opt, n_obj, threads=cores, **kw)       # caller-owned output buffers, reused: the C call is what is timed
         best = None
-        for _ in range(3):
+        for _ in range(4):
             t0 = time.perf_counter()
-            packed, st = eg.pack_json(text, n_opt, threads=cores, max_objects=n_obj, **kw)
+            got = native.pack(text)
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
+        packed = native.packed.raw[: distinct * params.ballot_size]
+        st = list(native.status[:got])
         t0 = time.perf_counter()
         packer = egserde.pack_qv_ballot if args.workload == "qv" else egserde.pack_encrypted_choice
         ref = b"".join(packer(o) for o in json.loads(text[: 1 + sum(len(x) + 1 for x in one) - 1].decode() + "]"))
         py_s = time.perf_counter() - t0
         out["wire_ingest"] = {"value": n_obj / best, "unit": "ballots/s", "threads": cores, "json_bytes": len(text), "objects": n_obj,
                               "json_mb_per_s": len(text) / best / 1e6, "all_packed": st.count(0) == n_obj,
-                              "equals_device_ballots": packed[: distinct * params.ballot_size] == raw == ref,
+                              "equals_device_ballots": got == n_obj and packed == raw == ref,
                               "python_mirror_value": distinct / py_s,
                               "note": "JSON text (serde layout, base64url) -> packed bytes on the host, before the PCIe-inclusive path above"}
 

@@ -21,7 +21,7 @@ from pathlib import Path
 
 __all__ = [
     "Context", "Ristretto", "ChoiceParams", "QuadraticVotingParams", "PublicKeyVerifier", "DecryptionShareVerifier", "SumOfSquaresVerifier", "EgError", "library_path", "build",
-    "STATUS_NAMES", "status_kind", "status_detail", "pack_json", "PACK_RESHAPE",
+    "STATUS_NAMES", "status_kind", "status_detail", "pack_json", "JsonPacker", "PACK_RESHAPE",
 ]
 
 _PKG = Path(__file__).resolve().parent
@@ -184,6 +184,33 @@ def pack_json(text, n_options: int, single: bool | None = None, credits: int | N
 
 
 sz_t = C.c_size_t
+
+
+class JsonPacker:
+    """The native packer with caller-owned, reusable output buffers (what a native host does): no allocation or copy per call.
+    `pack(text)` returns the number of objects; `packed` (a ctypes buffer) and `status` hold the results."""
+
+    def __init__(self, n_options: int, max_objects: int, single: bool | None = None, credits: int | None = None, threads: int = 0):
+        lib = _load()
+        self.n_options, self.single, self.credits, self.max_objects = n_options, single, credits, max_objects
+        self.threads = threads or (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+        self.ballot_size = (lib.eg_qv_ballot_size_for(n_options, credits) if credits is not None
+                            else lib.eg_choice_ballot_size(n_options, int(bool(single))))
+        if not self.ballot_size:
+            raise EgError("bad election parameters")
+        self.packed = C.create_string_buffer(max(max_objects * self.ballot_size, 1))
+        self.status = (C.c_uint32 * max(max_objects, 1))()
+
+    def pack(self, data: bytes) -> int:
+        n = sz_t(0)
+        lib = _load()
+        if self.credits is not None:
+            _check(lib.eg_qv_pack_json(self.n_options, self.credits, data, len(data), self.threads, self.max_objects, self.packed,
+                                       self.status, C.byref(n)))
+        else:
+            _check(lib.eg_choice_pack_json(self.n_options, int(bool(self.single)), data, len(data), self.threads, self.max_objects,
+                                           self.packed, self.status, C.byref(n)))
+        return n.value
 
 
 def range_decomposition(upper_bound: int) -> str:

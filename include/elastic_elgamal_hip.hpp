@@ -180,6 +180,44 @@ class QuadraticVotingParams {
   size_t n_;
 };
 
+// Wire ingest (src/serde.rs:19-80,179-355): ballots as JSON text in the reference's serde layout -> packed ballots, on the host.
+// status[k]: EG_ST_OK (packed[k] valid), EG_ST_MALFORMED (does not deserialise) or EG_PACK_RESHAPE (wrong number of choices /
+// responses / partial ciphertexts for this election: OptionsLenMismatch / LenMismatch territory).
+struct PackedJson {
+  Bytes packed;                  // n objects x ballot size; rejected slots are zero
+  std::vector<uint32_t> status;
+  size_t ballot_size = 0;
+  Bytes accepted() const {       // the packed ballots with status OK, back to back (what verify_batch takes)
+    Bytes out;
+    for (size_t k = 0; k < status.size(); ++k)
+      if (status[k] == EG_ST_OK) out.insert(out.end(), packed.begin() + k * ballot_size, packed.begin() + (k + 1) * ballot_size);
+    return out;
+  }
+};
+inline PackedJson pack_choice_json(size_t options, bool single, const std::string& text, int threads = 1) {
+  PackedJson r;
+  r.ballot_size = eg_choice_ballot_size((int)options, single);
+  size_t n = 0;
+  // first call sizes the output: with max_objects = 0 the library only counts (EG_ERR_BAD_ARG says "more objects than max_objects")
+  const int rc = eg_choice_pack_json((int)options, single, text.data(), text.size(), threads, 0, nullptr, nullptr, &n);
+  if (rc != EG_OK && n == 0) throw Error(rc, eg_last_error());
+  r.packed.resize(n * r.ballot_size);
+  r.status.resize(n);
+  if (n) check(eg_choice_pack_json((int)options, single, text.data(), text.size(), threads, n, r.packed.data(), r.status.data(), &n));
+  return r;
+}
+inline PackedJson pack_qv_json(size_t options, uint64_t credits, const std::string& text, int threads = 1) {
+  PackedJson r;
+  r.ballot_size = eg_qv_ballot_size_for((int)options, credits);
+  size_t n = 0;
+  const int rc = eg_qv_pack_json((int)options, credits, text.data(), text.size(), threads, 0, nullptr, nullptr, &n);
+  if (rc != EG_OK && n == 0) throw Error(rc, eg_last_error());
+  r.packed.resize(n * r.ballot_size);
+  r.status.resize(n);
+  if (n) check(eg_qv_pack_json((int)options, credits, text.data(), text.size(), threads, n, r.packed.data(), r.status.data(), &n));
+  return r;
+}
+
 // Ristretto: the Group backend (ristretto.rs), one problem per call shown here; *_batch in eg_hip.h for many.
 // The reference's typed Elements cannot be invalid; here elements are byte strings, so the operations that take
 // elements throw Error(EG_ERR_BAD_ARG) when an operand is not a valid ristretto255 encoding instead of silently

@@ -135,3 +135,37 @@ def test_native_ingest_throughput(objs):
     assert ref == packed[: 2000 * 736]
     print(f"native {n / native:,.0f} objects/s ({len(text) / native / 1e6:.0f} MB/s of JSON), python mirror {n / python:,.0f} objects/s")
     assert native < python / 5
+
+
+def test_cpp_mirror_packs_json(tmp_path, objs):
+    """include/elastic_elgamal_hip.hpp: pack_choice_json / pack_qv_json on the host (no GPU), compiled with g++."""
+    import subprocess
+
+    root = Path(__file__).resolve().parent.parent
+    one = json.dumps(objs["encrypted-choice"])
+    q = json.dumps(objs["qv-ballot"])
+    (tmp_path / "c.json").write_text("[" + one + "," + one + ',{"choices":1}]')
+    (tmp_path / "q.json").write_text(q + "\n" + q)
+    (tmp_path / "t.cpp").write_text(r"""
+        #include "elastic_elgamal_hip.hpp"
+        #include <fstream>
+        #include <sstream>
+        #include <cstdio>
+        using namespace elastic_elgamal_hip;
+        static std::string slurp(const char* p) { std::ifstream f(p); std::stringstream ss; ss << f.rdbuf(); return ss.str(); }
+        int main(int argc, char** argv) {
+          PackedJson c = pack_choice_json(5, true, slurp(argv[1]), 2);
+          PackedJson q = pack_qv_json(5, 15, slurp(argv[2]), 2);
+          bool threw = false;
+          try { pack_choice_json(5, true, "garbage"); } catch (const Error&) { threw = true; }
+          printf("%zu %u %u %u %zu | %zu %u %u %zu | %d\n", c.status.size(), c.status[0], c.status[1], c.status[2], c.accepted().size(),
+                 q.status.size(), q.status[0], q.status[1], q.accepted().size(), (int)threw);
+          return 0;
+        }""")
+    exe = tmp_path / "t"
+    subprocess.check_call(["g++", "-std=c++17", f"-I{root / 'include'}", str(tmp_path / "t.cpp"), f"-L{root / 'elastic_elgamal_amd'}", "-leg_hip",
+                           f"-Wl,-rpath,{root / 'elastic_elgamal_amd'}", "-o", str(exe)])
+    out = subprocess.run([str(exe), str(tmp_path / "c.json"), str(tmp_path / "q.json")], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    qsize = len(serde.pack_qv_ballot(objs["qv-ballot"]))
+    assert out.stdout.strip() == f"3 0 0 13 {2 * 736} | 2 0 0 {2 * qsize} | 1"
