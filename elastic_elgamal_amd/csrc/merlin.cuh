@@ -76,6 +76,8 @@ EG_HD void strobe_xor_byte(S& st, u32 pos, u32 byte) {
   st.wr(w, st.rd(w) ^ (byte << sh));
 }
 
+// (Kept inline: an out-of-line permutation - one copy instead of ~90 - measured -1.5 % on single-choice and -3 % on QV ballots;
+// the call ABI costs more than the instruction-cache misses of the 420 KB kernel.)
 template <class S>
 EG_HD void strobe_run_f(Transcript<S>& t) {
   strobe_xor_byte(t.st, t.pos, t.pos_begin);
