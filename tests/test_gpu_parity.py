@@ -717,6 +717,47 @@ def test_large_election_chunks_follow_device_memory(eg, ctx, oracle, pk):
     assert got == want and gt == op.tally(sample, want) and want.count(0) == 4
 
 
+def test_maximum_election_sizes(eg, ctx, oracle, pk):
+    """The largest elections the C ABI accepts (eg_hip.h: 4000 options for choice ballots, 256 options / 100 000 credits for
+    quadratic voting).  Up to the oracle's capacity (256 options) prover and verifier are compared with it; beyond it the checks
+    are properties: GPU-made ballots verify, a flipped bit is caught, the tally is the sum of the accepted ciphertexts."""
+    grp = eg.Ristretto(ctx)
+    # multi-choice, 256 options: GPU prover == oracle prover, verdicts == oracle
+    m = eg.ChoiceParams.multi_choice(ctx, pk, 256)
+    om = oracle.ChoiceParams(pk, 256, False)
+    b = bytearray(_gen_on_gpu(eg, m, 3, 0, 4, n_selected=7))
+    assert bytes(b) == om.generate_batch(3, 0, 4, n_selected=7, threads=8)
+    b[2 * m.ballot_size + 64 * 256 + 32 * 100] ^= 1
+    st, tally = m.verify_batch(bytes(b))
+    assert st == om.verify_batch(bytes(b), threads=8) and st.count(0) == 3 and tally == om.tally(bytes(b), st)
+    # quadratic voting, 256 options / 100 000 credits (7-ring credit range, 4-ring vote range, 255 712-byte ballots)
+    q = eg.QuadraticVotingParams(ctx, pk, 256, 100000)
+    oq = oracle.QvParams(pk, 256, 100000)
+    assert q.ballot_size == oq.ballot_size == 255712
+    import torch
+    out = torch.zeros(2 * q.ballot_size, dtype=torch.uint8, device="cuda")
+    q.encrypt_batch_device(3, 0, 2, out.data_ptr())
+    ctx.synchronize()
+    qb = bytearray(out.cpu().numpy().tobytes())
+    assert bytes(qb) == oq.generate_batch(3, 0, 2, threads=8)
+    qb[q.ballot_size + q.ballot_size - 1] ^= 1 if qb[q.ballot_size + q.ballot_size - 1] & 0x0F else 2
+    st, tally = q.verify_batch(bytes(qb))
+    assert st == oq.verify_batch(bytes(qb), threads=8) and st[0] == 0 and st[1] != 0 and tally == oq.tally(bytes(qb), st)
+    # single-choice, 4000 options (beyond the oracle): properties only
+    p = eg.ChoiceParams.single_choice(ctx, pk, 4000)
+    assert p.ballot_size == 4000 * 64 + 32 * 8001 + 64
+    pb = bytearray(p.encrypt_selected(11, 0, [1 << 3999, 1 << 0, 1 << 1234]))
+    st, tally = p.verify_batch(bytes(pb))
+    assert st == [0, 0, 0]
+    summed = grp.element_add(grp.element_add(bytes(pb[: 256000]), bytes(pb[p.ballot_size : p.ballot_size + 256000]))[0],
+                             bytes(pb[2 * p.ballot_size : 2 * p.ballot_size + 256000]))[0]
+    assert tally == summed
+    pb[p.ballot_size + 256000 + 32 * 4001] ^= 1                        # a ring response of ballot 1
+    pb[2 * p.ballot_size + p.ballot_size - 32] ^= 1                    # the sum-proof response of ballot 2
+    st, _ = p.verify_batch(bytes(pb))
+    assert st == [0, eg.RANGE_CHALLENGE, eg.SUM_CHALLENGE]
+
+
 @pytest.mark.parametrize("options,credits", [(12, 200), (20, 1000), (3, 10000)])
 def test_qv_large_parameters_oracle_ballots(eg, ctx, oracle, pk, options, credits):
     """Large quadratic-voting shapes (multi-ring vote ranges, long rings): ballots from the oracle prover, tampered in every
