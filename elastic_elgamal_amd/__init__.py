@@ -140,6 +140,8 @@ def _load() -> C.CDLL:
         "eg_choice_pack_json": (C.c_int, [C.c_int, C.c_int, cp, sz, C.c_int, sz, vp, vp, C.POINTER(sz)]),
         "eg_qv_pack_json": (C.c_int, [C.c_int, C.c_uint64, cp, sz, C.c_int, sz, vp, vp, C.POINTER(sz)]),
         "eg_qv_ballot_size_for": (sz, [C.c_int, C.c_uint64]),
+        "eg_verify_choice_json": (C.c_int, [vp, vp, sz, C.c_int, sz, vp, C.POINTER(sz), vp]),
+        "eg_verify_qv_json": (C.c_int, [vp, vp, sz, C.c_int, sz, vp, C.POINTER(sz), vp]),
         "eg_range_decomposition": (C.c_int, [C.c_uint64, cp, sz]),
         "eg_plan_describe": (C.c_int, [C.c_int, C.c_int, C.c_uint64, cp, sz]),
         "eg_profile_enable": (C.c_int, [vp, C.c_int]),
@@ -408,6 +410,29 @@ class _BatchParams:
         fn = getattr(_load(), f"eg_verify_{self._prefix}_batch")
         _check(fn(self._h, n, buf, st, tally))
         return list(st[:n]), (tally.raw if with_tally else None)
+
+    def verify_json(self, text, max_objects: int = 0, threads: int = 0, with_tally: bool = True):
+        """JSON text (serde's layout; one array or objects back to back) -> (status words, tally of this call) through the
+        native entry point: host threads pack piece k+1 while the GPU verifies piece k.  Objects that do not deserialise get
+        MALFORMED; objects of another shape than the election's get PACK_RESHAPE (route those through ingest.verify_*_objects)."""
+        data = text.encode() if isinstance(text, str) else bytes(text)
+        if not threads:
+            threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        if not max_objects:
+            max_objects = data.count(b"{") + 1
+        st = (C.c_uint32 * max(max_objects, 1))()
+        n = sz_t(0)
+        tally = C.create_string_buffer(64 * self.n_options) if with_tally else None
+        fn = getattr(_load(), f"eg_verify_{self._prefix}_json")
+        _check(fn(self._h, data, len(data), threads, max_objects, st, C.byref(n), tally))
+        return list(st[: n.value]), (tally.raw if with_tally else None)
+
+    def verify_json_into(self, data: bytes, status, threads: int, tally=None) -> int:
+        """The same with caller-owned buffers (status: ctypes uint32 array): the bare C call, for timing.  Returns the object count."""
+        n = sz_t(0)
+        fn = getattr(_load(), f"eg_verify_{self._prefix}_json")
+        _check(fn(self._h, data, len(data), threads, len(status), status, C.byref(n), tally))
+        return n.value
 
     def verify_batch_host_ptr(self, n: int, ballots_ptr: int, status_ptr: int, tally_ptr: int = 0):
         """The host-buffer entry point on raw host addresses (e.g. pinned torch tensors): no Python-side copies."""

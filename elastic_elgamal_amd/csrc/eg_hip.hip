@@ -11,9 +11,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/eg_hip.h"
@@ -131,6 +133,9 @@ struct Engine {
   int tally_blocks = 64;
   u32* tally = nullptr;        // [2n][40] running tally (extended points)
   u32* tally_saved = nullptr;  // [2n][40] the running tally set aside while a host call computes its per-batch tally
+  u32* tally_saved2 = nullptr; // the same for the JSON entry points, which call the host form piece by piece
+  uint8_t* json_stage[2] = {nullptr, nullptr};     // pinned staging of the JSON entry points (two windows in flight)
+  size_t json_stage_bytes[2] = {0, 0};
   // staging for the host-pointer API
   hipStream_t copy_stream = nullptr;
   unsigned char* d_wire = nullptr;
@@ -165,9 +170,10 @@ static void engine_free(Engine* e) {
   if (!e) return;
   void* ptrs[] = {e->d_pt_items, e->d_sc_items, e->d_dclasses, e->d_dterms, e->d_jobs, e->d_vterms, e->d_insts, e->d_ops,
                   e->d_rules, e->d_tally_slots, e->d_base_slots, e->d_defer_slots, e->btab, e->dpt, e->encw, e->d_blob, e->d_tabK, e->d_cpts, e->d_prefixes, e->d_key_words, e->pts, e->cmp,
-                  e->chal, e->states, e->flags, e->bad_item, e->partial, e->tally, e->tally_saved, e->d_wire, e->d_status, e->gen_ws, e->d_gen_desc};
+                  e->chal, e->states, e->flags, e->bad_item, e->partial, e->tally, e->tally_saved, e->tally_saved2, e->d_wire, e->d_status, e->gen_ws, e->d_gen_desc};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
+  for (uint8_t* p : e->json_stage) if (p) (void)hipHostFree(p);
   delete e;
 }
 
@@ -326,6 +332,7 @@ static int engine_create(eg_ctx* ctx, eghost::Plan&& plan, const uint8_t pk[32],
   HIPCHK(hipMalloc((void**)&e->partial, std::max<size_t>(P.tally_slots.size(), 1) * e->tally_blocks * 40 * sizeof(u32)));
   HIPCHK(hipMalloc((void**)&e->tally, std::max<size_t>(P.tally_slots.size(), 1) * 40 * sizeof(u32)));
   HIPCHK(hipMalloc((void**)&e->tally_saved, std::max<size_t>(P.tally_slots.size(), 1) * 40 * sizeof(u32)));
+  HIPCHK(hipMalloc((void**)&e->tally_saved2, std::max<size_t>(P.tally_slots.size(), 1) * 40 * sizeof(u32)));
   HIPCHK(hipMalloc((void**)&e->d_prefixes, (size_t)std::max(P.n_prefixes, 1) * 52 * sizeof(u32)));
   hipLaunchKernelGGL(k_tally_init, dim3(blocks_of(P.tally_slots.size())), dim3(NT), 0, s, e->tally, (int)P.tally_slots.size());
 
@@ -1005,6 +1012,103 @@ int eg_qv_pack_json(int n_options, uint64_t credits, const char* json, size_t js
     return egwire::pack_qv(c, n_options, vote, credit, sh.ballot_size, dst);
   });
   return EG_OK;
+}
+// JSON text -> verdicts + tally in one call.  The text is cut into windows (egwire::split_next); a producer thread splits and packs
+// window k+1 on `threads` host threads into pinned staging while window k is uploaded and verified on the GPU (engine_verify_host
+// pipelines the upload inside a window).  Objects that do not pack keep their pack verdict; their zeroed slots are verified like
+// any other ballot (an all-zero ballot never verifies, so nothing of it reaches the tally) and the verdict is overwritten afterwards.
+typedef std::function<void(const char*, const std::vector<std::pair<size_t, size_t>>&, int, uint8_t*, uint32_t*)> PackPieceFn;
+static int verify_json_common(Engine* e, const char* json, size_t json_len, int threads, size_t max_objects, uint32_t* status,
+                              size_t* n_objects, uint8_t* tally_out, const PackPieceFn& pack_piece) {
+  if ((json_len && !json) || (max_objects && !status)) return fail(EG_ERR_BAD_ARG, "bad argument");
+  if (n_objects) *n_objects = 0;
+  HIPCHK(hipSetDevice(e->ctx->device));
+  const size_t stride = e->plan.stride;
+  const int ns = (int)e->plan.tally_slots.size();
+  hipStream_t s = e->ctx->stream;
+  HIPCHK(hipDeviceSynchronize());
+  if (tally_out && ns) {        // tally_out = the tally of THIS call; the running tally keeps accumulating (eg_hip.h)
+    HIPCHK(hipMemcpyAsync(e->tally_saved2, e->tally, (size_t)ns * 40 * sizeof(u32), hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_tally_init, dim3(blocks_of((size_t)ns)), dim3(NT), 0, s, e->tally, ns);
+    HIPCHK(hipStreamSynchronize(s));
+  }
+  // windows: a small first one (its split + parse is the only one nothing overlaps with), then ~2^18 single-choice ballots' worth of text
+  const size_t big_window = std::max<size_t>((size_t)384 << 20, 64 * stride), first_window = big_window / 4;
+  egwire::SplitCursor cur;
+  std::vector<std::pair<size_t, size_t>> spans[2];
+  std::vector<uint32_t> pack_status[2];
+  size_t first_index[2] = {0, 0};
+  bool done = false, split_ok = true, too_many = false, nomem = false;
+  auto produce = [&](int b, size_t window) {
+    spans[b].clear();
+    first_index[b] = cur.count;
+    if (!egwire::split_next(json, json_len, window, threads, cur, spans[b], done)) { split_ok = false; return; }
+    if (cur.count > max_objects) { too_many = true; return; }
+    const size_t need = spans[b].size() * stride;
+    if (need > e->json_stage_bytes[b]) {          // pinned staging, kept with the engine across calls
+      if (e->json_stage[b]) (void)hipHostFree(e->json_stage[b]);
+      e->json_stage[b] = nullptr; e->json_stage_bytes[b] = 0;
+      const size_t want = std::max(need, window * 3 / 4 + stride);     // an object takes >= 4/3 of its packed size as JSON
+      if (hipHostMalloc((void**)&e->json_stage[b], want, hipHostMallocDefault) != hipSuccess) { nomem = true; return; }
+      e->json_stage_bytes[b] = want;
+    }
+    pack_status[b].resize(spans[b].size());
+    if (!spans[b].empty()) pack_piece(json, spans[b], threads, e->json_stage[b], pack_status[b].data());
+  };
+  int rc = EG_OK;
+  produce(0, first_window);
+  for (int b = 0; rc == EG_OK; b ^= 1) {
+    if (!split_ok) { rc = fail(EG_ERR_BAD_ARG, "the text is neither a JSON array of objects nor a sequence of JSON objects"); break; }
+    if (too_many) { rc = fail(EG_ERR_BAD_ARG, "more objects in the text than max_objects"); break; }
+    if (nomem) { rc = fail(EG_ERR_NOMEM, "pinned staging allocation failed"); break; }
+    const bool last = done;
+    std::thread producer;
+    if (!last) producer = std::thread(produce, b ^ 1, big_window);      // split + parse the next window meanwhile
+    const size_t m = spans[b].size(), first = first_index[b];
+    if (m) {
+      rc = engine_verify_host(e, m, e->json_stage[b], status + first, nullptr);
+      if (rc == EG_OK)
+        for (size_t i = 0; i < m; ++i)
+          if (pack_status[b][i] != EG_ST_OK) status[first + i] = pack_status[b][i];
+    }
+    if (producer.joinable()) producer.join();
+    if (last) break;
+  }
+  if (n_objects) *n_objects = cur.count;
+  if (tally_out && ns) {
+    int rc2 = EG_OK;
+    if (rc == EG_OK) rc2 = engine_tally_encode(e, tally_out);
+    hipLaunchKernelGGL(k_tally_add_points, dim3(blocks_of((size_t)ns)), dim3(NT), 0, s, e->tally_saved2, ns, e->tally);
+    (void)hipStreamSynchronize(s);
+    if (rc == EG_OK) rc = rc2;
+  }
+  return rc;
+}
+int eg_verify_choice_json(eg_choice_params* p, const char* json, size_t json_len, int threads, size_t max_objects, uint32_t* status,
+                          size_t* n_objects, uint8_t* tally_out) { EG_LOCK_P(p);
+  if (!p) return fail(EG_ERR_BAD_ARG, "bad argument");
+  const int n_options = p->n_options, single = p->single;
+  const size_t stride = p->eng->plan.stride;
+  return verify_json_common(p->eng, json, json_len, threads, max_objects, status, n_objects, tally_out,
+                            [=](const char* text, const std::vector<std::pair<size_t, size_t>>& sub, int th, uint8_t* dst, uint32_t* st) {
+                              egwire::pack_parallel(text, sub, stride, th, dst, st, [&](egwire::Cursor& c, uint8_t* d) {
+                                return egwire::pack_choice(c, n_options, single != 0, d);
+                              });
+                            });
+}
+int eg_verify_qv_json(eg_qv_params* p, const char* json, size_t json_len, int threads, size_t max_objects, uint32_t* status,
+                      size_t* n_objects, uint8_t* tally_out) { EG_LOCK_P(p);
+  if (!p) return fail(EG_ERR_BAD_ARG, "bad argument");
+  const int n_options = p->n_options;
+  const eghost::QvShape sh = p->shape;
+  const egwire::RangeShape vote{sh.vote_range.rings.size(), (size_t)sh.vote_range.rings_size()};
+  const egwire::RangeShape credit{sh.credit_range.rings.size(), (size_t)sh.credit_range.rings_size()};
+  return verify_json_common(p->eng, json, json_len, threads, max_objects, status, n_objects, tally_out,
+                            [=](const char* text, const std::vector<std::pair<size_t, size_t>>& sub, int th, uint8_t* dst, uint32_t* st) {
+                              egwire::pack_parallel(text, sub, sh.ballot_size, th, dst, st, [&](egwire::Cursor& c, uint8_t* d) {
+                                return egwire::pack_qv(c, n_options, vote, credit, sh.ballot_size, d);
+                              });
+                            });
 }
 size_t eg_qv_ballot_size_for(int n_options, uint64_t credits) {
   if (n_options < 1 || n_options > 256 || credits < 1 || credits > 100000) return 0;

@@ -444,6 +444,126 @@ inline bool split_objects_parallel(const char* s, size_t len, int threads, std::
   return closed;
 }
 
+// ---- streaming splitter: the text is cut window by window, so that parsing and GPU verification of the first ballots start before
+// the last bytes have been looked at (eg_verify_*_json).  Same verdicts as split_objects on the whole text.
+struct SplitCursor {
+  size_t pos = 0;        // next unread byte (always at the base depth, outside strings)
+  size_t count = 0;      // values emitted so far
+  bool started = false, array = false, closed = false;
+};
+// Emits the complete values that start in s[cur.pos, cur.pos + window) and advances the cursor past them; `done` = end of text
+// reached (then the tail has been checked as well).  A window that holds no complete value is grown.  false = not a sequence of
+// JSON objects.  Work inside a window: every chunk counts unescaped quotes (-> string state of the next chunks), then records its
+// bracket events outside strings; a short sequential walk over the events (about 1 % of the bytes) finds the values.
+inline bool split_next(const char* s, size_t len, size_t window, int threads, SplitCursor& cur,
+                       std::vector<std::pair<size_t, size_t>>& spans, bool& done) {
+  auto is_ws = [](char ch) { return ch == ' ' || ch == '\n' || ch == '\t' || ch == '\r'; };
+  done = false;
+  if (!cur.started) {
+    while (cur.pos < len && is_ws(s[cur.pos])) ++cur.pos;
+    if (cur.pos < len && s[cur.pos] == '[') { cur.array = true; ++cur.pos; }
+    cur.started = true;
+  }
+  if (threads < 1) threads = 1;
+  for (;;) {
+    const size_t a = cur.pos, b = (window >= len - a) ? len : a + window;
+    const size_t T = std::max<size_t>(1, std::min<size_t>((size_t)threads, (b - a) / 256 + 1));
+    auto lo = [&](size_t t) { return a + (b - a) * t / T; };
+    auto is_delim = [&](size_t q) { size_t bs = 0; while (q > a + bs && s[q - 1 - bs] == '\\') ++bs; return (bs & 1) == 0; };
+    auto run = [&](auto fn) {
+      std::vector<std::thread> pool;
+      for (size_t t = 1; t < T; ++t) pool.emplace_back(fn, t);
+      fn(0);
+      for (auto& th : pool) th.join();
+    };
+    std::vector<size_t> quotes(T, 0);
+    run([&](size_t t) {
+      size_t n = 0;
+      const char* p = s + lo(t);
+      const char* e = s + lo(t + 1);
+      while (p < e) {
+        const void* hit = memchr(p, '"', (size_t)(e - p));
+        if (!hit) break;
+        p = (const char*)hit;
+        n += is_delim((size_t)(p - s));
+        ++p;
+      }
+      quotes[t] = n;
+    });
+    std::vector<char> in_str(T, 0);
+    for (size_t t = 1; t < T; ++t) in_str[t] = (char)((in_str[t - 1] + quotes[t - 1]) & 1);
+    struct Ev { size_t pos; int step; };      // +1 open, -1 close, 0 stray backslash
+    std::vector<std::vector<Ev>> events(T);
+    run([&](size_t t) {
+      size_t i = lo(t);
+      const size_t e = lo(t + 1);
+      bool str = in_str[t] != 0;
+      auto& ev = events[t];
+      while (i < e) {
+        if (str) {
+          const void* hit = memchr(s + i, '"', e - i);
+          if (!hit) return;
+          i = (size_t)((const char*)hit - s);
+          if (is_delim(i)) str = false;
+          ++i;
+          continue;
+        }
+        const char ch = s[i];
+        if (ch == '"') str = true;
+        else if (ch == '{' || ch == '[') ev.push_back({i, +1});
+        else if (ch == '}' || ch == ']') ev.push_back({i, -1});
+        else if (ch == '\\') ev.push_back({i, 0});
+        ++i;
+      }
+    });
+    // sequential walk over the events
+    long depth = 0;
+    size_t start = 0, prev_end = a, emitted = 0, close_pos = 0;
+    bool closed_here = false, bad = false;
+    auto separators_ok = [&](size_t from, size_t to, bool before_value) {
+      size_t commas = 0;
+      for (size_t i = from; i < to; ++i) {
+        if (s[i] == ',') ++commas;
+        else if (!is_ws(s[i])) return false;
+      }
+      if (!before_value) return commas == 0;
+      return cur.array ? commas == ((cur.count + emitted) ? 1u : 0u) : commas == 0;
+    };
+    for (size_t t = 0; t < T && !bad && !closed_here; ++t)
+      for (const Ev& e : events[t]) {
+        if (e.step == 0) { if (depth == 0) { bad = true; } else { bad = true; } break; }
+        if (e.step > 0) {
+          if (depth == 0) {
+            if (s[e.pos] != '{' || !separators_ok(prev_end, e.pos, true)) { bad = true; break; }
+            start = e.pos;
+          }
+          ++depth;
+        } else {
+          if (depth == 0) {                       // the closing bracket of a top-level array
+            if (!cur.array || s[e.pos] != ']' || !separators_ok(prev_end, e.pos, false)) { bad = true; break; }
+            closed_here = true; close_pos = e.pos;
+            break;
+          }
+          if (--depth == 0) { spans.push_back({start, e.pos + 1 - start}); ++emitted; prev_end = e.pos + 1; }
+        }
+      }
+    if (bad) return false;
+    if (closed_here) {
+      for (size_t i = close_pos + 1; i < len; ++i) if (!is_ws(s[i])) return false;    // nothing but white space after the array
+      cur.closed = true; cur.count += emitted; cur.pos = len; done = true;
+      return true;
+    }
+    if (b == len) {                               // end of text without a closing bracket
+      if (depth != 0 || cur.array) return false;  // truncated value, or an array that never closes
+      if (!separators_ok(prev_end, len, false)) return false;
+      cur.count += emitted; cur.pos = len; done = true;
+      return true;
+    }
+    if (emitted) { cur.count += emitted; cur.pos = prev_end; return true; }
+    window *= 2;                                  // no complete value in the window: look further
+  }
+}
+
 template <class PackOne>
 inline void pack_parallel(const char* json, const std::vector<std::pair<size_t, size_t>>& spans, size_t stride, int threads,
                           uint8_t* packed, uint32_t* status, PackOne pack_one) {

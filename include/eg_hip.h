@@ -240,6 +240,14 @@ int eg_choice_pack_json(int n_options, int single, const char* json, size_t json
 int eg_qv_pack_json(int n_options, uint64_t credits, const char* json, size_t json_len, int threads, size_t max_objects,
                     uint8_t* packed, uint32_t* status, size_t* n_objects);
 size_t eg_qv_ballot_size_for(int n_options, uint64_t credits);   /* eg_qv_ballot_size without a params object (host only) */
+/* JSON text -> verdicts and tally in one call (what a service that receives the output of examples/voting.rs:195-198 needs): the
+ * objects are packed on `threads` host threads piece by piece while the previous piece is uploaded and verified on the GPU.
+ * status[k]: the verify verdict of object k (as eg_verify_*_batch), or EG_ST_MALFORMED / EG_PACK_RESHAPE from the packer for
+ * objects that never reach the GPU as themselves; tally semantics as eg_verify_*_batch.  *n_objects = objects found. */
+int eg_verify_choice_json(eg_choice_params*, const char* json, size_t json_len, int threads, size_t max_objects, uint32_t* status,
+                          size_t* n_objects, uint8_t* tally_out);
+int eg_verify_qv_json(eg_qv_params*, const char* json, size_t json_len, int threads, size_t max_objects, uint32_t* status,
+                      size_t* n_objects, uint8_t* tally_out);
 
 /* ---- host-only introspection (no GPU needed; used by the CPU-side tests of the host logic) -------------------------------------
  * RangeDecomposition::optimal(upper_bound).to_string() (range.rs:110-124,148-305): the string hashed into the transcript */

@@ -62,5 +62,16 @@ int pc_pack_qv(int n_options, unsigned long long credits, const char* json, size
                         [&](egwire::Cursor& c, uint8_t* dst) { return egwire::pack_qv(c, n_options, vote, credit, sh.ballot_size, dst); });
   return (int)spans.size();
 }
+// the streaming splitter with windows of `window` bytes against the whole-text splitter: 1 = same verdict and spans, 0 = differ
+int pc_split_windows(const char* json, size_t len, size_t window, int threads) {
+  std::vector<std::pair<size_t, size_t>> whole, parts;
+  const bool ok_whole = egwire::split_objects(json, len, whole);
+  egwire::SplitCursor cur;
+  bool done = false, ok = true;
+  for (int guard = 0; ok && !done && guard < 1000000; ++guard) ok = egwire::split_next(json, len, window, threads, cur, parts, done);
+  if (ok != ok_whole) return 0;
+  if (ok && (parts != whole || cur.count != whole.size())) return 0;
+  return 1;
+}
 unsigned long long pc_qv_size(int n_options, unsigned long long credits) { return qv_shape(n_options, credits).ballot_size; }
 }
