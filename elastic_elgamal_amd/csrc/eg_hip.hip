@@ -1039,7 +1039,9 @@ static int verify_json_common(Engine* e, const char* json, size_t json_len, int 
   std::vector<uint32_t> pack_status[2];
   size_t first_index[2] = {0, 0};
   bool done = false, split_ok = true, too_many = false, nomem = false;
+  const int device = e->ctx->device;
   auto produce = [&](int b, size_t window) {
+    (void)hipSetDevice(device);                  // runs on a producer thread: HIP's current device is per thread
     spans[b].clear();
     first_index[b] = cur.count;
     if (!egwire::split_next(json, json_len, window, threads, cur, spans[b], done)) { split_ok = false; return; }
@@ -1049,7 +1051,7 @@ static int verify_json_common(Engine* e, const char* json, size_t json_len, int 
       if (e->json_stage[b]) (void)hipHostFree(e->json_stage[b]);
       e->json_stage[b] = nullptr; e->json_stage_bytes[b] = 0;
       const size_t want = std::max(need, window * 3 / 4 + stride);     // an object takes >= 4/3 of its packed size as JSON
-      if (hipHostMalloc((void**)&e->json_stage[b], want, hipHostMallocDefault) != hipSuccess) { nomem = true; return; }
+      if (hipHostMalloc((void**)&e->json_stage[b], want, hipHostMallocPortable) != hipSuccess) { nomem = true; return; }
       e->json_stage_bytes[b] = want;
     }
     pack_status[b].resize(spans[b].size());
