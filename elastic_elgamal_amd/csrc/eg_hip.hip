@@ -95,7 +95,7 @@ static int upload(T** dptr, const std::vector<T>& v, hipStream_t s) {
 
 // ---------------------------------------------------------------------------------------------------------------
 using eghost::StageDev; using eghost::LevelDev;
-using eghost::FAM_TABLE1; using eghost::FAM_TABLEN; using eghost::FAM_GENERIC; using eghost::FAM_ENCODE; using eghost::N_FAM;
+using eghost::FAM_TABLE1; using eghost::FAM_TABLEN; using eghost::FAM_DIRECT1; using eghost::FAM_GENERIC; using eghost::FAM_ENCODE; using eghost::N_FAM;
 using eghost::EG_MULTI_GROUP; using eghost::job_family;
 
 struct Engine {
@@ -401,6 +401,9 @@ static int engine_verify_device(Engine* e, size_t n, const void* d_ballots, void
                            (size_t)group * 9 * NT * sizeof(u32), s, B, e->d_jobs, e->d_vterms, st.fam_first[FAM_TABLEN],
                            st.fam_count[FAM_TABLEN], group);
       }
+      if (st.fam_count[FAM_DIRECT1])
+        hipLaunchKernelGGL(k_eq_direct, dim3(grid_for((size_t)st.fam_count[FAM_DIRECT1] * cn, ctx->msm_blocks)), dim3(NT), 0, s, B,
+                           e->d_jobs, e->d_vterms, st.fam_first[FAM_DIRECT1], st.fam_count[FAM_DIRECT1]);
       if (st.fam_count[FAM_GENERIC])
         hipLaunchKernelGGL(k_eq_generic, dim3(grid_for((size_t)st.fam_count[FAM_GENERIC] * cn, ctx->msm_blocks)), dim3(NT), 0, s, B,
                            e->d_jobs, e->d_vterms, st.fam_first[FAM_GENERIC], st.fam_count[FAM_GENERIC]);
@@ -951,6 +954,7 @@ int eg_plan_describe(int kind, int n_options, uint64_t credits_or_bound, char* b
             chain_extra_terms += std::min<int>(EG_MULTI_GROUP, j.term_count - t0) - 1;
           }
           break;
+        case FAM_DIRECT1: ++direct_terms; break;
         case FAM_GENERIC:
           for (unsigned t = 0; t < j.term_count; ++t)
             if (P.vterms[j.term_first + t].base == 0xffff) ++direct_terms; else ++loose_table_terms;

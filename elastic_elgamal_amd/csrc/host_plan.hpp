@@ -613,14 +613,15 @@ inline Plan build_share_plan(uint64_t shares, uint64_t threshold, const uint8_t 
 
 // ---- flattening of a plan into the arrays the kernels index (pure host logic, sanitizer-tested in tests/hostcheck) ------------
 // the equations of a stage, sorted by kernel family (kernels.cuh): FAM_TABLE1 one table-backed base, FAM_TABLEN several
-// table-backed bases on shared doubling chains, FAM_GENERIC everything else, FAM_ENCODE plain encodings of point slots
-enum { FAM_TABLE1 = 0, FAM_TABLEN = 1, FAM_GENERIC = 2, FAM_ENCODE = 3, N_FAM = 4 };
+// table-backed bases on shared doubling chains, FAM_DIRECT1 one base without a table, FAM_GENERIC everything else, FAM_ENCODE plain
+// encodings of point slots
+enum { FAM_TABLE1 = 0, FAM_TABLEN = 1, FAM_DIRECT1 = 2, FAM_GENERIC = 3, FAM_ENCODE = 4, N_FAM = 5 };
 constexpr int EG_MULTI_GROUP = 8;           // terms per shared doubling chain: 8 sign vectors = 72 KiB of LDS per block, two blocks per CU
 inline int job_family(const JobClass& j, const std::vector<VarTerm>& vterms) {
   if (!j.defer) return FAM_ENCODE;
   if (j.term_count == 0) return FAM_GENERIC;
   for (unsigned t = 0; t < j.term_count; ++t)
-    if (vterms[j.term_first + t].base == 0xffff) return FAM_GENERIC;
+    if (vterms[j.term_first + t].base == 0xffff) return j.term_count == 1 ? FAM_DIRECT1 : FAM_GENERIC;
   return j.term_count == 1 ? FAM_TABLE1 : FAM_TABLEN;
 }
 struct StageDev { int fam_first[N_FAM], fam_count[N_FAM], max_terms, inst_first, inst_count, defer_first, defer_count; };

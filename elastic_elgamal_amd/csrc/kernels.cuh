@@ -116,7 +116,8 @@ __global__ void __launch_bounds__(NT, EG_TAB_WAVES) k_base_tables(EngineBufs B, 
 // (one kernel carrying every shape spilled 159 VGPRs):
 //   k_eq_table<false>  one variable base with a comb table (every ring equation) + the fixed-base combs   -- the dominant kernel
 //   k_eq_table<true>   several table-backed bases evaluated on ONE doubling chain (Straus); sign vectors of the scalars in LDS
-//   k_eq_generic       anything else: bases without a table (radix-16 ladder over a per-lane workspace table), any mix of terms
+//   k_eq_direct        one base without a table (radix-16 ladder over a per-lane workspace table): the log-equality equations
+//   k_eq_generic       anything else (any mix of terms, evaluated term by term)
 //   k_encode_plain     serialize_element of points that are not produced by an equation (derived ciphertexts)
 __device__ __forceinline__ void eq_fixed_terms(ge& acc, const EngineBufs& B, u32 b, const egplan::JobClass& jc) {
   const FixedTable tg{B.tabG}, tk{B.tabK};
@@ -184,6 +185,29 @@ __global__ void __launch_bounds__(NT, EG_EQ_WAVES) k_eq_table(EngineBufs B, cons
     }
     eq_fixed_terms(acc, B, b, jc);
     store_pt(B.dpt, B.cap, jc.out_slot, b, acc);       // encoded (as 2 * acc) by k_encode_batch
+  }
+}
+
+// one base WITHOUT a table (used once: the sum of the ciphertexts in the log-equality proof, log_equality.rs:160-164): uniform signed
+// radix-16 ladder over a per-lane table {1..8}P kept in a workspace slice
+__global__ void __launch_bounds__(NT, 2) k_eq_direct(EngineBufs B, const egplan::JobClass* classes, const egplan::VarTerm* terms,
+                                                     int class_first, int n_classes) {
+  const size_t total = (size_t)n_classes * B.n;
+  WsTable tab;
+  tab.init(B.ws);
+  for (size_t j = (size_t)blockIdx.x * NT + threadIdx.x; j < total; j += (size_t)gridDim.x * NT) {
+    const u32 c = class_first + (u32)(j / B.n), b = (u32)(j % B.n);
+    const egplan::JobClass jc = classes[c];
+    const egplan::VarTerm vt = terms[jc.term_first];
+    u32 s[8], dg[8];
+    load_scalar(s, B, b, vt.s, true);
+    sc_recode_radix16(dg, s);
+    ge p, acc;
+    load_pt(p, B.pts, B.cap, vt.slot, b);
+    ge_var_table_build(tab, p);
+    ge_var_mul(acc, tab, dg);
+    eq_fixed_terms(acc, B, b, jc);
+    store_pt(B.dpt, B.cap, jc.out_slot, b, acc);
   }
 }
 
