@@ -36,7 +36,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # (tests/hostcheck: hc_op_counts) as (fe_mul, fe_sq); one fe_mul = 100 and one fe_sq = 55 v_mad_u64_u32.
 OPS = {"decode": (27, 257), "direct_table": (64, 0), "direct_mul": (1269, 1008), "comb": (91, 0), "encode": (32, 255),
        "base_table": (994, 860), "base_mul": (463, 168), "enc_batch_each": (23, 10), "enc_batch_inversion": (11, 254),
-       "multi_first": (470, 168), "multi_extra": (344, 0)}
+       "multi_first": (470, 168), "multi_extra": (344, 0), "sum_table_first": (296, 0), "sum_table_extra": (48, 0)}
 # memory-side traffic per ballot and launch of the profiled kernels comes from profiles/traffic.json, which
 # tools/profile_summary.py writes from the separate rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of tools/profile_round.sh
 TRAFFIC_JSON = ROOT / "profiles" / "traffic.json"
@@ -60,6 +60,8 @@ def plan_field_ops(desc: dict):
                mul(OPS["multi_first"], desc["chains"]),                   # several table-backed bases on one doubling chain
                mul(OPS["multi_extra"], desc["chain_extra_terms"]),
                mul(add(OPS["direct_table"], OPS["direct_mul"]), desc["direct_terms"]),
+               mul(OPS["sum_table_first"], desc["sum_tables"]),           # tables of sums of ring bases, made from their tables
+               mul(OPS["sum_table_extra"], desc["sum_table_members"] - desc["sum_tables"]),
                mul(OPS["comb"], desc["combs"]),
                mul(OPS["enc_batch_each"], desc["deferred"]),
                mul(OPS["enc_batch_inversion"], desc["inversion_groups"]),

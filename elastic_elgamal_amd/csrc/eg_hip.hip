@@ -113,6 +113,8 @@ struct Engine {
   egplan::StatusRule* d_rules = nullptr;
   u32* d_tally_slots = nullptr;
   unsigned short* d_base_slots = nullptr;
+  egplan::SumBase* d_sum_bases = nullptr;
+  unsigned short* d_sum_members = nullptr;
   unsigned short* d_defer_slots = nullptr;
   uint4* btab = nullptr;
   uint4* dpt = nullptr;
@@ -169,7 +171,7 @@ static int gen_workspace(Engine* e, size_t n, unsigned words, int* blocks_out) {
 static void engine_free(Engine* e) {
   if (!e) return;
   void* ptrs[] = {e->d_pt_items, e->d_sc_items, e->d_dclasses, e->d_dterms, e->d_jobs, e->d_vterms, e->d_insts, e->d_ops,
-                  e->d_rules, e->d_tally_slots, e->d_base_slots, e->d_defer_slots, e->btab, e->dpt, e->encw, e->d_blob, e->d_tabK, e->d_cpts, e->d_prefixes, e->d_key_words, e->pts, e->cmp,
+                  e->d_rules, e->d_tally_slots, e->d_base_slots, e->d_sum_bases, e->d_sum_members, e->d_defer_slots, e->btab, e->dpt, e->encw, e->d_blob, e->d_tabK, e->d_cpts, e->d_prefixes, e->d_key_words, e->pts, e->cmp,
                   e->chal, e->states, e->flags, e->bad_item, e->partial, e->tally, e->tally_saved, e->tally_saved2, e->d_wire, e->d_status, e->gen_ws, e->d_gen_desc};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
@@ -198,7 +200,7 @@ static size_t engine_bytes_per_ballot(const Engine* e) {
   const eghost::Plan& P = e->plan;
   return (size_t)std::max(P.n_pt_slots, 1) * 160 + (size_t)std::max(P.n_cmp_slots, 1) * (32 + 160) + (size_t)std::max(P.n_chal_slots, 1) * 32 +
          (size_t)std::max(P.n_state_slots, 1) * 208 + (size_t)std::max(P.n_flag_slots, 1) * 4 + 4 +
-         std::max<size_t>(P.base_slots.size(), 1) * BTAB_QUADS * 16 + (size_t)std::max(e->max_defer, 1) * 80;
+         std::max<size_t>(P.n_tables(), 1) * BTAB_QUADS * 16 + (size_t)std::max(e->max_defer, 1) * 80;
 }
 
 // (re)allocate the per-chunk SoA buffers for chunks of up to `want` ballots
@@ -217,7 +219,7 @@ static int engine_reserve(Engine* e, u32 want) {
                           (size_t)std::max(P.n_state_slots, 1) * 52 * cap * sizeof(u32),
                           (size_t)std::max(P.n_flag_slots, 1) * cap * sizeof(u32),
                           cap * sizeof(u32),
-                          std::max<size_t>(P.base_slots.size(), 1) * cap * BTAB_QUADS * sizeof(uint4),
+                          std::max<size_t>(P.n_tables(), 1) * cap * BTAB_QUADS * sizeof(uint4),
                           (size_t)std::max(P.n_cmp_slots, 1) * 10 * cap * sizeof(uint4),
                           (size_t)std::max(e->max_defer, 1) * 2 * 10 * cap * sizeof(u32)};
   for (size_t i = 0; i < sizeof(sizes) / sizeof(sizes[0]); ++i) {
@@ -280,6 +282,8 @@ static int engine_create(eg_ctx* ctx, eghost::Plan&& plan, const uint8_t pk[32],
   if ((rc = upload(&e->d_rules, P.rules, s))) return rc;
   if ((rc = upload(&e->d_tally_slots, P.tally_slots, s))) return rc;
   if ((rc = upload(&e->d_base_slots, P.base_slots, s))) return rc;
+  if ((rc = upload(&e->d_sum_bases, P.sum_bases, s))) return rc;
+  if ((rc = upload(&e->d_sum_members, P.sum_members, s))) return rc;
   if ((rc = upload(&e->d_defer_slots, defer_slots, s))) return rc;
   if ((rc = upload(&e->d_blob, P.blob, s))) return rc;
 
@@ -387,6 +391,9 @@ static int engine_verify_device(Engine* e, size_t n, const void* d_ballots, void
                          e->d_base_slots, (int)P.base_slots.size());
       if ((rc = prof_end(ctx, s, pi))) return rc;
     }
+    if (!P.sum_bases.empty())
+      hipLaunchKernelGGL(k_sum_tables, dim3(grid_for((size_t)P.sum_bases.size() * cn, ctx->msm_blocks)), dim3(NT), 0, s, B,
+                         e->d_sum_bases, e->d_sum_members, (int)P.sum_bases.size());
     for (auto& st : e->stages) {
       if (st.fam_count[FAM_TABLE1]) {
         size_t pi = 0;
@@ -972,10 +979,11 @@ int eg_plan_describe(int kind, int n_options, uint64_t credits_or_bound, char* b
            "\"stages\": %zu, \"jobs\": %zu, \"jobs_per_stage\": [%s], \"var_terms\": %zu, \"table_terms\": %zu, "
            "\"combs\": %zu, \"deferred\": %zu, \"plain_encodes\": %zu, \"inversion_groups\": %zu, "
            "\"single_table_jobs\": %zu, \"chains\": %zu, \"chain_extra_terms\": %zu, \"loose_table_terms\": %zu, \"direct_terms\": %zu, "
+           "\"sum_tables\": %zu, \"sum_table_members\": %zu, "
            "\"hash_programs\": %zu, \"prefixes\": %d, \"flags\": %d, \"rules\": %zu, \"tally_slots\": %zu}",
            P.stride, P.pt_items.size(), P.sc_items.size(), derived, derive_terms, P.base_slots.size(), P.stages.size(), jobs, per_stage.c_str(),
            var_terms, table_terms, combs, deferred, plain_encodes, inversion_groups, jobs_table1, chains, chain_extra_terms,
-           loose_table_terms, direct_terms, insts, P.n_prefixes, P.n_flag_slots, P.rules.size(),
+           loose_table_terms, direct_terms, P.sum_bases.size(), P.sum_members.size(), insts, P.n_prefixes, P.n_flag_slots, P.rules.size(),
            P.tally_slots.size());
   if (strlen(tmp) + 1 > cap) return fail(EG_ERR_BAD_ARG, "buffer too small");
   memcpy(buf, tmp, strlen(tmp) + 1);

@@ -527,6 +527,70 @@ EG_HD void ge_teeth_tables_build(TableIO& io, TmpIO& tmp, const ge& p) {
   }
 }
 
+// (Y+X, Y-X, 2Z, 2dT) -> the same point as (2X : 2Y : 2Z : 2T); accepts the lazily stored classes of table entries.
+// Result {X [1], Y [1], Z [2], T [1]}.
+EG_HD void ge_cached_to_p3(ge& p, const ge_cached& c) {
+  const fe dinv = EG_FE_DINV;
+  fe_sub4(p.X, c.YpX, c.YmX); fe_carry(p.X);
+  fe_add(p.Y, c.YpX, c.YmX); fe_carry(p.Y);
+  p.Z = c.Z2;
+  fe_mul(p.T, c.T2d, dinv);
+}
+
+// Comb table of S = B_1 + .. + B_m when every B_i already has its table: the table is LINEAR in the base (entry g of S is the
+// sum of the members' entries g), so no doubling is needed at all.  Only the six entries where the Gray-code walk of
+// ge_teeth_tables_build flips a tooth for the first time (steps 0, 1, 2, 4, 8, 16) are summed over the members; their differences
+// to the walk's previous entry are the steps +-2 P_j of S, and the other 26 entries follow with one addition each:
+// 6 (m - 1) + 5 + 26 additions against 215 doublings + 37 additions for a table built from S itself, or 252 doublings + 71
+// additions for a ladder over S.  Used for the log-equality proof over the sum of a ballot's ciphertexts (choice.rs:363,
+// log_equality.rs:160-164), whose two bases are the sums of the ring bases.
+// src(k, g, entry) loads entry g of member k; io: the table of S; tmp: scratch for the five cached steps (entries 0..4).
+// (Requesting a member's entry one addition ahead of its use, with the walk re-reading its own output, measured slower:
+// the kernel is bound by the scattered two-line reads themselves, not by their latency.)
+template <class SrcFn, class TableIO, class TmpIO>
+EG_HD void ge_teeth_tables_sum(TableIO& io, TmpIO& tmp, int m, SrcFn src) {
+  ge sum;
+  ge_identity(sum);
+#pragma unroll 1
+  for (int i = 0; i < EG_TEETH_ENTRIES; ++i) {
+    const int g = i ^ (i >> 1);
+    int j = 0;
+    while (i != 0 && ((i >> j) & 1) == 0) ++j;      // Gray code: step i flips tooth ctz(i)
+    ge_p1p1 t;
+    if ((i & (i - 1)) == 0) {                       // first flip of tooth j (or the start): entry g summed over the members
+      ge acc;
+      {
+        ge_cached c; src(0, g, c);
+        ge_cached_to_p3(acc, c);
+      }
+#pragma unroll 1
+      for (int k = 1; k < m; ++k) {
+        ge_cached c; src(k, g, c);
+        ge_add(t, acc, c);
+        ge_add_to_p3(acc, t);
+      }
+      if (i != 0) {                                 // step of tooth j: 2 P_j(S) = entry g - previous entry
+        ge_cached pc; ge_to_cached_lazy(pc, sum);
+        ge_cached_cneg(pc, true);
+        ge d;
+        ge_add(t, acc, pc);
+        ge_add_to_p3(d, t);
+        ge_cached dc; ge_to_cached_lazy(dc, d);
+        tmp.store(j, dc);
+      }
+      sum = acc;
+      fe_carry(sum.Z);                              // [2] after ge_cached_to_p3 when m == 1
+    } else {
+      ge_cached qc; tmp.load(qc, j);
+      ge_cached_cneg(qc, ((g >> j) & 1) == 0);
+      ge_add(t, sum, qc);
+      ge_add_to_p3(sum, t);
+    }
+    ge_cached e; ge_to_cached_lazy(e, sum);
+    io.store(g, e);
+  }
+}
+
 // acc = [k]P from the teeth table; rows = sc_recode_teeth(k) (consumed).  A column's entry is requested before the doubling and
 // used after it, which hides the load without a second entry buffer (requesting it a whole column ahead, in a second register
 // buffer, measured -0.4 % in round 1 and +-0.2 % = nothing in round 2, when the kernel had the 40 registers to spare).

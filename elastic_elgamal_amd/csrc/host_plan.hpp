@@ -106,9 +106,16 @@ struct Plan {
   // bases with a precomputed comb table (ge_teeth_tables_build): point slots that several equations multiply
   std::vector<uint16_t> base_slots;
   std::map<uint16_t, uint16_t> base_index_of;
+  // bases that are sums of ordinary bases: their tables are made from the members' tables (k_sum_tables) and are indexed after
+  // all ordinary bases, so no ordinary base may be registered once the first sum exists (`late_base` records a violation,
+  // check_flat_plan refuses the plan)
+  std::vector<SumBase> sum_bases;
+  std::vector<uint16_t> sum_members;
+  bool late_base = false;
   uint16_t base_index(uint16_t slot) {
     auto it = base_index_of.find(slot);
     if (it != base_index_of.end()) return it->second;
+    if (!sum_bases.empty()) late_base = true;
     const uint16_t i = (uint16_t)base_slots.size();
     base_slots.push_back(slot);
     base_index_of[slot] = i;
@@ -117,6 +124,21 @@ struct Plan {
   bool has_base(uint16_t slot) const { return base_index_of.count(slot) != 0; }
   VarTerm term(uint16_t slot, ScalarSrc sc) { return VarTerm{slot, has_base(slot) ? base_index_of[slot] : (uint16_t)0xffff, sc}; }
   VarTerm bterm(uint16_t slot, ScalarSrc sc) { return VarTerm{slot, base_index(slot), sc}; }
+  // [sc](sum of the points in `member_slots`), every member a ring base: one table-backed term over the sum's own table.
+  // `slot` is the derived point that holds the sum (not read by the equation kernel).
+  VarTerm sum_term(uint16_t slot, const std::vector<uint16_t>& member_slots, ScalarSrc sc) {
+    std::vector<uint16_t> members;
+    for (uint16_t m : member_slots) members.push_back(base_index(m));
+    SumBase sb;
+    sb.first = (uint16_t)sum_members.size();
+    sb.count = (uint16_t)members.size();
+    sb.out_base = (uint16_t)(base_slots.size() + sum_bases.size());
+    sb.pad = 0;
+    sum_members.insert(sum_members.end(), members.begin(), members.end());
+    sum_bases.push_back(sb);
+    return VarTerm{slot, sb.out_base, sc};
+  }
+  size_t n_tables() const { return base_slots.size() + sum_bases.size(); }
 
   uint32_t ref(const std::string& s) {  // label / constant message in the blob
     auto it = blob_index.find(s);
@@ -323,17 +345,20 @@ inline Plan build_choice_plan(int n, bool single) {
     // LogEqualityProof::verify (log_equality.rs:153-180)
     const ScalarSrc c = wire_src(sum_items, true), s = wire_src((uint16_t)(sum_items + 1));
     uint16_t xg, xk;
-    if (n <= 4) {
-      // few options: [-c](sum R_k) and [-c](sum B_k - G) = sum [-c]B_k + [c]G over the comb tables the rings need anyway,
-      // all terms on one doubling chain (42 doublings + 43 n additions, against 252 + 71 for a ladder over the sum)
+    if (n <= 2) {
+      // [-c](sum R_k) and [-c](sum B_k - G) = sum [-c]B_k + [c]G over the comb tables the rings need anyway, all terms on one
+      // doubling chain (42 doublings + 43 n additions, against 252 + 71 for a ladder over the sum)
       std::vector<VarTerm> tg, tk;
       push_sum_terms(P, tg, R, c);
       push_sum_terms(P, tk, B, c);
       xg = P.job(0, tg, s, no_src());
       xk = P.job(0, tk, wire_src(sum_items), s);
     } else {
-      xg = P.job(0, {P.term(p0, c)}, s, no_src());
-      xk = P.job(0, {P.term(p1, c)}, no_src(), s);
+      // more options: the comb tables of sum R_k and sum B_k are summed up from the ring bases' tables (6 (n - 1) + 31 additions,
+      // no doublings: ge_teeth_tables_sum), and the two equations become ordinary one-table equations
+      for (int k = 0; k < n; ++k) { (void)P.base_index(R[k]); (void)P.base_index(B[k]); }   // ring bases first, in ring order
+      xg = P.job(0, {P.sum_term(p0, R, c)}, s, no_src());
+      xk = P.job(0, {P.sum_term(p1, B, c)}, wire_src(sum_items), s);
     }
     const uint16_t e0 = P.encode_job(0, p0), e1 = P.encode_job(0, p1);
     sum_flag = P.new_flag();
@@ -693,6 +718,14 @@ inline std::string check_flat_plan(const Plan& P, const FlatPlan& F) {
     }
   }
   for (uint16_t b : P.base_slots) if ((int)b >= P.n_pt_slots) return "base slot out of range";
+  if (P.late_base) return "ordinary base registered after a sum base";
+  for (size_t i = 0; i < P.sum_bases.size(); ++i) {
+    const SumBase& sb = P.sum_bases[i];
+    if (sb.out_base != P.base_slots.size() + i) return "sum base index out of order";
+    if (sb.count == 0 || (size_t)sb.first + sb.count > P.sum_members.size()) return "sum base members out of range";
+    for (unsigned t = 0; t < sb.count; ++t)
+      if (P.sum_members[sb.first + t] >= P.base_slots.size()) return "sum base member is not an ordinary base";
+  }
   size_t counted = 0;
   for (auto& sd : F.stages) {
     for (int f = 0; f < N_FAM; ++f) {
@@ -708,7 +741,7 @@ inline std::string check_flat_plan(const Plan& P, const FlatPlan& F) {
         for (unsigned t = 0; t < j.term_count; ++t) {
           const VarTerm& v = P.vterms[j.term_first + t];
           if (!scalar_ok(v.s) || v.s.kind == SRC_NONE) return "term scalar out of range";
-          if (v.base == 0xffff ? (int)v.slot >= P.n_pt_slots : v.base >= P.base_slots.size()) return "term base out of range";
+          if (v.base == 0xffff ? (int)v.slot >= P.n_pt_slots : v.base >= P.n_tables()) return "term base out of range";
         }
       }
     }

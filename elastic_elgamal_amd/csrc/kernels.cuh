@@ -109,6 +109,22 @@ __global__ void __launch_bounds__(NT, EG_TAB_WAVES) k_base_tables(EngineBufs B, 
   }
 }
 
+// ---- k_sum_tables: comb table of a base that is the sum of ring bases, from their tables (ge_teeth_tables_sum; no doublings) ----
+__global__ void __launch_bounds__(NT, 2) k_sum_tables(EngineBufs B, const egplan::SumBase* sums, const unsigned short* members, int n_sums) {
+  const size_t total = (size_t)n_sums * B.n;
+  WsTable tmp;
+  tmp.init(B.ws);
+  for (size_t j = (size_t)blockIdx.x * NT + threadIdx.x; j < total; j += (size_t)gridDim.x * NT) {
+    const u32 k = (u32)(j / B.n), b = (u32)(j % B.n);
+    const egplan::SumBase sb = sums[k];
+    BaseTable out{B.btab + ((size_t)sb.out_base * B.cap + b) * BTAB_QUADS};
+    ge_teeth_tables_sum(out, tmp, (int)sb.count, [&](int t, int g, ge_cached& e) {
+      const BaseTable bt{B.btab + ((size_t)members[sb.first + t] * B.cap + b) * BTAB_QUADS};
+      bt.load(e, g);
+    });
+  }
+}
+
 // ---- group equations: P = sum_i [a_i]P_i + [g]G + [k]K (halved scalars; k_encode_batch then emits encode(2P)) ------------------
 // One lane = one group equation of one ballot: vartime_double_mul_generator / vartime_multi_mul (ring.rs:342-350,
 // log_equality.rs:160-164, mul.rs:213-247).  Persistent blocks stride over (class, ballot); lanes of a wave share the class, so

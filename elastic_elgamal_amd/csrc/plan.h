@@ -32,6 +32,14 @@ struct VarTerm {
   ScalarSrc s;
 };
 
+// A base that is the sum of other table-backed bases: its comb table is the entry-wise sum of theirs (k_sum_tables), tables
+// being linear in the base.  Table index out_base >= the number of ordinary bases.
+struct SumBase {
+  uint16_t first, count;  // members: sum_members[first .. first + count), indices of ordinary bases
+  uint16_t out_base;      // table index of the sum
+  uint16_t pad;
+};
+
 struct JobClass {
   uint16_t term_first, term_count;  // variable-base terms
   ScalarSrc g, k;                   // fixed-base scalars for G and K

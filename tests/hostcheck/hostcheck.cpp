@@ -126,6 +126,41 @@ int hc_multi_mul_teeth(int n, const uint8_t* ks, const uint8_t* ps, const uint8_
   return 1;
 }
 
+// out = enc([k](P_1 + .. + P_n) + [r]G) through the table that ge_teeth_tables_sum makes from the members' tables (what k_sum_tables +
+// k_eq_table<false> run for the log-equality proof over the sum of the ciphertexts).  Returns 1 when, in addition, every entry of
+// that table is the same curve point as the entry of a table built from the sum itself; 0 when one differs; -1 for a bad encoding.
+int hc_sum_table_mul(int n, const uint8_t* ps, const uint8_t k[32], const uint8_t r[32], uint8_t out[32]) {
+  if (!g_base_table.ready) { ge g; ge_generator(g); build_fixed(g_base_table, g); }
+  std::vector<ArrBase> tabs(n);
+  ge total; ge_identity(total);
+  for (int i = 0; i < n; ++i) {
+    u32 pw[8]; words_from_bytes(pw, ps + 32 * i, 8);
+    ge p; if (!ristretto_decode(p, pw)) return -1;
+    ArrTable tmp; ge_teeth_tables_build(tabs[i], tmp, p);
+    ge t; ge_add_full(t, total, p); total = t;
+  }
+  ArrBase sum_tab, ref_tab; ArrTable tmp, tmp2;
+  ge_teeth_tables_sum(sum_tab, tmp, n, [&](int t, int g, ge_cached& e) { tabs[t].load(e, g); });
+  ge_teeth_tables_build(ref_tab, tmp2, total);
+  int same = 1;
+  for (int g = 0; g < EG_TEETH_ENTRIES; ++g) {
+    ge a, b; ge_cached_to_p3(a, sum_tab.e[g]); ge_cached_to_p3(b, ref_tab.e[g]);
+    fe az, bz, l, rr;
+    az = a.Z; fe_carry(az); bz = b.Z; fe_carry(bz);
+    fe_mul(l, a.X, bz); fe_mul(rr, b.X, az); if (!fe_eq(l, rr)) same = 0;
+    fe_mul(l, a.Y, bz); fe_mul(rr, b.Y, az); if (!fe_eq(l, rr)) same = 0;
+    fe_mul(l, a.T, bz); fe_mul(rr, b.T, az); if (!fe_eq(l, rr)) same = 0;
+  }
+  u32 kw[8], rw[8], o[8];
+  words_from_bytes(kw, k, 8); words_from_bytes(rw, r, 8);
+  u64 rows[EG_TEETH]; u32 dr[EG_COMB_WORDS]; sc_recode_teeth(rows, kw); sc_recode_comb(dr, rw);
+  ge acc; ge_teeth_mul(acc, sum_tab, rows);
+  ge_fixed_mul_add(acc, g_base_table, dr);
+  ristretto_encode(o, acc);
+  bytes_from_words(out, o, 8);
+  return same;
+}
+
 // encode(2P) through the batched-inversion path vs the plain encoder; returns 1 when they agree
 int hc_double_encode(const uint8_t p_enc[32], uint8_t out[32]) {
   u32 pw[8], o[8], ref[8]; words_from_bytes(pw, p_enc, 8);
@@ -202,7 +237,8 @@ int hc_merlin(const char* label, const char* l1, const uint8_t* m1, int m1_len, 
 // 0: ristretto_decode  1: direct table build  2: direct variable-base multiply  3: fixed-base comb
 // 4: ristretto_encode  5: comb-table build (per base)  6: comb multiply (per equation)
 // 9: shared-chain product of ONE term (ge_teeth_mul_multi)   10: every further term of it
-void hc_op_counts(unsigned long long out[22]) {
+// 11: table of a sum base with ONE member (ge_teeth_tables_sum)   12: every further member of it
+void hc_op_counts(unsigned long long out[26]) {
   if (!g_base_table.ready) { ge g; ge_generator(g); build_fixed(g_base_table, g); }
   u32 gw[8] = {0x0aaef2e2u, 0x714ebc6au, 0x61a984a8u, 0x5f5100c5u, 0x6a0be358u, 0x8ddd82a5u, 0x4559a6b6u, 0x762d8de0u};
   u32 k[8] = {0x12345678u, 0x9abcdef0u, 0x0fedcba9u, 0x87654321u, 0x11111111u, 0x22222222u, 0x33333333u, 0x04444444u};
@@ -244,6 +280,13 @@ void hc_op_counts(unsigned long long out[22]) {
   m0 = g_fe_mul_count; s0 = g_fe_sq_count;
   ge_teeth_mul_multi(acc, 2, column, load);
   out[20] = g_fe_mul_count - m0 - out[18]; out[21] = g_fe_sq_count - s0 - out[19];
+  ArrBase sum_tab;
+  auto src = [&](int, int g, ge_cached& e) { st.load(e, g); };
+  m0 = g_fe_mul_count; s0 = g_fe_sq_count;
+  ge_teeth_tables_sum(sum_tab, tmp, 1, src); snap(11, m0, s0);
+  m0 = g_fe_mul_count; s0 = g_fe_sq_count;
+  ge_teeth_tables_sum(sum_tab, tmp, 2, src);
+  out[24] = g_fe_mul_count - m0 - out[22]; out[25] = g_fe_sq_count - s0 - out[23];
 }
 
 void hc_fe_roundtrip(const uint8_t in[32], uint8_t out[32]) {

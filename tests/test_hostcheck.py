@@ -149,6 +149,28 @@ def test_shared_chain_multi_mul(hc, oracle):
             assert out.raw == want, (n, trial)
 
 
+def test_sum_of_tables(hc, oracle):
+    """ge_teeth_tables_sum: the comb table of a sum of bases, made from the members' tables without doublings, holds the same 32
+    curve points as a table built from the sum, and a product over it equals the oracle's (incl. the identity as a member, equal
+    members, a member and its negative: sums that hit the identity)."""
+    rnd = random.Random(45)
+    pts = [oracle.point_mul_generator(rnd.randrange(L).to_bytes(32, "little")) for _ in range(9)] + [b"\x00" * 32]
+    neg0 = oracle.point_mul_generator((L - 1).to_bytes(32, "little"))
+    g1 = oracle.point_mul_generator((1).to_bytes(32, "little"))
+    sets = [[pts[0]], pts[:2], pts[:3], pts[:5], pts[2:9], [pts[9], pts[1]], [pts[3], pts[3], pts[3]], [g1, neg0], [g1, neg0, pts[4]],
+            pts[:9] + pts[:7]]
+    edge = [0, 1, 2, L - 1, 2**252 + 2**251 + 12345, 8]
+    for si, ps in enumerate(sets):
+        for trial in range(3):
+            k = edge[(si + trial) % len(edge)] if trial < 2 else rnd.randrange(L)
+            r = rnd.randrange(L)
+            out = _b()
+            kb, rb = k.to_bytes(32, "little"), r.to_bytes(32, "little")
+            assert hc.hc_sum_table_mul(len(ps), b"".join(ps), kb, rb, out) == 1, (si, trial)
+            want = oracle.point_multi_mul(kb * len(ps) + rb, b"".join(ps) + oracle.const_bytes(4))
+            assert out.raw == want, (si, trial)
+
+
 def test_merlin(hc, oracle):
     out = _b(64)
     hc.hc_merlin.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_uint64, C.c_char_p, C.c_char_p]
@@ -179,10 +201,10 @@ def test_doubled_encoder(hc, oracle):
 def test_bench_work_model_matches_the_code(hc):
     """bench.py prices a ballot with per-building-block (fe_mul, fe_sq) counts; they must be the counts of the shipped code."""
     import ast
-    out = (C.c_ulonglong * 22)()
+    out = (C.c_ulonglong * 26)()
     hc.hc_op_counts(out)
     names = ["decode", "direct_table", "direct_mul", "comb", "encode", "base_table", "base_mul", "enc_batch_each", "enc_batch_inversion",
-             "multi_first", "multi_extra"]
+             "multi_first", "multi_extra", "sum_table_first", "sum_table_extra"]
     got = {n: (out[2 * i], out[2 * i + 1]) for i, n in enumerate(names)}
     src = (HERE.parent.parent / "bench.py").read_text()
     tree = ast.parse(src)
