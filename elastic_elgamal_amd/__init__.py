@@ -147,6 +147,7 @@ def _load() -> C.CDLL:
         "eg_profile_enable": (C.c_int, [vp, C.c_int]),
         "eg_profile_read": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
         "eg_profile_read_tables": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+        "eg_selfcheck_generator_table": (C.c_int, [vp, C.c_int, sz, C.c_uint64, C.POINTER(C.c_uint64)]),
     }
     for name, (res, args) in sig.items():
         if "EG_LIB" in os.environ and not hasattr(lib, name):
@@ -306,6 +307,14 @@ class Context:
         a, n = C.c_double(), C.c_uint64()
         _check(_load().eg_profile_read_tables(self._h, C.byref(a), C.byref(n)))
         return a.value, n.value
+
+
+    def selfcheck_generator_table(self, wide: bool = False, samples: int = 4096, seed: int = 1) -> int:
+        """Entries of the generator's comb table that differ from an entry-by-entry recomputation (must be 0); wide=True
+        checks (and first builds) the wide table that large batches use."""
+        bad = C.c_uint64()
+        _check(_load().eg_selfcheck_generator_table(self._h, int(wide), samples, seed, C.byref(bad)))
+        return bad.value
 
 
 class Ristretto:

@@ -23,7 +23,7 @@ struct EngineBufs {
   u32* flags;
   u32* bad_item;
   u32* status;          // [n] output
-  const uint4* tabG;    // fixed-base table of the generator   [64][8] x 8 uint4
+  const uint4* tabG;    // fixed-base comb table of the generator (FixedTable: header + [window][entry] x 8 uint4)
   const uint4* tabK;    // fixed-base table of the election key
   const uint4* cpts;    // election-constant points [idx][10]
   u32* prefixes;        // hoisted transcript prefixes [idx][52]
@@ -144,9 +144,12 @@ struct BaseTable {
     for (int i = 0; i < 10; ++i) { c.YpX.v[i] = w[i]; c.YmX.v[i] = w[10 + i]; c.Z2.v[i] = w[20 + i]; c.T2d.v[i] = w[30 + i]; }
   }
 };
-// fixed-base comb table shared by every lane (34 MiB per base at 15-bit windows): entry = 8 uint4 (30 limbs used)
+// fixed-base comb table shared by every lane: entry = 8 uint4 (30 limbs used).  The uint4 in front of the first entry is the
+// table's header {window bits, windows, entries per window, 0} (k_build_fixed_table), so a table pointer says how it is cut.
 struct FixedTable {
   const uint4* tab;
+  int bits;
+  __device__ __forceinline__ explicit FixedTable(const uint4* t) : tab(t), bits((int)reinterpret_cast<const u32*>(t)[-4]) {}
   __device__ __forceinline__ void load(ge_niels& c, int idx) const {
     u32 w[32];
 #pragma unroll

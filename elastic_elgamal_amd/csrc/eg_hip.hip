@@ -55,7 +55,11 @@ struct eg_ctx {
   hipStream_t stream = nullptr;
   int cus = 0;
   std::string name;
-  uint4* tabG = nullptr;     // fixed-base table of the generator
+  uint4* tabG = nullptr;     // fixed-base comb table of the generator, EG_COMB_BITS wide (points at the first entry; comb_table_build)
+  uint4* tabG_big = nullptr; // the same, big_bits wide: built when the first large batch arrives (ensure_big_tables)
+  int big_bits = EG_COMB_BITS_BIG;      // 0: never build wide tables (EG_COMB_BIG_BITS)
+  size_t big_min = (size_t)1 << 19;     // an engine that has verified this many items gets the wide tables (EG_COMB_BIG_MIN)
+  bool big_failed = false;              // the wide tables did not fit the device memory: do not try again
   u32* gen_words = nullptr;  // generator as 40 limbs
   int msm_blocks = 0;        // persistent grid of the equation kernels
   uint4* ws = nullptr;       // variable-base table workspace (msm_blocks * 80 * NT uint4)
@@ -93,6 +97,37 @@ static int upload(T** dptr, const std::vector<T>& v, hipStream_t s) {
   return EG_OK;
 }
 
+// Builds the comb table of one fixed base (kernels.cuh: k_comb_window_bases + k_build_fixed_table) on stream s and waits for it
+// (the scratch of the batched inversion is released before returning).  *out points at the first entry; the allocation starts
+// COMB_HEADER_QUADS uint4 earlier (a whole cache line, so that the 128-byte entries stay line-aligned; the table's header is the
+// last uint4 of it): release with comb_table_free.
+static void comb_table_free(uint4* tab) { if (tab) (void)hipFree(tab - COMB_HEADER_QUADS); }
+static int comb_table_build(const u32* d_base_words, int bits, hipStream_t s, uint4** out, bool soft_nomem = false) {
+  *out = nullptr;
+  if (bits < 8 || bits > 26) return fail(EG_ERR_BAD_ARG, "comb width out of range");
+  const int windows = comb_windows(bits), entries = comb_entries(bits);
+  const size_t lanes = (size_t)windows * (entries / COMB_RUN);
+  uint4* base = nullptr;
+  u32 *d_bases = nullptr, *scratch = nullptr;
+  hipError_t he = hipMalloc((void**)&base, ((size_t)windows * entries * 8 + COMB_HEADER_QUADS) * sizeof(uint4));
+  if (he == hipSuccess) he = hipMalloc((void**)&d_bases, (size_t)windows * 40 * sizeof(u32));
+  if (he == hipSuccess) he = hipMalloc((void**)&scratch, (size_t)COMB_RUN * 10 * lanes * sizeof(u32));
+  if (he != hipSuccess) {
+    if (base) (void)hipFree(base);
+    if (d_bases) (void)hipFree(d_bases);
+    if (scratch) (void)hipFree(scratch);
+    if (he == hipErrorOutOfMemory && soft_nomem) { (void)hipGetLastError(); return EG_ERR_NOMEM; }
+    HIPCHK(he);
+  }
+  hipLaunchKernelGGL(k_comb_window_bases, dim3(1), dim3(64), 0, s, d_base_words, bits, d_bases);
+  hipLaunchKernelGGL(k_build_fixed_table, dim3((unsigned)((lanes + NT - 1) / NT)), dim3(NT), 0, s, d_bases, bits, base + COMB_HEADER_QUADS, scratch);
+  const hipError_t se = hipStreamSynchronize(s);
+  (void)hipFree(d_bases); (void)hipFree(scratch);
+  if (se != hipSuccess) { (void)hipFree(base); HIPCHK(se); }
+  *out = base + COMB_HEADER_QUADS;
+  return EG_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 using eghost::StageDev; using eghost::LevelDev;
 using eghost::FAM_TABLE1; using eghost::FAM_TABLEN; using eghost::FAM_DIRECT1; using eghost::FAM_GENERIC; using eghost::FAM_ENCODE; using eghost::N_FAM;
@@ -121,7 +156,10 @@ struct Engine {
   u32* encw = nullptr;
   int max_defer = 0;
   unsigned char* d_blob = nullptr;
-  uint4 *d_tabK = nullptr, *d_cpts = nullptr;
+  uint4 *d_tabK = nullptr, *d_cpts = nullptr;   // d_tabK: comb table of the election key (first entry; see comb_table_build)
+  uint4* d_tabK_big = nullptr;                 // its wide form, built with the context's (ensure_big_tables)
+  bool use_big = false;                        // this call reads the wide tables
+  size_t items_seen = 0;                       // items verified by this engine so far (the wide tables are built once it passes ctx->big_min)
   u32* d_prefixes = nullptr;
   u32* d_key_words = nullptr;   // [0..40) generator, [40..80) key
   std::vector<StageDev> stages;
@@ -171,9 +209,10 @@ static int gen_workspace(Engine* e, size_t n, unsigned words, int* blocks_out) {
 static void engine_free(Engine* e) {
   if (!e) return;
   void* ptrs[] = {e->d_pt_items, e->d_sc_items, e->d_dclasses, e->d_dterms, e->d_jobs, e->d_vterms, e->d_insts, e->d_ops,
-                  e->d_rules, e->d_tally_slots, e->d_base_slots, e->d_sum_bases, e->d_sum_members, e->d_defer_slots, e->btab, e->dpt, e->encw, e->d_blob, e->d_tabK, e->d_cpts, e->d_prefixes, e->d_key_words, e->pts, e->cmp,
+                  e->d_rules, e->d_tally_slots, e->d_base_slots, e->d_sum_bases, e->d_sum_members, e->d_defer_slots, e->btab, e->dpt, e->encw, e->d_blob, e->d_cpts, e->d_prefixes, e->d_key_words, e->pts, e->cmp,
                   e->chal, e->states, e->flags, e->bad_item, e->partial, e->tally, e->tally_saved, e->tally_saved2, e->d_wire, e->d_status, e->gen_ws, e->d_gen_desc};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  comb_table_free(e->d_tabK); comb_table_free(e->d_tabK_big);
   if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
   for (uint8_t* p : e->json_stage) if (p) (void)hipHostFree(p);
   delete e;
@@ -187,7 +226,7 @@ static EngineBufs make_bufs(const Engine* e, const void* d_ballots, u32 n, void*
   B.cap = e->cap;
   B.pts = e->pts; B.cmp = e->cmp; B.chal = e->chal; B.states = e->states; B.flags = e->flags; B.bad_item = e->bad_item;
   B.status = reinterpret_cast<u32*>(d_status);
-  B.tabG = e->ctx->tabG; B.tabK = e->d_tabK; B.cpts = e->d_cpts; B.prefixes = e->d_prefixes; B.blob = e->d_blob;
+  B.tabG = e->use_big ? e->ctx->tabG_big : e->ctx->tabG; B.tabK = e->use_big ? e->d_tabK_big : e->d_tabK; B.cpts = e->d_cpts; B.prefixes = e->d_prefixes; B.blob = e->d_blob;
   B.ws = e->ctx->ws;
   B.btab = e->btab;
   B.dpt = e->dpt;
@@ -301,8 +340,7 @@ static int engine_create(eg_ctx* ctx, eghost::Plan&& plan, const uint8_t pk[32],
   (void)hipFree(d_pk); (void)hipFree(d_flags);
   if (!hflags[0]) return fail(EG_ERR_BAD_PUBLIC_KEY, "public key is not a valid ristretto255 encoding");
   if (hflags[1]) return fail(EG_ERR_BAD_PUBLIC_KEY, "public key is the identity");
-  HIPCHK(hipMalloc((void**)&e->d_tabK, (size_t)EG_FIXED_WINDOWS * EG_FIXED_ENTRIES * 8 * sizeof(uint4)));
-  hipLaunchKernelGGL(k_build_fixed_table, dim3((EG_FIXED_WINDOWS * EG_FIXED_ENTRIES + NT - 1) / NT), dim3(NT), 0, s, e->d_key_words + 40, e->d_tabK);
+  if ((rc = comb_table_build(e->d_key_words + 40, EG_COMB_BITS, s, &e->d_tabK))) return rc;
 
   // election-constant points [m]G
   {
@@ -353,12 +391,33 @@ static int engine_create(eg_ctx* ctx, eghost::Plan&& plan, const uint8_t pk[32],
   return EG_OK;
 }
 
+// Wide comb tables for G (per context) and K (per engine): built when an engine has seen ctx->big_min items (in one batch or over
+// many calls: a host batch arrives in pieces, JSON text window by window), kept for the life of the objects.  A table that does not fit the device memory is not an error: the narrow tables stay in use.
+static int ensure_big_tables(Engine* e, hipStream_t s) {
+  eg_ctx* ctx = e->ctx;
+  if (ctx->big_bits == 0 || ctx->big_failed) return EG_OK;
+  if (!ctx->tabG_big) {
+    const int rc = comb_table_build(ctx->gen_words, ctx->big_bits, s, &ctx->tabG_big, true);
+    if (rc == EG_ERR_NOMEM) { ctx->big_failed = true; return EG_OK; }
+    if (rc) return rc;
+  }
+  if (!e->d_tabK_big) {
+    const int rc = comb_table_build(e->d_key_words + 40, ctx->big_bits, s, &e->d_tabK_big, true);
+    if (rc == EG_ERR_NOMEM) { ctx->big_failed = true; return EG_OK; }
+    if (rc) return rc;
+  }
+  return EG_OK;
+}
+
 // verify n ballots (device pointers), accumulating accepted ciphertexts into the running tally
 static int engine_verify_device(Engine* e, size_t n, const void* d_ballots, void* d_status, hipStream_t s) {
   eg_ctx* ctx = e->ctx;     // s may be the null stream: a NULL hipStream_t means what it means everywhere in HIP
   const eghost::Plan& P = e->plan;
   size_t all_idx = 0;
   int rc;
+  e->items_seen += n;
+  if (e->items_seen >= ctx->big_min && (rc = ensure_big_tables(e, s))) return rc;
+  e->use_big = e->d_tabK_big != nullptr && ctx->tabG_big != nullptr;
   if ((rc = prof_begin(ctx, s, PROF_CALL, &all_idx))) return rc;
   // equal-sized chunks (each a multiple of the block size) so that the persistent grids stay balanced on the last chunk
   size_t n_chunks = (n + e->max_cap - 1) / e->max_cap;
@@ -490,6 +549,10 @@ static int engine_verify_host(Engine* e, size_t n, const uint8_t* ballots, uint3
   auto merge_saved = [&]() {   // running tally = saved + this batch (also on the error paths: nothing is lost)
     if (tally_out && ns) hipLaunchKernelGGL(k_tally_add_points, dim3(blocks_of((size_t)ns)), dim3(NT), 0, s, e->tally_saved, ns, e->tally);
   };
+  if (n && e->items_seen + n >= e->ctx->big_min) {     // the whole batch counts: its first piece already reads the wide comb tables
+    const int rc = ensure_big_tables(e, s);
+    if (rc) { merge_saved(); (void)hipStreamSynchronize(s); return rc; }
+  }
   if (n) {
     // Pipeline: the copy stream uploads piece k+1 while piece k is verified (host staging, not the kernels, is
     // the scaling risk when ballots arrive in host memory).  The first piece is small so that the exposed upload is short;
@@ -550,7 +613,7 @@ static void ctx_release(eg_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (auto& sp : c->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
   for (auto& ev : c->event_pool) (void)hipEventDestroy(ev);
-  if (c->tabG) (void)hipFree(c->tabG);
+  comb_table_free(c->tabG); comb_table_free(c->tabG_big);
   if (c->gen_words) (void)hipFree(c->gen_words);
   if (c->ws) (void)hipFree(c->ws);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -593,9 +656,14 @@ int eg_init(int device, eg_ctx** out) {
     return fail(EG_ERR_NO_DEVICE, "device is " + c->name + ", this library is built for gfx950 (MI355X) only");
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIPCHK(hipMalloc((void**)&c->gen_words, 80 * sizeof(u32)));
-  HIPCHK(hipMalloc((void**)&c->tabG, (size_t)EG_FIXED_WINDOWS * EG_FIXED_ENTRIES * 8 * sizeof(uint4)));
   hipLaunchKernelGGL(k_setup_points, dim3(1), dim3(64), 0, c->stream, (const u32*)nullptr, c->gen_words, (u32*)nullptr);
-  hipLaunchKernelGGL(k_build_fixed_table, dim3((EG_FIXED_WINDOWS * EG_FIXED_ENTRIES + NT - 1) / NT), dim3(NT), 0, c->stream, c->gen_words, c->tabG);
+  {
+    const int rc = comb_table_build(c->gen_words, EG_COMB_BITS, c->stream, &c->tabG);
+    if (rc) return rc;
+  }
+  if (const char* v = getenv("EG_COMB_BIG_BITS")) c->big_bits = atoi(v);
+  if (const char* v = getenv("EG_COMB_BIG_MIN")) c->big_min = (size_t)strtoull(v, nullptr, 10);
+  if (c->big_bits != 0 && (c->big_bits <= EG_COMB_BITS || c->big_bits > 26)) return fail(EG_ERR_BAD_ARG, "EG_COMB_BIG_BITS must be 0 or in (EG_COMB_BITS, 26]");
   int per_cu = 0;
   HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_eq_table<false>, NT, 0));
   // the shared-chain kernel keeps up to EG_MULTI_GROUP sign vectors per lane in dynamic LDS (9 KiB per term and block)
@@ -657,6 +725,31 @@ int eg_profile_read_tables(eg_ctx* c, double* tables_ms_total, uint64_t* tables_
   if (tables_ms_total) *tables_ms_total = c->tables_ms;
   if (tables_launches) *tables_launches = c->tables_launches;
   c->tables_ms = 0; c->tables_launches = 0;
+  return EG_OK;
+}
+
+int eg_selfcheck_generator_table(eg_ctx* c, int wide, size_t samples, uint64_t seed, uint64_t* mismatches) { EG_LOCK(c);
+  if (!c || !mismatches) return fail(EG_ERR_BAD_ARG, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  if (wide && !c->tabG_big) {
+    if (c->big_bits == 0) return fail(EG_ERR_BAD_ARG, "wide comb tables are switched off (EG_COMB_BIG_BITS=0)");
+    const int rc = comb_table_build(c->gen_words, c->big_bits, s, &c->tabG_big, true);
+    if (rc == EG_ERR_NOMEM) return fail(EG_ERR_NOMEM, "the wide comb table does not fit the device memory");
+    if (rc) return rc;
+  }
+  unsigned long long* d_bad = nullptr;
+  HIPCHK(hipMalloc((void**)&d_bad, sizeof(unsigned long long)));
+  HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(unsigned long long), s));
+  if (samples)
+    hipLaunchKernelGGL(k_check_fixed_table, dim3(blocks_of(samples)), dim3(NT), 0, s, c->gen_words, wide ? c->tabG_big : c->tabG, samples,
+                       (u64)seed, d_bad);
+  unsigned long long bad = 0;
+  const hipError_t he = hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, s);
+  const hipError_t se = hipStreamSynchronize(s);
+  (void)hipFree(d_bad);
+  HIPCHK(he); HIPCHK(se);
+  *mismatches = (uint64_t)bad;
   return EG_OK;
 }
 

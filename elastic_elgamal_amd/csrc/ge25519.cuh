@@ -660,17 +660,23 @@ EG_HD void ge_teeth_mul_multi(ge& acc, int n_terms, ColumnFn column, LoadFn load
 }
 
 // ---- fixed-base scalar multiplication -----------------------------------------------------------------------------
-// Signed radix-2^B comb (B = EG_COMB_BITS: ceil(254 / B) windows x 2^(B-1) affine-Niels entries of 128 B per base), built once
-// per base on the device (k_build_fixed_table).  Default 20 bits = 13 windows, 832 MiB per base, read from HBM one addition ahead
-// of its use; measured in one call against 15 bits (17 windows, 34 MiB, Infinity-Cache resident): +1.5 % single-choice, +2.8 %
-// quadratic voting (round 1: 8 -> 13 bits +3 %, 13 -> 15 +0.9 %).  Table index = window * 2^(B-1) + (|digit| - 1).
-// acc += [k]Base with one mixed addition (7M) per window and no doublings.
+// Signed radix-2^B comb: ceil(254 / B) windows x 2^(B-1) affine-Niels entries of 128 B per base, built on the device
+// (k_build_fixed_table).  B is a property of the TABLE (the table I/O policy carries it), so tables of different widths coexist:
+//   EG_COMB_BITS (20)      13 windows, 832 MiB per base: built when the parameters are created;
+//   EG_COMB_BITS_BIG (24)  11 windows, 11 GiB per base: built the first time a large batch arrives (engine, eg_hip.hip) - HBM
+//                          traded for two additions per comb (measured +1.0 % single-choice, +1.9 % quadratic voting).
+// Entries are read from HBM one addition ahead of their use.  Measured in one call against 15 bits (17 windows, 34 MiB,
+// Infinity-Cache resident): 20 bits +1.5 % single-choice, +2.8 % quadratic voting (round 1: 8 -> 13 bits +3 %, 13 -> 15 +0.9 %).
+// Table index = window * 2^(B-1) + (|digit| - 1).  acc += [k]Base with one mixed addition (7M) per window and no doublings.
 #ifndef EG_COMB_BITS
 #define EG_COMB_BITS 20
 #endif
-#define EG_FIXED_WINDOWS ((254 + EG_COMB_BITS - 1) / EG_COMB_BITS)     // scalars (also halved ones) are < 2^254
-#define EG_FIXED_ENTRIES (1 << (EG_COMB_BITS - 1))
+#ifndef EG_COMB_BITS_BIG
+#define EG_COMB_BITS_BIG 24
+#endif
 #define EG_COMB_WORDS 8
+EG_HD int comb_windows(int bits) { return (254 + bits - 1) / bits; }      // scalars (also halved ones) are < 2^254
+EG_HD int comb_entries(int bits) { return 1 << (bits - 1); }
 // The signed digits are cut from the scalar on the fly, lowest window first (a comb has no doublings, so its windows can be
 // summed in any order): no digit array, only a running carry.  sc_recode_comb is kept as the (now trivial) hand-over of the scalar.
 EG_HD void sc_recode_comb(u32 out[EG_COMB_WORDS], const u32 k[8]) {
@@ -678,34 +684,36 @@ EG_HD void sc_recode_comb(u32 out[EG_COMB_WORDS], const u32 k[8]) {
   for (int w = 0; w < 8; ++w) out[w] = k[w];
 }
 // signed digit in [-2^(B-1), 2^(B-1)) of window i of a scalar < 2^254, given the carry of window i - 1
-EG_HD int sc_comb_digit(const u32 k[8], int i, u32& carry) {
-  const int off = i * EG_COMB_BITS, wi = off >> 5, sh = off & 31;
+EG_HD int sc_comb_digit(const u32 k[8], int i, u32& carry, int bits) {
+  const int off = i * bits, wi = off >> 5, sh = off & 31;
   u32 lo = 0, hi = 0;
 #pragma unroll
   for (int j = 0; j < 8; ++j) { lo = (wi == j) ? k[j] : lo; hi = (wi + 1 == j) ? k[j] : hi; }
   const u64 v = (u64)lo | ((u64)hi << 32);
-  const u32 raw = ((u32)(v >> sh) & ((1u << EG_COMB_BITS) - 1u)) + carry;      // 0 .. 2^B
-  carry = (raw + (1u << (EG_COMB_BITS - 1))) >> EG_COMB_BITS;
-  return (int)raw - (int)(carry << EG_COMB_BITS);
+  const u32 raw = ((u32)(v >> sh) & ((1u << bits) - 1u)) + carry;      // 0 .. 2^B
+  carry = (raw + (1u << (bits - 1))) >> bits;
+  return (int)raw - (int)(carry << bits);
 }
-EG_HD int ge_fixed_index(int i, int d) {
+EG_HD int ge_fixed_index(int i, int d, int bits) {
   const int ad = d < 0 ? -d : d;
-  return i * EG_FIXED_ENTRIES + (ad == 0 ? 0 : ad - 1);
+  return i * comb_entries(bits) + (ad == 0 ? 0 : ad - 1);
 }
+// io.bits = window width of the table behind io
 template <class NielsIO>
 EG_HD void ge_fixed_mul_add(ge& acc, NielsIO& io, const u32 k[EG_COMB_WORDS]) {
   ge_niels ident; ge_niels_identity(ident);
   ge_niels nxt;
+  const int bits = io.bits, windows = comb_windows(bits);
   u32 carry = 0;
-  int d_nxt = sc_comb_digit(k, 0, carry);
-  io.load(nxt, ge_fixed_index(0, d_nxt));
+  int d_nxt = sc_comb_digit(k, 0, carry, bits);
+  io.load(nxt, ge_fixed_index(0, d_nxt, bits));
 #pragma unroll 1
-  for (int i = 0; i < EG_FIXED_WINDOWS; ++i) {
+  for (int i = 0; i < windows; ++i) {
     ge_niels c = nxt;
     const int d = d_nxt;
-    if (i + 1 < EG_FIXED_WINDOWS) {                     // one addition ahead of its use
-      d_nxt = sc_comb_digit(k, i + 1, carry);
-      io.load(nxt, ge_fixed_index(i + 1, d_nxt));
+    if (i + 1 < windows) {                              // one addition ahead of its use
+      d_nxt = sc_comb_digit(k, i + 1, carry, bits);
+      io.load(nxt, ge_fixed_index(i + 1, d_nxt, bits));
     }
     fe_cmov(c.ypx, ident.ypx, d == 0); fe_cmov(c.ymx, ident.ymx, d == 0); fe_cmov(c.xy2d, ident.xy2d, d == 0);
     ge_niels_cneg(c, d < 0);

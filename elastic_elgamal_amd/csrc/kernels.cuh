@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(NT, 2) k_sum_tables(EngineBufs B, const egplan
 //   k_eq_generic       anything else (any mix of terms, evaluated term by term)
 //   k_encode_plain     serialize_element of points that are not produced by an equation (derived ciphertexts)
 __device__ __forceinline__ void eq_fixed_terms(ge& acc, const EngineBufs& B, u32 b, const egplan::JobClass& jc) {
-  const FixedTable tg{B.tabG}, tk{B.tabK};
+  const FixedTable tg(B.tabG), tk(B.tabK);
   if (jc.g.kind != egplan::SRC_NONE) {
     u32 s[8], dg[EG_COMB_WORDS];
     load_scalar(s, B, b, jc.g, true);
@@ -568,29 +568,125 @@ __global__ void k_points_sum(const u32* in, int n_ranks, int n_points, u32* out,
 }
 
 // ---- election setup --------------------------------------------------------------------------------------------------------------------------------
-// tab[w*E + k-1] = niels([k * 2^(B w)] Base), w < EG_FIXED_WINDOWS, 1 <= k <= E = 2^(B-1): one lane per entry
-__global__ void __launch_bounds__(NT) k_build_fixed_table(const u32* base_words /* 40 */, uint4* tab) {
-  const int lane = blockIdx.x * NT + threadIdx.x;
-  if (lane >= EG_FIXED_WINDOWS * EG_FIXED_ENTRIES) return;
-  const int w = lane / EG_FIXED_ENTRIES, k = (lane % EG_FIXED_ENTRIES) + 1;
+// Fixed-base comb tables: tab[w*E + k-1] = niels([k * 2^(B w)] Base), w < ceil(254 / B), 1 <= k <= E = 2^(B-1).
+// k_comb_window_bases: bases[w] = [2^(B w)] Base (one lane, B * windows doublings).
+__global__ void k_comb_window_bases(const u32* base_words /* 40 */, int bits, u32* bases /* [windows][40] */) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
   u32 bw[40];
   for (int i = 0; i < 40; ++i) bw[i] = base_words[i];
   ge p; words_to_ge(p, bw);
+  const int windows = comb_windows(bits);
 #pragma unroll 1
-  for (int i = 0; i < EG_COMB_BITS * w; ++i) { ge d; ge_dbl_full(d, p); p = d; }
+  for (int w = 0; w < windows; ++w) {
+    ge_to_words(bw, p);
+    for (int i = 0; i < 40; ++i) bases[w * 40 + i] = bw[i];
+#pragma unroll 1
+    for (int i = 0; i < bits; ++i) { ge d; ge_dbl_full(d, p); p = d; }
+  }
+}
+// k_build_fixed_table: one lane = a run of COMB_RUN consecutive entries of one window.  The run starts from [k0]P_w (double-and-add)
+// and proceeds by additions of P_w; the entries are made affine with ONE field inversion per run (Montgomery's trick: the prefix
+// products of the Z coordinates sit in `scratch`, the projective points wait in their own table slots).  ~16 field multiplications
+// per entry, against ~440 + an inversion when every entry was computed on its own (round 1): a 20-bit table takes ~1 ms instead of
+// 70 ms, which is what makes the 24-bit tables (92 M entries per base) affordable.
+constexpr int COMB_RUN = 64;
+constexpr int COMB_HEADER_QUADS = 8;      // the allocation starts one cache line before the first entry; tab[-1] is the header
+__global__ void __launch_bounds__(NT) k_build_fixed_table(const u32* bases, int bits, uint4* tab, u32* scratch /* [COMB_RUN][10][lanes] */) {
+  const int windows = comb_windows(bits), entries = comb_entries(bits), runs = entries / COMB_RUN;
+  const size_t lanes = (size_t)windows * runs;
+  const size_t lane = (size_t)blockIdx.x * NT + threadIdx.x;
+  if (lane == 0) tab[-1] = make_uint4((u32)bits, (u32)windows, (u32)entries, 0u);
+  if (lane >= lanes) return;
+  const int w = (int)(lane / runs), k0 = (int)(lane % runs) * COMB_RUN + 1;
+  u32 bw[40];
+#pragma unroll 1
+  for (int i = 0; i < 40; ++i) bw[i] = bases[w * 40 + i];
+  ge p; words_to_ge(p, bw);
+  ge_cached pc; ge_to_cached(pc, p);
   ge q; ge_identity(q);
 #pragma unroll 1
-  for (int bit = EG_COMB_BITS - 1; bit >= 0; --bit) {        // k <= 2^(B-1)
+  for (int bit = bits - 1; bit >= 0; --bit) {        // k0 <= 2^(B-1)
+    ge d; ge_dbl_full(d, q); q = d;
+    if ((k0 >> bit) & 1) { ge_p1p1 t; ge_add(t, q, pc); ge_add_to_p3(q, t); }
+  }
+  uint4* slot = tab + ((size_t)w * entries + (k0 - 1)) * 8;
+  fe prod; fe_1(prod);
+#pragma unroll 1
+  for (int i = 0; i < COMB_RUN; ++i) {
+    u32 o[32];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) { o[j] = q.X.v[j]; o[10 + j] = q.Y.v[j]; o[20 + j] = q.Z.v[j]; }
+    o[30] = 0; o[31] = 0;
+#pragma unroll
+    for (int qd = 0; qd < 8; ++qd) slot[(size_t)i * 8 + qd] = make_uint4(o[4 * qd], o[4 * qd + 1], o[4 * qd + 2], o[4 * qd + 3]);
+#pragma unroll
+    for (int j = 0; j < 10; ++j) scratch[((size_t)i * 10 + j) * lanes + lane] = prod.v[j];     // product of the Z's before entry i
+    fe t; fe_mul(t, prod, q.Z); prod = t;
+    if (i + 1 < COMB_RUN) { ge_p1p1 s; ge_add(s, q, pc); ge_add_to_p3(q, s); }
+  }
+  fe inv;
+  fe_invert(inv, prod);
+  const fe d2 = EG_FE_2D;
+#pragma unroll 1
+  for (int i = COMB_RUN - 1; i >= 0; --i) {
+    u32 o[32];
+#pragma unroll
+    for (int qd = 0; qd < 8; ++qd) {
+      const uint4 v = slot[(size_t)i * 8 + qd];
+      o[4 * qd] = v.x; o[4 * qd + 1] = v.y; o[4 * qd + 2] = v.z; o[4 * qd + 3] = v.w;
+    }
+    fe X, Y, Z, pre;
+    fe_0(X); fe_0(Y); fe_0(Z); fe_0(pre);
+#pragma unroll
+    for (int j = 0; j < 10; ++j) { X.v[j] = o[j]; Y.v[j] = o[10 + j]; Z.v[j] = o[20 + j]; pre.v[j] = scratch[((size_t)i * 10 + j) * lanes + lane]; }
+    fe zi, t, x, y;
+    fe_mul(zi, inv, pre);                 // 1 / Z_i
+    fe_mul(t, inv, Z); inv = t;           // inverse of the product before entry i
+    fe_mul(x, X, zi);
+    fe_mul(y, Y, zi);
+    ge_niels n;
+    fe_add(n.ypx, y, x); fe_carry(n.ypx);
+    fe_sub(n.ymx, y, x); fe_carry(n.ymx);
+    fe_mul(n.xy2d, x, y);
+    fe_mul(n.xy2d, n.xy2d, d2);
+#pragma unroll
+    for (int j = 0; j < 10; ++j) { o[j] = n.ypx.v[j]; o[10 + j] = n.ymx.v[j]; o[20 + j] = n.xy2d.v[j]; }
+    o[30] = 0; o[31] = 0;
+#pragma unroll
+    for (int qd = 0; qd < 8; ++qd) slot[(size_t)i * 8 + qd] = make_uint4(o[4 * qd], o[4 * qd + 1], o[4 * qd + 2], o[4 * qd + 3]);
+  }
+}
+// self-check of a comb table: sampled entries (and the corners of windows and runs) recomputed one by one, the way round 1 built every
+// entry ([k 2^(B w)]Base by doublings and a double-and-add, an inversion per entry), compared as canonical field elements
+__global__ void __launch_bounds__(NT) k_check_fixed_table(const u32* base_words /* 40 */, const uint4* tab, size_t samples, u64 seed,
+                                                          unsigned long long* mismatches) {
+  const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+  if (i >= samples) return;
+  const int bits = (int)reinterpret_cast<const u32*>(tab)[-4];
+  const int windows = comb_windows(bits), entries = comb_entries(bits);
+  const size_t total = (size_t)windows * entries;
+  u64 x = seed + 0x9e3779b97f4a7c15ull * (u64)(i + 1);                 // splitmix64
+  x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull; x = (x ^ (x >> 27)) * 0x94d049bb133111ebull; x ^= x >> 31;
+  size_t idx = (size_t)(x % total);
+  const size_t corners[8] = {0, 1, COMB_RUN - 1, COMB_RUN, (size_t)entries - 1, (size_t)entries, total - COMB_RUN, total - 1};
+  if (i < 8) idx = corners[i];
+  const int w = (int)(idx / entries), k = (int)(idx % entries) + 1;
+  u32 bw[40];
+  for (int j = 0; j < 40; ++j) bw[j] = base_words[j];
+  ge p; words_to_ge(p, bw);
+#pragma unroll 1
+  for (int j = 0; j < bits * w; ++j) { ge d; ge_dbl_full(d, p); p = d; }
+  ge q; ge_identity(q);
+#pragma unroll 1
+  for (int bit = bits - 1; bit >= 0; --bit) {
     ge d; ge_dbl_full(d, q); q = d;
     if ((k >> bit) & 1) { ge s; ge_add_full(s, q, p); q = s; }
   }
-  ge_niels n; ge_to_niels(n, q);
-  u32 o[32];
-#pragma unroll
-  for (int i = 0; i < 10; ++i) { o[i] = n.ypx.v[i]; o[10 + i] = n.ymx.v[i]; o[20 + i] = n.xy2d.v[i]; }
-  o[30] = 0; o[31] = 0;
-#pragma unroll
-  for (int qd = 0; qd < 8; ++qd) tab[(size_t)lane * 8 + qd] = make_uint4(o[4 * qd], o[4 * qd + 1], o[4 * qd + 2], o[4 * qd + 3]);
+  ge_niels want; ge_to_niels(want, q);
+  ge_niels got;
+  const FixedTable ft(tab);
+  ft.load(got, (int)idx);
+  if (!(fe_eq(want.ypx, got.ypx) & fe_eq(want.ymx, got.ymx) & fe_eq(want.xy2d, got.xy2d))) atomicAdd(mismatches, 1ull);
 }
 // out[0] = generator words (always); if pk != null: out[1] = decoded key, flags[0] = valid, flags[1] = identity
 __global__ void k_setup_points(const u32* pk_words, u32* out_words, u32* flags) {
@@ -617,7 +713,7 @@ __global__ void __launch_bounds__(NT) k_const_points(const u64* mults, int n, co
   sc_from_u64(s, mults[i]);
   sc_recode_comb(dg, s);
   ge acc; ge_identity(acc);
-  const FixedTable tg{tabG};
+  const FixedTable tg(tabG);
   ge_fixed_mul_add(acc, tg, dg);
   u32 w[40]; ge_to_words(w, acc);
   for (int q = 0; q < 10; ++q) cpts[(size_t)i * 10 + q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
@@ -745,7 +841,7 @@ __global__ void __launch_bounds__(NT) k_prim_msm(size_t n, int terms, const u32*
     if (r) {
       u32 s[8], dg[EG_COMB_WORDS]; ld8(s, r + i * 8);
       sc_recode_comb(dg, s);
-      const FixedTable tg{tabG};
+      const FixedTable tg(tabG);
       ge_fixed_mul_add(acc, tg, dg);
     }
     u32 o[8]; ristretto_encode(o, acc);

@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(NT) k_choice_encrypt(u64 seed0, size_t n, int 
                                                        int pre_main, int pre_ring, int pre_logeq, u32* out, u32 stride_words,
                                                        u32* gws) {
   __shared__ u32 lds[50 * NT];
-  const FixedTable tg{tabG}, tk{tabK};
+  const FixedTable tg(tabG), tk(tabK);
   const LaneWs ws{gws + ((size_t)blockIdx.x * NT + threadIdx.x), (size_t)gridDim.x * NT};
   const u32 SW = (u32)((n_options + 31) / 32);
   for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
@@ -473,7 +473,7 @@ __global__ void __launch_bounds__(NT) k_qv_encrypt(u64 seed0, size_t n, int n_op
                                                    const u32* prefixes, u32* out, u32 stride_words, u32 vote_words,
                                                    u32 credit_words, u32* gws) {
   __shared__ u32 lds[50 * NT];
-  const FixedTable tg{tabG}, tk{tabK};
+  const FixedTable tg(tabG), tk(tabK);
   const LaneWs ws{gws + ((size_t)blockIdx.x * NT + threadIdx.x), (size_t)gridDim.x * NT};
   const u32 NO = (u32)n_options, per = NO, rb = NO * 25u;     // votes at [0, NO); option k's scalars at per + 24 k; range area at rb
   for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {

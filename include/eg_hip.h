@@ -264,6 +264,14 @@ int eg_profile_read(eg_ctx*, double* msm_ms_total, uint64_t* msm_launches, doubl
 /* same for the second kernel (k_base_tables), covering the launches folded in by the last eg_profile_read */
 int eg_profile_read_tables(eg_ctx*, double* tables_ms_total, uint64_t* tables_launches);
 
+/* ---- self-check of the fixed-base comb tables (election setup; no reference analogue: dalek's basepoint table is a compile-time
+ * constant) ---------------------------------------------------------------------------------------------------------------------
+ * The tables of G are built on the device run by run with one batched inversion per run.  This recomputes `samples` entries (the
+ * corners of windows and runs first, the rest drawn from `seed`) one at a time from the generator and counts the entries that differ.
+ * wide = 0: the table built by eg_init (EG_COMB_BITS windows); wide = 1: the wide table that large batches use (built now if absent;
+ * EG_ERR_NOMEM if it does not fit).  *mismatches must come back 0. */
+int eg_selfcheck_generator_table(eg_ctx*, int wide, size_t samples, uint64_t seed, uint64_t* mismatches);
+
 #ifdef __cplusplus
 }
 #endif

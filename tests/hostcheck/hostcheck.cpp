@@ -24,17 +24,18 @@ struct ArrBase {
 // fixed-base comb table with entries computed on demand (the product's table has millions of entries; a comb touches one per window)
 struct ArrNiels {
   ge base;
+  int bits = EG_COMB_BITS;
   bool ready = false;
   mutable std::map<int, ge_niels> cache;
   void load(ge_niels& c, int idx) const {
     auto it = cache.find(idx);
     if (it == cache.end()) {
       const unsigned long long m0 = g_fe_mul_count, s0 = g_fe_sq_count;     // table construction is not the comb's work
-      const int w = idx / EG_FIXED_ENTRIES, k = idx % EG_FIXED_ENTRIES + 1;    // entry = [k * 2^(B w)] base
+      const int w = idx / comb_entries(bits), k = idx % comb_entries(bits) + 1;    // entry = [k * 2^(B w)] base
       ge p = base;
-      for (int i = 0; i < EG_COMB_BITS * w; ++i) { ge d; ge_dbl_full(d, p); p = d; }
+      for (int i = 0; i < bits * w; ++i) { ge d; ge_dbl_full(d, p); p = d; }
       ge q; ge_identity(q);
-      for (int bit = EG_COMB_BITS - 1; bit >= 0; --bit) {
+      for (int bit = bits - 1; bit >= 0; --bit) {
         ge d; ge_dbl_full(d, q); q = d;
         if ((k >> bit) & 1) { ge t; ge_add_full(t, q, p); q = t; }
       }

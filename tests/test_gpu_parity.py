@@ -120,6 +120,51 @@ def test_scalar_multiplication(grp, oracle):
     assert ok == b"\0"
 
 
+def test_comb_tables_selfcheck_and_digit_corners(eg, ctx, grp, oracle):
+    """The fixed-base comb tables are built run by run with a batched inversion (k_build_fixed_table): sampled entries and the corners
+    of windows and runs equal an entry-by-entry recomputation, for the table built at start-up and for the wide one; scalars whose
+    comb digits sit on the corners of the 64-entry runs and on the extreme digits give the oracle's products."""
+    assert ctx.selfcheck_generator_table(False, 30000, 7) == 0
+    assert ctx.selfcheck_generator_table(True, 30000, 8) == 0
+    digits = [1, 2, 63, 64, 65, 127, 128, 129, 2**19 - 1, 2**19, 2**19 + 1, 2**20 - 1, 2**20 - 64, 2**20 - 65]
+    ks = []
+    for w in range(13):
+        for d in digits:
+            ks.append((d << (20 * w)) % L)
+    ks += [sum(d << (20 * w) for w, d in enumerate([2**19] * 12)) % L, sum((2**20 - 1) << (20 * w) for w in range(12)) % L]
+    got = grp.mul_generator(b"".join(sc(k) for k in ks))
+    for i, k in enumerate(ks):
+        assert got[32 * i : 32 * i + 32] == oracle.point_mul_generator(sc(k)), hex(k)
+
+
+def test_wide_comb_tables_give_the_same_verdicts(eg, oracle, pk, monkeypatch):
+    """An engine that has verified EG_COMB_BIG_MIN items switches to the wide comb tables (24-bit windows, 11 instead of 13 additions
+    per comb).  Forced from the first ballot here: verdicts, tally and the GPU prover's bytes are those of the oracle."""
+    monkeypatch.setenv("EG_COMB_BIG_MIN", "1")
+    c = eg.Context(0)
+    try:
+        rnd = random.Random(11)
+        op = oracle.ChoiceParams(pk, 5, True)
+        ballots = _tamper_choice(op.generate_batch(78, 0, 200), op.ballot_size, oracle, rnd)
+        want = op.verify_batch(ballots)
+        p = eg.ChoiceParams(c, pk, 5, True)
+        got, tally = p.verify_batch(ballots)
+        assert got == want and tally == op.tally(ballots, want)
+        got2, _ = p.verify_batch(ballots)                 # second call: tables already there
+        assert got2 == want
+        oq = oracle.QvParams(pk, 5, 20)
+        qb = bytearray(oq.generate_batch(10, 0, 40))
+        qb[3 * oq.ballot_size + oq.ballot_size - 32] ^= 1
+        qb = bytes(qb)
+        q = eg.QuadraticVotingParams(c, pk, 5, 20)
+        gq, tq = q.verify_batch(qb)
+        wq = oq.verify_batch(qb)
+        assert gq == wq and tq == oq.tally(qb, wq)
+        assert c.selfcheck_generator_table(True, 2000, 3) == 0
+    finally:
+        c.close()
+
+
 # ------------------------------------------------------------------ golden fixtures through the batch tier
 def test_golden_encrypted_choice(eg, ctx, golden, pk):
     p = eg.ChoiceParams(ctx, pk, 5, True)
