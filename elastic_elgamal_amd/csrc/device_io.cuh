@@ -113,6 +113,30 @@ struct WsTable {
     for (int i = 0; i < 10; ++i) { c.YpX.v[i] = w[i]; c.YmX.v[i] = w[10 + i]; c.Z2.v[i] = w[20 + i]; c.T2d.v[i] = w[30 + i]; }
   }
 };
+// The same workspace, word-interleaved across the lanes of the grid ([entry][quad][lane]): for scratch whose entry index is the SAME
+// in every lane (the five steps of a table's Gray-code walk), so that a wave's access is one coalesced 1-KiB row per quad.
+struct WsRows {
+  uint4* base;     // ws + global lane
+  size_t stride;   // lanes of the grid
+  __device__ __forceinline__ void init(uint4* ws) { base = ws + ((size_t)blockIdx.x * NT + threadIdx.x); stride = (size_t)gridDim.x * NT; }
+  __device__ __forceinline__ void store(int e, const ge_cached& c) {
+    u32 w[40];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) { w[i] = c.YpX.v[i]; w[10 + i] = c.YmX.v[i]; w[20 + i] = c.Z2.v[i]; w[30 + i] = c.T2d.v[i]; }
+#pragma unroll
+    for (int q = 0; q < 10; ++q) base[(size_t)(e * 10 + q) * stride] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+  }
+  __device__ __forceinline__ void load(ge_cached& c, int e) const {
+    u32 w[40];
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {
+      const uint4 v = base[(size_t)(e * 10 + q) * stride];
+      w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 10; ++i) { c.YpX.v[i] = w[i]; c.YmX.v[i] = w[10 + i]; c.Z2.v[i] = w[20 + i]; c.T2d.v[i] = w[30 + i]; }
+  }
+};
 // comb table of one (base, ballot): 32 cached entries, contiguous (ge_teeth_tables_build / ge_teeth_mul)
 struct BaseTable {
   uint4* base;

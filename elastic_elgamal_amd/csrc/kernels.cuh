@@ -98,13 +98,17 @@ __global__ void __launch_bounds__(NT) k_derive_points(EngineBufs B, const egplan
 // ---- k_base_tables: comb tables of every ring base (once per base and ballot; shared by all equations of the ring) -----------
 __global__ void __launch_bounds__(NT, EG_TAB_WAVES) k_base_tables(EngineBufs B, const unsigned short* base_slots, int n_bases) {
   const size_t total = (size_t)n_bases * B.n;
-  WsTable tmp;
+  WsRows tmp;
   tmp.init(B.ws);
   for (size_t j = (size_t)blockIdx.x * NT + threadIdx.x; j < total; j += (size_t)gridDim.x * NT) {
     const u32 k = (u32)(j / B.n), b = (u32)(j % B.n);
     ge p;
     load_pt(p, B.pts, B.cap, base_slots[k], b);
+#ifdef EG_AB_TAB_NOSTORE      // measurement-only: every lane writes ballot 0's table (wrong results): what the scattered stores cost
+    BaseTable bt{B.btab + ((size_t)k * B.cap) * BTAB_QUADS};
+#else
     BaseTable bt{B.btab + ((size_t)k * B.cap + b) * BTAB_QUADS};
+#endif
     ge_teeth_tables_build(bt, tmp, p);
   }
 }
@@ -112,14 +116,22 @@ __global__ void __launch_bounds__(NT, EG_TAB_WAVES) k_base_tables(EngineBufs B, 
 // ---- k_sum_tables: comb table of a base that is the sum of ring bases, from their tables (ge_teeth_tables_sum; no doublings) ----
 __global__ void __launch_bounds__(NT, 2) k_sum_tables(EngineBufs B, const egplan::SumBase* sums, const unsigned short* members, int n_sums) {
   const size_t total = (size_t)n_sums * B.n;
-  WsTable tmp;
+  WsRows tmp;
   tmp.init(B.ws);
   for (size_t j = (size_t)blockIdx.x * NT + threadIdx.x; j < total; j += (size_t)gridDim.x * NT) {
     const u32 k = (u32)(j / B.n), b = (u32)(j % B.n);
     const egplan::SumBase sb = sums[k];
+#ifdef EG_AB_SUM_NOSTORE      // measurement-only: every lane writes ballot 0's table (wrong results)
+    BaseTable out{B.btab + ((size_t)sb.out_base * B.cap) * BTAB_QUADS};
+#else
     BaseTable out{B.btab + ((size_t)sb.out_base * B.cap + b) * BTAB_QUADS};
+#endif
     ge_teeth_tables_sum(out, tmp, (int)sb.count, [&](int t, int g, ge_cached& e) {
+#ifdef EG_AB_SUM_NOLOAD       // measurement-only: every lane reads ballot 0's tables (wrong results)
+      const BaseTable bt{B.btab + ((size_t)members[sb.first + t] * B.cap) * BTAB_QUADS};
+#else
       const BaseTable bt{B.btab + ((size_t)members[sb.first + t] * B.cap + b) * BTAB_QUADS};
+#endif
       bt.load(e, g);
     });
   }
