@@ -19,6 +19,7 @@ for w in single multi qv; do
     python3 bench.py --steps 3 --warmup 1 --workload $w --no-cpu-baseline --no-host-inclusive --no-wire-ingest > gpurun_out/prof_stats_$w.log 2>&1 || exit 1
 done
 [ "$1" = "pmc" ] || exit 0
+export EG_COMB_BIG_MIN=1     # the counter passes run 2^18 ballots: give them the wide comb tables that the 1 M-ballot steps use
 for w in single multi qv; do
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf gpurun_out/pmc_${c}_$w

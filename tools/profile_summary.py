@@ -50,7 +50,7 @@ for w in WORKLOADS:
     (PROF / f"{tag}_kernel_stats_{w}.txt").write_text("\n".join(lines) + "\n")
 
 # ---- PMC passes ----------------------------------------------------------------------------------------------------
-want = ["eg::k_eq_table<false>", "eg::k_eq_table<true>", "eg::k_eq_direct", "eg::k_eq_generic", "eg::k_base_tables", "eg::k_encode_batch", "eg::k_decode_points", "eg::k_hash"]
+want = ["eg::k_eq_table<false>", "eg::k_eq_table<true>", "eg::k_eq_direct", "eg::k_eq_generic", "eg::k_base_tables", "eg::k_sum_tables", "eg::k_encode_batch", "eg::k_decode_points", "eg::k_hash"]
 text = [f"# rocprofv3 --pmc <counter> -- python3 bench.py --steps 1 --warmup 0 --workload W --no-cpu-baseline --no-host-inclusive --no-wire-ingest --ballots {PMC_BALLOTS}   (MI355X)",
         "# separate passes per counter (FETCH_SIZE, WRITE_SIZE; for the single-choice workload also two groups of SQ counters); values are",
         "# summed over the launches of the one step (1 chunk).  FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the",
