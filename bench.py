@@ -36,7 +36,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # (tests/hostcheck: hc_op_counts) as (fe_mul, fe_sq); one fe_mul = 100 and one fe_sq = 55 v_mad_u64_u32.
 OPS = {"decode": (27, 257), "direct_table": (64, 0), "direct_mul": (1269, 1008), "comb": (91, 0), "encode": (32, 255),
        "base_table": (994, 860), "base_mul": (463, 168), "enc_batch_each": (23, 10), "enc_batch_inversion": (11, 254),
-       "multi_first": (470, 168), "multi_extra": (344, 0), "sum_table_first": (296, 0), "sum_table_extra": (48, 0)}
+       "multi_first": (470, 168), "multi_extra": (344, 0), "sum_table_first": (296, 0), "sum_table_extra": (48, 0),
+       "comb_wide": (77, 0)}
 # memory-side traffic per ballot and launch of the profiled kernels comes from profiles/traffic.json, which
 # tools/profile_summary.py writes from the separate rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of tools/profile_round.sh
 TRAFFIC_JSON = ROOT / "profiles" / "traffic.json"
@@ -45,7 +46,7 @@ FMUL_PEAK_G = 256.0            # profiles/r01_ubench_fmul_candidates.txt: radix-
 DOMINANT_KERNEL = "eg::k_eq_table<false>"   # one table-backed base + fixed-base combs: every ring equation (kernels.cuh)
 
 
-def plan_field_ops(desc: dict):
+def plan_field_ops(desc: dict, wide_combs: bool = False):
     """(fe_mul, fe_sq) per ballot of the shipped pipeline, from the flattened verification plan (eg_plan_describe) and the
     per-building-block counts above.  Not counted: the few point additions of the derived points, scalar arithmetic, hashing."""
     def add(*xs):
@@ -62,7 +63,7 @@ def plan_field_ops(desc: dict):
                mul(add(OPS["direct_table"], OPS["direct_mul"]), desc["direct_terms"]),
                mul(OPS["sum_table_first"], desc["sum_tables"]),           # tables of sums of ring bases, made from their tables
                mul(OPS["sum_table_extra"], desc["sum_table_members"] - desc["sum_tables"]),
-               mul(OPS["comb"], desc["combs"]),
+               mul(OPS["comb_wide" if wide_combs else "comb"], desc["combs"]),   # wide tables: 11 instead of 13 additions per comb
                mul(OPS["enc_batch_each"], desc["deferred"]),
                mul(OPS["enc_batch_inversion"], desc["inversion_groups"]),
                mul(OPS["encode"], desc["plain_encodes"]))
@@ -318,8 +319,10 @@ def main():
     }
 
     if True:
-        fm, fs = plan_field_ops(desc)
+        narrow_bits, wide_bits = ctx.comb_table_bits()        # wide comb tables exist once an engine has seen 2^19 items
+        fm, fs = plan_field_ops(desc, wide_combs=wide_bits != 0)
         mads = fm * 100 + fs * 55
+        out["config"]["comb_bits"] = wide_bits or narrow_bits
         out["valu_roofline"] = {
             "bound": "valu-int-mad",
             "fe_mul_per_ballot": fm,

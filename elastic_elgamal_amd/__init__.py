@@ -148,6 +148,7 @@ def _load() -> C.CDLL:
         "eg_profile_read": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
         "eg_profile_read_tables": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
         "eg_selfcheck_generator_table": (C.c_int, [vp, C.c_int, sz, C.c_uint64, C.POINTER(C.c_uint64)]),
+        "eg_comb_table_bits": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     }
     for name, (res, args) in sig.items():
         if "EG_LIB" in os.environ and not hasattr(lib, name):
@@ -308,6 +309,12 @@ class Context:
         _check(_load().eg_profile_read_tables(self._h, C.byref(a), C.byref(n)))
         return a.value, n.value
 
+
+    def comb_table_bits(self):
+        """(window bits of the comb tables built at start-up, window bits of the wide tables or 0 while they do not exist)."""
+        a, b = C.c_int(), C.c_int()
+        _check(_load().eg_comb_table_bits(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def selfcheck_generator_table(self, wide: bool = False, samples: int = 4096, seed: int = 1) -> int:
         """Entries of the generator's comb table that differ from an entry-by-entry recomputation (must be 0); wide=True

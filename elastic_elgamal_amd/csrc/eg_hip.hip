@@ -753,6 +753,13 @@ int eg_selfcheck_generator_table(eg_ctx* c, int wide, size_t samples, uint64_t s
   return EG_OK;
 }
 
+int eg_comb_table_bits(eg_ctx* c, int* narrow_bits, int* wide_bits) { EG_LOCK(c);
+  if (!c) return fail(EG_ERR_BAD_ARG, "ctx is null");
+  if (narrow_bits) *narrow_bits = EG_COMB_BITS;
+  if (wide_bits) *wide_bits = c->tabG_big ? c->big_bits : 0;
+  return EG_OK;
+}
+
 // ---- primitive tier ---------------------------------------------------------------------------------------------
 struct DevBuf {
   void* p = nullptr;

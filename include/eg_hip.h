@@ -271,6 +271,9 @@ int eg_profile_read_tables(eg_ctx*, double* tables_ms_total, uint64_t* tables_la
  * wide = 0: the table built by eg_init (EG_COMB_BITS windows); wide = 1: the wide table that large batches use (built now if absent;
  * EG_ERR_NOMEM if it does not fit).  *mismatches must come back 0. */
 int eg_selfcheck_generator_table(eg_ctx*, int wide, size_t samples, uint64_t seed, uint64_t* mismatches);
+/* window widths of the generator's comb tables: the one built by eg_init, and the wide one (0 until an engine of this context has
+ * verified enough items to get it, or eg_selfcheck_generator_table(wide = 1) built it) */
+int eg_comb_table_bits(eg_ctx*, int* narrow_bits, int* wide_bits);
 
 #ifdef __cplusplus
 }

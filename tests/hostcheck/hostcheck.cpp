@@ -239,7 +239,8 @@ int hc_merlin(const char* label, const char* l1, const uint8_t* m1, int m1_len, 
 // 4: ristretto_encode  5: comb-table build (per base)  6: comb multiply (per equation)
 // 9: shared-chain product of ONE term (ge_teeth_mul_multi)   10: every further term of it
 // 11: table of a sum base with ONE member (ge_teeth_tables_sum)   12: every further member of it
-void hc_op_counts(unsigned long long out[26]) {
+// 13: fixed-base comb over a wide (EG_COMB_BITS_BIG) table
+void hc_op_counts(unsigned long long out[28]) {
   if (!g_base_table.ready) { ge g; ge_generator(g); build_fixed(g_base_table, g); }
   u32 gw[8] = {0x0aaef2e2u, 0x714ebc6au, 0x61a984a8u, 0x5f5100c5u, 0x6a0be358u, 0x8ddd82a5u, 0x4559a6b6u, 0x762d8de0u};
   u32 k[8] = {0x12345678u, 0x9abcdef0u, 0x0fedcba9u, 0x87654321u, 0x11111111u, 0x22222222u, 0x33333333u, 0x04444444u};
@@ -288,6 +289,22 @@ void hc_op_counts(unsigned long long out[26]) {
   m0 = g_fe_mul_count; s0 = g_fe_sq_count;
   ge_teeth_tables_sum(sum_tab, tmp, 2, src);
   out[24] = g_fe_mul_count - m0 - out[22]; out[25] = g_fe_sq_count - s0 - out[23];
+  static ArrNiels wide;
+  if (!wide.ready) { ge g; ge_generator(g); wide.bits = EG_COMB_BITS_BIG; build_fixed(wide, g); }
+  m0 = g_fe_mul_count; s0 = g_fe_sq_count;
+  ge_fixed_mul_add(acc, wide, dg8); snap(13, m0, s0);
+}
+// enc([r]G) through a comb of the given window width (the wide tables of large batches use EG_COMB_BITS_BIG)
+void hc_mul_generator_bits(int bits, const uint8_t r[32], uint8_t out[32]) {
+  static std::map<int, ArrNiels> tabs;
+  ArrNiels& t = tabs[bits];
+  if (!t.ready) { ge g; ge_generator(g); t.bits = bits; build_fixed(t, g); }
+  u32 rw[8], dr[EG_COMB_WORDS], o[8];
+  words_from_bytes(rw, r, 8); sc_recode_comb(dr, rw);
+  ge acc; ge_identity(acc);
+  ge_fixed_mul_add(acc, t, dr);
+  ristretto_encode(o, acc);
+  bytes_from_words(out, o, 8);
 }
 
 void hc_fe_roundtrip(const uint8_t in[32], uint8_t out[32]) {

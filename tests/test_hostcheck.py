@@ -132,6 +132,20 @@ def test_double_mul_generator(hc, oracle):
         assert out.raw == oracle.point_double_mul_generator(kb, p, rb), (k, r)
 
 
+def test_comb_widths(hc, oracle):
+    """ge_fixed_mul_add takes the window width from the table: every width the engine may use gives the oracle's [r]G, also for
+    scalars whose digits sit on the extremes of the signed windows."""
+    rnd = random.Random(46)
+    for bits in (8, 15, 20, 22, 24, 26):
+        half = 1 << (bits - 1)
+        edge = [0, 1, half - 1, half, half + 1, (1 << bits) - 1, L - 1, 2**252, sum(half << (bits * w) for w in range(254 // bits)) % L]
+        for r in edge + [rnd.randrange(L) for _ in range(6)]:
+            out = _b()
+            rb = r.to_bytes(32, "little")
+            hc.hc_mul_generator_bits(bits, rb, out)
+            assert out.raw == oracle.point_mul_generator(rb), (bits, r)
+
+
 def test_shared_chain_multi_mul(hc, oracle):
     """ge_teeth_mul_multi (Straus over teeth tables, one doubling chain for all terms) against the oracle's multi_mul."""
     rnd = random.Random(44)
@@ -201,10 +215,10 @@ def test_doubled_encoder(hc, oracle):
 def test_bench_work_model_matches_the_code(hc):
     """bench.py prices a ballot with per-building-block (fe_mul, fe_sq) counts; they must be the counts of the shipped code."""
     import ast
-    out = (C.c_ulonglong * 26)()
+    out = (C.c_ulonglong * 28)()
     hc.hc_op_counts(out)
     names = ["decode", "direct_table", "direct_mul", "comb", "encode", "base_table", "base_mul", "enc_batch_each", "enc_batch_inversion",
-             "multi_first", "multi_extra", "sum_table_first", "sum_table_extra"]
+             "multi_first", "multi_extra", "sum_table_first", "sum_table_extra", "comb_wide"]
     got = {n: (out[2 * i], out[2 * i + 1]) for i, n in enumerate(names)}
     src = (HERE.parent.parent / "bench.py").read_text()
     tree = ast.parse(src)
