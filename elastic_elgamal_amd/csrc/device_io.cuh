@@ -149,6 +149,9 @@ struct BaseTable {
   }
   __device__ __forceinline__ void load(ge_cached& c, int e) const {
     u32 w[40];
+#ifdef EG_AB_UNIFORM_ENTRY      // measurement-only (with EG_AB_SHARED_ENTRY): every lane reads the SAME entry: no address divergence at all
+    e = (e >> 8) & 1;
+#endif
 #ifdef EG_AB_ONE_LINE
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
