@@ -137,10 +137,12 @@ def test_comb_tables_selfcheck_and_digit_corners(eg, ctx, grp, oracle):
         assert got[32 * i : 32 * i + 32] == oracle.point_mul_generator(sc(k)), hex(k)
 
 
-def test_wide_comb_tables_give_the_same_verdicts(eg, oracle, pk, monkeypatch):
+@pytest.mark.parametrize("big_bits", [24, 22, 0])
+def test_wide_comb_tables_give_the_same_verdicts(eg, oracle, pk, monkeypatch, big_bits):
     """An engine that has verified EG_COMB_BIG_MIN items switches to the wide comb tables (24-bit windows, 11 instead of 13 additions
-    per comb).  Forced from the first ballot here: verdicts, tally and the GPU prover's bytes are those of the oracle."""
+    per comb).  Forced from the first ballot here, also with another width and switched off: verdicts and tally are the oracle's."""
     monkeypatch.setenv("EG_COMB_BIG_MIN", "1")
+    monkeypatch.setenv("EG_COMB_BIG_BITS", str(big_bits))
     c = eg.Context(0)
     try:
         rnd = random.Random(11)
@@ -160,7 +162,12 @@ def test_wide_comb_tables_give_the_same_verdicts(eg, oracle, pk, monkeypatch):
         gq, tq = q.verify_batch(qb)
         wq = oq.verify_batch(qb)
         assert gq == wq and tq == oq.tally(qb, wq)
-        assert c.selfcheck_generator_table(True, 2000, 3) == 0
+        assert c.comb_table_bits() == (20, big_bits)
+        if big_bits:
+            assert c.selfcheck_generator_table(True, 2000, 3) == 0
+        else:
+            with pytest.raises(eg.EgError):
+                c.selfcheck_generator_table(True, 10, 3)
     finally:
         c.close()
 
