@@ -61,8 +61,9 @@ struct eg_ctx {
   size_t big_min = (size_t)1 << 19;     // an engine that has verified this many items gets the wide tables (EG_COMB_BIG_MIN)
   bool big_failed = false;              // the wide tables did not fit the device memory: do not try again
   u32* gen_words = nullptr;  // generator as 40 limbs
-  int msm_blocks = 0;        // persistent grid of the equation kernels
-  uint4* ws = nullptr;       // variable-base table workspace (msm_blocks * 80 * NT uint4)
+  int resident_blocks = 0;   // blocks of the equation kernel that the chip holds at once (two per CU)
+  int msm_blocks = 0;        // grid of the table / equation kernels: EG_GRID_OVERSUBSCRIBE x resident_blocks, each block striding over its share
+  uint4* ws = nullptr;       // per-lane workspace of those kernels (msm_blocks * WS_QUADS * NT uint4)
   bool prof = false;
   std::vector<ProfSpan> spans;
   std::vector<hipEvent_t> event_pool;
@@ -360,9 +361,8 @@ static int engine_create(eg_ctx* ctx, eghost::Plan&& plan, const uint8_t pk[32],
   const char* env = getenv("EG_CHUNK");
   e->max_cap = env ? (u32)strtoul(env, nullptr, 10) : 1048576u;
   {
-    // Chunks are large (default 2^20 ballots: ~61 GB of workspace for 5 options) because every kernel is a persistent grid
-    // of msm_blocks * NT lanes striding over jobs x ballots: a chunk of 250k ballots is ~20 rounds per kernel and wastes
-    // most of its last round (measured 4.53 M ballots/s at 2^18 per chunk, 4.83 M/s at 2^20).  Large elections keep the
+    // Chunks are large (default 2^20 ballots: ~61 GB of workspace for 5 options): a chunk of 250k ballots is ~20 rounds of the
+    // resident blocks per kernel and wastes most of its last round (measured 4.53 M ballots/s at 2^18 per chunk, 4.83 M/s at 2^20).  Large elections keep the
     // workspace within half of the free device memory (~58 KB per ballot for 5 options, ~5.5 KB more per ring base).
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
@@ -433,7 +433,7 @@ static int engine_verify_device(Engine* e, size_t n, const void* d_ballots, void
     const u32 cn = (u32)std::min<size_t>(even, n - off);
     EngineBufs B = make_bufs(e, reinterpret_cast<const unsigned char*>(d_ballots) + off * P.stride, cn,
                              reinterpret_cast<u32*>(d_status) + off);
-    const int wide = ctx->cus * 8;
+    const int wide = ctx->cus * 32;     // grid-stride kernels that need no per-lane workspace: well oversubscribed (see eg_init)
     HIPCHK(hipMemsetAsync(e->bad_item, 0xff, (size_t)cn * sizeof(u32), s));
     hipLaunchKernelGGL(k_decode_points, dim3(grid_for((size_t)P.pt_items.size() * cn, wide)), dim3(NT), 0, s, B, e->d_pt_items,
                        (int)P.pt_items.size());
@@ -560,7 +560,7 @@ static int engine_verify_host(Engine* e, size_t n, const uint8_t* ballots, uint3
     if (!e->copy_stream) HIPCHK(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
     std::vector<std::pair<size_t, size_t>> pieces;   // (offset, count)
     {
-      const size_t lanes = (size_t)e->ctx->msm_blocks * NT;
+      const size_t lanes = (size_t)e->ctx->resident_blocks * NT;
       size_t off = 0;
       if (n > 2 * lanes) { pieces.push_back({0, lanes}); off = lanes; }
       const size_t rem = n - off, k = (rem + e->max_cap - 1) / e->max_cap;
@@ -670,6 +670,12 @@ int eg_init(int device, eg_ctx** out) {
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_eq_table<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                              EG_MULTI_GROUP * 9 * NT * (int)sizeof(u32)));
   if (per_cu < 1) per_cu = 1;
+  c->resident_blocks = per_cu * c->cus;
+  // A grid of exactly the resident blocks makes every block do the same number of rounds, so the slowest CU sets the time and the
+  // last round runs part-empty; 16 times as many blocks, handed out as others finish, measured +1.5 % (single) / +1.8 % (QV) in one
+  // call (2 -> 4 -> 8 -> 16 -> 32 -> 64 blocks per CU: 5.33 / 5.38 / 5.41 / 5.39 / 5.40 / 5.44 M ballots/s).  The price is the
+  // per-lane workspace: 2.7 GB.
+  per_cu *= 16;
   const char* env = getenv("EG_MSM_BLOCKS_PER_CU");
   if (env) per_cu = std::max(1, atoi(env));
   c->msm_blocks = per_cu * c->cus;
