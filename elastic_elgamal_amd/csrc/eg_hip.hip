@@ -1150,8 +1150,10 @@ static int verify_json_common(Engine* e, const char* json, size_t json_len, int 
     hipLaunchKernelGGL(k_tally_init, dim3(blocks_of((size_t)ns)), dim3(NT), 0, s, e->tally, ns);
     HIPCHK(hipStreamSynchronize(s));
   }
-  // windows: a small first one (its split + parse is the only one nothing overlaps with), then ~2^18 single-choice ballots' worth of text
-  const size_t big_window = std::max<size_t>((size_t)384 << 20, 64 * stride), first_window = big_window / 4;
+  // windows: a small first one (its split + parse is the only one nothing overlaps with), doubling up to ~2^18 single-choice ballots'
+  // worth of text: the host threads parse only ~1.4x as fast as the GPU verifies, so a window may grow only as fast as the GPU falls behind
+  const size_t big_window = std::max<size_t>((size_t)384 << 20, 64 * stride), first_window = big_window / 8;
+  size_t next_window = first_window * 2;
   egwire::SplitCursor cur;
   std::vector<std::pair<size_t, size_t>> spans[2];
   std::vector<uint32_t> pack_status[2];
@@ -1168,7 +1170,8 @@ static int verify_json_common(Engine* e, const char* json, size_t json_len, int 
     if (need > e->json_stage_bytes[b]) {          // pinned staging, kept with the engine across calls
       if (e->json_stage[b]) (void)hipHostFree(e->json_stage[b]);
       e->json_stage[b] = nullptr; e->json_stage_bytes[b] = 0;
-      const size_t want = std::max(need, window * 3 / 4 + stride);     // an object takes >= 4/3 of its packed size as JSON
+      // for the largest window of this text at once (an object takes >= 4/3 of its packed size as JSON)
+      const size_t want = std::max(need, std::min(big_window, json_len) * 3 / 4 + stride);
       if (hipHostMalloc((void**)&e->json_stage[b], want, hipHostMallocPortable) != hipSuccess) { nomem = true; return; }
       e->json_stage_bytes[b] = want;
     }
@@ -1183,7 +1186,10 @@ static int verify_json_common(Engine* e, const char* json, size_t json_len, int 
     if (nomem) { rc = fail(EG_ERR_NOMEM, "pinned staging allocation failed"); break; }
     const bool last = done;
     std::thread producer;
-    if (!last) producer = std::thread(produce, b ^ 1, big_window);      // split + parse the next window meanwhile
+    if (!last) {
+      producer = std::thread(produce, b ^ 1, next_window);               // split + parse the next window meanwhile
+      next_window = std::min(big_window, next_window * 2);
+    }
     const size_t m = spans[b].size(), first = first_index[b];
     if (m) {
       rc = engine_verify_host(e, m, e->json_stage[b], status + first, nullptr);
