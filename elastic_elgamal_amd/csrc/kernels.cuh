@@ -114,7 +114,10 @@ __global__ void __launch_bounds__(NT, EG_TAB_WAVES) k_base_tables(EngineBufs B, 
 }
 
 // ---- k_sum_tables: comb table of a base that is the sum of ring bases, from their tables (ge_teeth_tables_sum; no doublings) ----
-__global__ void __launch_bounds__(NT, 2) k_sum_tables(EngineBufs B, const egplan::SumBase* sums, const unsigned short* members, int n_sums) {
+#ifndef EG_SUM_WAVES
+#define EG_SUM_WAVES 2
+#endif
+__global__ void __launch_bounds__(NT, EG_SUM_WAVES) k_sum_tables(EngineBufs B, const egplan::SumBase* sums, const unsigned short* members, int n_sums) {
   const size_t total = (size_t)n_sums * B.n;
   WsRows tmp;
   tmp.init(B.ws);
