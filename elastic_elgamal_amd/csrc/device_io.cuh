@@ -33,10 +33,12 @@ struct EngineBufs {
   u32* encw;            // k_encode_batch scratch: prefix products and N   [2 * slot][10][cap]
   uint4* btab;          // comb tables of the ring bases [base][cap] x 320 uint4 (32 cached entries, 5 KiB)
 };
-#ifdef EG_AB_ONE_LINE      // measurement-only build: entries at a 256-B stride, lookups read ONE 128-B line (results are wrong)
+#if defined(EG_AB_ONE_LINE)   // measurement-only build: entries at a 256-B stride, lookups read ONE 128-B line (results are wrong)
 constexpr int BTAB_ENTRY_QUADS = 16;
-#else
+#elif defined(EG_UNPACKED_ENTRIES)   // A/B: the 160-byte entries of rounds 1-2 (40 limbs in 40 words, two cache lines per lookup)
 constexpr int BTAB_ENTRY_QUADS = 10;
+#else                         // packed entries: 4 field elements x 256 bits = 128 bytes = ONE cache line per lookup
+constexpr int BTAB_ENTRY_QUADS = 8;
 #endif
 constexpr int BTAB_QUADS = 32 * BTAB_ENTRY_QUADS;
 
@@ -137,9 +139,60 @@ struct WsRows {
     for (int i = 0; i < 10; ++i) { c.YpX.v[i] = w[i]; c.YmX.v[i] = w[10 + i]; c.Z2.v[i] = w[20 + i]; c.T2d.v[i] = w[30 + i]; }
   }
 };
+// ---- packed table entries ------------------------------------------------------------------------------------------------------------
+// A field element with limbs in class 1 (every limb within its 26 / 25 bits, limb 1 a hair above) is < 2^256 as an integer: eight
+// 32-bit words.  Four of them are 128 bytes - ONE cache line per table lookup instead of the two that a 160-byte entry straddles
+// (the lookups' traffic is ~11 % of the equation kernel).  Packing costs a carry sweep and ~15 instructions per
+// element when an entry is stored, unpacking ~16 per element at every lookup.  Limb offsets: 0 26 51 77 102 128 153 179 204 230.
+__device__ __forceinline__ void fe_pack8(u32 w[8], const fe& f) {
+  u64 acc = (u64)f.v[0] + ((u64)f.v[1] << 26);
+  w[0] = (u32)acc; acc >>= 32;
+  acc += (u64)f.v[2] << 19; w[1] = (u32)acc; acc >>= 32;
+  acc += (u64)f.v[3] << 13; w[2] = (u32)acc; acc >>= 32;
+  acc += (u64)f.v[4] << 6;  w[3] = (u32)acc; acc >>= 32;
+  acc += (u64)f.v[5] + ((u64)f.v[6] << 25); w[4] = (u32)acc; acc >>= 32;
+  acc += (u64)f.v[7] << 19; w[5] = (u32)acc; acc >>= 32;
+  acc += (u64)f.v[8] << 12; w[6] = (u32)acc; acc >>= 32;
+  acc += (u64)f.v[9] << 6;  w[7] = (u32)acc;           // < 2^32: the value is < 2^256
+}
+// limbs 0..8 within their widths, limb 9 = the top 26 bits (class 2 at most)
+__device__ __forceinline__ void fe_unpack8(fe& f, const u32 w[8]) {
+  f.v[0] = w[0] & 0x3ffffffu;
+  f.v[1] = __builtin_amdgcn_alignbit(w[1], w[0], 26) & 0x1ffffffu;
+  f.v[2] = __builtin_amdgcn_alignbit(w[2], w[1], 19) & 0x3ffffffu;
+  f.v[3] = __builtin_amdgcn_alignbit(w[3], w[2], 13) & 0x1ffffffu;
+  f.v[4] = w[3] >> 6;
+  f.v[5] = w[4] & 0x1ffffffu;
+  f.v[6] = __builtin_amdgcn_alignbit(w[5], w[4], 25) & 0x3ffffffu;
+  f.v[7] = __builtin_amdgcn_alignbit(w[6], w[5], 19) & 0x1ffffffu;
+  f.v[8] = __builtin_amdgcn_alignbit(w[7], w[6], 12) & 0x3ffffffu;
+  f.v[9] = w[7] >> 6;
+}
 // comb table of one (base, ballot): 32 cached entries, contiguous (ge_teeth_tables_build / ge_teeth_mul)
 struct BaseTable {
   uint4* base;
+#if !defined(EG_UNPACKED_ENTRIES) && !defined(EG_AB_ONE_LINE)
+  __device__ __forceinline__ void store(int e, const ge_cached& c) {
+    fe a = c.YpX, b = c.YmX, z = c.Z2;
+    fe_carry(a); fe_carry(b); fe_carry(z);          // stored entries come lazily: classes 2, 3, 2 (T2d is a product: class 1)
+    u32 w[32];
+    fe_pack8(w, a); fe_pack8(w + 8, b); fe_pack8(w + 16, z); fe_pack8(w + 24, c.T2d);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) base[e * BTAB_ENTRY_QUADS + q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+  }
+  __device__ __forceinline__ void load(ge_cached& c, int e) const {
+#ifdef EG_AB_UNIFORM_ENTRY      // measurement-only (with EG_AB_SHARED_ENTRY): every lane reads the SAME entry: no address divergence at all
+    e = (e >> 8) & 1;
+#endif
+    u32 w[32];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const uint4 v = base[e * BTAB_ENTRY_QUADS + q];
+      w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+    }
+    fe_unpack8(c.YpX, w); fe_unpack8(c.YmX, w + 8); fe_unpack8(c.Z2, w + 16); fe_unpack8(c.T2d, w + 24);
+  }
+#else
   __device__ __forceinline__ void store(int e, const ge_cached& c) {
     u32 w[40];
 #pragma unroll
@@ -149,7 +202,7 @@ struct BaseTable {
   }
   __device__ __forceinline__ void load(ge_cached& c, int e) const {
     u32 w[40];
-#ifdef EG_AB_UNIFORM_ENTRY      // measurement-only (with EG_AB_SHARED_ENTRY): every lane reads the SAME entry: no address divergence at all
+#ifdef EG_AB_UNIFORM_ENTRY
     e = (e >> 8) & 1;
 #endif
 #ifdef EG_AB_ONE_LINE
@@ -170,6 +223,7 @@ struct BaseTable {
 #pragma unroll
     for (int i = 0; i < 10; ++i) { c.YpX.v[i] = w[i]; c.YmX.v[i] = w[10 + i]; c.Z2.v[i] = w[20 + i]; c.T2d.v[i] = w[30 + i]; }
   }
+#endif
 };
 // fixed-base comb table shared by every lane: entry = 8 uint4 (30 limbs used).  The uint4 in front of the first entry is the
 // table's header {window bits, windows, entries per window, 0} (k_build_fixed_table), so a table pointer says how it is cut.
