@@ -143,31 +143,7 @@ struct WsRows {
 // A field element with limbs in class 1 (every limb within its 26 / 25 bits, limb 1 a hair above) is < 2^256 as an integer: eight
 // 32-bit words.  Four of them are 128 bytes - ONE cache line per table lookup instead of the two that a 160-byte entry straddles
 // (the lookups' traffic is ~11 % of the equation kernel).  Packing costs a carry sweep and ~15 instructions per
-// element when an entry is stored, unpacking ~16 per element at every lookup.  Limb offsets: 0 26 51 77 102 128 153 179 204 230.
-__device__ __forceinline__ void fe_pack8(u32 w[8], const fe& f) {
-  u64 acc = (u64)f.v[0] + ((u64)f.v[1] << 26);
-  w[0] = (u32)acc; acc >>= 32;
-  acc += (u64)f.v[2] << 19; w[1] = (u32)acc; acc >>= 32;
-  acc += (u64)f.v[3] << 13; w[2] = (u32)acc; acc >>= 32;
-  acc += (u64)f.v[4] << 6;  w[3] = (u32)acc; acc >>= 32;
-  acc += (u64)f.v[5] + ((u64)f.v[6] << 25); w[4] = (u32)acc; acc >>= 32;
-  acc += (u64)f.v[7] << 19; w[5] = (u32)acc; acc >>= 32;
-  acc += (u64)f.v[8] << 12; w[6] = (u32)acc; acc >>= 32;
-  acc += (u64)f.v[9] << 6;  w[7] = (u32)acc;           // < 2^32: the value is < 2^256
-}
-// limbs 0..8 within their widths, limb 9 = the top 26 bits (class 2 at most)
-__device__ __forceinline__ void fe_unpack8(fe& f, const u32 w[8]) {
-  f.v[0] = w[0] & 0x3ffffffu;
-  f.v[1] = __builtin_amdgcn_alignbit(w[1], w[0], 26) & 0x1ffffffu;
-  f.v[2] = __builtin_amdgcn_alignbit(w[2], w[1], 19) & 0x3ffffffu;
-  f.v[3] = __builtin_amdgcn_alignbit(w[3], w[2], 13) & 0x1ffffffu;
-  f.v[4] = w[3] >> 6;
-  f.v[5] = w[4] & 0x1ffffffu;
-  f.v[6] = __builtin_amdgcn_alignbit(w[5], w[4], 25) & 0x3ffffffu;
-  f.v[7] = __builtin_amdgcn_alignbit(w[6], w[5], 19) & 0x1ffffffu;
-  f.v[8] = __builtin_amdgcn_alignbit(w[7], w[6], 12) & 0x3ffffffu;
-  f.v[9] = w[7] >> 6;
-}
+// element when an entry is stored, unpacking ~16 per element at every lookup (fe_pack8 / fe_unpack8, fe25519.cuh).
 // comb table of one (base, ballot): 32 cached entries, contiguous (ge_teeth_tables_build / ge_teeth_mul)
 struct BaseTable {
   uint4* base;

@@ -272,6 +272,40 @@ EG_HD void fe_cmov(fe& h, const fe& g, bool flag) {
 #endif
 }
 
+// ---- 256-bit packing (table entries: device_io.cuh BaseTable) --------------------------------------------------------------------
+// A class-1 element (every limb within its 26 / 25 bits, limb 1 a hair above: what fe_mul, fe_sq and fe_carry return) is < 2^256 as an
+// integer: eight 32-bit words.  Limb offsets: 0 26 51 77 102 128 153 179 204 230.  Unpacking slices the integer again: limbs 0..8 within
+// their widths, limb 9 <= 2^25 (the integer is < 2^255 + 2^40), i.e. class 1.
+EG_HD void fe_pack8(u32 w[8], const fe& f) {
+  EG_REQUIRE(EG_GETCLS(f) <= 1.02f, "fe_pack8: operand must be class 1");
+  fe_check_values(f);
+  u64 acc = (u64)f.v[0] + ((u64)f.v[1] << 26);
+  w[0] = (u32)acc; acc >>= 32;
+  acc += (u64)f.v[2] << 19; w[1] = (u32)acc; acc >>= 32;
+  acc += (u64)f.v[3] << 13; w[2] = (u32)acc; acc >>= 32;
+  acc += (u64)f.v[4] << 6;  w[3] = (u32)acc; acc >>= 32;
+  acc += (u64)f.v[5] + ((u64)f.v[6] << 25); w[4] = (u32)acc; acc >>= 32;
+  acc += (u64)f.v[7] << 19; w[5] = (u32)acc; acc >>= 32;
+  acc += (u64)f.v[8] << 12; w[6] = (u32)acc; acc >>= 32;
+  acc += (u64)f.v[9] << 6;  w[7] = (u32)acc;
+  EG_REQUIRE((acc >> 32) == 0, "fe_pack8: value does not fit 256 bits");
+}
+EG_HD u32 eg_funnel(u32 hi, u32 lo, int s) { return (hi << (32 - s)) | (lo >> s); }      // v_alignbit_b32
+EG_HD void fe_unpack8(fe& f, const u32 w[8]) {
+  f.v[0] = w[0] & 0x3ffffffu;
+  f.v[1] = eg_funnel(w[1], w[0], 26) & 0x1ffffffu;
+  f.v[2] = eg_funnel(w[2], w[1], 19) & 0x3ffffffu;
+  f.v[3] = eg_funnel(w[3], w[2], 13) & 0x1ffffffu;
+  f.v[4] = w[3] >> 6;
+  f.v[5] = w[4] & 0x1ffffffu;
+  f.v[6] = eg_funnel(w[5], w[4], 25) & 0x3ffffffu;
+  f.v[7] = eg_funnel(w[6], w[5], 19) & 0x1ffffffu;
+  f.v[8] = eg_funnel(w[7], w[6], 12) & 0x3ffffffu;
+  f.v[9] = w[7] >> 6;
+  EG_SETCLS(f, 1.0f);
+  fe_check_values(f);
+}
+
 // ---- constants (values checked against the oracle / SURVEY Appendix E in tests) --------------------
 #ifdef EG_BOUNDCHECK
 #define EG_FE_CONST(...) {{__VA_ARGS__}, 1.0f}

@@ -16,10 +16,17 @@ struct ArrTable {
   void store(int i, const ge_cached& c) { e[i] = c; }
   void load(ge_cached& c, int i) const { c = e[i]; }
 };
+// the comb table of a base, stored the way the device stores it (device_io.cuh BaseTable): packed, 4 x 256 bits per entry
 struct ArrBase {
-  ge_cached e[32];
-  void store(int i, const ge_cached& c) { e[i] = c; }
-  void load(ge_cached& c, int i) const { c = e[i]; }
+  u32 w[32][32];
+  void store(int i, const ge_cached& c) {
+    fe a = c.YpX, b = c.YmX, z = c.Z2;
+    fe_carry(a); fe_carry(b); fe_carry(z);
+    fe_pack8(w[i], a); fe_pack8(w[i] + 8, b); fe_pack8(w[i] + 16, z); fe_pack8(w[i] + 24, c.T2d);
+  }
+  void load(ge_cached& c, int i) const {
+    fe_unpack8(c.YpX, w[i]); fe_unpack8(c.YmX, w[i] + 8); fe_unpack8(c.Z2, w[i] + 16); fe_unpack8(c.T2d, w[i] + 24);
+  }
 };
 // fixed-base comb table with entries computed on demand (the product's table has millions of entries; a comb touches one per window)
 struct ArrNiels {
@@ -145,7 +152,8 @@ int hc_sum_table_mul(int n, const uint8_t* ps, const uint8_t k[32], const uint8_
   ge_teeth_tables_build(ref_tab, tmp2, total);
   int same = 1;
   for (int g = 0; g < EG_TEETH_ENTRIES; ++g) {
-    ge a, b; ge_cached_to_p3(a, sum_tab.e[g]); ge_cached_to_p3(b, ref_tab.e[g]);
+    ge_cached ea, eb; sum_tab.load(ea, g); ref_tab.load(eb, g);
+    ge a, b; ge_cached_to_p3(a, ea); ge_cached_to_p3(b, eb);
     fe az, bz, l, rr;
     az = a.Z; fe_carry(az); bz = b.Z; fe_carry(bz);
     fe_mul(l, a.X, bz); fe_mul(rr, b.X, az); if (!fe_eq(l, rr)) same = 0;
@@ -307,6 +315,16 @@ void hc_mul_generator_bits(int bits, const uint8_t r[32], uint8_t out[32]) {
   bytes_from_words(out, o, 8);
 }
 
+// pack / unpack of a field element given as 10 raw limbs (any class-1 representation, not only the canonical one): returns 1 when
+// the unpacked element equals the input as a field element; out = its canonical bytes
+int hc_fe_pack_roundtrip(const uint32_t limbs[10], uint8_t out[32]) {
+  fe f; for (int i = 0; i < 10; ++i) f.v[i] = limbs[i];
+  EG_SETCLS(f, 1.0f);
+  u32 w[8], o[8]; fe_pack8(w, f);
+  fe g; fe_unpack8(g, w);
+  fe_to_words(o, g); bytes_from_words(out, o, 8);
+  return fe_eq(f, g) ? 1 : 0;
+}
 void hc_fe_roundtrip(const uint8_t in[32], uint8_t out[32]) {
   u32 w[8], o[8]; words_from_bytes(w, in, 8); fe f; fe_from_words(f, w); fe_to_words(o, f); bytes_from_words(out, o, 8);
 }

@@ -51,6 +51,22 @@ def test_field_ops(hc):
             assert r[4] == (a - b) % P
 
 
+def test_packed_field_elements(hc):
+    """fe_pack8 / fe_unpack8 (the 128-byte table entries): any class-1 limb vector - limbs at their maxima, limb 1 a hair above, values
+    just below and above p and 2^255 - comes back as the same field element, with every limb inside its bounds (asserted in the build)."""
+    rnd = random.Random(12)
+    top = [(1 << 26) - 1 if i % 2 == 0 else (1 << 25) - 1 for i in range(10)]
+    cases = [[0] * 10, top, [top[0], (1 << 25) + 12000] + top[2:], [1] + [0] * 9, [0] * 9 + [(1 << 25) - 1], [(1 << 26) - 19] + top[1:]]
+    for _ in range(300):
+        cases.append([rnd.randrange(1 << 26) if i % 2 == 0 else rnd.randrange(1 << 25) for i in range(10)])
+    offs = [0, 26, 51, 77, 102, 128, 153, 179, 204, 230]
+    for limbs in cases:
+        out = _b()
+        arr = (C.c_uint32 * 10)(*limbs)
+        assert hc.hc_fe_pack_roundtrip(arr, out) == 1, limbs
+        assert int.from_bytes(out.raw, "little") == sum(l << o for l, o in zip(limbs, offs)) % P
+
+
 def test_scalar_ops(hc):
     rnd = random.Random(2)
     for _ in range(300):
