@@ -31,7 +31,7 @@ struct EngineBufs {
   uint4* ws;            // per-lane variable-base tables (direct multiplications)
   uint4* dpt;           // deferred commitments P with out = encode(2P)   [cmp slot][10][cap]
   u32* encw;            // k_encode_batch scratch: prefix products and N   [2 * slot][10][cap]
-  uint4* btab;          // comb tables of the ring bases [base][cap] x 320 uint4 (32 cached entries, 5 KiB)
+  uint4* btab;          // comb tables of the ring bases [base][cap] x BTAB_QUADS uint4 (32 packed entries of 128 B: 4 KiB)
 };
 #if defined(EG_AB_ONE_LINE)   // measurement-only build: entries at a 256-B stride, lookups read ONE 128-B line (results are wrong)
 constexpr int BTAB_ENTRY_QUADS = 16;

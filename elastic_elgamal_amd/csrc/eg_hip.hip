@@ -361,9 +361,9 @@ static int engine_create(eg_ctx* ctx, eghost::Plan&& plan, const uint8_t pk[32],
   const char* env = getenv("EG_CHUNK");
   e->max_cap = env ? (u32)strtoul(env, nullptr, 10) : 1048576u;
   {
-    // Chunks are large (default 2^20 ballots: ~61 GB of workspace for 5 options): a chunk of 250k ballots is ~20 rounds of the
+    // Chunks are large (default 2^20 ballots: ~50 GB of workspace for 5 options): a chunk of 250k ballots is ~20 rounds of the
     // resident blocks per kernel and wastes most of its last round (measured 4.53 M ballots/s at 2^18 per chunk, 4.83 M/s at 2^20).  Large elections keep the
-    // workspace within half of the free device memory (~58 KB per ballot for 5 options, ~5.5 KB more per ring base).
+    // workspace within half of the free device memory (~48 KB per ballot for 5 options, ~4.5 KB more per ring base).
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
     const size_t limit = engine_bytes_per_ballot(e.get()) ? free_b / 2 / engine_bytes_per_ballot(e.get()) : e->max_cap;

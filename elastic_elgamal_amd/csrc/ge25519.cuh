@@ -414,7 +414,7 @@ EG_HD void ge_var_mul(ge& acc, TableIO& io, const u32 digits[8]) {
 // multiplier k < 2^258 is written with 258 signed bits s_i = +-1 (k = sum s_i 2^i: s_i = 2 bit_(i+1)(k) - 1, s_257 = +1).
 // Column c = (s_c, s_(43+c), .., s_(215+c)) selects +-entry, so [k]P = sum_c 2^c D_c costs 42 doublings + 43 additions
 // (every digit is non-zero: no identity select) instead of 252 + 64 for a fresh ladder; the table costs 215 doublings +
-// 37 additions (Gray-code walk, each step adds +-2 P_j), 32 cached entries = 5 KiB per base and ballot.  (Round 1 first
+// 37 additions (Gray-code walk, each step adds +-2 P_j), 32 cached entries = 4 KiB per base and ballot (packed, device_io.cuh).  (Round 1 first
 // used four radix-16 tables of P, 2^64 P, 2^128 P, 2^192 P: 192 + 28 for the tables but 60 + 64 per product; the comb
 // measured +10 % on 2-equation rings and +23 % on the QV ballot.)  Even multipliers use k + l, which changes the
 // product by the 4-torsion point [l]P only - invisible to the Ristretto encoding, like the halving in sc_halve.
