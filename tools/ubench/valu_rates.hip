@@ -1,131 +1,199 @@
-// Microbenchmark: per-instruction VALU issue rates on gfx950 that decide the field-arithmetic
-// representation (32-bit limb MADs vs 24-bit vs fp64). Not part of the product; measurement tool.
-// Build: hipcc --offload-arch=gfx950 -O3 -o valu_rates valu_rates.hip
+// Microbenchmark (measurement tool, not product): VALU issue cost per wave64 instruction on gfx950, the denominator of the VALU
+// roofline (bench.py MAD_PEAK_T).
+// Round 3 rewrite ("What's weak" 2): the first version ran 0.1-0.3 ms kernels, 8 chains, and converted time to cycles at a
+// NOMINAL 2.4 GHz; it read v_fma_f32 at 3.7 cycles where the architecture does 2.  This one
+//   * runs >= 20 ms per kernel, 16 independent chains per lane (no dependency stalls at any tested occupancy),
+//   * takes cycles from s_memtime inside the kernel (shader clock: immune to DVFS) and reports the clock the chip held
+//     (s_memtime / s_memrealtime x 100 MHz),
+//   * times every instruction in two operand shapes: all sources in VGPRs ("vvv") and one source an SGPR / inline constant ("vvs"),
+//     because a three-VGPR-source VOP3 can cost a second operand-read cycle.
+// cycles per wave-instruction per SIMD = median wave cycles / (instructions per wave x waves per SIMD).
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/ubench/valu_rates tools/ubench/valu_rates.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstdint>
 #include <vector>
-#include <string>
-
+#include <algorithm>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
+typedef unsigned long long u64;
+struct Stamp { u64 cyc, rt; };
+constexpr int CHAINS = 16;
+constexpr int UNROLL = 4;
 
-constexpr int ITERS = 2048;
-constexpr int CHAINS = 8;   // independent dependency chains per lane
-constexpr int UNROLL = 4;   // instrs per chain per loop iteration
+#define PROLOGUE                                                                                   \
+  const u64 c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#define EPILOGUE                                                                                   \
+  const u64 c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();              \
+  if ((threadIdx.x & 63) == 0) { Stamp s; s.cyc = c1 - c0; s.rt = r1 - r0; st[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = s; }
 
-// 32-bit in/out instruction:  d = op(d, a, b)
-#define KERNEL32(NAME, ASM)                                                                 \
-__global__ void __launch_bounds__(256) k_##NAME(uint32_t* out, uint32_t a0, uint32_t b0) {     \
-  uint32_t r[CHAINS];                                                                        \
-  uint32_t a = a0 + threadIdx.x, b = b0 ^ threadIdx.x;                                       \
-  for (int c = 0; c < CHAINS; ++c) r[c] = a * (c + 1) + b;                                    \
-  for (int it = 0; it < ITERS; ++it) {                                                       \
-    _Pragma("unroll") for (int u = 0; u < UNROLL; ++u) {                                     \
-      _Pragma("unroll") for (int c = 0; c < CHAINS; ++c) {                                   \
-        asm volatile(ASM : "+v"(r[c]) : "v"(a), "v"(b));                                      \
-      }                                                                                      \
-    }                                                                                        \
-  }                                                                                          \
-  uint32_t s = 0;                                                                            \
-  for (int c = 0; c < CHAINS; ++c) s ^= r[c];                                                \
-  out[blockIdx.x * blockDim.x + threadIdx.x] = s;                                            \
+// One asm statement carries all 16 chains (hipcc puts an s_nop after EVERY inline-asm statement, 4 issue cycles each: with one
+// instruction per statement the first version of this rewrite measured the s_nops, not the instructions).
+#define R16(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
+#define OUT16(r) "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]), \
+                 "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15])
+// operands: %0..%15 chains, %16 = a (VGPR), %17 = b (VGPR), %18 = s (SGPR), %19 = SGPR pair (32-bit kernels) / a64 (VGPR pair, 64-bit kernels)
+#define KERNEL32(NAME, I)                                                                          \
+__global__ void __launch_bounds__(256) k_##NAME(uint32_t* out, Stamp* st, uint32_t a0, uint32_t b0, int iters) { \
+  uint32_t r[CHAINS];                                                                              \
+  uint32_t a = a0 + threadIdx.x, b = b0 ^ threadIdx.x; const uint32_t s = a0 | 3u;                 \
+  const u64 m64 = 0x5555aaaa3333ccccull * (u64)(a0 | 1u);                                          \
+  for (int c = 0; c < CHAINS; ++c) r[c] = a * (c + 1) + b;                                         \
+  PROLOGUE                                                                                         \
+  for (int it = 0; it < iters; ++it) {                                                             \
+    _Pragma("unroll") for (int u = 0; u < UNROLL; ++u) {                                           \
+      asm volatile(R16(I) : OUT16(r) : "v"(a), "v"(b), "s"(s), "s"(m64) : "vcc");                  \
+    }                                                                                              \
+  }                                                                                                \
+  EPILOGUE                                                                                         \
+  uint32_t x = 0;                                                                                  \
+  for (int c = 0; c < CHAINS; ++c) x ^= r[c];                                                      \
+  out[blockIdx.x * blockDim.x + threadIdx.x] = x;                                                  \
 }
+#define I_add_u32(n)      "v_add_u32 %" #n ", %" #n ", %16\n\t"
+#define I_and_b32(n)      "v_and_b32 %" #n ", %" #n ", %16\n\t"
+#define I_lshrrev_b32(n)  "v_lshrrev_b32 %" #n ", 3, %" #n "\n\t"
+#define I_fmac_f32(n)     "v_fmac_f32 %" #n ", %16, %17\n\t"
+#define I_fma_vvv(n)      "v_fma_f32 %" #n ", %" #n ", %16, %17\n\t"
+#define I_fma_vvs(n)      "v_fma_f32 %" #n ", %" #n ", %16, %18\n\t"
+#define I_add3_vvv(n)     "v_add3_u32 %" #n ", %" #n ", %16, %17\n\t"
+#define I_add3_vvs(n)     "v_add3_u32 %" #n ", %" #n ", %16, %18\n\t"
+#define I_mul_lo(n)       "v_mul_lo_u32 %" #n ", %" #n ", %16\n\t"
+#define I_mul_lo_k(n)     "v_mul_lo_u32 %" #n ", %" #n ", 19\n\t"
+#define I_mul_hi(n)       "v_mul_hi_u32 %" #n ", %" #n ", %16\n\t"
+#define I_mad24_vvv(n)    "v_mad_u32_u24 %" #n ", %" #n ", %16, %17\n\t"
+#define I_mad24_vkv(n)    "v_mad_u32_u24 %" #n ", %" #n ", 19, %16\n\t"
+#define I_mul24(n)        "v_mul_u32_u24 %" #n ", %" #n ", %16\n\t"
+#define I_alignbit(n)     "v_alignbit_b32 %" #n ", %" #n ", %16, 13\n\t"
+#define I_lshl_add(n)     "v_lshl_add_u32 %" #n ", %" #n ", 4, %16\n\t"
+#define I_and_or(n)       "v_and_or_b32 %" #n ", %" #n ", %16, %17\n\t"
+#define I_bfe(n)          "v_bfe_u32 %" #n ", %" #n ", 3, 26\n\t"
+#define I_cndmask(n)      "v_cndmask_b32 %" #n ", %" #n ", %16, vcc\n\t"
+#define I_addc_pair(n)    "v_add_co_u32 %" #n ", vcc, %" #n ", %16\n\tv_addc_co_u32 %" #n ", vcc, %" #n ", %17, vcc\n\t"
+KERNEL32(add_u32, I_add_u32)
+KERNEL32(and_b32, I_and_b32)
+KERNEL32(lshrrev_b32, I_lshrrev_b32)
+KERNEL32(fmac_f32, I_fmac_f32)
+KERNEL32(fma_f32_vvv, I_fma_vvv)
+KERNEL32(fma_f32_vvs, I_fma_vvs)
+KERNEL32(add3_u32_vvv, I_add3_vvv)
+KERNEL32(add3_u32_vvs, I_add3_vvs)
+KERNEL32(mul_lo_u32, I_mul_lo)
+KERNEL32(mul_lo_u32_k, I_mul_lo_k)
+KERNEL32(mul_hi_u32, I_mul_hi)
+KERNEL32(mad_u32_u24_vvv, I_mad24_vvv)
+KERNEL32(mad_u32_u24_vks, I_mad24_vkv)
+KERNEL32(mul_u32_u24, I_mul24)
+KERNEL32(alignbit_vvk, I_alignbit)
+KERNEL32(lshl_add_u32, I_lshl_add)
+KERNEL32(and_or_vvv, I_and_or)
+KERNEL32(bfe_u32, I_bfe)
+KERNEL32(cndmask, I_cndmask)
+#define I_cndmask_e64(n)  "v_cndmask_b32_e64 %" #n ", %" #n ", %16, %19\n\t"
+#define I_bfi(n)          "v_bfi_b32 %" #n ", %17, %16, %" #n "\n\t"
+#define I_xor(n)          "v_xor_b32 %" #n ", %" #n ", %16\n\t"
+#define I_sub(n)          "v_sub_u32 %" #n ", %" #n ", %16\n\t"
+#define I_lshlrev(n)      "v_lshlrev_b32 %" #n ", 1, %" #n "\n\t"
+#define I_mov(n)          "v_mov_b32 %" #n ", %16\n\t"
+KERNEL32(cndmask_e64, I_cndmask_e64)
+KERNEL32(bfi, I_bfi)
+KERNEL32(xor_b32, I_xor)
+KERNEL32(sub_u32, I_sub)
+KERNEL32(lshlrev_b32, I_lshlrev)
+KERNEL32(mov_b32, I_mov)
+KERNEL32(addc_pair, I_addc_pair)
 
-KERNEL32(add_u32,        "v_add_u32 %0, %0, %1")
-KERNEL32(add3_u32,       "v_add3_u32 %0, %0, %1, %2")
-KERNEL32(fma_f32,        "v_fma_f32 %0, %0, %1, %2")
-KERNEL32(mul_lo_u32,     "v_mul_lo_u32 %0, %0, %1")
-KERNEL32(mul_hi_u32,     "v_mul_hi_u32 %0, %0, %1")
-KERNEL32(mad_u32_u24,    "v_mad_u32_u24 %0, %0, %1, %2")
-KERNEL32(mul_u32_u24,    "v_mul_u32_u24 %0, %0, %1")
-KERNEL32(mul_hi_u32_u24, "v_mul_hi_u32_u24 %0, %0, %1")
-KERNEL32(mad_u32_u16,    "v_mad_u32_u16 %0, %0, %1, %2")
-KERNEL32(pk_mul_lo_u16,  "v_pk_mul_lo_u16 %0, %0, %1")
-KERNEL32(pk_mad_u16,     "v_pk_mad_u16 %0, %0, %1, %2")
-KERNEL32(dot4_u32_u8,    "v_dot4_u32_u8 %0, %0, %1, %2")
-KERNEL32(dot2_u32_u16,   "v_dot2_u32_u16 %0, %0, %1, %2")
-KERNEL32(alignbit,       "v_alignbit_b32 %0, %0, %1, 13")
-KERNEL32(and_or,         "v_and_or_b32 %0, %0, %1, %2")
-KERNEL32(lshl_add,       "v_lshl_add_u32 %0, %0, 3, %1")
-KERNEL32(addc_pair,      "v_add_co_u32 %0, vcc, %0, %1\n\tv_addc_co_u32 %0, vcc, %0, %2, vcc")
-
-// 64-bit accumulate:  d(64) = op(a32, b32, d64)
-#define KERNEL64(NAME, ASM)                                                                 \
-__global__ void __launch_bounds__(256) k_##NAME(uint32_t* out, uint32_t a0, uint32_t b0) {     \
-  unsigned long long r[CHAINS];                                                              \
-  uint32_t a = a0 + threadIdx.x, b = b0 ^ threadIdx.x;                                       \
-  unsigned long long a64 = ((unsigned long long)a << 32) | b;                                \
-  for (int c = 0; c < CHAINS; ++c) r[c] = a64 * (c + 1);                                      \
-  for (int it = 0; it < ITERS; ++it) {                                                       \
-    _Pragma("unroll") for (int u = 0; u < UNROLL; ++u) {                                     \
-      _Pragma("unroll") for (int c = 0; c < CHAINS; ++c) {                                   \
-        asm volatile(ASM : "+v"(r[c]) : "v"(a), "v"(b), "v"(a64) : "vcc");                    \
-      }                                                                                      \
-    }                                                                                        \
-  }                                                                                          \
-  unsigned long long s = 0;                                                                  \
-  for (int c = 0; c < CHAINS; ++c) s ^= r[c];                                                \
-  out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(s ^ (s >> 32));                    \
+#define KERNEL64(NAME, I)                                                                          \
+__global__ void __launch_bounds__(256) k_##NAME(uint32_t* out, Stamp* st, uint32_t a0, uint32_t b0, int iters) { \
+  u64 r[CHAINS];                                                                                   \
+  uint32_t a = a0 + threadIdx.x, b = b0 ^ threadIdx.x; const uint32_t s = a0 | 3u;                 \
+  u64 a64 = ((u64)a << 32) | b;                                                                    \
+  for (int c = 0; c < CHAINS; ++c) r[c] = a64 * (c + 1);                                           \
+  PROLOGUE                                                                                         \
+  for (int it = 0; it < iters; ++it) {                                                             \
+    _Pragma("unroll") for (int u = 0; u < UNROLL; ++u) {                                           \
+      asm volatile(R16(I) : OUT16(r) : "v"(a), "v"(b), "s"(s), "v"(a64) : "vcc");                  \
+    }                                                                                              \
+  }                                                                                                \
+  EPILOGUE                                                                                         \
+  u64 x = 0;                                                                                       \
+  for (int c = 0; c < CHAINS; ++c) x ^= r[c];                                                      \
+  out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(x ^ (x >> 32));                          \
 }
+#define I_mad64_vvv(n)    "v_mad_u64_u32 %" #n ", vcc, %16, %17, %" #n "\n\t"
+#define I_mad64_vsv(n)    "v_mad_u64_u32 %" #n ", vcc, %16, %18, %" #n "\n\t"
+#define I_mad64_vkv(n)    "v_mad_u64_u32 %" #n ", vcc, %16, 19, %" #n "\n\t"
+#define I_fma_f64(n)      "v_fma_f64 %" #n ", %" #n ", %19, %19\n\t"
+#define I_lshl_add_u64(n) "v_lshl_add_u64 %" #n ", %" #n ", 0, %19\n\t"
+#define I_lshrrev_b64(n)  "v_lshrrev_b64 %" #n ", 26, %" #n "\n\t"
+#define I_pk_fma_f32(n)   "v_pk_fma_f32 %" #n ", %" #n ", %19, %19\n\t"
+// the mix of a field multiplication's inner code: 5 MADs, a 64-bit shift and a 64-bit add per chain
+#define I_mix(n)          "v_mad_u64_u32 %" #n ", vcc, %16, %17, %" #n "\n\tv_mad_u64_u32 %" #n ", vcc, %17, %16, %" #n "\n\t" \
+                          "v_mad_u64_u32 %" #n ", vcc, %16, %17, %" #n "\n\tv_mad_u64_u32 %" #n ", vcc, %17, %16, %" #n "\n\t" \
+                          "v_mad_u64_u32 %" #n ", vcc, %16, %17, %" #n "\n\tv_lshrrev_b64 %" #n ", 1, %" #n "\n\t"            \
+                          "v_lshl_add_u64 %" #n ", %" #n ", 0, %19\n\t"
+KERNEL64(mad_u64_u32_vvv, I_mad64_vvv)
+KERNEL64(mad_u64_u32_vsv, I_mad64_vsv)
+KERNEL64(mad_u64_u32_vkv, I_mad64_vkv)
+KERNEL64(fma_f64, I_fma_f64)
+KERNEL64(lshl_add_u64, I_lshl_add_u64)
+KERNEL64(lshrrev_b64, I_lshrrev_b64)
+KERNEL64(pk_fma_f32, I_pk_fma_f32)
+KERNEL64(mix_fmul, I_mix)
 
-KERNEL64(mad_u64_u32,  "v_mad_u64_u32 %0, vcc, %1, %2, %0")
-KERNEL64(mad_i64_i32,  "v_mad_i64_i32 %0, vcc, %1, %2, %0")
-KERNEL64(fma_f64,      "v_fma_f64 %0, %0, %3, %3")
-KERNEL64(add_f64,      "v_add_f64 %0, %0, %3")
-KERNEL64(mul_f64,      "v_mul_f64 %0, %0, %3")
-KERNEL64(lshl_add_u64, "v_lshl_add_u64 %0, %0, 0, %3")
-KERNEL64(lshlrev_b64,  "v_lshlrev_b64 %0, 1, %0")
-KERNEL64(pk_fma_f32,   "v_pk_fma_f32 %0, %0, %3, %3")
-KERNEL64(pk_mul_f32,   "v_pk_mul_f32 %0, %0, %3")
-KERNEL64(pk_add_f32,   "v_pk_add_f32 %0, %0, %3")
-
-typedef void (*kern_t)(uint32_t*, uint32_t, uint32_t);
+typedef void (*kern_t)(uint32_t*, Stamp*, uint32_t, uint32_t, int);
 struct Entry { const char* name; kern_t k; int instr_per_step; };
 
 int main(int argc, char** argv) {
-  int dev = 0; CK(hipSetDevice(dev));
-  hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, dev));
-  int cus = prop.multiProcessorCount;
-  printf("device %s CUs %d clock %d kHz\n", prop.name, cus, prop.clockRate);
+  CK(hipSetDevice(0));
+  hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+  const int cus = prop.multiProcessorCount;
+  const double target_ms = argc > 1 ? atof(argv[1]) : 25.0;
+  printf("device %s, %d CUs; >= %.0f ms per kernel, %d chains per lane; cycles from s_memtime, clock from s_memrealtime\n",
+         prop.name, cus, target_ms, CHAINS);
   std::vector<Entry> es = {
-    {"v_add_u32", k_add_u32, 1}, {"v_add3_u32", k_add3_u32, 1}, {"v_fma_f32", k_fma_f32, 1},
-    {"v_mul_lo_u32", k_mul_lo_u32, 1}, {"v_mul_hi_u32", k_mul_hi_u32, 1},
-    {"v_mad_u32_u24", k_mad_u32_u24, 1}, {"v_mul_u32_u24", k_mul_u32_u24, 1},
-    {"v_mul_hi_u32_u24", k_mul_hi_u32_u24, 1}, {"v_mad_u32_u16", k_mad_u32_u16, 1},
-    {"v_pk_mul_lo_u16", k_pk_mul_lo_u16, 1}, {"v_pk_mad_u16", k_pk_mad_u16, 1},
-    {"v_dot4_u32_u8", k_dot4_u32_u8, 1}, {"v_dot2_u32_u16", k_dot2_u32_u16, 1},
-    {"v_alignbit_b32", k_alignbit, 1}, {"v_and_or_b32", k_and_or, 1}, {"v_lshl_add_u32", k_lshl_add, 1},
-    {"add_co+addc_co", k_addc_pair, 2},
-    {"v_mad_u64_u32", k_mad_u64_u32, 1}, {"v_mad_i64_i32", k_mad_i64_i32, 1},
-    {"v_fma_f64", k_fma_f64, 1}, {"v_add_f64", k_add_f64, 1}, {"v_mul_f64", k_mul_f64, 1},
-    {"v_lshl_add_u64", k_lshl_add_u64, 1}, {"v_lshlrev_b64", k_lshlrev_b64, 1},
-    {"v_pk_fma_f32", k_pk_fma_f32, 1}, {"v_pk_mul_f32", k_pk_mul_f32, 1}, {"v_pk_add_f32", k_pk_add_f32, 1},
+    {"v_add_u32 (VOP2)", k_add_u32, 1}, {"v_and_b32 (VOP2)", k_and_b32, 1}, {"v_lshrrev_b32 (VOP2)", k_lshrrev_b32, 1},
+    {"v_fmac_f32 (VOP2)", k_fmac_f32, 1}, {"v_fma_f32 v,v,v", k_fma_f32_vvv, 1}, {"v_fma_f32 v,v,s", k_fma_f32_vvs, 1},
+    {"v_add3_u32 v,v,v", k_add3_u32_vvv, 1}, {"v_add3_u32 v,v,s", k_add3_u32_vvs, 1},
+    {"v_mul_lo_u32 v,v", k_mul_lo_u32, 1}, {"v_mul_lo_u32 v,19", k_mul_lo_u32_k, 1}, {"v_mul_hi_u32", k_mul_hi_u32, 1},
+    {"v_mad_u32_u24 v,v,v", k_mad_u32_u24_vvv, 1}, {"v_mad_u32_u24 v,19,v", k_mad_u32_u24_vks, 1}, {"v_mul_u32_u24 (VOP2)", k_mul_u32_u24, 1},
+    {"v_alignbit_b32 v,v,13", k_alignbit_vvk, 1}, {"v_lshl_add_u32 v,4,v", k_lshl_add_u32, 1}, {"v_and_or_b32 v,v,v", k_and_or_vvv, 1},
+    {"v_bfe_u32 v,3,26", k_bfe_u32, 1}, {"v_cndmask_b32 vcc (VOP2)", k_cndmask, 1},
+    {"v_cndmask_b32_e64 v,v,s[2]", k_cndmask_e64, 1}, {"v_bfi_b32 v,v,v", k_bfi, 1}, {"v_xor_b32 (VOP2)", k_xor_b32, 1}, {"v_sub_u32 (VOP2)", k_sub_u32, 1},
+    {"v_lshlrev_b32 (VOP2)", k_lshlrev_b32, 1}, {"v_mov_b32 (VOP1)", k_mov_b32, 1}, {"v_add_co + v_addc_co", k_addc_pair, 2},
+    {"v_mad_u64_u32 v,v,v64", k_mad_u64_u32_vvv, 1}, {"v_mad_u64_u32 v,s,v64", k_mad_u64_u32_vsv, 1}, {"v_mad_u64_u32 v,19,v64", k_mad_u64_u32_vkv, 1},
+    {"v_fma_f64", k_fma_f64, 1}, {"v_lshl_add_u64", k_lshl_add_u64, 1}, {"v_lshrrev_b64", k_lshrrev_b64, 1}, {"v_pk_fma_f32", k_pk_fma_f32, 1},
+    {"fmul mix (5 mad, 2 x64)", k_mix_fmul, 7},
   };
-  int waves_per_simd_list[] = {1, 2, 4, 8};
-  uint32_t* out; CK(hipMalloc(&out, sizeof(uint32_t) * cus * 8 * 256 * 4));
+  uint32_t* out; Stamp* d_st;
+  CK(hipMalloc(&out, sizeof(uint32_t) * cus * 8 * 256));
+  CK(hipMalloc(&d_st, sizeof(Stamp) * cus * 8 * 4));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  printf("%-18s", "instr");
-  for (int w : waves_per_simd_list) printf("  w/simd=%d: Glane-op/s  cyc/wave-instr", w);
+  printf("%-30s", "instruction");
+  const int wlist[] = {1, 2, 4, 8};
+  for (int w : wlist) printf(" | w/SIMD=%d cyc/instr  GHz   ms", w);
   printf("\n");
   for (auto& e : es) {
-    printf("%-18s", e.name);
-    for (int w : waves_per_simd_list) {
-      // 256 threads = 4 waves = 1 wave per SIMD per block; w blocks per CU
-      int blocks = cus * w;
-      hipLaunchKernelGGL(e.k, dim3(blocks), dim3(256), 0, 0, out, 12345u, 6789u);
+    printf("%-30s", e.name);
+    for (int w : wlist) {
+      const int blocks = cus * w;          // 256 threads = one wave per SIMD; w blocks per CU
+      // size the loop for the target time assuming ~4 cycles per instruction at 2 GHz
+      const double per_iter = (double)UNROLL * CHAINS * e.instr_per_step * w * 4.0 / 2.0e9;
+      const int iters = (int)(target_ms * 1e-3 / per_iter) + 1;
+      hipLaunchKernelGGL(e.k, dim3(blocks), dim3(256), 0, 0, out, d_st, 12345u, 6789u, iters / 16 + 1);
       CK(hipDeviceSynchronize());
       CK(hipEventRecord(e0));
-      const int reps = 3;
-      for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(e.k, dim3(blocks), dim3(256), 0, 0, out, 12345u, 6789u);
+      hipLaunchKernelGGL(e.k, dim3(blocks), dim3(256), 0, 0, out, d_st, 12345u, 6789u, iters);
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
-      float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
-      double wave_instr_per_simd = (double)ITERS * UNROLL * CHAINS * e.instr_per_step * w;
-      double lane_ops = wave_instr_per_simd * 64.0 * cus * 4;
-      double glops = lane_ops / (ms * 1e-3) / 1e9;
-      // cycles per wave-instruction per SIMD at nominal 2.4 GHz
-      double cyc = (ms * 1e-3) * 2.4e9 / wave_instr_per_simd;
-      printf("  %10.1f %8.2f        ", glops, cyc);
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      const int waves = blocks * 4;
+      std::vector<Stamp> st(waves);
+      CK(hipMemcpy(st.data(), d_st, sizeof(Stamp) * waves, hipMemcpyDeviceToHost));
+      std::vector<double> cyc(waves), ghz(waves);
+      for (int i = 0; i < waves; ++i) { cyc[i] = (double)st[i].cyc; ghz[i] = (double)st[i].cyc / ((double)st[i].rt * 10.0); }
+      std::sort(cyc.begin(), cyc.end()); std::sort(ghz.begin(), ghz.end());
+      const double n_instr = (double)iters * UNROLL * CHAINS * e.instr_per_step;
+      printf(" | %10.2f        %5.2f %6.1f", cyc[waves / 2] / n_instr / w, ghz[waves / 2], ms);
     }
     printf("\n");
   }
