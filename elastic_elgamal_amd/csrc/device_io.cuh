@@ -9,7 +9,10 @@
 namespace eg {
 
 constexpr int NT = 256;               // threads per block everywhere (4 wavefronts, one per SIMD)
-constexpr int WS_QUADS = 8 * 10;      // var-base table: 8 entries x 10 uint4 per lane
+constexpr int PT_WORDS = 4 * EG_NL;   // a point (four field elements) as limbs: 36 words
+constexpr int PT_QUADS = PT_WORDS / 4;   // = 9 uint4: the unit of every SoA point row
+static_assert(PT_WORDS % 4 == 0, "a point must be a whole number of uint4");
+constexpr int WS_QUADS = 8 * PT_QUADS;   // var-base table: 8 entries x 9 uint4 per lane
 
 struct EngineBufs {
   const u32* wire;      // packed ballots of this chunk
@@ -25,52 +28,48 @@ struct EngineBufs {
   u32* status;          // [n] output
   const uint4* tabG;    // fixed-base comb table of the generator (FixedTable: header + [window][entry] x 8 uint4)
   const uint4* tabK;    // fixed-base table of the election key
-  const uint4* cpts;    // election-constant points [idx][10]
+  const uint4* cpts;    // election-constant points [idx][PT_QUADS]
   u32* prefixes;        // hoisted transcript prefixes [idx][52]
   const unsigned char* blob;  // labels and constant messages
   uint4* ws;            // per-lane variable-base tables (direct multiplications)
-  uint4* dpt;           // deferred commitments P with out = encode(2P)   [cmp slot][10][cap]
-  u32* encw;            // k_encode_batch scratch: prefix products and N   [2 * slot][10][cap]
+  uint4* dpt;           // deferred commitments P with out = encode(2P)   [cmp slot][PT_QUADS][cap]
+  u32* encw;            // k_encode_batch scratch: prefix products and N   [2 * slot][EG_NL][cap]
   uint4* btab;          // comb tables of the ring bases [base][cap] x BTAB_QUADS uint4 (32 packed entries of 128 B: 4 KiB)
 };
-#if defined(EG_AB_ONE_LINE)   // measurement-only build: entries at a 256-B stride, lookups read ONE 128-B line (results are wrong)
-constexpr int BTAB_ENTRY_QUADS = 16;
-#elif defined(EG_UNPACKED_ENTRIES)   // A/B: the 160-byte entries of rounds 1-2 (40 limbs in 40 words, two cache lines per lookup)
-constexpr int BTAB_ENTRY_QUADS = 10;
-#else                         // packed entries: 4 field elements x 256 bits = 128 bytes = ONE cache line per lookup
-constexpr int BTAB_ENTRY_QUADS = 8;
-#endif
+constexpr int BTAB_ENTRY_QUADS = 8;   // packed entries: 4 field elements x 256 bits = 128 bytes = ONE cache line per lookup
 constexpr int BTAB_QUADS = 32 * BTAB_ENTRY_QUADS;
 
 // ---- SoA accessors ------------------------------------------------------------------------------------
-__device__ __forceinline__ void words_to_ge(ge& p, const u32 w[40]) {
+__device__ __forceinline__ void words_to_fe4(fe& a, fe& b, fe& c, fe& d, const u32 w[PT_WORDS]) {
 #pragma unroll
-  for (int i = 0; i < 10; ++i) { p.X.v[i] = w[i]; p.Y.v[i] = w[10 + i]; p.Z.v[i] = w[20 + i]; p.T.v[i] = w[30 + i]; }
+  for (int i = 0; i < EG_NL; ++i) { a.v[i] = w[i]; b.v[i] = w[EG_NL + i]; c.v[i] = w[2 * EG_NL + i]; d.v[i] = w[3 * EG_NL + i]; }
 }
-__device__ __forceinline__ void ge_to_words(u32 w[40], const ge& p) {
+__device__ __forceinline__ void fe4_to_words(u32 w[PT_WORDS], const fe& a, const fe& b, const fe& c, const fe& d) {
 #pragma unroll
-  for (int i = 0; i < 10; ++i) { w[i] = p.X.v[i]; w[10 + i] = p.Y.v[i]; w[20 + i] = p.Z.v[i]; w[30 + i] = p.T.v[i]; }
+  for (int i = 0; i < EG_NL; ++i) { w[i] = a.v[i]; w[EG_NL + i] = b.v[i]; w[2 * EG_NL + i] = c.v[i]; w[3 * EG_NL + i] = d.v[i]; }
 }
+__device__ __forceinline__ void words_to_ge(ge& p, const u32 w[PT_WORDS]) { words_to_fe4(p.X, p.Y, p.Z, p.T, w); }
+__device__ __forceinline__ void ge_to_words(u32 w[PT_WORDS], const ge& p) { fe4_to_words(w, p.X, p.Y, p.Z, p.T); }
 __device__ __forceinline__ void load_pt(ge& p, const uint4* pts, u32 cap, u32 slot, u32 b) {
-  u32 w[40];
+  u32 w[PT_WORDS];
 #pragma unroll
-  for (int q = 0; q < 10; ++q) {
-    const uint4 v = pts[((size_t)slot * 10 + q) * cap + b];
+  for (int q = 0; q < PT_QUADS; ++q) {
+    const uint4 v = pts[((size_t)slot * PT_QUADS + q) * cap + b];
     w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
   }
   words_to_ge(p, w);
 }
 __device__ __forceinline__ void store_pt(uint4* pts, u32 cap, u32 slot, u32 b, const ge& p) {
-  u32 w[40];
+  u32 w[PT_WORDS];
   ge_to_words(w, p);
 #pragma unroll
-  for (int q = 0; q < 10; ++q) pts[((size_t)slot * 10 + q) * cap + b] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+  for (int q = 0; q < PT_QUADS; ++q) pts[((size_t)slot * PT_QUADS + q) * cap + b] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
 }
 __device__ __forceinline__ void load_const_pt(ge& p, const uint4* cpts, u32 idx) {
-  u32 w[40];
+  u32 w[PT_WORDS];
 #pragma unroll
-  for (int q = 0; q < 10; ++q) {
-    const uint4 v = cpts[(size_t)idx * 10 + q];
+  for (int q = 0; q < PT_QUADS; ++q) {
+    const uint4 v = cpts[(size_t)idx * PT_QUADS + q];
     w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
   }
   words_to_ge(p, w);
@@ -90,29 +89,27 @@ __device__ __forceinline__ void load_wire_item(u32 w[8], const EngineBufs& B, u3
 }
 
 // ---- table I/O policies --------------------------------------------------------------------------------------
-// per-lane variable-base table {1..8}P in a global workspace (1.25 KiB per lane: too big for registers or LDS)
-// Each lane owns 1280 contiguous bytes (8 entries x 160 B): a lookup touches only the lane's own 2 cache lines.
+// per-lane variable-base table {1..8}P in a global workspace (1.1 KiB per lane: too big for registers or LDS)
+// Each lane owns 1152 contiguous bytes (8 entries x 144 B): a lookup touches only the lane's own 2 cache lines.
 // (The first layout, [entry][quad][lane], fetched ~5x more lines than it used because lanes with different digits
 // shared 128-B lines: profiles/r01_bench_pmc_counters.txt of the first measurement.)
 struct WsTable {
   uint4* base;   // ws + global_lane * 80
   __device__ __forceinline__ void init(uint4* ws) { base = ws + ((size_t)blockIdx.x * NT + threadIdx.x) * WS_QUADS; }
   __device__ __forceinline__ void store(int e, const ge_cached& c) {
-    u32 w[40];
+    u32 w[PT_WORDS];
+    fe4_to_words(w, c.YpX, c.YmX, c.Z2, c.T2d);
 #pragma unroll
-    for (int i = 0; i < 10; ++i) { w[i] = c.YpX.v[i]; w[10 + i] = c.YmX.v[i]; w[20 + i] = c.Z2.v[i]; w[30 + i] = c.T2d.v[i]; }
-#pragma unroll
-    for (int q = 0; q < 10; ++q) base[e * 10 + q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+    for (int q = 0; q < PT_QUADS; ++q) base[e * PT_QUADS + q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
   }
   __device__ __forceinline__ void load(ge_cached& c, int e) const {
-    u32 w[40];
+    u32 w[PT_WORDS];
 #pragma unroll
-    for (int q = 0; q < 10; ++q) {
-      const uint4 v = base[e * 10 + q];
+    for (int q = 0; q < PT_QUADS; ++q) {
+      const uint4 v = base[e * PT_QUADS + q];
       w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
     }
-#pragma unroll
-    for (int i = 0; i < 10; ++i) { c.YpX.v[i] = w[i]; c.YmX.v[i] = w[10 + i]; c.Z2.v[i] = w[20 + i]; c.T2d.v[i] = w[30 + i]; }
+    words_to_fe4(c.YpX, c.YmX, c.Z2, c.T2d, w);
   }
 };
 // The same workspace, word-interleaved across the lanes of the grid ([entry][quad][lane]): for scratch whose entry index is the SAME
@@ -122,32 +119,31 @@ struct WsRows {
   size_t stride;   // lanes of the grid
   __device__ __forceinline__ void init(uint4* ws) { base = ws + ((size_t)blockIdx.x * NT + threadIdx.x); stride = (size_t)gridDim.x * NT; }
   __device__ __forceinline__ void store(int e, const ge_cached& c) {
-    u32 w[40];
+    u32 w[PT_WORDS];
+    fe4_to_words(w, c.YpX, c.YmX, c.Z2, c.T2d);
 #pragma unroll
-    for (int i = 0; i < 10; ++i) { w[i] = c.YpX.v[i]; w[10 + i] = c.YmX.v[i]; w[20 + i] = c.Z2.v[i]; w[30 + i] = c.T2d.v[i]; }
-#pragma unroll
-    for (int q = 0; q < 10; ++q) base[(size_t)(e * 10 + q) * stride] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+    for (int q = 0; q < PT_QUADS; ++q) base[(size_t)(e * PT_QUADS + q) * stride] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
   }
   __device__ __forceinline__ void load(ge_cached& c, int e) const {
-    u32 w[40];
+    u32 w[PT_WORDS];
 #pragma unroll
-    for (int q = 0; q < 10; ++q) {
-      const uint4 v = base[(size_t)(e * 10 + q) * stride];
+    for (int q = 0; q < PT_QUADS; ++q) {
+      const uint4 v = base[(size_t)(e * PT_QUADS + q) * stride];
       w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
     }
-#pragma unroll
-    for (int i = 0; i < 10; ++i) { c.YpX.v[i] = w[i]; c.YmX.v[i] = w[10 + i]; c.Z2.v[i] = w[20 + i]; c.T2d.v[i] = w[30 + i]; }
+    words_to_fe4(c.YpX, c.YmX, c.Z2, c.T2d, w);
   }
 };
 // ---- packed table entries ------------------------------------------------------------------------------------------------------------
-// A field element with limbs in class 1 (every limb within its 26 / 25 bits, limb 1 a hair above) is < 2^256 as an integer: eight
+// A field element with limbs in class 1 (every limb within its 29 / 28 bits, limb 1 a hair above) is < 2^256 as an integer: eight
 // 32-bit words.  Four of them are 128 bytes - ONE cache line per table lookup instead of the two that a 160-byte entry straddles
 // (the lookups' traffic is ~11 % of the equation kernel).  Packing costs a carry sweep and ~15 instructions per
-// element when an entry is stored, unpacking ~16 per element at every lookup (fe_pack8 / fe_unpack8, fe25519.cuh).
+// element when an entry is stored, unpacking ~16 per element at every lookup (fe_pack8 / fe_unpack8, fe25519.cuh).  (The measurement-only
+// layouts of round 2 - unpacked 160-byte entries, one-line and shared-entry bounds - are logged in profiles/r02_ab_experiments.txt
+// and no longer live in this header.)
 // comb table of one (base, ballot): 32 cached entries, contiguous (ge_teeth_tables_build / ge_teeth_mul)
 struct BaseTable {
   uint4* base;
-#if !defined(EG_UNPACKED_ENTRIES) && !defined(EG_AB_ONE_LINE)
   __device__ __forceinline__ void store(int e, const ge_cached& c) {
     fe a = c.YpX, b = c.YmX, z = c.Z2;
     fe_carry(a); fe_carry(b); fe_carry(z);          // stored entries come lazily: classes 2, 3, 2 (T2d is a product: class 1)
@@ -157,9 +153,6 @@ struct BaseTable {
     for (int q = 0; q < 8; ++q) base[e * BTAB_ENTRY_QUADS + q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
   }
   __device__ __forceinline__ void load(ge_cached& c, int e) const {
-#ifdef EG_AB_UNIFORM_ENTRY      // measurement-only (with EG_AB_SHARED_ENTRY): every lane reads the SAME entry: no address divergence at all
-    e = (e >> 8) & 1;
-#endif
     u32 w[32];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -168,40 +161,8 @@ struct BaseTable {
     }
     fe_unpack8(c.YpX, w); fe_unpack8(c.YmX, w + 8); fe_unpack8(c.Z2, w + 16); fe_unpack8(c.T2d, w + 24);
   }
-#else
-  __device__ __forceinline__ void store(int e, const ge_cached& c) {
-    u32 w[40];
-#pragma unroll
-    for (int i = 0; i < 10; ++i) { w[i] = c.YpX.v[i]; w[10 + i] = c.YmX.v[i]; w[20 + i] = c.Z2.v[i]; w[30 + i] = c.T2d.v[i]; }
-#pragma unroll
-    for (int q = 0; q < 10; ++q) base[e * BTAB_ENTRY_QUADS + q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
-  }
-  __device__ __forceinline__ void load(ge_cached& c, int e) const {
-    u32 w[40];
-#ifdef EG_AB_UNIFORM_ENTRY
-    e = (e >> 8) & 1;
-#endif
-#ifdef EG_AB_ONE_LINE
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const uint4 v = base[e * BTAB_ENTRY_QUADS + q];
-      w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
-    }
-#pragma unroll
-    for (int i = 32; i < 40; ++i) w[i] = w[i - 32];
-#else
-#pragma unroll
-    for (int q = 0; q < 10; ++q) {
-      const uint4 v = base[e * BTAB_ENTRY_QUADS + q];
-      w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
-    }
-#endif
-#pragma unroll
-    for (int i = 0; i < 10; ++i) { c.YpX.v[i] = w[i]; c.YmX.v[i] = w[10 + i]; c.Z2.v[i] = w[20 + i]; c.T2d.v[i] = w[30 + i]; }
-  }
-#endif
 };
-// fixed-base comb table shared by every lane: entry = 8 uint4 (30 limbs used).  The uint4 in front of the first entry is the
+// fixed-base comb table shared by every lane: entry = 8 uint4 (3 x EG_NL = 27 limbs used).  The uint4 in front of the first entry is the
 // table's header {window bits, windows, entries per window, 0} (k_build_fixed_table), so a table pointer says how it is cut.
 struct FixedTable {
   const uint4* tab;
@@ -215,7 +176,7 @@ struct FixedTable {
       w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
     }
 #pragma unroll
-    for (int i = 0; i < 10; ++i) { c.ypx.v[i] = w[i]; c.ymx.v[i] = w[10 + i]; c.xy2d.v[i] = w[20 + i]; }
+    for (int i = 0; i < EG_NL; ++i) { c.ypx.v[i] = w[i]; c.ymx.v[i] = w[EG_NL + i]; c.xy2d.v[i] = w[2 * EG_NL + i]; }
   }
 };
 // transcript state: word-interleaved LDS column per lane (positions are wave-uniform => conflict free)

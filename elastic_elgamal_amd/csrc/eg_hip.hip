@@ -60,7 +60,7 @@ struct eg_ctx {
   int big_bits = EG_COMB_BITS_BIG;      // 0: never build wide tables (EG_COMB_BIG_BITS)
   size_t big_min = (size_t)1 << 19;     // an engine that has verified this many items gets the wide tables (EG_COMB_BIG_MIN)
   bool big_failed = false;              // the wide tables did not fit the device memory: do not try again
-  u32* gen_words = nullptr;  // generator as 40 limbs
+  u32* gen_words = nullptr;  // generator as PT_WORDS limbs
   int resident_blocks = 0;   // blocks of the equation kernel that the chip holds at once (two per CU)
   int msm_blocks = 0;        // grid of the table / equation kernels: EG_GRID_OVERSUBSCRIBE x resident_blocks, each block striding over its share
   uint4* ws = nullptr;       // per-lane workspace of those kernels (msm_blocks * WS_QUADS * NT uint4)
@@ -111,8 +111,8 @@ static int comb_table_build(const u32* d_base_words, int bits, hipStream_t s, ui
   uint4* base = nullptr;
   u32 *d_bases = nullptr, *scratch = nullptr;
   hipError_t he = hipMalloc((void**)&base, ((size_t)windows * entries * 8 + COMB_HEADER_QUADS) * sizeof(uint4));
-  if (he == hipSuccess) he = hipMalloc((void**)&d_bases, (size_t)windows * 40 * sizeof(u32));
-  if (he == hipSuccess) he = hipMalloc((void**)&scratch, (size_t)COMB_RUN * 10 * lanes * sizeof(u32));
+  if (he == hipSuccess) he = hipMalloc((void**)&d_bases, (size_t)windows * PT_WORDS * sizeof(u32));
+  if (he == hipSuccess) he = hipMalloc((void**)&scratch, (size_t)COMB_RUN * EG_NL * lanes * sizeof(u32));
   if (he != hipSuccess) {
     if (base) (void)hipFree(base);
     if (d_bases) (void)hipFree(d_bases);
@@ -162,7 +162,7 @@ struct Engine {
   bool use_big = false;                        // this call reads the wide tables
   size_t items_seen = 0;                       // items verified by this engine so far (the wide tables are built once it passes ctx->big_min)
   u32* d_prefixes = nullptr;
-  u32* d_key_words = nullptr;   // [0..40) generator, [40..80) key
+  u32* d_key_words = nullptr;   // [0..PT_WORDS) generator, [PT_WORDS..2 PT_WORDS) key
   std::vector<StageDev> stages;
   std::vector<LevelDev> levels;
   int prefix_inst_first = 0, prefix_inst_count = 0;
@@ -172,8 +172,8 @@ struct Engine {
   u32 *states = nullptr, *flags = nullptr, *bad_item = nullptr;
   u32* partial = nullptr;
   int tally_blocks = 64;
-  u32* tally = nullptr;        // [2n][40] running tally (extended points)
-  u32* tally_saved = nullptr;  // [2n][40] the running tally set aside while a host call computes its per-batch tally
+  u32* tally = nullptr;        // [2n][PT_WORDS] running tally (extended points)
+  u32* tally_saved = nullptr;  // [2n][PT_WORDS] the running tally set aside while a host call computes its per-batch tally
   u32* tally_saved2 = nullptr; // the same for the JSON entry points, which call the host form piece by piece
   uint8_t* json_stage[2] = {nullptr, nullptr};     // pinned staging of the JSON entry points (two windows in flight)
   size_t json_stage_bytes[2] = {0, 0};
@@ -238,9 +238,10 @@ static EngineBufs make_bufs(const Engine* e, const void* d_ballots, u32 n, void*
 // bytes of chunk workspace per ballot (the buffers engine_reserve allocates)
 static size_t engine_bytes_per_ballot(const Engine* e) {
   const eghost::Plan& P = e->plan;
-  return (size_t)std::max(P.n_pt_slots, 1) * 160 + (size_t)std::max(P.n_cmp_slots, 1) * (32 + 160) + (size_t)std::max(P.n_chal_slots, 1) * 32 +
+  const size_t pt = (size_t)PT_WORDS * sizeof(u32);
+  return (size_t)std::max(P.n_pt_slots, 1) * pt + (size_t)std::max(P.n_cmp_slots, 1) * (32 + pt) + (size_t)std::max(P.n_chal_slots, 1) * 32 +
          (size_t)std::max(P.n_state_slots, 1) * 208 + (size_t)std::max(P.n_flag_slots, 1) * 4 + 4 +
-         std::max<size_t>(P.n_tables(), 1) * BTAB_QUADS * 16 + (size_t)std::max(e->max_defer, 1) * 80;
+         std::max<size_t>(P.n_tables(), 1) * BTAB_QUADS * 16 + (size_t)std::max(e->max_defer, 1) * 2 * EG_NL * sizeof(u32);
 }
 
 // (re)allocate the per-chunk SoA buffers for chunks of up to `want` ballots
@@ -253,15 +254,15 @@ static int engine_reserve(Engine* e, u32 want) {
   for (void** b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
   e->cap = 0;
   const size_t cap = (want + NT - 1) / NT * NT;
-  const size_t sizes[] = {(size_t)std::max(P.n_pt_slots, 1) * 10 * cap * sizeof(uint4),
+  const size_t sizes[] = {(size_t)std::max(P.n_pt_slots, 1) * PT_QUADS * cap * sizeof(uint4),
                           (size_t)std::max(P.n_cmp_slots, 1) * 2 * cap * sizeof(uint4),
                           (size_t)std::max(P.n_chal_slots, 1) * 2 * cap * sizeof(uint4),
                           (size_t)std::max(P.n_state_slots, 1) * 52 * cap * sizeof(u32),
                           (size_t)std::max(P.n_flag_slots, 1) * cap * sizeof(u32),
                           cap * sizeof(u32),
                           std::max<size_t>(P.n_tables(), 1) * cap * BTAB_QUADS * sizeof(uint4),
-                          (size_t)std::max(P.n_cmp_slots, 1) * 10 * cap * sizeof(uint4),
-                          (size_t)std::max(e->max_defer, 1) * 2 * 10 * cap * sizeof(u32)};
+                          (size_t)std::max(P.n_cmp_slots, 1) * PT_QUADS * cap * sizeof(uint4),
+                          (size_t)std::max(e->max_defer, 1) * 2 * EG_NL * cap * sizeof(u32)};
   for (size_t i = 0; i < sizeof(sizes) / sizeof(sizes[0]); ++i) {
     const hipError_t he = hipMalloc(bufs[i], sizes[i]);
     if (he == hipErrorOutOfMemory) {        // the caller retries with smaller chunks
@@ -332,7 +333,7 @@ static int engine_create(eg_ctx* ctx, eghost::Plan&& plan, const uint8_t pk[32],
   u32* d_flags = nullptr;
   HIPCHK(hipMalloc((void**)&d_pk, 32));
   HIPCHK(hipMalloc((void**)&d_flags, 8));
-  HIPCHK(hipMalloc((void**)&e->d_key_words, 80 * sizeof(u32)));
+  HIPCHK(hipMalloc((void**)&e->d_key_words, 2 * PT_WORDS * sizeof(u32)));
   HIPCHK(hipMemcpyAsync(d_pk, pk, 32, hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(k_setup_points, dim3(1), dim3(64), 0, s, d_pk, e->d_key_words, d_flags);
   u32 hflags[2] = {0, 0};
@@ -341,7 +342,7 @@ static int engine_create(eg_ctx* ctx, eghost::Plan&& plan, const uint8_t pk[32],
   (void)hipFree(d_pk); (void)hipFree(d_flags);
   if (!hflags[0]) return fail(EG_ERR_BAD_PUBLIC_KEY, "public key is not a valid ristretto255 encoding");
   if (hflags[1]) return fail(EG_ERR_BAD_PUBLIC_KEY, "public key is the identity");
-  if ((rc = comb_table_build(e->d_key_words + 40, EG_COMB_BITS, s, &e->d_tabK))) return rc;
+  if ((rc = comb_table_build(e->d_key_words + PT_WORDS, EG_COMB_BITS, s, &e->d_tabK))) return rc;
 
   // election-constant points [m]G
   {
@@ -350,7 +351,7 @@ static int engine_create(eg_ctx* ctx, eghost::Plan&& plan, const uint8_t pk[32],
     if (mults.empty()) mults.push_back(0);
     HIPCHK(hipMalloc((void**)&d_m, mults.size() * 8));
     HIPCHK(hipMemcpyAsync(d_m, mults.data(), mults.size() * 8, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMalloc((void**)&e->d_cpts, mults.size() * 10 * sizeof(uint4)));
+    HIPCHK(hipMalloc((void**)&e->d_cpts, mults.size() * PT_QUADS * sizeof(uint4)));
     hipLaunchKernelGGL(k_const_points, dim3((unsigned)((mults.size() + NT - 1) / NT)), dim3(NT), 0, s, d_m, (int)mults.size(),
                        ctx->tabG, e->d_cpts);
     HIPCHK(hipStreamSynchronize(s));
@@ -371,10 +372,10 @@ static int engine_create(eg_ctx* ctx, eghost::Plan&& plan, const uint8_t pk[32],
   }
   if (e->max_cap < NT) e->max_cap = NT;
   e->max_cap = (e->max_cap + NT - 1) / NT * NT;
-  HIPCHK(hipMalloc((void**)&e->partial, std::max<size_t>(P.tally_slots.size(), 1) * e->tally_blocks * 40 * sizeof(u32)));
-  HIPCHK(hipMalloc((void**)&e->tally, std::max<size_t>(P.tally_slots.size(), 1) * 40 * sizeof(u32)));
-  HIPCHK(hipMalloc((void**)&e->tally_saved, std::max<size_t>(P.tally_slots.size(), 1) * 40 * sizeof(u32)));
-  HIPCHK(hipMalloc((void**)&e->tally_saved2, std::max<size_t>(P.tally_slots.size(), 1) * 40 * sizeof(u32)));
+  HIPCHK(hipMalloc((void**)&e->partial, std::max<size_t>(P.tally_slots.size(), 1) * e->tally_blocks * PT_WORDS * sizeof(u32)));
+  HIPCHK(hipMalloc((void**)&e->tally, std::max<size_t>(P.tally_slots.size(), 1) * PT_WORDS * sizeof(u32)));
+  HIPCHK(hipMalloc((void**)&e->tally_saved, std::max<size_t>(P.tally_slots.size(), 1) * PT_WORDS * sizeof(u32)));
+  HIPCHK(hipMalloc((void**)&e->tally_saved2, std::max<size_t>(P.tally_slots.size(), 1) * PT_WORDS * sizeof(u32)));
   HIPCHK(hipMalloc((void**)&e->d_prefixes, (size_t)std::max(P.n_prefixes, 1) * 52 * sizeof(u32)));
   hipLaunchKernelGGL(k_tally_init, dim3(blocks_of(P.tally_slots.size())), dim3(NT), 0, s, e->tally, (int)P.tally_slots.size());
 
@@ -402,7 +403,7 @@ static int ensure_big_tables(Engine* e, hipStream_t s) {
     if (rc) return rc;
   }
   if (!e->d_tabK_big) {
-    const int rc = comb_table_build(e->d_key_words + 40, ctx->big_bits, s, &e->d_tabK_big, true);
+    const int rc = comb_table_build(e->d_key_words + PT_WORDS, ctx->big_bits, s, &e->d_tabK_big, true);
     if (rc == EG_ERR_NOMEM) { ctx->big_failed = true; return EG_OK; }
     if (rc) return rc;
   }
@@ -543,7 +544,7 @@ static int engine_verify_host(Engine* e, size_t n, const uint8_t* ballots, uint3
   // tally_out is the tally of THIS batch; the running tally keeps accumulating across calls (only eg_*_tally_reset clears
   // it).  The running tally is set aside, the batch is tallied from the identity, and the two are merged afterwards.
   if (tally_out && ns) {
-    HIPCHK(hipMemcpyAsync(e->tally_saved, e->tally, (size_t)ns * 40 * sizeof(u32), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(e->tally_saved, e->tally, (size_t)ns * PT_WORDS * sizeof(u32), hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(k_tally_init, dim3(blocks_of((size_t)ns)), dim3(NT), 0, s, e->tally, ns);
   }
   auto merge_saved = [&]() {   // running tally = saved + this batch (also on the error paths: nothing is lost)
@@ -655,7 +656,7 @@ int eg_init(int device, eg_ctx** out) {
   if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos && !getenv("EG_ALLOW_ANY_ARCH"))
     return fail(EG_ERR_NO_DEVICE, "device is " + c->name + ", this library is built for gfx950 (MI355X) only");
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  HIPCHK(hipMalloc((void**)&c->gen_words, 80 * sizeof(u32)));
+  HIPCHK(hipMalloc((void**)&c->gen_words, 2 * PT_WORDS * sizeof(u32)));
   hipLaunchKernelGGL(k_setup_points, dim3(1), dim3(64), 0, c->stream, (const u32*)nullptr, c->gen_words, (u32*)nullptr);
   {
     const int rc = comb_table_build(c->gen_words, EG_COMB_BITS, c->stream, &c->tabG);
@@ -672,10 +673,10 @@ int eg_init(int device, eg_ctx** out) {
   if (per_cu < 1) per_cu = 1;
   c->resident_blocks = per_cu * c->cus;
   // A grid of exactly the resident blocks makes every block do the same number of rounds, so the slowest CU sets the time and the
-  // last round runs part-empty; 16 times as many blocks, handed out as others finish, measured +1.5 % (single) / +1.8 % (QV) in one
-  // call (2 -> 4 -> 8 -> 16 -> 32 -> 64 blocks per CU: 5.33 / 5.38 / 5.41 / 5.39 / 5.40 / 5.44 M ballots/s).  The price is the
-  // per-lane workspace: 2.7 GB.
-  per_cu *= 16;
+  // last round runs part-empty; 32 blocks per CU, handed out as others finish, measured +1.5 % (single) / +1.8 % (QV) in one
+  // call in round 2 (2 -> 4 -> 8 -> 16 -> 32 -> 64 blocks per CU: 5.33 / 5.38 / 5.41 / 5.39 / 5.40 / 5.44 M ballots/s).  The price is the
+  // per-lane workspace: 2.4 GB.
+  per_cu = 32;
   const char* env = getenv("EG_MSM_BLOCKS_PER_CU");
   if (env) per_cu = std::max(1, atoi(env));
   c->msm_blocks = per_cu * c->cus;
@@ -1146,7 +1147,7 @@ static int verify_json_common(Engine* e, const char* json, size_t json_len, int 
   hipStream_t s = e->ctx->stream;
   HIPCHK(hipDeviceSynchronize());
   if (tally_out && ns) {        // tally_out = the tally of THIS call; the running tally keeps accumulating (eg_hip.h)
-    HIPCHK(hipMemcpyAsync(e->tally_saved2, e->tally, (size_t)ns * 40 * sizeof(u32), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(e->tally_saved2, e->tally, (size_t)ns * PT_WORDS * sizeof(u32), hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(k_tally_init, dim3(blocks_of((size_t)ns)), dim3(NT), 0, s, e->tally, ns);
     HIPCHK(hipStreamSynchronize(s));
   }

@@ -1,17 +1,26 @@
-// fe25519.cuh -- GF(2^255-19) for gfx950 (CDNA4): 10 unsigned limbs, radix 2^25.5, 64-bit column sums.
+// fe25519.cuh -- GF(2^255-19) for gfx950 (CDNA4): 9 unsigned limbs, radix 2^(255/9) (widths 29,28,28 repeating), 64-bit column sums.
 //
-// Why this representation (measured on MI355X, profiles/r01_ubench_*.txt): v_mad_u64_u32 issues at
-// ~4.7 cycles per wave64 -- within 10 % of any other VOP3 op -- so a field multiply is priced by its
-// total instruction count, not by its multiply count.  100 MADs that accumulate straight into 64-bit
-// column sums (no per-product carry handling) beat 64 MADs on saturated 32-bit limbs + carry plumbing
-// (256 vs 184..228 G field-mul/s chip-wide).  MFMA is not used: every product has two per-lane operands.
+// Why this representation (measured on MI355X, profiles/r03_ubench_valu_rates.txt, r03_ubench_field_bench.txt).  A wave64 VALU
+// instruction costs ~2.25 cycles of a SIMD's issue when it is a plain 32-bit add / sub / and / xor / shift-right / move and ~4.2-4.7
+// for everything else (v_mad_u64_u32, every VOP3, 64-bit shifts and adds, shift-left, v_cndmask), whatever the occupancy from two
+// waves per SIMD up: a field operation is priced by its instruction count.  Rounds 1-2 used 10 limbs of 25.5 bits with the wrap
+// constant pre-multiplied into one operand (100 multiply-adds + 10 v_mul_lo + an 11-step carry chain: 167 instructions per
+// multiplication).  With 9 limbs 19 * limb no longer fits 32 bits, so the full 17-column product is accumulated and the eight high
+// columns are folded in afterwards, each with two multiply-adds (low word x 19 into column k, high word x 19 * 2^(32 - w) into column
+// k + 1): 81 + 16 + 1 multiply-adds, no pre-multiplications, a 9-step carry chain: 152 instructions, -3.5 % time per multiplication
+// in the bench, squarings +2 % (62 multiply-adds against 56), and 10 % fewer registers and bytes per point, which is what lets the
+// equation kernel hold three waves per SIMD without scratch (+5 % on the comb column in the bench).  Saturated 8 x 32 limbs and
+// operand scanning were measured in round 1 and are slower (carry plumbing); MFMA does not apply: every product has two per-lane
+// operands.  The north star's "4 x u64 limbs" do not exist on this ISA (no 64 x 64 multiply).
 //
-// Bound discipline.  "class c" means even limbs <= c*2^26, odd limbs <= c*2^25 (a hair above for c = 1).
-//   fe_mul(h, f, g): needs class(g) <= 3.3 (19*g_i must fit 32 bits) and class(f)*class(g) <= 32
-//                    (column sums < 2^64); output class 1.
-//   fe_sq(h, f):     needs class(f) <= 3.3; output class 1.
-//   fe_add:          class(f)+class(g).     fe_sub: class(f)+2 (g must be class 1).
-//   fe_sub4:         class(f)+4 (g <= class 3.3).   fe_carry: any class <= 60 -> class 1.
+// Limb i sits at bit POS(i) = ceil(85 i / 3): 0 29 57 85 114 142 170 199 227.  A product of limbs i and j lands on limb i + j times
+// 2^e, e = 1 when (i mod 3, j mod 3) is (1,1), (1,2) or (2,1) and 0 otherwise (fe_mul doubles limb i of the first operand there).
+//
+// Bound discipline.  "class c" means limb i <= c * 2^W(i) (limb 1 a hair above for c = 1).
+//   fe_mul(h, f, g): needs class(f) * class(g) <= 12.5 (column sums < 2^64) and both classes < 7.9; output class 1.
+//   fe_sq(h, f):     needs class(f) <= 3.5; output class 1.
+//   fe_add:          class(f) + class(g) <= 7.9.     fe_sub: class(f) + 2 (g must be class 1).
+//   fe_sub4:         class(f) + 4 (g < class 4).     fe_carry: any class <= 7.9 -> class 1.
 // Compiled with -DEG_BOUNDCHECK on the host (tests/hostcheck) every fe carries its class and each
 // operation asserts its precondition, so any executed code path is a proof of the discipline.
 #pragma once
@@ -22,7 +31,7 @@
 #define EG_HD __host__ __device__ __forceinline__
 #define EG_D __device__ __forceinline__
 // Keeps the backend scheduler from interleaving independent field multiplications: one multiply already has
-// 10 independent 10-MAD columns of ILP, while interleaving several multiplies only inflates live registers
+// independent columns of ILP, while interleaving several multiplies only inflates live registers
 // (256 VGPR + AGPR spills, 1 wave/SIMD).  See DESIGN.md section 9.
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(EG_NO_SCHED_FENCE)
 #define EG_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -45,25 +54,44 @@
 #define EG_REQUIRE(cond, msg) ((void)0)
 #endif
 
+#define EG_NL 9      // limbs per field element
+
 namespace eg {
 
 typedef uint32_t u32;
 typedef uint64_t u64;
 
 struct fe {
-  u32 v[10];
+  u32 v[EG_NL];
 #ifdef EG_BOUNDCHECK
   float cls;
 #endif
 };
 
+constexpr int fe_w(int i) { return (i % 3 == 0) ? 29 : 28; }            // width of limb i
+constexpr int fe_pos(int i) { return (85 * i + 2) / 3; }                // its bit position
+constexpr u32 fe_mask(int i) { return (1u << fe_w(i)) - 1u; }
+// the product of limbs i and j carries an extra factor 2 (their positions add up to one bit more than the position of limb i + j)
+constexpr bool fe_dbl(int i, int j) { return (i % 3 == 1 && j % 3 != 0) || (i % 3 == 2 && j % 3 == 1); }
+
+// 2 x as an ADD: v_add_u32 issues in about half the cycles of the v_lshlrev_b32 hipcc picks for x << 1 (profiles/r03_ubench_valu_rates.txt)
+EG_HD u32 fe_twice(u32 x) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(EG_NO_ADD_DOUBLING)
+  u32 y;
+  asm("v_add_u32 %0, %1, %1" : "=v"(y) : "v"(x));
+  return y;
+#else
+  return 2u * x;
+#endif
+}
+
 #ifdef EG_BOUNDCHECK
 #define EG_SETCLS(h, c) ((h).cls = (c))
 #define EG_GETCLS(h) ((h).cls)
 static inline void fe_check_values(const fe& f) {
-  for (int i = 0; i < 10; ++i) {
-    double nominal = (i & 1) ? 33554432.0 : 67108864.0;
-    double lim = nominal * f.cls * 1.01 + 64.0;
+  for (int i = 0; i < EG_NL; ++i) {
+    double nominal = (double)(1u << fe_w(i));
+    double lim = nominal * f.cls * 1.001 + 4096.0;
     if ((double)f.v[i] > lim) { fprintf(stderr, "limb %d = %u exceeds class %.2f\n", i, f.v[i], f.cls); abort(); }
   }
 }
@@ -81,93 +109,94 @@ static unsigned long long g_fe_mul_count = 0, g_fe_sq_count = 0;
 
 EG_HD void fe_0(fe& h) {
 #pragma unroll
-  for (int i = 0; i < 10; ++i) h.v[i] = 0;
+  for (int i = 0; i < EG_NL; ++i) h.v[i] = 0;
   EG_SETCLS(h, 1.0f);
 }
 EG_HD void fe_1(fe& h) { fe_0(h); h.v[0] = 1; }
 
 EG_HD void fe_add(fe& h, const fe& f, const fe& g) {
 #pragma unroll
-  for (int i = 0; i < 10; ++i) h.v[i] = f.v[i] + g.v[i];
+  for (int i = 0; i < EG_NL; ++i) h.v[i] = f.v[i] + g.v[i];
   EG_SETCLS(h, EG_GETCLS(f) + EG_GETCLS(g));
-  EG_REQUIRE(EG_GETCLS(h) <= 60.0f, "fe_add overflow");
+  EG_REQUIRE(EG_GETCLS(h) <= 7.9f, "fe_add overflow");
 }
 
 // h = f + 2p - g ; g must be class 1
 EG_HD void fe_sub(fe& h, const fe& f, const fe& g) {
   EG_REQUIRE(EG_GETCLS(g) <= 1.02f, "fe_sub: subtrahend must be class 1");
   float c = EG_GETCLS(f) + 2.0f; (void)c;
-  h.v[0] = f.v[0] + 0x7ffffdau - g.v[0];
+  EG_REQUIRE(c <= 7.9f, "fe_sub overflow");
+  h.v[0] = f.v[0] + ((2u << 29) - 38u) - g.v[0];
 #pragma unroll
-  for (int i = 1; i < 10; ++i) h.v[i] = f.v[i] + ((i & 1) ? 0x3fffffeu : 0x7fffffeu) - g.v[i];
+  for (int i = 1; i < EG_NL; ++i) h.v[i] = f.v[i] + ((2u << fe_w(i)) - 2u) - g.v[i];
   EG_SETCLS(h, c);
 }
 
-// h = f + 4p - g ; g up to class 3.3 (in fact < 4)
+// h = f + 4p - g ; g below class 4
 EG_HD void fe_sub4(fe& h, const fe& f, const fe& g) {
   EG_REQUIRE(EG_GETCLS(g) <= 3.9f, "fe_sub4: subtrahend class too large");
   float c = EG_GETCLS(f) + 4.0f; (void)c;
-  h.v[0] = f.v[0] + 0xfffffb4u - g.v[0];
+  EG_REQUIRE(c <= 7.9f, "fe_sub4 overflow");
+  h.v[0] = f.v[0] + ((4u << 29) - 76u) - g.v[0];
 #pragma unroll
-  for (int i = 1; i < 10; ++i) h.v[i] = f.v[i] + ((i & 1) ? 0x7fffffcu : 0xffffffcu) - g.v[i];
+  for (int i = 1; i < EG_NL; ++i) h.v[i] = f.v[i] + ((4u << fe_w(i)) - 4u) - g.v[i];
   EG_SETCLS(h, c);
 }
 
 // weak reduction to class 1 (one carry sweep + wrap)
 EG_HD void fe_carry(fe& h) {
-  EG_REQUIRE(EG_GETCLS(h) <= 60.0f, "fe_carry input too large");
+  EG_REQUIRE(EG_GETCLS(h) <= 7.9f, "fe_carry input too large");
   u32 c;
 #pragma unroll
-  for (int i = 0; i < 9; ++i) {
-    const int bits = (i & 1) ? 25 : 26;
-    c = h.v[i] >> bits; h.v[i] &= ((1u << bits) - 1); h.v[i + 1] += c;
-  }
-  c = h.v[9] >> 25; h.v[9] &= 0x1ffffffu; h.v[0] += 19u * c;
-  c = h.v[0] >> 26; h.v[0] &= 0x3ffffffu; h.v[1] += c;
+  for (int i = 0; i < EG_NL - 1; ++i) { c = h.v[i] >> fe_w(i); h.v[i] &= fe_mask(i); h.v[i + 1] += c; }
+  c = h.v[8] >> 28; h.v[8] &= fe_mask(8); h.v[0] += 19u * c;
+  c = h.v[0] >> 29; h.v[0] &= fe_mask(0); h.v[1] += c;
   EG_SETCLS(h, 1.0f);
 }
 
-EG_HD void fe_neg(fe& h, const fe& f) {  // class 1 in -> class 3 out (0 + 2p - f)
+EG_HD void fe_neg(fe& h, const fe& f) {  // class 1 in -> class 2 out (0 + 2p - f)
   fe z; fe_0(z);
   EG_SETCLS(z, 0.0f);
   fe_sub(h, z, f);
 }
 
-EG_HD void fe_reduce_columns(fe& h, u64 c[10]) {
+// 17 column sums of a product -> class 1.  Columns 9..16 sit 255 bits above columns 0..8 (2^255 = 19): the low word of column k
+// goes into column k - 9 times 19, its high word (2^32 = 2^W(k-9) * 2^(32 - W(k-9)) above) into column k - 8 times 19 * 2^(32 - W).
+EG_HD void fe_reduce_columns(fe& h, u64 c[2 * EG_NL - 1]) {
+#pragma unroll
+  for (int k = EG_NL; k < 2 * EG_NL - 1; ++k) {
+    const u32 lo = (u32)c[k], hi = (u32)(c[k] >> 32);
+    c[k - 9] += (u64)lo * 19u;
+    c[k - 8] += (u64)hi * (19u << (32 - fe_w(k - 9)));
+  }
   u64 t;
 #pragma unroll
-  for (int i = 0; i < 9; ++i) {
-    const int bits = (i & 1) ? 25 : 26;
-    t = c[i] >> bits; c[i] &= ((1ull << bits) - 1); c[i + 1] += t;
-  }
-  t = c[9] >> 25; c[9] &= 0x1ffffffull; c[0] += 19ull * t;
-  t = c[0] >> 26; c[0] &= 0x3ffffffull; c[1] += t;
+  for (int i = 0; i < EG_NL - 1; ++i) { t = c[i] >> fe_w(i); c[i] &= fe_mask(i); c[i + 1] += t; }
+  t = c[8] >> 28; c[8] &= fe_mask(8); c[0] += 19ull * t;
+  t = c[0] >> 29; c[0] &= fe_mask(0); c[1] += t;
 #pragma unroll
-  for (int i = 0; i < 10; ++i) h.v[i] = (u32)c[i];
+  for (int i = 0; i < EG_NL; ++i) h.v[i] = (u32)c[i];
   EG_SETCLS(h, 1.0f);
 }
 
 EG_HD void fe_mul(fe& h, const fe& f, const fe& g) {
-  EG_REQUIRE(EG_GETCLS(g) <= 3.31f, "fe_mul: g operand class > 3.3");
-  EG_REQUIRE(EG_GETCLS(f) * EG_GETCLS(g) <= 32.0f, "fe_mul: class product > 32");
+  EG_REQUIRE(EG_GETCLS(f) * EG_GETCLS(g) <= 12.5f, "fe_mul: class product > 12.5");
+  EG_REQUIRE(EG_GETCLS(f) <= 7.9f && EG_GETCLS(g) <= 7.9f, "fe_mul: operand class > 7.9");
   fe_check_values(f); fe_check_values(g);
   EG_COUNT_MUL();
   EG_SCHED_FENCE();
-  u32 g19[10], f2[10];
+  u32 f2[EG_NL];
 #pragma unroll
-  for (int i = 0; i < 10; ++i) { g19[i] = 19u * g.v[i]; f2[i] = 2u * f.v[i]; }
-  u64 c[10];
+  for (int i = 0; i < EG_NL; ++i) f2[i] = (i % 3 != 0) ? fe_twice(f.v[i]) : 0u;
+  u64 c[2 * EG_NL - 1];
 #pragma unroll
-  for (int k = 0; k < 10; ++k) {
+  for (int k = 0; k < 2 * EG_NL - 1; ++k) {
     u64 acc = 0;
 #pragma unroll
-    for (int i = 0; i < 10; ++i) {
-      int j = k - i;
-      bool wrap = false;
-      if (j < 0) { j += 10; wrap = true; }
-      const u32 fi = ((i & 1) && (j & 1)) ? f2[i] : f.v[i];
-      const u32 gj = wrap ? g19[j] : g.v[j];
-      acc += (u64)fi * gj;
+    for (int i = 0; i < EG_NL; ++i) {
+      const int j = k - i;
+      if (j < 0 || j >= EG_NL) continue;
+      acc += (u64)(fe_dbl(i, j) ? f2[i] : f.v[i]) * g.v[j];
     }
     c[k] = acc;
   }
@@ -176,26 +205,26 @@ EG_HD void fe_mul(fe& h, const fe& f, const fe& g) {
 }
 
 EG_HD void fe_sq(fe& h, const fe& f) {
-  EG_REQUIRE(EG_GETCLS(f) <= 3.31f, "fe_sq: operand class > 3.3");
+  EG_REQUIRE(EG_GETCLS(f) <= 3.51f, "fe_sq: operand class > 3.5");
   fe_check_values(f);
   EG_COUNT_SQ();
   EG_SCHED_FENCE();
-  const u32 f0 = f.v[0], f1 = f.v[1], f2 = f.v[2], f3 = f.v[3], f4 = f.v[4];
-  const u32 f5 = f.v[5], f6 = f.v[6], f7 = f.v[7], f8 = f.v[8], f9 = f.v[9];
-  const u32 f0_2 = 2 * f0, f1_2 = 2 * f1, f2_2 = 2 * f2, f3_2 = 2 * f3, f4_2 = 2 * f4;
-  const u32 f5_2 = 2 * f5, f6_2 = 2 * f6, f7_2 = 2 * f7;
-  const u32 f5_38 = 38 * f5, f6_19 = 19 * f6, f7_38 = 38 * f7, f8_19 = 19 * f8, f9_38 = 38 * f9;
-  u64 c[10];
-  c[0] = (u64)f0 * f0 + (u64)f1_2 * f9_38 + (u64)f2_2 * f8_19 + (u64)f3_2 * f7_38 + (u64)f4_2 * f6_19 + (u64)f5 * f5_38;
-  c[1] = (u64)f0_2 * f1 + (u64)f2 * f9_38 + (u64)f3_2 * f8_19 + (u64)f4 * f7_38 + (u64)f5_2 * f6_19;
-  c[2] = (u64)f0_2 * f2 + (u64)f1_2 * f1 + (u64)f3_2 * f9_38 + (u64)f4_2 * f8_19 + (u64)f5_2 * f7_38 + (u64)f6 * f6_19;
-  c[3] = (u64)f0_2 * f3 + (u64)f1_2 * f2 + (u64)f4 * f9_38 + (u64)f5_2 * f8_19 + (u64)f6 * f7_38;
-  c[4] = (u64)f0_2 * f4 + (u64)f1_2 * f3_2 + (u64)f2 * f2 + (u64)f5_2 * f9_38 + (u64)f6_2 * f8_19 + (u64)f7 * f7_38;
-  c[5] = (u64)f0_2 * f5 + (u64)f1_2 * f4 + (u64)f2_2 * f3 + (u64)f6 * f9_38 + (u64)f7_2 * f8_19;
-  c[6] = (u64)f0_2 * f6 + (u64)f1_2 * f5_2 + (u64)f2_2 * f4 + (u64)f3_2 * f3 + (u64)f7_2 * f9_38 + (u64)f8 * f8_19;
-  c[7] = (u64)f0_2 * f7 + (u64)f1_2 * f6 + (u64)f2_2 * f5 + (u64)f3_2 * f4 + (u64)f8 * f9_38;
-  c[8] = (u64)f0_2 * f8 + (u64)f1_2 * f7_2 + (u64)f2_2 * f6 + (u64)f3_2 * f5_2 + (u64)f4 * f4 + (u64)f9 * f9_38;
-  c[9] = (u64)f0_2 * f9 + (u64)f1_2 * f8 + (u64)f2_2 * f7 + (u64)f3_2 * f6 + (u64)f4_2 * f5;
+  u32 d[EG_NL];
+#pragma unroll
+  for (int i = 0; i < EG_NL; ++i) d[i] = fe_twice(f.v[i]);
+  u64 c[2 * EG_NL - 1];
+#pragma unroll
+  for (int k = 0; k < 2 * EG_NL - 1; ++k) {
+    u64 acc = 0;
+#pragma unroll
+    for (int i = 0; i < EG_NL; ++i) {
+      const int j = k - i;
+      if (j < i || j >= EG_NL) continue;
+      if (i == j) acc += (u64)(fe_dbl(i, i) ? d[i] : f.v[i]) * f.v[i];
+      else acc += (u64)d[i] * (fe_dbl(i, j) ? d[j] : f.v[j]);          // cross terms count twice
+    }
+    c[k] = acc;
+  }
   fe_reduce_columns(h, c);
   EG_SCHED_FENCE();
 }
@@ -205,19 +234,45 @@ EG_HD void fe_sqn(fe& h, const fe& f, int n) {
   for (int i = 1; i < n; ++i) fe_sq(h, h);
 }
 
+// ---- 256-bit packing (wire encodings; table entries: device_io.cuh BaseTable) --------------------------------------------------------
+// A class-1 element (every limb within its width, limb 1 a hair above: what fe_mul, fe_sq and fe_carry return) is < 2^255 + 2^41 as an
+// integer: eight 32-bit words.  Unpacking slices the integer again: limbs 0..7 within their widths, limb 8 <= 2^28, i.e. class 1.
+EG_HD void fe_pack8(u32 w[8], const fe& f) {
+  EG_REQUIRE(EG_GETCLS(f) <= 1.02f, "fe_pack8: operand must be class 1");
+  fe_check_values(f);
+  u64 acc = 0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+#pragma unroll
+    for (int i = 0; i < EG_NL; ++i)
+      if (fe_pos(i) >= 32 * q && fe_pos(i) < 32 * (q + 1)) acc += (u64)f.v[i] << (fe_pos(i) - 32 * q);
+    w[q] = (u32)acc; acc >>= 32;
+  }
+  EG_REQUIRE(acc == 0, "fe_pack8: value does not fit 256 bits");
+}
+EG_HD u32 eg_funnel(u32 hi, u32 lo, int s) { return (hi << (32 - s)) | (lo >> s); }      // v_alignbit_b32
+EG_HD void fe_unpack_raw(fe& f, const u32 w[8]) {          // limbs 0..7 within their widths, limb 8 = bits 227..255
+#pragma unroll
+  for (int i = 0; i < EG_NL; ++i) {
+    const int q = fe_pos(i) >> 5, s = fe_pos(i) & 31;
+    u32 v;
+    if (s == 0) v = w[q];
+    else if (s + fe_w(i) > 32 && q + 1 < 8) v = eg_funnel(w[q + 1], w[q], s);
+    else v = w[q] >> s;
+    f.v[i] = (i == EG_NL - 1) ? v : (v & fe_mask(i));
+  }
+}
+EG_HD void fe_unpack8(fe& f, const u32 w[8]) {             // a packed class-1 element: the top limb is <= 2^28, class 1 again
+  fe_unpack_raw(f, w);
+  EG_SETCLS(f, 1.0f);
+  fe_check_values(f);
+}
+
 // ---- byte codec ---------------------------------------------------------------------------------
 // w[0..7] = little-endian 32-bit words of the 32-byte encoding; bit 255 is ignored (as dalek does).
 EG_HD void fe_from_words(fe& h, const u32 w[8]) {
-  h.v[0] = w[0] & 0x3ffffffu;
-  h.v[1] = ((w[0] >> 26) | (w[1] << 6)) & 0x1ffffffu;
-  h.v[2] = ((w[1] >> 19) | (w[2] << 13)) & 0x3ffffffu;
-  h.v[3] = ((w[2] >> 13) | (w[3] << 19)) & 0x1ffffffu;
-  h.v[4] = (w[3] >> 6) & 0x3ffffffu;
-  h.v[5] = w[4] & 0x1ffffffu;
-  h.v[6] = ((w[4] >> 25) | (w[5] << 7)) & 0x3ffffffu;
-  h.v[7] = ((w[5] >> 19) | (w[6] << 13)) & 0x1ffffffu;
-  h.v[8] = ((w[6] >> 12) | (w[7] << 20)) & 0x3ffffffu;
-  h.v[9] = (w[7] >> 6) & 0x1ffffffu;
+  fe_unpack_raw(h, w);
+  h.v[EG_NL - 1] &= fe_mask(EG_NL - 1);
   EG_SETCLS(h, 1.0f);
 }
 
@@ -227,25 +282,15 @@ EG_HD void fe_to_words(u32 w[8], const fe& f) {
   fe_carry(t);
   fe_carry(t);
   // t < 2^255 + small; q = 1 iff t >= p
-  u32 q = (t.v[0] + 19) >> 26;
+  u32 q = (t.v[0] + 19u) >> 29;
 #pragma unroll
-  for (int i = 1; i < 10; ++i) q = (t.v[i] + q) >> ((i & 1) ? 25 : 26);
-  t.v[0] += 19 * q;
+  for (int i = 1; i < EG_NL; ++i) q = (t.v[i] + q) >> fe_w(i);
+  t.v[0] += 19u * q;
   u32 c;
 #pragma unroll
-  for (int i = 0; i < 9; ++i) {
-    const int bits = (i & 1) ? 25 : 26;
-    c = t.v[i] >> bits; t.v[i] &= ((1u << bits) - 1); t.v[i + 1] += c;
-  }
-  t.v[9] &= 0x1ffffffu;
-  w[0] = t.v[0] | (t.v[1] << 26);
-  w[1] = (t.v[1] >> 6) | (t.v[2] << 19);
-  w[2] = (t.v[2] >> 13) | (t.v[3] << 13);
-  w[3] = (t.v[3] >> 19) | (t.v[4] << 6);
-  w[4] = t.v[5] | (t.v[6] << 25);
-  w[5] = (t.v[6] >> 7) | (t.v[7] << 19);
-  w[6] = (t.v[7] >> 13) | (t.v[8] << 12);
-  w[7] = (t.v[8] >> 20) | (t.v[9] << 6);
+  for (int i = 0; i < EG_NL - 1; ++i) { c = t.v[i] >> fe_w(i); t.v[i] &= fe_mask(i); t.v[i + 1] += c; }
+  t.v[EG_NL - 1] &= fe_mask(EG_NL - 1);
+  fe_pack8(w, t);
 }
 
 EG_HD bool fe_isnegative(const fe& f) { u32 w[8]; fe_to_words(w, f); return w[0] & 1; }
@@ -266,44 +311,10 @@ EG_HD bool fe_eq(const fe& f, const fe& g) {
 // h = flag ? g : h   (both must already be in comparable classes; class becomes the max)
 EG_HD void fe_cmov(fe& h, const fe& g, bool flag) {
 #pragma unroll
-  for (int i = 0; i < 10; ++i) h.v[i] = flag ? g.v[i] : h.v[i];
+  for (int i = 0; i < EG_NL; ++i) h.v[i] = flag ? g.v[i] : h.v[i];
 #ifdef EG_BOUNDCHECK
   if (g.cls > h.cls) h.cls = g.cls;
 #endif
-}
-
-// ---- 256-bit packing (table entries: device_io.cuh BaseTable) --------------------------------------------------------------------
-// A class-1 element (every limb within its 26 / 25 bits, limb 1 a hair above: what fe_mul, fe_sq and fe_carry return) is < 2^256 as an
-// integer: eight 32-bit words.  Limb offsets: 0 26 51 77 102 128 153 179 204 230.  Unpacking slices the integer again: limbs 0..8 within
-// their widths, limb 9 <= 2^25 (the integer is < 2^255 + 2^40), i.e. class 1.
-EG_HD void fe_pack8(u32 w[8], const fe& f) {
-  EG_REQUIRE(EG_GETCLS(f) <= 1.02f, "fe_pack8: operand must be class 1");
-  fe_check_values(f);
-  u64 acc = (u64)f.v[0] + ((u64)f.v[1] << 26);
-  w[0] = (u32)acc; acc >>= 32;
-  acc += (u64)f.v[2] << 19; w[1] = (u32)acc; acc >>= 32;
-  acc += (u64)f.v[3] << 13; w[2] = (u32)acc; acc >>= 32;
-  acc += (u64)f.v[4] << 6;  w[3] = (u32)acc; acc >>= 32;
-  acc += (u64)f.v[5] + ((u64)f.v[6] << 25); w[4] = (u32)acc; acc >>= 32;
-  acc += (u64)f.v[7] << 19; w[5] = (u32)acc; acc >>= 32;
-  acc += (u64)f.v[8] << 12; w[6] = (u32)acc; acc >>= 32;
-  acc += (u64)f.v[9] << 6;  w[7] = (u32)acc;
-  EG_REQUIRE((acc >> 32) == 0, "fe_pack8: value does not fit 256 bits");
-}
-EG_HD u32 eg_funnel(u32 hi, u32 lo, int s) { return (hi << (32 - s)) | (lo >> s); }      // v_alignbit_b32
-EG_HD void fe_unpack8(fe& f, const u32 w[8]) {
-  f.v[0] = w[0] & 0x3ffffffu;
-  f.v[1] = eg_funnel(w[1], w[0], 26) & 0x1ffffffu;
-  f.v[2] = eg_funnel(w[2], w[1], 19) & 0x3ffffffu;
-  f.v[3] = eg_funnel(w[3], w[2], 13) & 0x1ffffffu;
-  f.v[4] = w[3] >> 6;
-  f.v[5] = w[4] & 0x1ffffffu;
-  f.v[6] = eg_funnel(w[5], w[4], 25) & 0x3ffffffu;
-  f.v[7] = eg_funnel(w[6], w[5], 19) & 0x1ffffffu;
-  f.v[8] = eg_funnel(w[7], w[6], 12) & 0x3ffffffu;
-  f.v[9] = w[7] >> 6;
-  EG_SETCLS(f, 1.0f);
-  fe_check_values(f);
 }
 
 // ---- constants (values checked against the oracle / SURVEY Appendix E in tests) --------------------

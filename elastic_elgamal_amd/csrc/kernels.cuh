@@ -2,7 +2,7 @@
 // product has two per-lane operands: this is modular-integer VALU work), wave64 throughout.
 //
 // Data layout in HBM (all per chunk of `cap` ballots, SoA so that lane == ballot is always coalesced):
-//   pts   [slot][10][cap] uint4   extended points, 40 limbs (X,Y,Z,T x 10 x 25.5 bit)   160 B / point
+//   pts   [slot][9][cap]  uint4   extended points, 36 limbs (X,Y,Z,T x 9 x 28.3 bit)    144 B / point
 //   cmp   [slot][2][cap]  uint4   compressed outputs of the group equations               32 B
 //   chal  [slot][2][cap]  uint4   derived challenges e_j                                   32 B
 //   states[slot][52][cap] u32     saved ring transcripts (only when a ring has > 2 equations)
@@ -19,9 +19,11 @@
 #include <hip/hip_runtime.h>
 #include "device_io.cuh"
 
-// waves per SIMD the register allocation of the two dominant kernels is held to (A/B knobs; 3 would need <= 168 VGPRs)
+// Waves per SIMD the register allocation of the two dominant kernels is held to (A/B knobs).  With 9 limbs the equation kernel fits
+// 168 registers without scratch: three waves measured +0.6 % single-choice / +0.5..0.9 % quadratic voting in one call
+// (profiles/r03_ab_experiments.txt); the table builder gains nothing from a third wave.
 #ifndef EG_EQ_WAVES
-#define EG_EQ_WAVES 2        // waves per SIMD the register allocation of the equation kernel is held to
+#define EG_EQ_WAVES 3
 #endif
 #ifndef EG_TAB_WAVES
 #define EG_TAB_WAVES 2
@@ -104,11 +106,7 @@ __global__ void __launch_bounds__(NT, EG_TAB_WAVES) k_base_tables(EngineBufs B, 
     const u32 k = (u32)(j / B.n), b = (u32)(j % B.n);
     ge p;
     load_pt(p, B.pts, B.cap, base_slots[k], b);
-#ifdef EG_AB_TAB_NOSTORE      // measurement-only: every lane writes ballot 0's table (wrong results): what the scattered stores cost
-    BaseTable bt{B.btab + ((size_t)k * B.cap) * BTAB_QUADS};
-#else
     BaseTable bt{B.btab + ((size_t)k * B.cap + b) * BTAB_QUADS};
-#endif
     ge_teeth_tables_build(bt, tmp, p);
   }
 }
@@ -124,17 +122,9 @@ __global__ void __launch_bounds__(NT, EG_SUM_WAVES) k_sum_tables(EngineBufs B, c
   for (size_t j = (size_t)blockIdx.x * NT + threadIdx.x; j < total; j += (size_t)gridDim.x * NT) {
     const u32 k = (u32)(j / B.n), b = (u32)(j % B.n);
     const egplan::SumBase sb = sums[k];
-#ifdef EG_AB_SUM_NOSTORE      // measurement-only: every lane writes ballot 0's table (wrong results)
-    BaseTable out{B.btab + ((size_t)sb.out_base * B.cap) * BTAB_QUADS};
-#else
     BaseTable out{B.btab + ((size_t)sb.out_base * B.cap + b) * BTAB_QUADS};
-#endif
     ge_teeth_tables_sum(out, tmp, (int)sb.count, [&](int t, int g, ge_cached& e) {
-#ifdef EG_AB_SUM_NOLOAD       // measurement-only: every lane reads ballot 0's tables (wrong results)
-      const BaseTable bt{B.btab + ((size_t)members[sb.first + t] * B.cap) * BTAB_QUADS};
-#else
       const BaseTable bt{B.btab + ((size_t)members[sb.first + t] * B.cap + b) * BTAB_QUADS};
-#endif
       bt.load(e, g);
     });
   }
@@ -181,11 +171,7 @@ __global__ void __launch_bounds__(NT, EG_EQ_WAVES) k_eq_table(EngineBufs B, cons
       load_scalar(s, B, b, vt.s, true);
       u64 rows[EG_TEETH];
       sc_recode_teeth(rows, s);
-#ifdef EG_AB_SHARED_ENTRY   // measurement-only build: every lane reads ballot 0's table (upper bound on what less table traffic can buy)
-      BaseTable bt{B.btab + ((size_t)vt.base * B.cap) * BTAB_QUADS};
-#else
       BaseTable bt{B.btab + ((size_t)vt.base * B.cap + b) * BTAB_QUADS};
-#endif
       ge_teeth_mul(acc, bt, rows);
     } else {
       // groups of up to `group` terms share a doubling chain (the group size is what fits LDS at two blocks per CU)
@@ -298,11 +284,11 @@ __global__ void __launch_bounds__(NT, 2) k_encode_plain(EngineBufs B, const egpl
 // (ge_double_encode_prepare / _finish: the commitments were evaluated with halved scalars, out = encode(2P).)
 __device__ __forceinline__ void encw_store(u32* encw, u32 cap, u32 slot, u32 b, const fe& f) {
 #pragma unroll
-  for (int i = 0; i < 10; ++i) encw[((size_t)slot * 10 + i) * cap + b] = f.v[i];
+  for (int i = 0; i < EG_NL; ++i) encw[((size_t)slot * EG_NL + i) * cap + b] = f.v[i];
 }
 __device__ __forceinline__ void encw_load(fe& f, const u32* encw, u32 cap, u32 slot, u32 b) {
 #pragma unroll
-  for (int i = 0; i < 10; ++i) f.v[i] = encw[((size_t)slot * 10 + i) * cap + b];
+  for (int i = 0; i < EG_NL; ++i) f.v[i] = encw[((size_t)slot * EG_NL + i) * cap + b];
 }
 __global__ void __launch_bounds__(NT, 2) k_encode_batch(EngineBufs B, const unsigned short* slots, int n_slots) {
   for (u32 b = blockIdx.x * NT + threadIdx.x; b < B.n; b += gridDim.x * NT) {
@@ -452,18 +438,18 @@ __global__ void __launch_bounds__(NT) k_status(EngineBufs B, const egplan::Statu
 }
 
 // ---- tally: totals[k] += vote[k] over accepted ballots (examples/voting.rs:199-203) ---------------------------------------------------------
-__device__ __forceinline__ void block_reduce_points(ge& acc, u32* lds /* [40][NT] */) {
-  u32 w[40];
+__device__ __forceinline__ void block_reduce_points(ge& acc, u32* lds /* [PT_WORDS][NT] */) {
+  u32 w[PT_WORDS];
 #pragma unroll 1
   for (int s = NT / 2; s >= 1; s >>= 1) {
     ge_to_words(w, acc);
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 40; ++i) lds[i * NT + threadIdx.x] = w[i];
+    for (int i = 0; i < PT_WORDS; ++i) lds[i * NT + threadIdx.x] = w[i];
     __syncthreads();
     if ((int)threadIdx.x < s) {
 #pragma unroll
-      for (int i = 0; i < 40; ++i) w[i] = lds[i * NT + threadIdx.x + s];
+      for (int i = 0; i < PT_WORDS; ++i) w[i] = lds[i * NT + threadIdx.x + s];
       ge other, sum;
       words_to_ge(other, w);
       ge_add_full(sum, acc, other);
@@ -473,8 +459,8 @@ __device__ __forceinline__ void block_reduce_points(ge& acc, u32* lds /* [40][NT
 }
 
 // grid (G, n_slots): block (x, k) sums point slot tally_slots[k] over its share of accepted ballots
-__global__ void __launch_bounds__(NT) k_tally_partial(EngineBufs B, const u32* tally_slots, u32* partial /* [n_slots][G][40] */) {
-  __shared__ u32 lds[40 * NT];
+__global__ void __launch_bounds__(NT) k_tally_partial(EngineBufs B, const u32* tally_slots, u32* partial /* [n_slots][G][PT_WORDS] */) {
+  __shared__ u32 lds[PT_WORDS * NT];
   const u32 slot = tally_slots[blockIdx.y];
   ge acc;
   ge_identity(acc);
@@ -487,19 +473,19 @@ __global__ void __launch_bounds__(NT) k_tally_partial(EngineBufs B, const u32* t
   }
   block_reduce_points(acc, lds);
   if (threadIdx.x == 0) {
-    u32 w[40];
+    u32 w[PT_WORDS];
     ge_to_words(w, acc);
-    for (int i = 0; i < 40; ++i) partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 40 + i] = w[i];
+    for (int i = 0; i < PT_WORDS; ++i) partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * PT_WORDS + i] = w[i];
   }
 }
 // one block per slot: tally[k] += sum_x partial[k][x]
-__global__ void __launch_bounds__(NT) k_tally_final(const u32* partial, int G, u32* tally /* [n_slots][40] */) {
-  __shared__ u32 lds[40 * NT];
+__global__ void __launch_bounds__(NT) k_tally_final(const u32* partial, int G, u32* tally /* [n_slots][PT_WORDS] */) {
+  __shared__ u32 lds[PT_WORDS * NT];
   ge acc;
   ge_identity(acc);
   for (int x = threadIdx.x; x < G; x += NT) {
-    u32 w[40];
-    for (int i = 0; i < 40; ++i) w[i] = partial[((size_t)blockIdx.x * G + x) * 40 + i];
+    u32 w[PT_WORDS];
+    for (int i = 0; i < PT_WORDS; ++i) w[i] = partial[((size_t)blockIdx.x * G + x) * PT_WORDS + i];
     ge p, sum;
     words_to_ge(p, w);
     ge_add_full(sum, acc, p);
@@ -507,27 +493,27 @@ __global__ void __launch_bounds__(NT) k_tally_final(const u32* partial, int G, u
   }
   block_reduce_points(acc, lds);
   if (threadIdx.x == 0) {
-    u32 w[40];
-    for (int i = 0; i < 40; ++i) w[i] = tally[(size_t)blockIdx.x * 40 + i];
+    u32 w[PT_WORDS];
+    for (int i = 0; i < PT_WORDS; ++i) w[i] = tally[(size_t)blockIdx.x * PT_WORDS + i];
     ge cur, sum;
     words_to_ge(cur, w);
     ge_add_full(sum, cur, acc);
     ge_to_words(w, sum);
-    for (int i = 0; i < 40; ++i) tally[(size_t)blockIdx.x * 40 + i] = w[i];
+    for (int i = 0; i < PT_WORDS; ++i) tally[(size_t)blockIdx.x * PT_WORDS + i] = w[i];
   }
 }
 __global__ void k_tally_init(u32* tally, int n_slots) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n_slots) return;
   ge id; ge_identity(id);
-  u32 w[40]; ge_to_words(w, id);
-  for (int i = 0; i < 40; ++i) tally[(size_t)k * 40 + i] = w[i];
+  u32 w[PT_WORDS]; ge_to_words(w, id);
+  for (int i = 0; i < PT_WORDS; ++i) tally[(size_t)k * PT_WORDS + i] = w[i];
 }
 __global__ void k_tally_encode(const u32* tally, int n_slots, u32* out /* [n_slots][8] */) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n_slots) return;
-  u32 w[40];
-  for (int i = 0; i < 40; ++i) w[i] = tally[(size_t)k * 40 + i];
+  u32 w[PT_WORDS];
+  for (int i = 0; i < PT_WORDS; ++i) w[i] = tally[(size_t)k * PT_WORDS + i];
   ge p; words_to_ge(p, w);
   u32 o[8]; ristretto_encode(o, p);
   for (int i = 0; i < 8; ++i) out[(size_t)k * 8 + i] = o[i];
@@ -542,24 +528,24 @@ __global__ void k_tally_add_encoded(const u32* in, int n_slots, u32* tally, u32*
   for (int i = 0; i < 8; ++i) w[i] = in[(size_t)k * 8 + i];
   ge p;
   if (!ristretto_decode(p, w)) { atomicAdd(bad, 1u); return; }
-  u32 t[40];
-  for (int i = 0; i < 40; ++i) t[i] = tally[(size_t)k * 40 + i];
+  u32 t[PT_WORDS];
+  for (int i = 0; i < PT_WORDS; ++i) t[i] = tally[(size_t)k * PT_WORDS + i];
   ge cur, sum; words_to_ge(cur, t);
   ge_add_full(sum, cur, p);
   ge_to_words(t, sum);
-  for (int i = 0; i < 40; ++i) tally[(size_t)k * 40 + i] = t[i];
+  for (int i = 0; i < PT_WORDS; ++i) tally[(size_t)k * PT_WORDS + i] = t[i];
 }
 
 // tally[k] += src[k] (extended points): puts a set-aside running tally back after a host call tallied its own batch
 __global__ void k_tally_add_points(const u32* src, int n_slots, u32* tally) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n_slots) return;
-  u32 a[40], b[40];
-  for (int i = 0; i < 40; ++i) { a[i] = src[(size_t)k * 40 + i]; b[i] = tally[(size_t)k * 40 + i]; }
+  u32 a[PT_WORDS], b[PT_WORDS];
+  for (int i = 0; i < PT_WORDS; ++i) { a[i] = src[(size_t)k * PT_WORDS + i]; b[i] = tally[(size_t)k * PT_WORDS + i]; }
   ge p, q, sum; words_to_ge(p, a); words_to_ge(q, b);
   ge_add_full(sum, q, p);
   ge_to_words(b, sum);
-  for (int i = 0; i < 40; ++i) tally[(size_t)k * 40 + i] = b[i];
+  for (int i = 0; i < PT_WORDS; ++i) tally[(size_t)k * PT_WORDS + i] = b[i];
 }
 
 // out[k] = encode( sum_r decode(in[r][k]) ): merges the per-GPU tallies after the all-gather.  Encodings are
@@ -585,16 +571,16 @@ __global__ void k_points_sum(const u32* in, int n_ranks, int n_points, u32* out,
 // ---- election setup --------------------------------------------------------------------------------------------------------------------------------
 // Fixed-base comb tables: tab[w*E + k-1] = niels([k * 2^(B w)] Base), w < ceil(254 / B), 1 <= k <= E = 2^(B-1).
 // k_comb_window_bases: bases[w] = [2^(B w)] Base (one lane, B * windows doublings).
-__global__ void k_comb_window_bases(const u32* base_words /* 40 */, int bits, u32* bases /* [windows][40] */) {
+__global__ void k_comb_window_bases(const u32* base_words /* PT_WORDS */, int bits, u32* bases /* [windows][PT_WORDS] */) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  u32 bw[40];
-  for (int i = 0; i < 40; ++i) bw[i] = base_words[i];
+  u32 bw[PT_WORDS];
+  for (int i = 0; i < PT_WORDS; ++i) bw[i] = base_words[i];
   ge p; words_to_ge(p, bw);
   const int windows = comb_windows(bits);
 #pragma unroll 1
   for (int w = 0; w < windows; ++w) {
     ge_to_words(bw, p);
-    for (int i = 0; i < 40; ++i) bases[w * 40 + i] = bw[i];
+    for (int i = 0; i < PT_WORDS; ++i) bases[w * PT_WORDS + i] = bw[i];
 #pragma unroll 1
     for (int i = 0; i < bits; ++i) { ge d; ge_dbl_full(d, p); p = d; }
   }
@@ -606,16 +592,16 @@ __global__ void k_comb_window_bases(const u32* base_words /* 40 */, int bits, u3
 // 70 ms, which is what makes the 24-bit tables (92 M entries per base) affordable.
 constexpr int COMB_RUN = 64;
 constexpr int COMB_HEADER_QUADS = 8;      // the allocation starts one cache line before the first entry; tab[-1] is the header
-__global__ void __launch_bounds__(NT) k_build_fixed_table(const u32* bases, int bits, uint4* tab, u32* scratch /* [COMB_RUN][10][lanes] */) {
+__global__ void __launch_bounds__(NT) k_build_fixed_table(const u32* bases, int bits, uint4* tab, u32* scratch /* [COMB_RUN][EG_NL][lanes] */) {
   const int windows = comb_windows(bits), entries = comb_entries(bits), runs = entries / COMB_RUN;
   const size_t lanes = (size_t)windows * runs;
   const size_t lane = (size_t)blockIdx.x * NT + threadIdx.x;
   if (lane == 0) tab[-1] = make_uint4((u32)bits, (u32)windows, (u32)entries, 0u);
   if (lane >= lanes) return;
   const int w = (int)(lane / runs), k0 = (int)(lane % runs) * COMB_RUN + 1;
-  u32 bw[40];
+  u32 bw[PT_WORDS];
 #pragma unroll 1
-  for (int i = 0; i < 40; ++i) bw[i] = bases[w * 40 + i];
+  for (int i = 0; i < PT_WORDS; ++i) bw[i] = bases[w * PT_WORDS + i];
   ge p; words_to_ge(p, bw);
   ge_cached pc; ge_to_cached(pc, p);
   ge q; ge_identity(q);
@@ -630,12 +616,13 @@ __global__ void __launch_bounds__(NT) k_build_fixed_table(const u32* bases, int 
   for (int i = 0; i < COMB_RUN; ++i) {
     u32 o[32];
 #pragma unroll
-    for (int j = 0; j < 10; ++j) { o[j] = q.X.v[j]; o[10 + j] = q.Y.v[j]; o[20 + j] = q.Z.v[j]; }
-    o[30] = 0; o[31] = 0;
+    for (int j = 0; j < EG_NL; ++j) { o[j] = q.X.v[j]; o[EG_NL + j] = q.Y.v[j]; o[2 * EG_NL + j] = q.Z.v[j]; }
+#pragma unroll
+    for (int j = 3 * EG_NL; j < 32; ++j) o[j] = 0;
 #pragma unroll
     for (int qd = 0; qd < 8; ++qd) slot[(size_t)i * 8 + qd] = make_uint4(o[4 * qd], o[4 * qd + 1], o[4 * qd + 2], o[4 * qd + 3]);
 #pragma unroll
-    for (int j = 0; j < 10; ++j) scratch[((size_t)i * 10 + j) * lanes + lane] = prod.v[j];     // product of the Z's before entry i
+    for (int j = 0; j < EG_NL; ++j) scratch[((size_t)i * EG_NL + j) * lanes + lane] = prod.v[j];     // product of the Z's before entry i
     fe t; fe_mul(t, prod, q.Z); prod = t;
     if (i + 1 < COMB_RUN) { ge_p1p1 s; ge_add(s, q, pc); ge_add_to_p3(q, s); }
   }
@@ -653,7 +640,7 @@ __global__ void __launch_bounds__(NT) k_build_fixed_table(const u32* bases, int 
     fe X, Y, Z, pre;
     fe_0(X); fe_0(Y); fe_0(Z); fe_0(pre);
 #pragma unroll
-    for (int j = 0; j < 10; ++j) { X.v[j] = o[j]; Y.v[j] = o[10 + j]; Z.v[j] = o[20 + j]; pre.v[j] = scratch[((size_t)i * 10 + j) * lanes + lane]; }
+    for (int j = 0; j < EG_NL; ++j) { X.v[j] = o[j]; Y.v[j] = o[EG_NL + j]; Z.v[j] = o[2 * EG_NL + j]; pre.v[j] = scratch[((size_t)i * EG_NL + j) * lanes + lane]; }
     fe zi, t, x, y;
     fe_mul(zi, inv, pre);                 // 1 / Z_i
     fe_mul(t, inv, Z); inv = t;           // inverse of the product before entry i
@@ -665,15 +652,16 @@ __global__ void __launch_bounds__(NT) k_build_fixed_table(const u32* bases, int 
     fe_mul(n.xy2d, x, y);
     fe_mul(n.xy2d, n.xy2d, d2);
 #pragma unroll
-    for (int j = 0; j < 10; ++j) { o[j] = n.ypx.v[j]; o[10 + j] = n.ymx.v[j]; o[20 + j] = n.xy2d.v[j]; }
-    o[30] = 0; o[31] = 0;
+    for (int j = 0; j < EG_NL; ++j) { o[j] = n.ypx.v[j]; o[EG_NL + j] = n.ymx.v[j]; o[2 * EG_NL + j] = n.xy2d.v[j]; }
+#pragma unroll
+    for (int j = 3 * EG_NL; j < 32; ++j) o[j] = 0;
 #pragma unroll
     for (int qd = 0; qd < 8; ++qd) slot[(size_t)i * 8 + qd] = make_uint4(o[4 * qd], o[4 * qd + 1], o[4 * qd + 2], o[4 * qd + 3]);
   }
 }
 // self-check of a comb table: sampled entries (and the corners of windows and runs) recomputed one by one, the way round 1 built every
 // entry ([k 2^(B w)]Base by doublings and a double-and-add, an inversion per entry), compared as canonical field elements
-__global__ void __launch_bounds__(NT) k_check_fixed_table(const u32* base_words /* 40 */, const uint4* tab, size_t samples, u64 seed,
+__global__ void __launch_bounds__(NT) k_check_fixed_table(const u32* base_words /* PT_WORDS */, const uint4* tab, size_t samples, u64 seed,
                                                           unsigned long long* mismatches) {
   const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
   if (i >= samples) return;
@@ -686,8 +674,8 @@ __global__ void __launch_bounds__(NT) k_check_fixed_table(const u32* base_words 
   const size_t corners[8] = {0, 1, COMB_RUN - 1, COMB_RUN, (size_t)entries - 1, (size_t)entries, total - COMB_RUN, total - 1};
   if (i < 8) idx = corners[i];
   const int w = (int)(idx / entries), k = (int)(idx % entries) + 1;
-  u32 bw[40];
-  for (int j = 0; j < 40; ++j) bw[j] = base_words[j];
+  u32 bw[PT_WORDS];
+  for (int j = 0; j < PT_WORDS; ++j) bw[j] = base_words[j];
   ge p; words_to_ge(p, bw);
 #pragma unroll 1
   for (int j = 0; j < bits * w; ++j) { ge d; ge_dbl_full(d, p); p = d; }
@@ -707,15 +695,15 @@ __global__ void __launch_bounds__(NT) k_check_fixed_table(const u32* base_words 
 __global__ void k_setup_points(const u32* pk_words, u32* out_words, u32* flags) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   ge g; ge_generator(g);
-  u32 w[40]; ge_to_words(w, g);
-  for (int i = 0; i < 40; ++i) out_words[i] = w[i];
+  u32 w[PT_WORDS]; ge_to_words(w, g);
+  for (int i = 0; i < PT_WORDS; ++i) out_words[i] = w[i];
   if (pk_words) {
     u32 pw[8];
     for (int i = 0; i < 8; ++i) pw[i] = pk_words[i];
     ge k;
     const bool ok = ristretto_decode(k, pw);
     ge_to_words(w, k);
-    for (int i = 0; i < 40; ++i) out_words[40 + i] = w[i];
+    for (int i = 0; i < PT_WORDS; ++i) out_words[PT_WORDS + i] = w[i];
     flags[0] = ok ? 1u : 0u;
     flags[1] = (fe_iszero(k.X) | fe_iszero(k.Y)) ? 1u : 0u;
   }
@@ -730,8 +718,8 @@ __global__ void __launch_bounds__(NT) k_const_points(const u64* mults, int n, co
   ge acc; ge_identity(acc);
   const FixedTable tg(tabG);
   ge_fixed_mul_add(acc, tg, dg);
-  u32 w[40]; ge_to_words(w, acc);
-  for (int q = 0; q < 10; ++q) cpts[(size_t)i * 10 + q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+  u32 w[PT_WORDS]; ge_to_words(w, acc);
+  for (int q = 0; q < PT_QUADS; ++q) cpts[(size_t)i * PT_QUADS + q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
 }
 
 // ---- primitive tier kernels (AoS 32-byte items, one lane per problem) ---------------------------------------------------------------------------------------

@@ -315,10 +315,10 @@ void hc_mul_generator_bits(int bits, const uint8_t r[32], uint8_t out[32]) {
   bytes_from_words(out, o, 8);
 }
 
-// pack / unpack of a field element given as 10 raw limbs (any class-1 representation, not only the canonical one): returns 1 when
+// pack / unpack of a field element given as EG_NL raw limbs (any class-1 representation, not only the canonical one): returns 1 when
 // the unpacked element equals the input as a field element; out = its canonical bytes
-int hc_fe_pack_roundtrip(const uint32_t limbs[10], uint8_t out[32]) {
-  fe f; for (int i = 0; i < 10; ++i) f.v[i] = limbs[i];
+int hc_fe_pack_roundtrip(const uint32_t limbs[EG_NL], uint8_t out[32]) {
+  fe f; for (int i = 0; i < EG_NL; ++i) f.v[i] = limbs[i];
   EG_SETCLS(f, 1.0f);
   u32 w[8], o[8]; fe_pack8(w, f);
   fe g; fe_unpack8(g, w);

@@ -33,7 +33,7 @@ def _b(n=32):
 
 def test_field_ops(hc):
     rnd = random.Random(1)
-    edge = [0, 1, 2, P - 1, P - 2, 2**255 - 20, 2**254, (1 << 255) - 1, 19, 2**26 - 1, 2**51 - 1]
+    edge = [0, 1, 2, P - 1, P - 2, 2**255 - 20, 2**254, (1 << 255) - 1, 19, 2**29 - 1, 2**57 - 1, 2**227, 2**228 - 1]
     vals = edge + [rnd.randrange(2**255) for _ in range(100)]
     for a in vals:
         out = _b()
@@ -55,14 +55,17 @@ def test_packed_field_elements(hc):
     """fe_pack8 / fe_unpack8 (the 128-byte table entries): any class-1 limb vector - limbs at their maxima, limb 1 a hair above, values
     just below and above p and 2^255 - comes back as the same field element, with every limb inside its bounds (asserted in the build)."""
     rnd = random.Random(12)
-    top = [(1 << 26) - 1 if i % 2 == 0 else (1 << 25) - 1 for i in range(10)]
-    cases = [[0] * 10, top, [top[0], (1 << 25) + 12000] + top[2:], [1] + [0] * 9, [0] * 9 + [(1 << 25) - 1], [(1 << 26) - 19] + top[1:]]
+    width = [29 if i % 3 == 0 else 28 for i in range(9)]
+    top = [(1 << w) - 1 for w in width]
+    cases = [[0] * 9, top, [top[0], (1 << 28) + 2500] + top[2:], [1] + [0] * 8, [0] * 8 + [(1 << 28) - 1], [(1 << 29) - 19] + top[1:],
+             [0] * 8 + [1 << 28]]
     for _ in range(300):
-        cases.append([rnd.randrange(1 << 26) if i % 2 == 0 else rnd.randrange(1 << 25) for i in range(10)])
-    offs = [0, 26, 51, 77, 102, 128, 153, 179, 204, 230]
+        cases.append([rnd.randrange(1 << w) for w in width])
+    offs = [(85 * i + 2) // 3 for i in range(9)]
+    assert offs == [0, 29, 57, 85, 114, 142, 170, 199, 227]
     for limbs in cases:
         out = _b()
-        arr = (C.c_uint32 * 10)(*limbs)
+        arr = (C.c_uint32 * 9)(*limbs)
         assert hc.hc_fe_pack_roundtrip(arr, out) == 1, limbs
         assert int.from_bytes(out.raw, "little") == sum(l << o for l, o in zip(limbs, offs)) % P
 

@@ -1,17 +1,17 @@
-// Microbenchmark (measurement tool, not product): field / point arithmetic of the shipped representation (10 limbs, radix 2^25.5,
-// elastic_elgamal_amd/csrc/fe25519.cuh) against the 9-limb radix-2^(255/9) candidate (fe9.cuh), in the shape of the dominant loop:
+// Microbenchmark (measurement tool, not product): field / point arithmetic of the shipped representation (9 limbs, radix 2^(255/9),
+// elastic_elgamal_amd/csrc/fe25519.cuh) against the one of rounds 1-2 (10 limbs, radix 2^25.5, fe10.cuh), in the shape of the dominant loop:
 // one comb column = doubling -> extended point -> addition of a cached table entry (ge_teeth_mul, ge25519.cuh).
 // Cycles come from s_memtime inside the kernel (shader clock, so DVFS does not distort them); the clock itself from s_memrealtime
 // (100 MHz).  Outputs of the two representations are compared word for word (canonical encodings), so the bench is also a check.
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I elastic_elgamal_amd/csrc -o tools/ubench/field_bench tools/ubench/field_bench.hip
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I elastic_elgamal_amd/csrc -I tools/ubench -o tools/ubench/field_bench tools/ubench/field_bench.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstdint>
 #include <vector>
 #include <algorithm>
-#include "ge25519.cuh"
-#include "fe9.cuh"
+#include "ge25519.cuh"     // the shipped representation (namespace eg)
+#include "fe10.cuh"       // the representation of rounds 1-2 (namespace eg10)
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
 typedef uint32_t u32; typedef uint64_t u64;
 
@@ -58,22 +58,22 @@ __global__ void __launch_bounds__(256) k_sq_chain(u32* out, Stamp* st, u32 seed,
   for (int i = 0; i < 8; ++i) out[g * 16 + 8 + i] = o[i];
 }
 struct Ops10 {
+  static __device__ __forceinline__ void from_words(eg10::fe& h, const u32 w[8]) { eg10::fe_from_words(h, w); }
+  static __device__ __forceinline__ void to_words(u32 w[8], const eg10::fe& f) { eg10::fe_to_words(w, f); }
+  static __device__ __forceinline__ void mul(eg10::fe& h, const eg10::fe& f, const eg10::fe& g) { eg10::fe_mul(h, f, g); }
+  static __device__ __forceinline__ void sq(eg10::fe& h, const eg10::fe& f) { eg10::fe_sq(h, f); }
+};
+struct Ops9 {
   static __device__ __forceinline__ void from_words(eg::fe& h, const u32 w[8]) { eg::fe_from_words(h, w); }
   static __device__ __forceinline__ void to_words(u32 w[8], const eg::fe& f) { eg::fe_to_words(w, f); }
   static __device__ __forceinline__ void mul(eg::fe& h, const eg::fe& f, const eg::fe& g) { eg::fe_mul(h, f, g); }
   static __device__ __forceinline__ void sq(eg::fe& h, const eg::fe& f) { eg::fe_sq(h, f); }
 };
-struct Ops9 {
-  static __device__ __forceinline__ void from_words(eg9::fe& h, const u32 w[8]) { eg9::fe_from_words(h, w); }
-  static __device__ __forceinline__ void to_words(u32 w[8], const eg9::fe& f) { eg9::fe_to_words(w, f); }
-  static __device__ __forceinline__ void mul(eg9::fe& h, const eg9::fe& f, const eg9::fe& g) { eg9::fe_mul(h, f, g); }
-  static __device__ __forceinline__ void sq(eg9::fe& h, const eg9::fe& f) { eg9::fe_sq(h, f); }
-};
 
 // ---- comb columns: acc = 2 acc + (+-entry), as ge_teeth_mul does (entry kept in registers; sign from a per-lane word) ----------
 template <int WAVES>
 __global__ void __launch_bounds__(256, WAVES) k_columns10(u32* out, Stamp* st, u32 seed, int iters) {
-  using namespace eg;
+  using namespace eg10;
   u32 w[8];
   ge_cached e;
   seed_words(w, seed, 3); fe_from_words(e.YpX, w);
@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(256, WAVES) k_columns10(u32* out, Stamp* st, u
 }
 template <int WAVES>
 __global__ void __launch_bounds__(256, WAVES) k_columns9(u32* out, Stamp* st, u32 seed, int iters) {
-  using namespace eg9;
+  using namespace eg;
   u32 w[8];
   ge_cached e;
   seed_words(w, seed, 3); fe_from_words(e.YpX, w);
@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(256, WAVES) k_columns9(u32* out, Stamp* st, u3
 // doubling chains (the table build: 215 doublings per base)
 template <int WAVES>
 __global__ void __launch_bounds__(256, WAVES) k_dbl10(u32* out, Stamp* st, u32 seed, int iters) {
-  using namespace eg;
+  using namespace eg10;
   u32 w[8]; ge_p2 q;
   seed_words(w, seed, 7); fe_from_words(q.X, w);
   seed_words(w, seed, 8); fe_from_words(q.Y, w);
@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(256, WAVES) k_dbl10(u32* out, Stamp* st, u32 s
 }
 template <int WAVES>
 __global__ void __launch_bounds__(256, WAVES) k_dbl9(u32* out, Stamp* st, u32 seed, int iters) {
-  using namespace eg9;
+  using namespace eg;
   u32 w[8]; ge_p2 q;
   seed_words(w, seed, 7); fe_from_words(q.X, w);
   seed_words(w, seed, 8); fe_from_words(q.Y, w);
@@ -220,16 +220,16 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&d_st, sizeof(Stamp) * cus * 8 * 4));
   struct Case { const char* name; kern_t k10, k9; int iters; int ops_per_iter; int words; int w; };
   const Case cases[] = {
-    {"fe_mul chain", k_mul_chain<eg::fe, Ops10>, k_mul_chain<eg9::fe, Ops9>, 20000 * scale, 2, 16, 1},
-    {"fe_mul chain", k_mul_chain<eg::fe, Ops10>, k_mul_chain<eg9::fe, Ops9>, 20000 * scale, 2, 16, 2},
-    {"fe_mul chain", k_mul_chain<eg::fe, Ops10>, k_mul_chain<eg9::fe, Ops9>, 20000 * scale, 2, 16, 3},
-    {"fe_mul chain", k_mul_chain<eg::fe, Ops10>, k_mul_chain<eg9::fe, Ops9>, 20000 * scale, 2, 16, 4},
-    {"fe_mul chain", k_mul_chain<eg::fe, Ops10>, k_mul_chain<eg9::fe, Ops9>, 15000 * scale, 2, 16, 6},
-    {"fe_mul chain", k_mul_chain<eg::fe, Ops10>, k_mul_chain<eg9::fe, Ops9>, 10000 * scale, 2, 16, 8},
-    {"fe_sq chain", k_sq_chain<eg::fe, Ops10>, k_sq_chain<eg9::fe, Ops9>, 20000 * scale, 2, 16, 2},
-    {"fe_sq chain", k_sq_chain<eg::fe, Ops10>, k_sq_chain<eg9::fe, Ops9>, 20000 * scale, 2, 16, 3},
-    {"fe_sq chain", k_sq_chain<eg::fe, Ops10>, k_sq_chain<eg9::fe, Ops9>, 20000 * scale, 2, 16, 4},
-    {"fe_sq chain", k_sq_chain<eg::fe, Ops10>, k_sq_chain<eg9::fe, Ops9>, 10000 * scale, 2, 16, 8},
+    {"fe_mul chain", k_mul_chain<eg10::fe, Ops10>, k_mul_chain<eg::fe, Ops9>, 20000 * scale, 2, 16, 1},
+    {"fe_mul chain", k_mul_chain<eg10::fe, Ops10>, k_mul_chain<eg::fe, Ops9>, 20000 * scale, 2, 16, 2},
+    {"fe_mul chain", k_mul_chain<eg10::fe, Ops10>, k_mul_chain<eg::fe, Ops9>, 20000 * scale, 2, 16, 3},
+    {"fe_mul chain", k_mul_chain<eg10::fe, Ops10>, k_mul_chain<eg::fe, Ops9>, 20000 * scale, 2, 16, 4},
+    {"fe_mul chain", k_mul_chain<eg10::fe, Ops10>, k_mul_chain<eg::fe, Ops9>, 15000 * scale, 2, 16, 6},
+    {"fe_mul chain", k_mul_chain<eg10::fe, Ops10>, k_mul_chain<eg::fe, Ops9>, 10000 * scale, 2, 16, 8},
+    {"fe_sq chain", k_sq_chain<eg10::fe, Ops10>, k_sq_chain<eg::fe, Ops9>, 20000 * scale, 2, 16, 2},
+    {"fe_sq chain", k_sq_chain<eg10::fe, Ops10>, k_sq_chain<eg::fe, Ops9>, 20000 * scale, 2, 16, 3},
+    {"fe_sq chain", k_sq_chain<eg10::fe, Ops10>, k_sq_chain<eg::fe, Ops9>, 20000 * scale, 2, 16, 4},
+    {"fe_sq chain", k_sq_chain<eg10::fe, Ops10>, k_sq_chain<eg::fe, Ops9>, 10000 * scale, 2, 16, 8},
     {"doubling (4S+3M) regs for 2", k_dbl10<2>, k_dbl9<2>, 6000 * scale, 1, 24, 2},
     {"doubling (4S+3M) regs for 3", k_dbl10<3>, k_dbl9<3>, 6000 * scale, 1, 24, 3},
     {"doubling (4S+3M) regs for 4", k_dbl10<4>, k_dbl9<4>, 6000 * scale, 1, 24, 4},
