@@ -33,7 +33,8 @@ sys.path.insert(0, str(ROOT))
 PUBLIC_KEY_HEX = "a6adb6e9c0ae8d54c26e6e56b5ccd7a16bb0e1951abe4d7ee7028e3d4eca8531"  # seed-12345 key of the snapshots
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # VALU model: field operations per building block counted by the host-check build
-# (tests/hostcheck: hc_op_counts) as (fe_mul, fe_sq); one fe_mul = 100 and one fe_sq = 55 v_mad_u64_u32.
+# (tests/hostcheck: hc_op_counts) as (fe_mul, fe_sq); one fe_mul issues 98 and one fe_sq 62 v_mad_u64_u32 (fe25519.cuh: 81 / 45 limb
+# products + 16 to fold the high columns + 1 for the top carry).
 OPS = {"decode": (27, 257), "direct_table": (64, 0), "direct_mul": (1269, 1008), "comb": (91, 0), "encode": (32, 255),
        "base_table": (994, 860), "base_mul": (463, 168), "enc_batch_each": (23, 10), "enc_batch_inversion": (11, 254),
        "multi_first": (470, 168), "multi_extra": (344, 0), "sum_table_first": (296, 0), "sum_table_extra": (48, 0),
@@ -41,8 +42,11 @@ OPS = {"decode": (27, 257), "direct_table": (64, 0), "direct_mul": (1269, 1008),
 # memory-side traffic per ballot and launch of the profiled kernels comes from profiles/traffic.json, which
 # tools/profile_summary.py writes from the separate rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of tools/profile_round.sh
 TRAFFIC_JSON = ROOT / "profiles" / "traffic.json"
-MAD_PEAK_T = 33.4              # profiles/r01_ubench_valu_rates.txt: v_mad_u64_u32, 8 waves/SIMD, T lane-ops/s chip-wide
-FMUL_PEAK_G = 256.0            # profiles/r01_ubench_fmul_candidates.txt: radix-25.5 field multiply, G/s chip-wide
+MAD_PER_MUL, MAD_PER_SQ = 98, 62
+MAD_PEAK_T = 36.8              # profiles/r03_ubench_valu_rates.txt: v_mad_u64_u32 alone, 8 waves/SIMD, T lane-ops/s chip-wide from the wall
+                               # clock (4.2 issue cycles per wave64 instruction; 32.8 T at the two or three waves per SIMD the kernels hold)
+FMUL_PEAK_G = 275.0            # profiles/r03_ubench_field_bench.txt: the shipped field multiplication in a bare chain, G/s chip-wide
+SQ_WEIGHT = 0.74               # a squaring in the same bench: 372 G/s
 DOMINANT_KERNEL = "eg::k_eq_table<false>"   # one table-backed base + fixed-base combs: every ring equation (kernels.cuh)
 
 
@@ -321,7 +325,7 @@ def main():
     if True:
         narrow_bits, wide_bits = ctx.comb_table_bits()        # wide comb tables exist once an engine has seen 2^19 items
         fm, fs = plan_field_ops(desc, wide_combs=wide_bits != 0)
-        mads = fm * 100 + fs * 55
+        mads = fm * MAD_PER_MUL + fs * MAD_PER_SQ
         out["config"]["comb_bits"] = wide_bits or narrow_bits
         out["valu_roofline"] = {
             "bound": "valu-int-mad",
@@ -332,8 +336,9 @@ def main():
             "peak": MAD_PEAK_T,
             "unit": "T v_mad_u64_u32 lane-ops/s per GPU",
             "frac": value / world * mads / 1e12 / MAD_PEAK_T,
-            "fmul_equiv_frac": value / world * (fm + 0.6 * fs) / 1e9 / FMUL_PEAK_G,
-            "note": "algorithmic multiply-adds only (no carries, adds, selects, hashing); peaks measured on this chip",
+            "fmul_equiv_frac": value / world * (fm + SQ_WEIGHT * fs) / 1e9 / FMUL_PEAK_G,
+            "note": "the multiply-adds of the field operations only (no carries, adds, selects, hashing); peaks measured on this chip: the "
+                    "instruction alone at 8 waves per SIMD, and the field multiplication in a bare chain (fmul_equiv_frac)",
         }
 
     # ---- PCIe-inclusive rate (first H2D byte to last status byte D2H): the same batch from a pinned host buffer

@@ -179,6 +179,35 @@ EG_HD void fe_reduce_columns(fe& h, u64 c[2 * EG_NL - 1]) {
   EG_SETCLS(h, 1.0f);
 }
 
+// One low column, finished: seed + its products are already in acc; adds the folds of the high columns, cuts the limb, returns the carry.
+// The carry of column k is the SEED of column k + 1's multiply-add chain (the addend of its first v_mad_u64_u32), so the carry chain
+// needs no 64-bit additions: per column one 64-bit shift and one mask.  (EG_FE_UNSEEDED: the independent-columns form measured against it.)
+#ifndef EG_FE_UNSEEDED
+// hipcc reassociates carry + sum of products into (sum of products) + carry, i.e. a chain seeded with 0 and a separate 64-bit add; the
+// empty asm pins "seed + first product" as one value, which selects to ONE v_mad_u64_u32 with the carry as its addend.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(EG_NO_SEED_FENCE)
+#define EG_SEED_FENCE(x) asm("" : "+v"(x))
+#else
+#define EG_SEED_FENCE(x) ((void)0)
+#endif
+#define EG_FE_COLUMNS_LOW(PRODUCTS)                                                                          \
+  u64 carry = 0;                                                                                            \
+  _Pragma("unroll") for (int k = 0; k < EG_NL; ++k) {                                                       \
+    u64 acc = carry;                                                                                        \
+    PRODUCTS                                                                                                \
+    if (k + EG_NL < 2 * EG_NL - 1) { acc += (u64)(u32)hc[k] * 19u; EG_SEED_FENCE(acc); }                    \
+    if (k >= 1) acc += (u64)(u32)(hc[k - 1] >> 32) * (19u << (32 - fe_w(k - 1)));                           \
+    h.v[k] = (u32)acc & fe_mask(k);                                                                         \
+    carry = acc >> fe_w(k);                                                                                 \
+  }                                                                                                         \
+  {                                                                                                         \
+    u64 c0 = (u64)h.v[0] + 19ull * carry;          /* carry < 2^36: wraps around to limb 0 times 19 */      \
+    h.v[0] = (u32)c0 & fe_mask(0);                                                                          \
+    h.v[1] += (u32)(c0 >> 29);                                                                              \
+  }                                                                                                         \
+  EG_SETCLS(h, 1.0f);
+#endif
+
 EG_HD void fe_mul(fe& h, const fe& f, const fe& g) {
   EG_REQUIRE(EG_GETCLS(f) * EG_GETCLS(g) <= 12.5f, "fe_mul: class product > 12.5");
   EG_REQUIRE(EG_GETCLS(f) <= 7.9f && EG_GETCLS(g) <= 7.9f, "fe_mul: operand class > 7.9");
@@ -188,6 +217,7 @@ EG_HD void fe_mul(fe& h, const fe& f, const fe& g) {
   u32 f2[EG_NL];
 #pragma unroll
   for (int i = 0; i < EG_NL; ++i) f2[i] = (i % 3 != 0) ? fe_twice(f.v[i]) : 0u;
+#ifdef EG_FE_UNSEEDED
   u64 c[2 * EG_NL - 1];
 #pragma unroll
   for (int k = 0; k < 2 * EG_NL - 1; ++k) {
@@ -201,6 +231,27 @@ EG_HD void fe_mul(fe& h, const fe& f, const fe& g) {
     c[k] = acc;
   }
   fe_reduce_columns(h, c);
+#else
+  u64 hc[EG_NL - 1];                        // columns 9..16
+#pragma unroll
+  for (int k = EG_NL; k < 2 * EG_NL - 1; ++k) {
+    u64 acc = 0;
+#pragma unroll
+    for (int i = k - EG_NL + 1; i < EG_NL; ++i) acc += (u64)(fe_dbl(i, k - i) ? f2[i] : f.v[i]) * g.v[k - i];
+    hc[k - EG_NL] = acc;
+  }
+  fe r;                                     // h may alias f or g
+  {
+    fe& h = r;
+    EG_FE_COLUMNS_LOW(
+      _Pragma("unroll") for (int i = 0; i <= k; ++i) {
+        acc += (u64)(fe_dbl(i, k - i) ? f2[i] : f.v[i]) * g.v[k - i];
+        EG_SEED_FENCE(acc);
+      }
+    )
+  }
+  h = r;
+#endif
   EG_SCHED_FENCE();
 }
 
@@ -212,6 +263,7 @@ EG_HD void fe_sq(fe& h, const fe& f) {
   u32 d[EG_NL];
 #pragma unroll
   for (int i = 0; i < EG_NL; ++i) d[i] = fe_twice(f.v[i]);
+#ifdef EG_FE_UNSEEDED
   u64 c[2 * EG_NL - 1];
 #pragma unroll
   for (int k = 0; k < 2 * EG_NL - 1; ++k) {
@@ -226,6 +278,30 @@ EG_HD void fe_sq(fe& h, const fe& f) {
     c[k] = acc;
   }
   fe_reduce_columns(h, c);
+#else
+#define EG_SQ_TERMS(K)                                                                                      \
+  _Pragma("unroll") for (int i = 0; i < EG_NL; ++i) {                                                       \
+    const int j = (K) - i;                                                                                  \
+    if (j < i || j >= EG_NL) continue;                                                                      \
+    if (i == j) acc += (u64)(fe_dbl(i, i) ? d[i] : f.v[i]) * f.v[i];                                        \
+    else acc += (u64)d[i] * (fe_dbl(i, j) ? d[j] : f.v[j]);          /* cross terms count twice */          \
+    EG_SEED_FENCE(acc);                                                                                     \
+  }
+  u64 hc[EG_NL - 1];
+#pragma unroll
+  for (int k = EG_NL; k < 2 * EG_NL - 1; ++k) {
+    u64 acc = 0;
+    EG_SQ_TERMS(k)
+    hc[k - EG_NL] = acc;
+  }
+  fe r;
+  {
+    fe& h = r;
+    EG_FE_COLUMNS_LOW(EG_SQ_TERMS(k))
+  }
+  h = r;
+#undef EG_SQ_TERMS
+#endif
   EG_SCHED_FENCE();
 }
 

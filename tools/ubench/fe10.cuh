@@ -200,6 +200,11 @@ E10 void ge_dbl(ge_p1p1& r, const fe& X, const fe& Y, const fe& Z) {
   fe_sub4(r.T, b2, r.Z);
   fe_carry(r.T);
 }
+E10 void ge_dbl_to_p2(ge_p2& r, const ge_p1p1& p) {
+  fe_mul(r.X, p.X, p.T);
+  fe_mul(r.Y, p.Z, p.Y);
+  fe_mul(r.Z, p.Z, p.T);
+}
 E10 void ge_dbl_to_p3(ge& r, const ge_p1p1& p) {
   fe_mul(r.X, p.X, p.T);
   fe_mul(r.Y, p.Z, p.Y);

@@ -7,7 +7,10 @@
 //     (s_memtime / s_memrealtime x 100 MHz),
 //   * times every instruction in two operand shapes: all sources in VGPRs ("vvv") and one source an SGPR / inline constant ("vvs"),
 //     because a three-VGPR-source VOP3 can cost a second operand-read cycle.
-// cycles per wave-instruction per SIMD = median wave cycles / (instructions per wave x waves per SIMD).
+// Reported per instruction and occupancy: issue cycles per wave-instruction and SIMD FROM THE WALL CLOCK (kernel time x measured clock
+// / instructions issued on a SIMD) and the chip-wide rate in T lane-ops/s; the median wave's own s_memtime span is printed beside it
+// ("wave"): it reads LOWER than the wall-clock figure above two waves per SIMD because issue is arbitrated oldest-first, so older
+// waves finish early and the kernel's tail runs at lower occupancy - the wall-clock figure is the throughput.
 // Build: hipcc --offload-arch=gfx950 -O3 -o tools/ubench/valu_rates tools/ubench/valu_rates.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -171,7 +174,7 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   printf("%-30s", "instruction");
   const int wlist[] = {1, 2, 4, 8};
-  for (int w : wlist) printf(" | w/SIMD=%d cyc/instr  GHz   ms", w);
+  for (int w : wlist) printf(" | w/SIMD=%d: cyc  T-op/s (wave cyc, GHz)", w);
   printf("\n");
   for (auto& e : es) {
     printf("%-30s", e.name);
@@ -192,8 +195,11 @@ int main(int argc, char** argv) {
       std::vector<double> cyc(waves), ghz(waves);
       for (int i = 0; i < waves; ++i) { cyc[i] = (double)st[i].cyc; ghz[i] = (double)st[i].cyc / ((double)st[i].rt * 10.0); }
       std::sort(cyc.begin(), cyc.end()); std::sort(ghz.begin(), ghz.end());
-      const double n_instr = (double)iters * UNROLL * CHAINS * e.instr_per_step;
-      printf(" | %10.2f        %5.2f %6.1f", cyc[waves / 2] / n_instr / w, ghz[waves / 2], ms);
+      const double n_instr = (double)iters * UNROLL * CHAINS * e.instr_per_step;      // per wave
+      const double clock = ghz[waves / 2] * 1e9;
+      const double wall_cyc = ms * 1e-3 * clock / (n_instr * w);
+      const double tops = n_instr * w * 64.0 * cus * 4 / (ms * 1e-3) / 1e12;
+      printf(" | %6.2f %7.2f (%5.2f, %4.2f)       ", wall_cyc, tops, cyc[waves / 2] / n_instr / w, ghz[waves / 2]);
     }
     printf("\n");
   }
