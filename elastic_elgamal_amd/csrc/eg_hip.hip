@@ -152,9 +152,6 @@ struct Engine {
   egplan::SumBase* d_sum_bases = nullptr;
   unsigned short* d_sum_members = nullptr;
   unsigned short* d_defer_slots = nullptr;
-  uint4* btab = nullptr;
-  uint4* dpt = nullptr;
-  u32* encw = nullptr;
   int max_defer = 0;
   unsigned char* d_blob = nullptr;
   uint4 *d_tabK = nullptr, *d_cpts = nullptr;   // d_tabK: comb table of the election key (first entry; see comb_table_build)
@@ -166,13 +163,25 @@ struct Engine {
   std::vector<StageDev> stages;
   std::vector<LevelDev> levels;
   int prefix_inst_first = 0, prefix_inst_count = 0;
-  // chunk workspace
+  // Chunk workspace: TWO sets, each with its own stream.  Consecutive chunks of a call alternate between the sets, so that the launch
+  // tail of one chunk's kernels (the last blocks of a grid leave most CUs idle) is filled by the other chunk's kernels; the sets join
+  // the caller's stream at the end of the call (fork / join with events).  Set 1 tallies into its own accumulator, which the join
+  // adds to the running tally: the order of the additions is fixed by the code, not by timing.  (EG_STREAMS=1: one set, one stream.)
+  struct WorkSet {
+    uint4 *pts = nullptr, *cmp = nullptr, *chal = nullptr;
+    u32 *states = nullptr, *flags = nullptr, *bad_item = nullptr;
+    uint4 *btab = nullptr, *dpt = nullptr;
+    u32* encw = nullptr;
+    u32* partial = nullptr;
+    u32* tally = nullptr;      // set 0: the engine's running tally; set 1: this call's share, added to set 0's at the join
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+  } set[2];
+  int n_sets = 2;
+  hipEvent_t fork = nullptr;
   u32 cap = 0, max_cap = 0;
-  uint4 *pts = nullptr, *cmp = nullptr, *chal = nullptr;
-  u32 *states = nullptr, *flags = nullptr, *bad_item = nullptr;
-  u32* partial = nullptr;
   int tally_blocks = 64;
-  u32* tally = nullptr;        // [2n][PT_WORDS] running tally (extended points)
+  u32* tally = nullptr;        // [2n][PT_WORDS] running tally (extended points) = set[0].tally
   u32* tally_saved = nullptr;  // [2n][PT_WORDS] the running tally set aside while a host call computes its per-batch tally
   u32* tally_saved2 = nullptr; // the same for the JSON entry points, which call the host form piece by piece
   uint8_t* json_stage[2] = {nullptr, nullptr};     // pinned staging of the JSON entry points (two windows in flight)
@@ -210,32 +219,41 @@ static int gen_workspace(Engine* e, size_t n, unsigned words, int* blocks_out) {
 static void engine_free(Engine* e) {
   if (!e) return;
   void* ptrs[] = {e->d_pt_items, e->d_sc_items, e->d_dclasses, e->d_dterms, e->d_jobs, e->d_vterms, e->d_insts, e->d_ops,
-                  e->d_rules, e->d_tally_slots, e->d_base_slots, e->d_sum_bases, e->d_sum_members, e->d_defer_slots, e->btab, e->dpt, e->encw, e->d_blob, e->d_cpts, e->d_prefixes, e->d_key_words, e->pts, e->cmp,
-                  e->chal, e->states, e->flags, e->bad_item, e->partial, e->tally, e->tally_saved, e->tally_saved2, e->d_wire, e->d_status, e->gen_ws, e->d_gen_desc};
+                  e->d_rules, e->d_tally_slots, e->d_base_slots, e->d_sum_bases, e->d_sum_members, e->d_defer_slots, e->d_blob, e->d_cpts, e->d_prefixes, e->d_key_words,
+                  e->tally_saved, e->tally_saved2, e->d_wire, e->d_status, e->gen_ws, e->d_gen_desc};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  for (auto& w : e->set) {
+    void* sp[] = {w.pts, w.cmp, w.chal, w.states, w.flags, w.bad_item, w.btab, w.dpt, w.encw, w.partial, w.tally};
+    for (void* p : sp) if (p) (void)hipFree(p);
+    if (w.stream) (void)hipStreamDestroy(w.stream);
+    if (w.done) (void)hipEventDestroy(w.done);
+  }
+  if (e->fork) (void)hipEventDestroy(e->fork);
   comb_table_free(e->d_tabK); comb_table_free(e->d_tabK_big);
   if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
   for (uint8_t* p : e->json_stage) if (p) (void)hipHostFree(p);
   delete e;
 }
 
-static EngineBufs make_bufs(const Engine* e, const void* d_ballots, u32 n, void* d_status) {
+static EngineBufs make_bufs(const Engine* e, int set, const void* d_ballots, u32 n, void* d_status) {
+  const Engine::WorkSet& w = e->set[set];
   EngineBufs B;
   B.wire = reinterpret_cast<const u32*>(d_ballots);
   B.stride_words = (u32)(e->plan.stride / 4);
   B.n = n;
   B.cap = e->cap;
-  B.pts = e->pts; B.cmp = e->cmp; B.chal = e->chal; B.states = e->states; B.flags = e->flags; B.bad_item = e->bad_item;
+  B.pts = w.pts; B.cmp = w.cmp; B.chal = w.chal; B.states = w.states; B.flags = w.flags; B.bad_item = w.bad_item;
   B.status = reinterpret_cast<u32*>(d_status);
   B.tabG = e->use_big ? e->ctx->tabG_big : e->ctx->tabG; B.tabK = e->use_big ? e->d_tabK_big : e->d_tabK; B.cpts = e->d_cpts; B.prefixes = e->d_prefixes; B.blob = e->d_blob;
-  B.ws = e->ctx->ws;
-  B.btab = e->btab;
-  B.dpt = e->dpt;
-  B.encw = e->encw;
+  // each set works in its own part of the context's per-lane workspace (the grids of its kernels are 1 / n_sets of msm_blocks)
+  B.ws = e->ctx->ws + (size_t)set * (e->ctx->msm_blocks / e->n_sets) * WS_QUADS * NT;
+  B.btab = w.btab;
+  B.dpt = w.dpt;
+  B.encw = w.encw;
   return B;
 }
 
-// bytes of chunk workspace per ballot (the buffers engine_reserve allocates)
+// bytes of chunk workspace per ballot of ONE work set (the buffers engine_reserve allocates for it)
 static size_t engine_bytes_per_ballot(const Engine* e) {
   const eghost::Plan& P = e->plan;
   const size_t pt = (size_t)PT_WORDS * sizeof(u32);
@@ -244,15 +262,20 @@ static size_t engine_bytes_per_ballot(const Engine* e) {
          std::max<size_t>(P.n_tables(), 1) * BTAB_QUADS * 16 + (size_t)std::max(e->max_defer, 1) * 2 * EG_NL * sizeof(u32);
 }
 
-// (re)allocate the per-chunk SoA buffers for chunks of up to `want` ballots
+// (re)allocate the per-chunk SoA buffers of every work set for chunks of up to `want` ballots
+static void engine_release_sets(Engine* e) {
+  for (auto& w : e->set) {
+    void** bufs[] = {(void**)&w.pts, (void**)&w.cmp, (void**)&w.chal, (void**)&w.states, (void**)&w.flags, (void**)&w.bad_item,
+                     (void**)&w.btab, (void**)&w.dpt, (void**)&w.encw};
+    for (void** b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
+  }
+  e->cap = 0;
+}
 static int engine_reserve(Engine* e, u32 want) {
   if (want <= e->cap) return EG_OK;
   const eghost::Plan& P = e->plan;
   HIPCHK(hipDeviceSynchronize());   // earlier batches may still be running on a caller's stream
-  void** bufs[] = {(void**)&e->pts, (void**)&e->cmp, (void**)&e->chal, (void**)&e->states, (void**)&e->flags, (void**)&e->bad_item,
-                   (void**)&e->btab, (void**)&e->dpt, (void**)&e->encw};
-  for (void** b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
-  e->cap = 0;
+  engine_release_sets(e);
   const size_t cap = (want + NT - 1) / NT * NT;
   const size_t sizes[] = {(size_t)std::max(P.n_pt_slots, 1) * PT_QUADS * cap * sizeof(uint4),
                           (size_t)std::max(P.n_cmp_slots, 1) * 2 * cap * sizeof(uint4),
@@ -263,14 +286,19 @@ static int engine_reserve(Engine* e, u32 want) {
                           std::max<size_t>(P.n_tables(), 1) * cap * BTAB_QUADS * sizeof(uint4),
                           (size_t)std::max(P.n_cmp_slots, 1) * PT_QUADS * cap * sizeof(uint4),
                           (size_t)std::max(e->max_defer, 1) * 2 * EG_NL * cap * sizeof(u32)};
-  for (size_t i = 0; i < sizeof(sizes) / sizeof(sizes[0]); ++i) {
-    const hipError_t he = hipMalloc(bufs[i], sizes[i]);
-    if (he == hipErrorOutOfMemory) {        // the caller retries with smaller chunks
-      (void)hipGetLastError();
-      for (void** b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
-      return fail(EG_ERR_NOMEM, "device memory exhausted while reserving the chunk workspace");
+  for (int k = 0; k < e->n_sets; ++k) {
+    Engine::WorkSet& w = e->set[k];
+    void** bufs[] = {(void**)&w.pts, (void**)&w.cmp, (void**)&w.chal, (void**)&w.states, (void**)&w.flags, (void**)&w.bad_item,
+                     (void**)&w.btab, (void**)&w.dpt, (void**)&w.encw};
+    for (size_t i = 0; i < sizeof(sizes) / sizeof(sizes[0]); ++i) {
+      const hipError_t he = hipMalloc(bufs[i], sizes[i]);
+      if (he == hipErrorOutOfMemory) {        // the caller retries with smaller chunks
+        (void)hipGetLastError();
+        engine_release_sets(e);
+        return fail(EG_ERR_NOMEM, "device memory exhausted while reserving the chunk workspace");
+      }
+      HIPCHK(he);
     }
-    HIPCHK(he);
   }
   e->cap = (u32)cap;
   return EG_OK;
@@ -358,30 +386,43 @@ static int engine_create(eg_ctx* ctx, eghost::Plan&& plan, const uint8_t pk[32],
     (void)hipFree(d_m);
   }
 
-  // chunk workspace: sized lazily by engine_reserve() for the batches actually seen (up to EG_CHUNK ballots per chunk)
+  // chunk workspace: sized lazily by engine_reserve() for the batches actually seen (up to EG_CHUNK ballots per chunk and work set)
+  if (const char* v = getenv("EG_STREAMS")) e->n_sets = atoi(v) >= 2 ? 2 : 1;
   const char* env = getenv("EG_CHUNK");
-  e->max_cap = env ? (u32)strtoul(env, nullptr, 10) : 1048576u;
+  // Two work sets whose kernels fill each other's launch tails (profiles/r03_ab_experiments.txt, block 3; M single-choice ballots/s):
+  // one set of 2^20 ballots 6.06 (45 GB of workspace), one set of 2^18 5.81 (-4 %), two sets of 2^18 6.05 (24 GB), two sets of 2^19
+  // 6.13 (+1 %, 47 GB: the default), two sets of 2^17 5.90.  EG_CHUNK=262144 halves the memory for 1 % of the throughput.
+  e->max_cap = env ? (u32)strtoul(env, nullptr, 10) : (e->n_sets == 2 ? 524288u : 1048576u);
   {
-    // Chunks are large (default 2^20 ballots: ~50 GB of workspace for 5 options): a chunk of 250k ballots is ~20 rounds of the
-    // resident blocks per kernel and wastes most of its last round (measured 4.53 M ballots/s at 2^18 per chunk, 4.83 M/s at 2^20).  Large elections keep the
-    // workspace within half of the free device memory (~48 KB per ballot for 5 options, ~4.5 KB more per ring base).
+    // Large elections keep the workspace within half of the free device memory (~45 KB per ballot and set for 5 options).
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
-    const size_t limit = engine_bytes_per_ballot(e.get()) ? free_b / 2 / engine_bytes_per_ballot(e.get()) : e->max_cap;
+    const size_t per = engine_bytes_per_ballot(e.get()) * (size_t)e->n_sets;
+    const size_t limit = per ? free_b / 2 / per : e->max_cap;
     if (limit < e->max_cap) e->max_cap = (u32)(limit / NT * NT);
   }
   if (e->max_cap < NT) e->max_cap = NT;
   e->max_cap = (e->max_cap + NT - 1) / NT * NT;
-  HIPCHK(hipMalloc((void**)&e->partial, std::max<size_t>(P.tally_slots.size(), 1) * e->tally_blocks * PT_WORDS * sizeof(u32)));
-  HIPCHK(hipMalloc((void**)&e->tally, std::max<size_t>(P.tally_slots.size(), 1) * PT_WORDS * sizeof(u32)));
-  HIPCHK(hipMalloc((void**)&e->tally_saved, std::max<size_t>(P.tally_slots.size(), 1) * PT_WORDS * sizeof(u32)));
-  HIPCHK(hipMalloc((void**)&e->tally_saved2, std::max<size_t>(P.tally_slots.size(), 1) * PT_WORDS * sizeof(u32)));
+  const size_t tally_bytes = std::max<size_t>(P.tally_slots.size(), 1) * PT_WORDS * sizeof(u32);
+  for (int k = 0; k < e->n_sets; ++k) {
+    Engine::WorkSet& w = e->set[k];
+    HIPCHK(hipMalloc((void**)&w.partial, tally_bytes * e->tally_blocks));
+    HIPCHK(hipMalloc((void**)&w.tally, tally_bytes));
+    hipLaunchKernelGGL(k_tally_init, dim3(blocks_of(P.tally_slots.size())), dim3(NT), 0, s, w.tally, (int)P.tally_slots.size());
+    if (e->n_sets > 1) {
+      HIPCHK(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+      HIPCHK(hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
+    }
+  }
+  if (e->n_sets > 1) HIPCHK(hipEventCreateWithFlags(&e->fork, hipEventDisableTiming));
+  e->tally = e->set[0].tally;
+  HIPCHK(hipMalloc((void**)&e->tally_saved, tally_bytes));
+  HIPCHK(hipMalloc((void**)&e->tally_saved2, tally_bytes));
   HIPCHK(hipMalloc((void**)&e->d_prefixes, (size_t)std::max(P.n_prefixes, 1) * 52 * sizeof(u32)));
-  hipLaunchKernelGGL(k_tally_init, dim3(blocks_of(P.tally_slots.size())), dim3(NT), 0, s, e->tally, (int)P.tally_slots.size());
 
   // hoisted transcript prefixes: run the prefix programs once (a single lane each)
   if (e->prefix_inst_count) {
-    EngineBufs B = make_bufs(e.get(), nullptr, 1, nullptr);
+    EngineBufs B = make_bufs(e.get(), 0, nullptr, 1, nullptr);
     hipLaunchKernelGGL(k_hash, dim3(grid_for(e->prefix_inst_count, 1 << 20)), dim3(NT), 0, s, B, e->d_insts, e->d_ops,
                        e->prefix_inst_first, e->prefix_inst_count);
   }
@@ -420,75 +461,103 @@ static int engine_verify_device(Engine* e, size_t n, const void* d_ballots, void
   if (e->items_seen >= ctx->big_min && (rc = ensure_big_tables(e, s))) return rc;
   e->use_big = e->d_tabK_big != nullptr && ctx->tabG_big != nullptr;
   if ((rc = prof_begin(ctx, s, PROF_CALL, &all_idx))) return rc;
-  // equal-sized chunks (each a multiple of the block size) so that the persistent grids stay balanced on the last chunk
-  size_t n_chunks = (n + e->max_cap - 1) / e->max_cap;
+  // equal-sized chunks (each a multiple of the block size) so that the persistent grids stay balanced on the last chunk; with two
+  // work sets a batch that is worth splitting gets an even number of chunks, so that both streams carry the same load
+  const bool two = e->n_sets == 2 && n >= (size_t)ctx->resident_blocks * NT / 2;
+  auto chunks_for = [&](size_t cap) {
+    size_t k = (n + cap - 1) / cap;
+    if (two) k = std::max<size_t>(2, (k + 1) / 2 * 2);
+    return k;
+  };
+  size_t n_chunks = chunks_for(e->max_cap);
   while (n) {
     const int rr = engine_reserve(e, (u32)(((n + n_chunks - 1) / n_chunks + NT - 1) / NT * NT));
     if (rr == EG_OK) break;
     if (rr != EG_ERR_NOMEM || e->max_cap <= 16 * NT) return rr;
     e->max_cap = (e->max_cap / 2 + NT - 1) / NT * NT;    // other allocations took the memory this engine counted on: halve the chunks
-    n_chunks = (n + e->max_cap - 1) / e->max_cap;
+    n_chunks = chunks_for(e->max_cap);
   }
   const size_t even = n_chunks ? ((n + n_chunks - 1) / n_chunks + NT - 1) / NT * NT : 0;
-  for (size_t off = 0; off < n; off += even) {
+  if (two) {                 // fork: both work sets start after whatever the caller's stream holds so far
+    HIPCHK(hipEventRecord(e->fork, s));
+    for (int k = 0; k < 2; ++k) HIPCHK(hipStreamWaitEvent(e->set[k].stream, e->fork, 0));
+  }
+  const int msm_blocks = ctx->msm_blocks / (two ? 2 : 1);
+  size_t chunk = 0;
+  for (size_t off = 0; off < n; off += even, ++chunk) {
+    const int set = two ? (int)(chunk & 1) : 0;
+    hipStream_t cs = two ? e->set[set].stream : s;
+    const Engine::WorkSet& w = e->set[set];
     const u32 cn = (u32)std::min<size_t>(even, n - off);
-    EngineBufs B = make_bufs(e, reinterpret_cast<const unsigned char*>(d_ballots) + off * P.stride, cn,
+    EngineBufs B = make_bufs(e, set, reinterpret_cast<const unsigned char*>(d_ballots) + off * P.stride, cn,
                              reinterpret_cast<u32*>(d_status) + off);
+    if (!two) B.ws = ctx->ws;
     const int wide = ctx->cus * 32;     // grid-stride kernels that need no per-lane workspace: well oversubscribed (see eg_init)
-    HIPCHK(hipMemsetAsync(e->bad_item, 0xff, (size_t)cn * sizeof(u32), s));
-    hipLaunchKernelGGL(k_decode_points, dim3(grid_for((size_t)P.pt_items.size() * cn, wide)), dim3(NT), 0, s, B, e->d_pt_items,
+    HIPCHK(hipMemsetAsync(w.bad_item, 0xff, (size_t)cn * sizeof(u32), cs));
+    hipLaunchKernelGGL(k_decode_points, dim3(grid_for((size_t)P.pt_items.size() * cn, wide)), dim3(NT), 0, cs, B, e->d_pt_items,
                        (int)P.pt_items.size());
-    hipLaunchKernelGGL(k_check_scalars, dim3(grid_for((size_t)P.sc_items.size() * cn, wide)), dim3(NT), 0, s, B, e->d_sc_items,
+    hipLaunchKernelGGL(k_check_scalars, dim3(grid_for((size_t)P.sc_items.size() * cn, wide)), dim3(NT), 0, cs, B, e->d_sc_items,
                        (int)P.sc_items.size());
     for (auto& lv : e->levels)
       if (lv.count)
-        hipLaunchKernelGGL(k_derive_points, dim3(grid_for((size_t)lv.count * cn, wide)), dim3(NT), 0, s, B, e->d_dclasses,
+        hipLaunchKernelGGL(k_derive_points, dim3(grid_for((size_t)lv.count * cn, wide)), dim3(NT), 0, cs, B, e->d_dclasses,
                            e->d_dterms, lv.first, lv.count);
     if (!P.base_slots.empty()) {
       size_t pi = 0;
-      if ((rc = prof_begin(ctx, s, PROF_TABLES, &pi))) return rc;
-      hipLaunchKernelGGL(k_base_tables, dim3(grid_for((size_t)P.base_slots.size() * cn, ctx->msm_blocks)), dim3(NT), 0, s, B,
+      if ((rc = prof_begin(ctx, cs, PROF_TABLES, &pi))) return rc;
+      hipLaunchKernelGGL(k_base_tables, dim3(grid_for((size_t)P.base_slots.size() * cn, msm_blocks)), dim3(NT), 0, cs, B,
                          e->d_base_slots, (int)P.base_slots.size());
-      if ((rc = prof_end(ctx, s, pi))) return rc;
+      if ((rc = prof_end(ctx, cs, pi))) return rc;
     }
     if (!P.sum_bases.empty())
-      hipLaunchKernelGGL(k_sum_tables, dim3(grid_for((size_t)P.sum_bases.size() * cn, ctx->msm_blocks)), dim3(NT), 0, s, B,
+      hipLaunchKernelGGL(k_sum_tables, dim3(grid_for((size_t)P.sum_bases.size() * cn, msm_blocks)), dim3(NT), 0, cs, B,
                          e->d_sum_bases, e->d_sum_members, (int)P.sum_bases.size());
     for (auto& st : e->stages) {
       if (st.fam_count[FAM_TABLE1]) {
         size_t pi = 0;
-        if ((rc = prof_begin(ctx, s, PROF_MSM, &pi))) return rc;
-        hipLaunchKernelGGL(k_eq_table<false>, dim3(grid_for((size_t)st.fam_count[FAM_TABLE1] * cn, ctx->msm_blocks)), dim3(NT), 0, s, B,
+        if ((rc = prof_begin(ctx, cs, PROF_MSM, &pi))) return rc;
+        hipLaunchKernelGGL(k_eq_table<false>, dim3(grid_for((size_t)st.fam_count[FAM_TABLE1] * cn, msm_blocks)), dim3(NT), 0, cs, B,
                            e->d_jobs, e->d_vterms, st.fam_first[FAM_TABLE1], st.fam_count[FAM_TABLE1], 1);
-        if ((rc = prof_end(ctx, s, pi))) return rc;
+        if ((rc = prof_end(ctx, cs, pi))) return rc;
       }
       if (st.fam_count[FAM_TABLEN]) {
         const int group = std::min(st.max_terms, EG_MULTI_GROUP);
-        hipLaunchKernelGGL(k_eq_table<true>, dim3(grid_for((size_t)st.fam_count[FAM_TABLEN] * cn, ctx->msm_blocks)), dim3(NT),
-                           (size_t)group * 9 * NT * sizeof(u32), s, B, e->d_jobs, e->d_vterms, st.fam_first[FAM_TABLEN],
+        hipLaunchKernelGGL(k_eq_table<true>, dim3(grid_for((size_t)st.fam_count[FAM_TABLEN] * cn, msm_blocks)), dim3(NT),
+                           (size_t)group * 9 * NT * sizeof(u32), cs, B, e->d_jobs, e->d_vterms, st.fam_first[FAM_TABLEN],
                            st.fam_count[FAM_TABLEN], group);
       }
       if (st.fam_count[FAM_DIRECT1])
-        hipLaunchKernelGGL(k_eq_direct, dim3(grid_for((size_t)st.fam_count[FAM_DIRECT1] * cn, ctx->msm_blocks)), dim3(NT), 0, s, B,
+        hipLaunchKernelGGL(k_eq_direct, dim3(grid_for((size_t)st.fam_count[FAM_DIRECT1] * cn, msm_blocks)), dim3(NT), 0, cs, B,
                            e->d_jobs, e->d_vterms, st.fam_first[FAM_DIRECT1], st.fam_count[FAM_DIRECT1]);
       if (st.fam_count[FAM_GENERIC])
-        hipLaunchKernelGGL(k_eq_generic, dim3(grid_for((size_t)st.fam_count[FAM_GENERIC] * cn, ctx->msm_blocks)), dim3(NT), 0, s, B,
+        hipLaunchKernelGGL(k_eq_generic, dim3(grid_for((size_t)st.fam_count[FAM_GENERIC] * cn, msm_blocks)), dim3(NT), 0, cs, B,
                            e->d_jobs, e->d_vterms, st.fam_first[FAM_GENERIC], st.fam_count[FAM_GENERIC]);
       if (st.fam_count[FAM_ENCODE])
-        hipLaunchKernelGGL(k_encode_plain, dim3(grid_for((size_t)st.fam_count[FAM_ENCODE] * cn, wide)), dim3(NT), 0, s, B, e->d_jobs,
+        hipLaunchKernelGGL(k_encode_plain, dim3(grid_for((size_t)st.fam_count[FAM_ENCODE] * cn, wide)), dim3(NT), 0, cs, B, e->d_jobs,
                            st.fam_first[FAM_ENCODE], st.fam_count[FAM_ENCODE]);
       for (int d0 = 0; d0 < st.defer_count; d0 += 32)   // one batched inversion per ballot and group of <= 32 commitments
-        hipLaunchKernelGGL(k_encode_batch, dim3(grid_for(cn, wide)), dim3(NT), 0, s, B, e->d_defer_slots + st.defer_first + d0,
+        hipLaunchKernelGGL(k_encode_batch, dim3(grid_for(cn, wide)), dim3(NT), 0, cs, B, e->d_defer_slots + st.defer_first + d0,
                            std::min(32, st.defer_count - d0));
       if (st.inst_count)
-        hipLaunchKernelGGL(k_hash, dim3(grid_for((size_t)st.inst_count * cn, 1 << 30)), dim3(NT), 0, s, B, e->d_insts, e->d_ops,
+        hipLaunchKernelGGL(k_hash, dim3(grid_for((size_t)st.inst_count * cn, 1 << 30)), dim3(NT), 0, cs, B, e->d_insts, e->d_ops,
                            st.inst_first, st.inst_count);
     }
-    hipLaunchKernelGGL(k_status, dim3((cn + NT - 1) / NT), dim3(NT), 0, s, B, e->d_rules, (int)P.rules.size());
+    hipLaunchKernelGGL(k_status, dim3((cn + NT - 1) / NT), dim3(NT), 0, cs, B, e->d_rules, (int)P.rules.size());
     if (P.tally_slots.empty()) continue;
     const int G = std::min<int>(e->tally_blocks, (int)((cn + NT - 1) / NT));
-    hipLaunchKernelGGL(k_tally_partial, dim3(G, (unsigned)P.tally_slots.size()), dim3(NT), 0, s, B, e->d_tally_slots, e->partial);
-    hipLaunchKernelGGL(k_tally_final, dim3((unsigned)P.tally_slots.size()), dim3(NT), 0, s, e->partial, G, e->tally);
+    hipLaunchKernelGGL(k_tally_partial, dim3(G, (unsigned)P.tally_slots.size()), dim3(NT), 0, cs, B, e->d_tally_slots, w.partial);
+    hipLaunchKernelGGL(k_tally_final, dim3((unsigned)P.tally_slots.size()), dim3(NT), 0, cs, w.partial, G, w.tally);
+  }
+  if (two) {                 // join: the caller's stream continues after both sets; set 1's share of the tally moves into the running tally
+    for (int k = 0; k < 2; ++k) {
+      HIPCHK(hipEventRecord(e->set[k].done, e->set[k].stream));
+      HIPCHK(hipStreamWaitEvent(s, e->set[k].done, 0));
+    }
+    const int ns = (int)P.tally_slots.size();
+    if (ns) {
+      hipLaunchKernelGGL(k_tally_add_points, dim3(blocks_of((size_t)ns)), dim3(NT), 0, s, e->set[1].tally, ns, e->set[0].tally);
+      hipLaunchKernelGGL(k_tally_init, dim3(blocks_of((size_t)ns)), dim3(NT), 0, s, e->set[1].tally, ns);
+    }
   }
   if ((rc = prof_end(ctx, s, all_idx))) return rc;
   HIPCHK(hipGetLastError());
@@ -564,14 +633,15 @@ static int engine_verify_host(Engine* e, size_t n, const uint8_t* ballots, uint3
       const size_t lanes = (size_t)e->ctx->resident_blocks * NT;
       size_t off = 0;
       if (n > 2 * lanes) { pieces.push_back({0, lanes}); off = lanes; }
-      const size_t rem = n - off, k = (rem + e->max_cap - 1) / e->max_cap;
+      const size_t piece_cap = (size_t)e->max_cap * e->n_sets;      // one piece = one chunk per work set
+      const size_t rem = n - off, k = (rem + piece_cap - 1) / piece_cap;
       const size_t even = ((rem + k - 1) / k + NT - 1) / NT * NT;
       for (; off < n; off += even) pieces.push_back({off, std::min(even, n - off)});
     }
     std::vector<hipEvent_t> uploaded(pieces.size(), nullptr);
     size_t largest = 0;
     for (auto& pc : pieces) largest = std::max(largest, pc.second);
-    int rc = engine_reserve(e, (u32)largest);          // no regrowth of the workspace mid-pipeline
+    int rc = engine_reserve(e, (u32)std::min<size_t>((largest + e->n_sets - 1) / e->n_sets + NT, e->max_cap));   // no regrowth of the workspace mid-pipeline
     if (rc == EG_ERR_NOMEM) rc = EG_OK;                // engine_verify_device falls back to smaller chunks
     for (size_t k = 0; k < pieces.size() && rc == EG_OK; ++k) {
       const size_t off = pieces[k].first, m = pieces[k].second;
