@@ -84,8 +84,10 @@ def parse():
                     help="fixed-total mode (BASELINE.json configs[4]: 10M ballots sharded across the GPUs of a node): the batch of "
                          "this many ballots is split into contiguous shards, one per rank; the line says \"scaling\": \"strong\"")
     ap.add_argument("--options", type=int, default=None)
-    ap.add_argument("--workload", choices=["single", "multi", "qv"], default="single",
-                    help="single = BASELINE configs[1] (the bench line); multi = 3-of-16 (configs[3]); qv = 5 options / 20 credits (configs[2])")
+    ap.add_argument("--workload", choices=["single", "multi", "qv", "msm"], default="single",
+                    help="single = BASELINE configs[1] (the bench line); multi = 3-of-16 (configs[3]); qv = 5 options / 20 credits (configs[2]); "
+                         "msm = the primitive tier (Group::vartime_double_mul_generator x --ballots and one 2^16-term vartime_multi_mul; "
+                         "benches/basics.rs:284-319 of the reference times these helpers)")
     ap.add_argument("--credits", type=int, default=20)
     ap.add_argument("--seed", type=int, default=20260612)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
@@ -124,6 +126,98 @@ def effective_cores() -> int:
     return n
 
 
+def bench_msm(args, ctx, eg, torch, dev, world):
+    """Primitive tier: n x vartime_double_mul_generator and one 2^16-term vartime_multi_mul, operands resident
+    in HBM, through the device entry point (eg_vartime_multi_mul_batch_device).  One step = both.  The oracle is timed beside them."""
+    if world != 1:
+        raise SystemExit("--workload msm is a one-GPU bench")
+    grp = eg.Ristretto(ctx)
+    n, big = args.ballots, 1 << 16
+    stream = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cpu").manual_seed(args.seed)
+
+    def scalars(count):          # uniform 252-bit scalars (canonical)
+        t = torch.randint(0, 256, (count, 32), dtype=torch.uint8, generator=g)
+        t[:, 31] &= 0x0F
+        return t.reshape(-1).to(dev)
+
+    def points(count):           # valid encodings: [x]G made on the GPU
+        src = scalars(count)
+        out = torch.empty(32 * count, dtype=torch.uint8, device=dev)
+        grp.vartime_multi_mul_device(count, 0, 0, 0, out.data_ptr(), d_r=src.data_ptr(), stream=stream)
+        return out
+
+    k, r, p = scalars(n), scalars(n), points(n)
+    bk, bp = scalars(big), points(big)
+    out1 = torch.empty(32 * n, dtype=torch.uint8, device=dev)
+    ok1 = torch.empty(n, dtype=torch.uint8, device=dev)
+    out2 = torch.empty(32, dtype=torch.uint8, device=dev)
+    scratch = torch.empty(max(grp.msm_scratch_bytes(1, big), 16), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    t_double, t_big = 0.0, 0.0
+
+    def step(timed):
+        nonlocal t_double, t_big
+        ev[0].record()
+        grp.vartime_multi_mul_device(n, 1, k.data_ptr(), p.data_ptr(), out1.data_ptr(), d_r=r.data_ptr(), d_ok=ok1.data_ptr(), stream=stream)
+        ev[1].record()
+        grp.vartime_multi_mul_device(1, big, bk.data_ptr(), bp.data_ptr(), out2.data_ptr(), d_scratch=scratch.data_ptr(), stream=stream)
+        ev[2].record()
+        if timed:
+            torch.cuda.synchronize()
+            t_double += ev[0].elapsed_time(ev[1])
+            t_big += ev[1].elapsed_time(ev[2])
+
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    double_ms, big_ms = t_double / args.steps, t_big / args.steps
+    value = n / (double_ms * 1e-3)
+    line = {
+        "metric": "Group::vartime_double_mul_generator operations/sec (Ristretto backend, primitive tier)",
+        "value": value, "unit": "ops/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
+        "data": "synthetic",
+        "config": {"workload": f"{n} x [k]P + [r]G with k, r uniform and P = [x]G, resident in HBM (eg_vartime_multi_mul_batch_device, terms = 1); "
+                               f"then one {big}-term vartime_multi_mul; NOT the BASELINE metric (that is the default workload)",
+                   "ops": n, "big_terms": big, "seed": args.seed, "all_points_decoded": bool(int(ok1.min().item()) == 1)},
+        "multi_mul_65536": {"ms": big_ms, "terms_per_s": big / (big_ms * 1e-3),
+                            "note": "one product, cut so that it covers the chip (65 536 lanes, one term each here; problems in batches share "
+                                    "doubling chains in chunks of 8 terms); the 252 sequential doublings of a ladder are ~0.4 ms for a lane "
+                                    "whatever the algorithm; wave-shuffle reduction, one encoding"},
+        "roofline": {"bound": "hbm", "kernel": "eg::k_prim_msm", "achieved": 128.0 * n / (double_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": 128.0 * n / (double_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": double_ms,
+                     "note": "algorithmic bytes per operation: two scalars, a point, an encoding = 128 B against ~2600 field "
+                             "multiplications: VALU-bound like the batch tier"},
+    }
+    if not args.no_cpu_baseline:
+        from oracle import oracle as o
+
+        hk, hp, hr = bytes(k.cpu().numpy()), bytes(p.cpu().numpy()), bytes(r.cpu().numpy())
+        got = bytes(out1.cpu().numpy())
+        t0, m = time.perf_counter(), 0
+        same = True
+        while time.perf_counter() - t0 < min(args.cpu_seconds, 6.0) and m < n:
+            want = o.point_double_mul_generator(hk[32 * m: 32 * m + 32], hp[32 * m: 32 * m + 32], hr[32 * m: 32 * m + 32])
+            same = same and want == got[32 * m: 32 * m + 32]
+            m += 1
+        cpu_s = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        want_big = o.point_multi_mul(bytes(bk.cpu().numpy()), bytes(bp.cpu().numpy()))
+        big_cpu_s = time.perf_counter() - t1
+        line["cpu_baseline"] = {"value": m / cpu_s, "unit": "ops/s", "cores": 1, "kind": "port",
+                                "sample": f"first {m} of the same operations through oracle/ (one thread, C restatement, not dalek)",
+                                "results_match_gpu": bool(same), "multi_mul_65536_s": big_cpu_s,
+                                "multi_mul_65536_matches_gpu": bool(want_big == bytes(out2.cpu().numpy())), "cpu_model": cpu_model()}
+    print(json.dumps(line))
+
+
 def main():
     args = parse()
     import torch
@@ -152,6 +246,8 @@ def main():
 
     ctx = eg.Context(local_rank)
     pk = bytes.fromhex(PUBLIC_KEY_HEX)
+    if args.workload == "msm":
+        return bench_msm(args, ctx, eg, torch, dev, world)
     n_opt = args.options or {"single": 5, "multi": 16, "qv": 5}[args.workload]
     if args.workload == "single":
         params = eg.ChoiceParams.single_choice(ctx, pk, n_opt)

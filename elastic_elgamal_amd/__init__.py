@@ -101,6 +101,8 @@ def _load() -> C.CDLL:
         "eg_mul_generator_batch": (C.c_int, [vp, sz, cp, cp]),
         "eg_vartime_double_mul_generator_batch": (C.c_int, [vp, sz, cp, cp, cp, cp, cp]),
         "eg_vartime_multi_mul_batch": (C.c_int, [vp, sz, sz, cp, cp, cp, cp]),
+        "eg_msm_scratch_bytes": (sz, [sz, sz]),
+        "eg_vartime_multi_mul_batch_device": (C.c_int, [vp, sz, sz, vp, vp, vp, vp, vp, vp, vp]),
         "eg_choice_params_create": (C.c_int, [vp, cp, C.c_int, C.c_int, C.POINTER(vp)]),
         "eg_choice_params_destroy": (None, [vp]),
         "eg_choice_ballot_size": (sz, [C.c_int, C.c_int]),
@@ -404,6 +406,14 @@ class Ristretto:
         out, ok = C.create_string_buffer(32 * max(n, 1)), C.create_string_buffer(max(n, 1))
         _check(_load().eg_vartime_multi_mul_batch(self.ctx._h, n, terms, scalars, points, out, ok))
         return out.raw[: 32 * n], ok.raw[:n]
+
+    def msm_scratch_bytes(self, n: int, terms: int) -> int:
+        return int(_load().eg_msm_scratch_bytes(n, terms))
+
+    def vartime_multi_mul_device(self, n: int, terms: int, d_scalars: int, d_points: int, d_out: int, d_r: int = 0, d_scratch: int = 0,
+                                 d_ok: int = 0, stream: int = 0):
+        """The multi-scalar multiplication on device buffers, asynchronous on `stream` (eg_vartime_multi_mul_batch_device)."""
+        _check(_load().eg_vartime_multi_mul_batch_device(self.ctx._h, n, terms, d_scalars, d_points, d_r, d_scratch, d_out, d_ok, stream))
 
 
 class _BatchParams:

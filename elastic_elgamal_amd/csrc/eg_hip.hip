@@ -64,6 +64,8 @@ struct eg_ctx {
   int resident_blocks = 0;   // blocks of the equation kernel that the chip holds at once (two per CU)
   int msm_blocks = 0;        // grid of the table / equation kernels: EG_GRID_OVERSUBSCRIBE x resident_blocks, each block striding over its share
   uint4* ws = nullptr;       // per-lane workspace of those kernels (msm_blocks * WS_QUADS * NT uint4)
+  void* prim_scratch = nullptr;   // device scratch of the primitive tier, kept between calls and grown on demand (prim_bufs)
+  size_t prim_scratch_bytes = 0;
   bool prof = false;
   std::vector<ProfSpan> spans;
   std::vector<hipEvent_t> event_pool;
@@ -687,6 +689,7 @@ static void ctx_release(eg_ctx* c) {
   comb_table_free(c->tabG); comb_table_free(c->tabG_big);
   if (c->gen_words) (void)hipFree(c->gen_words);
   if (c->ws) (void)hipFree(c->ws);
+  if (c->prim_scratch) (void)hipFree(c->prim_scratch);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -740,6 +743,8 @@ int eg_init(int device, eg_ctx** out) {
   // the shared-chain kernel keeps up to EG_MULTI_GROUP sign vectors per lane in dynamic LDS (9 KiB per term and block)
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_eq_table<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                              EG_MULTI_GROUP * 9 * NT * (int)sizeof(u32)));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_prim_msm), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             MSM_CHUNK * 8 * NT * (int)sizeof(u32)));
   if (per_cu < 1) per_cu = 1;
   c->resident_blocks = per_cu * c->cus;
   // A grid of exactly the resident blocks makes every block do the same number of rounds, so the slowest CU sets the time and the
@@ -838,7 +843,7 @@ int eg_comb_table_bits(eg_ctx* c, int* narrow_bits, int* wide_bits) { EG_LOCK(c)
 }
 
 // ---- primitive tier ---------------------------------------------------------------------------------------------
-struct DevBuf {
+struct DevBuf {      // a device buffer owned for the length of one call (batch-tier helpers)
   void* p = nullptr;
   ~DevBuf() { if (p) (void)hipFree(p); }
   int alloc(size_t bytes) { HIPCHK(hipMalloc(&p, std::max<size_t>(bytes, 16))); return EG_OK; }
@@ -846,104 +851,155 @@ struct DevBuf {
   int get(void* dst, size_t bytes, hipStream_t s) { if (bytes) HIPCHK(hipMemcpyAsync(dst, p, bytes, hipMemcpyDeviceToHost, s)); return EG_OK; }
 };
 #define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+// The primitive tier works out of ONE device scratch area per context, kept between calls (round 2 paid three to five hipMalloc /
+// hipFree per call).  Every primitive call runs under the context lock and ends with a stream synchronisation, so the area is free
+// again when the next call starts; it only ever grows.
+static int prim_bufs(eg_ctx* c, std::initializer_list<size_t> sizes, std::initializer_list<void**> ptrs) {
+  size_t total = 0;
+  for (size_t b : sizes) total += (b + 255) / 256 * 256;
+  if (total > c->prim_scratch_bytes) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->prim_scratch) (void)hipFree(c->prim_scratch);
+    c->prim_scratch = nullptr; c->prim_scratch_bytes = 0;
+    const size_t want = std::max<size_t>(total + total / 4, (size_t)1 << 20);
+    HIPCHK(hipMalloc(&c->prim_scratch, want));
+    c->prim_scratch_bytes = want;
+  }
+  size_t off = 0;
+  auto it = ptrs.begin();
+  for (size_t b : sizes) { **it = static_cast<char*>(c->prim_scratch) + off; off += (b + 255) / 256 * 256; ++it; }
+  return EG_OK;
+}
+static int h2d(void* dst, const void* src, size_t bytes, hipStream_t s) { if (bytes) HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s)); return EG_OK; }
+static int d2h(void* dst, const void* src, size_t bytes, hipStream_t s) { if (bytes) HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s)); return EG_OK; }
 
 int eg_scalar_from_wide_batch(eg_ctx* c, size_t n, const uint8_t* wide, uint8_t* out) { EG_LOCK(c);
   if (!c || (n && (!wide || !out))) return fail(EG_ERR_BAD_ARG, "bad argument");
   HIPCHK(hipSetDevice(c->device));
-  DevBuf a, o;
-  TRY(a.alloc(n * 64)); TRY(o.alloc(n * 32)); TRY(a.put(wide, n * 64, c->stream));
-  hipLaunchKernelGGL(k_prim_scalar_from_wide, dim3(blocks_of(n)), dim3(NT), 0, c->stream, n, (const u32*)a.p, (u32*)o.p);
-  TRY(o.get(out, n * 32, c->stream));
+  void *a, *o;
+  TRY(prim_bufs(c, {n * 64, n * 32}, {&a, &o})); TRY(h2d(a, wide, n * 64, c->stream));
+  hipLaunchKernelGGL(k_prim_scalar_from_wide, dim3(blocks_of(n)), dim3(NT), 0, c->stream, n, (const u32*)a, (u32*)o);
+  TRY(d2h(out, o, n * 32, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   return EG_OK;
 }
 int eg_scalar_is_canonical_batch(eg_ctx* c, size_t n, const uint8_t* s_, uint8_t* ok) { EG_LOCK(c);
   if (!c || (n && (!s_ || !ok))) return fail(EG_ERR_BAD_ARG, "bad argument");
   HIPCHK(hipSetDevice(c->device));
-  DevBuf a, o;
-  TRY(a.alloc(n * 32)); TRY(o.alloc(n)); TRY(a.put(s_, n * 32, c->stream));
-  hipLaunchKernelGGL(k_prim_scalar_canonical, dim3(blocks_of(n)), dim3(NT), 0, c->stream, n, (const u32*)a.p, (unsigned char*)o.p);
-  TRY(o.get(ok, n, c->stream));
+  void *a, *o;
+  TRY(prim_bufs(c, {n * 32, n}, {&a, &o})); TRY(h2d(a, s_, n * 32, c->stream));
+  hipLaunchKernelGGL(k_prim_scalar_canonical, dim3(blocks_of(n)), dim3(NT), 0, c->stream, n, (const u32*)a, (unsigned char*)o);
+  TRY(d2h(ok, o, n, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   return EG_OK;
 }
 int eg_scalar_muladd_batch(eg_ctx* c, size_t n, const uint8_t* a_, const uint8_t* b_, const uint8_t* c_, uint8_t* out) { EG_LOCK(c);
   if (!c || (n && (!a_ || !b_ || !c_ || !out))) return fail(EG_ERR_BAD_ARG, "bad argument");
   HIPCHK(hipSetDevice(c->device));
-  DevBuf a, b, cc, o;
-  TRY(a.alloc(n * 32)); TRY(b.alloc(n * 32)); TRY(cc.alloc(n * 32)); TRY(o.alloc(n * 32));
-  TRY(a.put(a_, n * 32, c->stream)); TRY(b.put(b_, n * 32, c->stream)); TRY(cc.put(c_, n * 32, c->stream));
-  hipLaunchKernelGGL(k_prim_scalar_muladd, dim3(blocks_of(n)), dim3(NT), 0, c->stream, n, (const u32*)a.p, (const u32*)b.p,
-                     (const u32*)cc.p, (u32*)o.p);
-  TRY(o.get(out, n * 32, c->stream));
+  void *a, *b, *cc, *o;
+  TRY(prim_bufs(c, {n * 32, n * 32, n * 32, n * 32}, {&a, &b, &cc, &o}));
+  TRY(h2d(a, a_, n * 32, c->stream)); TRY(h2d(b, b_, n * 32, c->stream)); TRY(h2d(cc, c_, n * 32, c->stream));
+  hipLaunchKernelGGL(k_prim_scalar_muladd, dim3(blocks_of(n)), dim3(NT), 0, c->stream, n, (const u32*)a, (const u32*)b,
+                     (const u32*)cc, (u32*)o);
+  TRY(d2h(out, o, n * 32, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   return EG_OK;
 }
 int eg_scalar_neg_batch(eg_ctx* c, size_t n, const uint8_t* a_, uint8_t* out) { EG_LOCK(c);
   if (!c || (n && (!a_ || !out))) return fail(EG_ERR_BAD_ARG, "bad argument");
   HIPCHK(hipSetDevice(c->device));
-  DevBuf a, o;
-  TRY(a.alloc(n * 32)); TRY(o.alloc(n * 32)); TRY(a.put(a_, n * 32, c->stream));
-  hipLaunchKernelGGL(k_prim_scalar_neg, dim3(blocks_of(n)), dim3(NT), 0, c->stream, n, (const u32*)a.p, (u32*)o.p);
-  TRY(o.get(out, n * 32, c->stream));
+  void *a, *o;
+  TRY(prim_bufs(c, {n * 32, n * 32}, {&a, &o})); TRY(h2d(a, a_, n * 32, c->stream));
+  hipLaunchKernelGGL(k_prim_scalar_neg, dim3(blocks_of(n)), dim3(NT), 0, c->stream, n, (const u32*)a, (u32*)o);
+  TRY(d2h(out, o, n * 32, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   return EG_OK;
 }
 int eg_scalar_invert_batch(eg_ctx* c, size_t n, const uint8_t* a_, uint8_t* out) { EG_LOCK(c);
   if (!c || (n && (!a_ || !out))) return fail(EG_ERR_BAD_ARG, "bad argument");
   HIPCHK(hipSetDevice(c->device));
-  DevBuf a, o;
-  TRY(a.alloc(n * 32)); TRY(o.alloc(n * 32)); TRY(a.put(a_, n * 32, c->stream));
-  hipLaunchKernelGGL(k_prim_scalar_invert, dim3(blocks_of(n)), dim3(NT), 0, c->stream, n, (const u32*)a.p, (u32*)o.p);
-  TRY(o.get(out, n * 32, c->stream));
+  void *a, *o;
+  TRY(prim_bufs(c, {n * 32, n * 32}, {&a, &o})); TRY(h2d(a, a_, n * 32, c->stream));
+  hipLaunchKernelGGL(k_prim_scalar_invert, dim3(blocks_of(n)), dim3(NT), 0, c->stream, n, (const u32*)a, (u32*)o);
+  TRY(d2h(out, o, n * 32, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   return EG_OK;
 }
 int eg_point_is_identity_batch(eg_ctx* c, size_t n, const uint8_t* in, uint8_t* is_identity, uint8_t* ok) { EG_LOCK(c);
   if (!c || (n && (!in || !is_identity || !ok))) return fail(EG_ERR_BAD_ARG, "bad argument");
   HIPCHK(hipSetDevice(c->device));
-  DevBuf a, f, o;
-  TRY(a.alloc(n * 32)); TRY(f.alloc(n)); TRY(o.alloc(n)); TRY(a.put(in, n * 32, c->stream));
-  hipLaunchKernelGGL(k_prim_point_is_identity, dim3(blocks_of(n)), dim3(NT), 0, c->stream, n, (const u32*)a.p,
-                     (unsigned char*)f.p, (unsigned char*)o.p);
-  TRY(f.get(is_identity, n, c->stream)); TRY(o.get(ok, n, c->stream));
+  void *a, *f, *o;
+  TRY(prim_bufs(c, {n * 32, n, n}, {&a, &f, &o})); TRY(h2d(a, in, n * 32, c->stream));
+  hipLaunchKernelGGL(k_prim_point_is_identity, dim3(blocks_of(n)), dim3(NT), 0, c->stream, n, (const u32*)a,
+                     (unsigned char*)f, (unsigned char*)o);
+  TRY(d2h(is_identity, f, n, c->stream)); TRY(d2h(ok, o, n, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   return EG_OK;
 }
 int eg_point_roundtrip_batch(eg_ctx* c, size_t n, const uint8_t* in, uint8_t* out, uint8_t* ok) { EG_LOCK(c);
   if (!c || (n && (!in || !out || !ok))) return fail(EG_ERR_BAD_ARG, "bad argument");
   HIPCHK(hipSetDevice(c->device));
-  DevBuf a, o, k;
-  TRY(a.alloc(n * 32)); TRY(o.alloc(n * 32)); TRY(k.alloc(n)); TRY(a.put(in, n * 32, c->stream));
-  hipLaunchKernelGGL(k_prim_point_roundtrip, dim3(blocks_of(n)), dim3(NT), 0, c->stream, n, (const u32*)a.p, (u32*)o.p,
-                     (unsigned char*)k.p);
-  TRY(o.get(out, n * 32, c->stream)); TRY(k.get(ok, n, c->stream));
+  void *a, *o, *k;
+  TRY(prim_bufs(c, {n * 32, n * 32, n}, {&a, &o, &k})); TRY(h2d(a, in, n * 32, c->stream));
+  hipLaunchKernelGGL(k_prim_point_roundtrip, dim3(blocks_of(n)), dim3(NT), 0, c->stream, n, (const u32*)a, (u32*)o,
+                     (unsigned char*)k);
+  TRY(d2h(out, o, n * 32, c->stream)); TRY(d2h(ok, k, n, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   return EG_OK;
 }
 int eg_point_add_batch(eg_ctx* c, size_t n, const uint8_t* a_, const uint8_t* b_, int subtract, uint8_t* out, uint8_t* ok) { EG_LOCK(c);
   if (!c || (n && (!a_ || !b_ || !out || !ok))) return fail(EG_ERR_BAD_ARG, "bad argument");
   HIPCHK(hipSetDevice(c->device));
-  DevBuf a, b, o, k;
-  TRY(a.alloc(n * 32)); TRY(b.alloc(n * 32)); TRY(o.alloc(n * 32)); TRY(k.alloc(n));
-  TRY(a.put(a_, n * 32, c->stream)); TRY(b.put(b_, n * 32, c->stream));
-  hipLaunchKernelGGL(k_prim_point_add, dim3(blocks_of(n)), dim3(NT), 0, c->stream, n, (const u32*)a.p, (const u32*)b.p, subtract,
-                     (u32*)o.p, (unsigned char*)k.p);
-  TRY(o.get(out, n * 32, c->stream)); TRY(k.get(ok, n, c->stream));
+  void *a, *b, *o, *k;
+  TRY(prim_bufs(c, {n * 32, n * 32, n * 32, n}, {&a, &b, &o, &k}));
+  TRY(h2d(a, a_, n * 32, c->stream)); TRY(h2d(b, b_, n * 32, c->stream));
+  hipLaunchKernelGGL(k_prim_point_add, dim3(blocks_of(n)), dim3(NT), 0, c->stream, n, (const u32*)a, (const u32*)b, subtract,
+                     (u32*)o, (unsigned char*)k);
+  TRY(d2h(out, o, n * 32, c->stream)); TRY(d2h(ok, k, n, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   return EG_OK;
 }
+// How the terms of a problem are cut: chunks of up to MSM_CHUNK terms share a doubling chain (less work per term), but a call with few
+// terms in all should still cover the chip (a lone 2^16-term product in chunks of 8 keeps only 8192 lanes busy: 3.1 ms; in chunks of 1
+// it is 65 536 independent ladders, ~1 ms): the chunk shrinks until the call has ~2 waves per SIMD worth of lanes.
+static void msm_plan(size_t n, size_t terms, int* chunk, int* n_chunks) {
+  const size_t lanes_wanted = (size_t)1 << 17;
+  size_t c = std::min<size_t>(std::max<size_t>(terms, 1), MSM_CHUNK);
+  c = std::min(c, std::max<size_t>(1, n * terms / lanes_wanted));
+  *chunk = (int)c;
+  *n_chunks = (int)std::max<size_t>(1, (terms + c - 1) / c);
+}
+// out[i] = enc( sum_t [k_it]P_it + [r_i]G ) on device pointers (kernels.cuh: k_prim_msm + k_prim_msm_reduce); asynchronous on s
+static int prim_msm_launch(eg_ctx* c, size_t n, size_t terms, const u32* d_scalars, const u32* d_points, const u32* d_r, u32* d_partial,
+                           unsigned char* d_ok_partial, u32* d_out, unsigned char* d_ok, hipStream_t s) {
+  int chunk, n_chunks;
+  msm_plan(n, terms, &chunk, &n_chunks);
+  // every lane owns `chunk` tables in the per-lane workspace: the grid shrinks accordingly (the workspace is msm_blocks x one table)
+  const int grid = grid_for(n * (size_t)n_chunks, std::max(1, c->msm_blocks / chunk));
+  hipLaunchKernelGGL(k_prim_msm, dim3(grid), dim3(NT), (size_t)chunk * 8 * NT * sizeof(u32), s, n, (int)terms, chunk, n_chunks, d_scalars,
+                     d_points, d_r, c->tabG, c->ws, d_partial, d_ok_partial, d_out, d_ok);
+  if (n_chunks > 1)
+    hipLaunchKernelGGL(k_prim_msm_reduce, dim3((unsigned)((n * 64 + NT - 1) / NT)), dim3(NT), 0, s, n, n_chunks, d_partial, d_ok_partial,
+                       d_r, c->tabG, d_out, d_ok);
+  HIPCHK(hipGetLastError());
+  return EG_OK;
+}
+static size_t msm_chunks(size_t n, size_t terms) { int c, k; msm_plan(n, terms, &c, &k); return (size_t)k; }
 static int prim_msm(eg_ctx* c, size_t n, size_t terms, const uint8_t* scalars, const uint8_t* points, const uint8_t* r,
                     uint8_t* out, uint8_t* ok) {
   HIPCHK(hipSetDevice(c->device));
-  DevBuf sc, pt, rr, o, k;
-  TRY(sc.alloc(n * terms * 32)); TRY(pt.alloc(n * terms * 32)); TRY(rr.alloc(n * 32)); TRY(o.alloc(n * 32)); TRY(k.alloc(n));
-  TRY(sc.put(scalars, n * terms * 32, c->stream)); TRY(pt.put(points, n * terms * 32, c->stream));
-  if (r) TRY(rr.put(r, n * 32, c->stream));
-  hipLaunchKernelGGL(k_prim_msm, dim3(grid_for(n, c->msm_blocks)), dim3(NT), 0, c->stream, n, (int)terms, (const u32*)sc.p,
-                     (const u32*)pt.p, r ? (const u32*)rr.p : (const u32*)nullptr, c->tabG, c->ws, (u32*)o.p, (unsigned char*)k.p);
-  TRY(o.get(out, n * 32, c->stream));
-  if (ok) TRY(k.get(ok, n, c->stream));
+  if (n == 0) return EG_OK;
+  if (terms > ((size_t)1 << 24) || n > ((size_t)1 << 32)) return fail(EG_ERR_BAD_ARG, "at most 2^24 terms per problem");
+  const size_t nc = msm_chunks(n, terms);
+  void *sc, *pt, *rr, *o, *k, *part, *okp;
+  TRY(prim_bufs(c, {n * terms * 32, n * terms * 32, n * 32, n * 32, n, nc > 1 ? n * nc * PT_WORDS * sizeof(u32) : 0, nc > 1 ? n * nc : 0},
+                {&sc, &pt, &rr, &o, &k, &part, &okp}));
+  TRY(h2d(sc, scalars, n * terms * 32, c->stream)); TRY(h2d(pt, points, n * terms * 32, c->stream));
+  if (r) TRY(h2d(rr, r, n * 32, c->stream));
+  TRY(prim_msm_launch(c, n, terms, (const u32*)sc, (const u32*)pt, r ? (const u32*)rr : (const u32*)nullptr, (u32*)part,
+                      (unsigned char*)okp, (u32*)o, (unsigned char*)k, c->stream));
+  TRY(d2h(out, o, n * 32, c->stream));
+  if (ok) TRY(d2h(ok, k, n, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(hipGetLastError());
   return EG_OK;
@@ -961,6 +1017,25 @@ int eg_vartime_multi_mul_batch(eg_ctx* c, size_t n, size_t terms, const uint8_t*
                                uint8_t* ok) { EG_LOCK(c);
   if (!c || (n && !out) || (n && terms && (!scalars || !points))) return fail(EG_ERR_BAD_ARG, "bad argument");
   return prim_msm(c, n, terms, scalars, points, nullptr, out, ok);
+}
+// the same on DEVICE buffers, asynchronous on `stream` (a caller that keeps its operands in HBM pays no copies and no synchronisation;
+// what bench.py --workload msm times).  d_scratch must hold eg_msm_scratch_bytes(n, terms) bytes (0 for <= 8 terms).
+size_t eg_msm_scratch_bytes(size_t n, size_t terms) {
+  const size_t nc = msm_chunks(n, terms);
+  return nc > 1 ? n * nc * (PT_WORDS * sizeof(u32) + 1) + 256 : 0;
+}
+int eg_vartime_multi_mul_batch_device(eg_ctx* c, size_t n, size_t terms, const void* d_scalars, const void* d_points, const void* d_r,
+                                      void* d_scratch, void* d_out, void* d_ok, void* stream) { EG_LOCK(c);
+  if (!c || (n && !d_out) || (n && terms && (!d_scalars || !d_points)) || (n && !terms && !d_r)) return fail(EG_ERR_BAD_ARG, "bad argument");
+  if (terms > ((size_t)1 << 24)) return fail(EG_ERR_BAD_ARG, "at most 2^24 terms per problem");
+  const size_t nc = msm_chunks(n, terms);
+  if (n && nc > 1 && !d_scratch) return fail(EG_ERR_BAD_ARG, "this call is cut into several chunks per problem and needs d_scratch (eg_msm_scratch_bytes)");
+  if (n == 0) return EG_OK;
+  HIPCHK(hipSetDevice(c->device));
+  u32* part = (u32*)d_scratch;
+  unsigned char* okp = nc > 1 ? (unsigned char*)d_scratch + (n * nc * PT_WORDS * sizeof(u32) + 255) / 256 * 256 : nullptr;
+  return prim_msm_launch(c, n, terms, (const u32*)d_scalars, (const u32*)d_points, (const u32*)d_r, part, okp, (u32*)d_out,
+                         (unsigned char*)d_ok, (hipStream_t)stream);
 }
 
 // ---- batch tier: choice ---------------------------------------------------------------------------------------------------

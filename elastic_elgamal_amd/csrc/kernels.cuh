@@ -820,36 +820,136 @@ __global__ void __launch_bounds__(NT) k_prim_merlin(size_t n, const unsigned cha
   for (int k = 0; k < out_len; ++k) out[i * (size_t)out_len + k] = (unsigned char)strobe_squeeze_byte(t);
 }
 
-// out = enc( sum_t [k_t]P_t + [r]G ); terms may be 0 (then r must be given).  Group::mul_generator,
-// vartime_double_mul_generator and vartime_multi_mul all map onto this kernel.
-__global__ void __launch_bounds__(NT) k_prim_msm(size_t n, int terms, const u32* scalars, const u32* points, const u32* r,
-                                                    const uint4* tabG, uint4* ws, u32* out, unsigned char* ok) {
-  WsTable tab;
-  tab.init(ws);
-  for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
-    ge acc; ge_identity(acc);
+// ---- Group::mul_generator / vartime_double_mul_generator / vartime_multi_mul (ristretto.rs:105-145) as ONE multi-scalar multiplication --------
+// out = enc( sum_t [k_t]P_t + [r]G ) for n problems of `terms` terms (terms may be 0, then r must be given).
+// Straus' interleaved method, what dalek's vartime_multiscalar_mul does below 190 terms: the terms of a problem are cut into chunks of
+// up to `chunk` (<= MSM_CHUNK) terms; one lane evaluates one chunk on ONE chain of 252 doublings shared by its terms (per-lane radix-16
+// tables {1..8}P_t in the workspace, signed digits in LDS): 252 doublings + 71 additions per TERM became 252 / chunk + 71.  Problems
+// with more than one chunk leave their partial sums in `partial`; k_prim_msm_reduce adds them up with wave shuffles (one wave per
+// problem) and finishes (generator term, encoding).  A bucket method does not pay at the sizes a GPU sees them: the 252 sequential
+// doublings of a single product are ~0.4 ms for one lane whatever the algorithm, and 2^16 terms in chunks of 8 already keep 8192 lanes
+// busy for about that long (bench.py --workload msm).
+constexpr int MSM_CHUNK = 8;
+__device__ __forceinline__ int msm_digit(const u32* dig, int t, int i) {
+  const u32 w = dig[(t * 8 + (i >> 3)) * NT + threadIdx.x];
+  const int nib = (int)((w >> (4 * (i & 7))) & 15u);
+  return nib >= 8 ? nib - 16 : nib;
+}
+__device__ __forceinline__ void msm_finish(ge& acc, size_t i, const u32* r, const uint4* tabG, u32* out) {
+  if (r) {
+    u32 s[8], dg[EG_COMB_WORDS]; ld8(s, r + i * 8);
+    sc_recode_comb(dg, s);
+    const FixedTable tg(tabG);
+    ge_fixed_mul_add(acc, tg, dg);
+  }
+  u32 o[8]; ristretto_encode(o, acc);
+  st8(out + i * 8, o);
+}
+__global__ void __launch_bounds__(NT, 2) k_prim_msm(size_t n, int terms, int chunk, int n_chunks, const u32* scalars, const u32* points,
+                                                    const u32* r, const uint4* tabG, uint4* ws, u32* partial, unsigned char* ok_partial,
+                                                    u32* out, unsigned char* ok) {
+  extern __shared__ u32 msm_dig[];                       // [chunk][8][NT] radix-16 digits of the chunk's scalars
+  uint4* my_ws = ws + ((size_t)blockIdx.x * NT + threadIdx.x) * (size_t)chunk * WS_QUADS;
+  const size_t total = n * (size_t)n_chunks;
+  for (size_t j = (size_t)blockIdx.x * NT + threadIdx.x; j < total; j += (size_t)gridDim.x * NT) {
+    const size_t i = j / n_chunks;
+    const int t0 = (int)(j % n_chunks) * chunk, m = min(chunk, terms - t0);
     bool okk = true;
 #pragma unroll 1
-    for (int t = 0; t < terms; ++t) {
+    for (int t = 0; t < m; ++t) {
       u32 pw[8], s[8], dg[8];
-      ld8(pw, points + (i * terms + t) * 8);
-      ld8(s, scalars + (i * terms + t) * 8);
+      ld8(pw, points + (i * terms + t0 + t) * 8);
+      ld8(s, scalars + (i * terms + t0 + t) * 8);
       ge p;
       okk = okk & ristretto_decode(p, pw);
       sc_recode_radix16(dg, s);
+#pragma unroll
+      for (int w = 0; w < 8; ++w) msm_dig[(t * 8 + w) * NT + threadIdx.x] = dg[w];
+      WsTable tab; tab.base = my_ws + (size_t)t * WS_QUADS;
       ge_var_table_build(tab, p);
-      ge part; ge_var_mul(part, tab, dg);
-      ge sum; ge_add_full(sum, acc, part); acc = sum;
     }
-    if (r) {
-      u32 s[8], dg[EG_COMB_WORDS]; ld8(s, r + i * 8);
-      sc_recode_comb(dg, s);
-      const FixedTable tg(tabG);
-      ge_fixed_mul_add(acc, tg, dg);
+    ge acc; ge_identity(acc);
+    ge_cached ident; ge_cached_identity(ident);
+#pragma unroll 1
+    for (int d = 63; d >= 0 && m > 0; --d) {
+      ge_p1p1 tt;
+      if (d != 63) {
+        ge_p2 q; q.X = acc.X; q.Y = acc.Y; q.Z = acc.Z;
+#pragma unroll 1
+        for (int k = 0; k < 3; ++k) { ge_dbl(tt, q.X, q.Y, q.Z); ge_dbl_to_p2(q, tt); }
+        ge_dbl(tt, q.X, q.Y, q.Z);
+        ge_dbl_to_p3(acc, tt);
+      }
+#pragma unroll 1
+      for (int t = 0; t < m; ++t) {
+        const int dv = msm_digit(msm_dig, t, d), ad = dv < 0 ? -dv : dv;
+        WsTable tab; tab.base = my_ws + (size_t)t * WS_QUADS;
+        ge_cached c; tab.load(c, ad == 0 ? 0 : ad - 1);
+        fe_cmov(c.YpX, ident.YpX, ad == 0); fe_cmov(c.YmX, ident.YmX, ad == 0);
+        fe_cmov(c.Z2, ident.Z2, ad == 0); fe_cmov(c.T2d, ident.T2d, ad == 0);
+        ge_cached_cneg(c, dv < 0);
+        ge_add(tt, acc, c);
+        if (t + 1 == m && d > 0) {              // a doubling follows: T is not needed
+          ge_p2 q; ge_add_to_p2(q, tt);
+          acc.X = q.X; acc.Y = q.Y; acc.Z = q.Z;
+        } else {
+          ge_add_to_p3(acc, tt);
+        }
+      }
     }
-    u32 o[8]; ristretto_encode(o, acc);
-    st8(out + i * 8, o);
-    if (ok) ok[i] = okk ? 1 : 0;
+    if (n_chunks == 1) {
+      msm_finish(acc, i, r, tabG, out);
+      if (ok) ok[i] = okk ? 1 : 0;
+    } else {
+      u32 w[PT_WORDS];
+      ge_to_words(w, acc);
+#pragma unroll
+      for (int q = 0; q < PT_QUADS; ++q)
+        reinterpret_cast<uint4*>(partial)[j * PT_QUADS + q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+      ok_partial[j] = okk ? 1 : 0;
+    }
+  }
+}
+// acc = sum over the 64 lanes of a wavefront, in lane 0: wavefront-shuffle point accumulation (six rounds of 36 shuffles + one addition)
+__device__ __forceinline__ void wave_reduce_points(ge& acc) {
+#pragma unroll 1
+  for (int off = 32; off >= 1; off >>= 1) {
+    u32 w[PT_WORDS];
+    ge_to_words(w, acc);
+#pragma unroll
+    for (int k = 0; k < PT_WORDS; ++k) w[k] = (u32)__shfl_down((int)w[k], off, 64);
+    ge other, sum;
+    words_to_ge(other, w);
+    ge_add_full(sum, acc, other);
+    acc = sum;
+  }
+}
+// one wavefront per problem: sums the problem's partial sums, adds the generator term, encodes
+__global__ void __launch_bounds__(NT, 2) k_prim_msm_reduce(size_t n, int n_chunks, const u32* partial, const unsigned char* ok_partial,
+                                                           const u32* r, const uint4* tabG, u32* out, unsigned char* ok) {
+  const size_t wave = ((size_t)blockIdx.x * NT + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (wave >= n) return;                                  // whole wavefronts leave together
+  ge acc; ge_identity(acc);
+  bool okk = true;
+#pragma unroll 1
+  for (int c = lane; c < n_chunks; c += 64) {
+    const size_t j = wave * (size_t)n_chunks + c;
+    u32 w[PT_WORDS];
+#pragma unroll
+    for (int q = 0; q < PT_QUADS; ++q) {
+      const uint4 v = reinterpret_cast<const uint4*>(partial)[j * PT_QUADS + q];
+      w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+    }
+    ge p, sum; words_to_ge(p, w);
+    ge_add_full(sum, acc, p); acc = sum;
+    okk = okk & (ok_partial[j] != 0);
+  }
+  wave_reduce_points(acc);
+  const bool all_ok = __all(okk ? 1 : 0) != 0;
+  if (lane == 0) {
+    msm_finish(acc, wave, r, tabG, out);
+    if (ok) ok[wave] = all_ok ? 1 : 0;
   }
 }
 

@@ -114,6 +114,15 @@ int eg_vartime_double_mul_generator_batch(eg_ctx*, size_t n, const uint8_t* k, c
  * scalars/points laid out [problem][term][32] */
 int eg_vartime_multi_mul_batch(eg_ctx*, size_t n, size_t terms, const uint8_t* scalars, const uint8_t* points,
                                uint8_t* out, uint8_t* ok);
+/* The same multi-scalar multiplication on DEVICE buffers, asynchronous on `stream`: out_i = enc( sum_t [k_it]P_it + [r_i]G ).
+ * d_r may be NULL (no generator term) unless terms == 0; d_ok may be NULL.  Any number of terms up to 2^24: the terms of a problem
+ * are evaluated in chunks of 8 on shared doubling chains (Straus, what dalek's vartime_multiscalar_mul does below 190 terms) and the
+ * chunks' partial sums are added up with wavefront shuffles; a call that is cut into several chunks per problem (more than 8 terms,
+ * or few problems of many terms) needs d_scratch of eg_msm_scratch_bytes(n, terms) bytes (0 when it needs none).  A caller that
+ * keeps its operands in HBM pays no copy and no synchronisation. */
+size_t eg_msm_scratch_bytes(size_t n, size_t terms);
+int eg_vartime_multi_mul_batch_device(eg_ctx*, size_t n, size_t terms, const void* d_scalars, const void* d_points, const void* d_r,
+                                      void* d_scratch, void* d_out, void* d_ok, void* stream);
 
 /* ---- batch tier: EncryptedChoice --------------------------------------------------------------------------------
  * wire layout of one ballot (stride = eg_choice_ballot_size):

@@ -563,19 +563,12 @@ static void add_digit(ge *acc, const ge t[8], int d) {
 }
 
 /* Straus interleaved signed 4-bit windows; vartime (skips zero digits) */
-void or_ge_multi_mul(ge *out, size_t n, const sc *k, const ge *p) {
+static void ge_multi_mul_block(ge *out, size_t n, const sc *k, const ge *p) {   /* n <= 64: one shared doubling chain (Straus) */
   enum { MAXN = 64 };
   ge tabs[MAXN][8];
   int8_t digs[MAXN][64];
   ge acc;
   or_ge_identity(&acc);
-  if (n > MAXN) { /* split recursively */
-    ge part;
-    or_ge_multi_mul(&acc, MAXN, k, p);
-    or_ge_multi_mul(&part, n - MAXN, k + MAXN, p + MAXN);
-    or_ge_add(out, &acc, &part);
-    return;
-  }
   for (size_t j = 0; j < n; j++) {
     table8(tabs[j], &p[j]);
     sc_to_radix16(digs[j], &k[j]);
@@ -584,6 +577,17 @@ void or_ge_multi_mul(ge *out, size_t n, const sc *k, const ge *p) {
     if (i != 63)
       for (int d = 0; d < 4; d++) or_ge_double(&acc, &acc);
     for (size_t j = 0; j < n; j++) add_digit(&acc, tabs[j], digs[j][i]);
+  }
+  *out = acc;
+}
+void or_ge_multi_mul(ge *out, size_t n, const sc *k, const ge *p) {   /* any n: blocks of 64 terms, summed (no recursion: 2^16 terms) */
+  ge acc, part;
+  or_ge_identity(&acc);
+  for (size_t off = 0; off < n || off == 0; off += 64) {
+    const size_t m = n - off < 64 ? n - off : 64;
+    ge_multi_mul_block(&part, m, k + off, p + off);
+    or_ge_add(&acc, &acc, &part);
+    if (n == 0) break;
   }
   *out = acc;
 }

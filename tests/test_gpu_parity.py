@@ -120,6 +120,47 @@ def test_scalar_multiplication(grp, oracle):
     assert ok == b"\0"
 
 
+def test_multi_scalar_mul_any_size(eg, ctx, grp, oracle):
+    """Group::vartime_multi_mul for every size class of the kernel (ristretto.rs:139-145; dalek: Straus / Pippenger): one chunk (<= 8
+    terms on one doubling chain), several chunks reduced with wave shuffles (9, 16, 255, 256 terms) and one 65 536-term product;
+    identity points, zero and edge scalars inside; an undecodable point anywhere flags the problem.  Host and device entry points agree."""
+    import torch
+
+    rnd = random.Random(77)
+    pool = [oracle.point_mul_generator(sc(rnd.randrange(L))) for _ in range(40)] + [b"\0" * 32]
+    edge = [0, 1, L - 1, 2**252, 8, 0x0888888888888888888888888888888888888888888888888888888888888888]
+    for terms, m in ((8, 5), (9, 4), (16, 4), (255, 2), (256, 2), (65536, 1)):
+        scal = [[sc(edge[(i + t) % len(edge)]) if t % 5 == 0 else sc(rnd.randrange(L)) for t in range(terms)] for i in range(m)]
+        pp = [[pool[rnd.randrange(len(pool))] for _ in range(terms)] for _ in range(m)]
+        sb, pb = b"".join(b"".join(x) for x in scal), b"".join(b"".join(x) for x in pp)
+        got, ok = grp.vartime_multi_mul(terms, sb, pb)
+        assert set(ok) == {1}
+        for i in range(m):
+            assert got[32 * i : 32 * i + 32] == oracle.point_multi_mul(b"".join(scal[i]), b"".join(pp[i])), (terms, i)
+        # device entry point with a generator term: [r]G + sum
+        r = b"".join(sc(rnd.randrange(L)) for _ in range(m))
+        ds = torch.frombuffer(bytearray(sb), dtype=torch.uint8).cuda()
+        dp = torch.frombuffer(bytearray(pb), dtype=torch.uint8).cuda()
+        dr = torch.frombuffer(bytearray(r), dtype=torch.uint8).cuda()
+        do = torch.zeros(32 * m, dtype=torch.uint8, device="cuda")
+        dok = torch.zeros(m, dtype=torch.uint8, device="cuda")
+        scratch = torch.zeros(max(grp.msm_scratch_bytes(m, terms), 16), dtype=torch.uint8, device="cuda")
+        grp.vartime_multi_mul_device(m, terms, ds.data_ptr(), dp.data_ptr(), do.data_ptr(), d_r=dr.data_ptr(), d_scratch=scratch.data_ptr(),
+                                     d_ok=dok.data_ptr())
+        ctx.synchronize()
+        out = bytes(do.cpu().numpy())
+        for i in range(m):
+            want = oracle.point_add(got[32 * i : 32 * i + 32], oracle.point_mul_generator(r[32 * i : 32 * i + 32]))
+            assert out[32 * i : 32 * i + 32] == want, (terms, i)
+        assert dok.cpu().tolist() == [1] * m
+        if terms in (9, 256):          # one undecodable point in the last chunk of problem 1
+            bad = bytearray(pb)
+            bad[(1 * terms + terms - 1) * 32 : (1 * terms + terms) * 32] = b"\xff" * 32
+            _, ok = grp.vartime_multi_mul(terms, sb, bytes(bad))
+            assert list(ok) == [1, 0] + [1] * (m - 2)
+    assert grp.vartime_multi_mul(0, b"", b"") == (b"", b"")
+
+
 def test_comb_tables_selfcheck_and_digit_corners(eg, ctx, grp, oracle):
     """The fixed-base comb tables are built run by run with a batched inversion (k_build_fixed_table): sampled entries and the corners
     of windows and runs equal an entry-by-entry recomputation, for the table built at start-up and for the wide one; scalars whose
@@ -506,6 +547,27 @@ def test_cpp_voting_example(tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     assert "199 of 200 ballots verified" in out.stdout and "voter #4 rejected" in out.stdout
     assert "OK: decrypted totals sum to 199" in out.stdout
+
+
+def test_cpp_tally_exchange_example(tmp_path):
+    """examples/tally_exchange.cpp: the one collective of the path through librccl directly (eg_*_tally_encode_device -> ncclAllGather
+    -> eg_points_sum_device on one stream), the recipe for a host that is not Python; one rank on the box's one GPU."""
+    import os
+    import subprocess
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    exe = tmp_path / "tally_exchange"
+    subprocess.check_call(["hipcc", "-std=c++17", f"-I{root / 'include'}", str(root / "examples" / "tally_exchange.cpp"),
+                           f"-L{root / 'elastic_elgamal_amd'}", "-leg_hip", "-lrccl", f"-Wl,-rpath,{root / 'elastic_elgamal_amd'}",
+                           "-o", str(exe)])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([str(exe), "50000", "5", "9"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "OK: the exchanged tally equals the engine's own tally, 50000 of 50000 ballots accepted" in out.stdout
+    assert "undecodable encodings 0" in out.stdout
 
 
 def test_qv_generator_matches_oracle_prover(eg, ctx, oracle, pk):
@@ -1176,6 +1238,61 @@ def test_bench_rccl_leg_in_a_fresh_process():
     assert line["config"]["accepted"] == 131072 and line["n_gpus"] == 1 and line["scaling"] == "weak"
     assert line["roofline"]["frac"] > 0 and line["value"] > 1e5
     assert line["host_inclusive"]["verdicts_match_device_path"] is True
+
+
+def test_two_ranks_real_gpu_tallies(eg, ctx, pk, tmp_path):
+    """N = 2 with REAL GPU tallies (BASELINE configs[4] in small): two fresh child processes, each initialising the GPU itself (both on
+    device 0), form a gloo group; each verifies its shard_range slab of one 200 000-ballot batch (1 % tampered) with the HIP engine,
+    the tallies are exchanged with gather_tallies and merged with eg_points_sum_device (d_bad == 0).  Both ranks must hold the
+    tally and the accepted count of a single-process run over the whole batch (examples/voting.rs:199-203)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import time
+    from pathlib import Path
+
+    import torch
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    from dist_gpu_worker import tamper
+
+    total, seed, world = 200_000, 424242, 2
+    port = 29900 + os.getpid() % 90
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    # the whole batch in THIS process first (its GPU runtime is up before the children start theirs)
+    p = eg.ChoiceParams.single_choice(ctx, pk, 5)
+    d = torch.empty(total * p.ballot_size, dtype=torch.uint8, device="cuda")
+    p.encrypt_batch_device(seed, 0, total, d.data_ptr())
+    ctx.synchronize()
+    assert tamper(d.view(total, p.ballot_size), 0, total) == total // 100
+    st = torch.empty(total, dtype=torch.int32, device="cuda")
+    p.tally_reset()
+    p.verify_batch_device(total, d.data_ptr(), st.data_ptr())
+    want_tally = p.tally_encode()
+    want_accepted = int((st == 0).sum())
+    assert want_accepted == total - total // 100
+    worker = str(Path(__file__).resolve().parent / "dist_gpu_worker.py")
+    del d, st
+    torch.cuda.empty_cache()
+    procs = []
+    for r in range(world):
+        procs.append(subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), str(total), str(seed),
+                                       str(tmp_path / f"r{r}.json")], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+        time.sleep(2.0)          # the ranks bring up their GPU runtimes one after the other (they meet in the gloo rendezvous anyway)
+    for pr in procs:
+        text, _ = pr.communicate(timeout=600)
+        assert pr.returncode == 0, text[-3000:]
+    res = sorted((json.loads((tmp_path / f"r{r}.json").read_text()) for r in range(world)), key=lambda x: x["rank"])
+    assert [tuple(r["range"]) for r in res] == [(0, total // 2), (total // 2, total)]
+    for r in res:
+        assert r["d_bad"] == 0
+        assert r["accepted"] == want_accepted
+        assert bytes.fromhex(r["merged"]) == want_tally              # sharding and the exchange do not change the tally
+    assert res[0]["local"] != res[1]["local"]                          # the shards really differ
+    assert res[0]["accepted_local"] + res[1]["accepted_local"] == want_accepted
 
 
 def test_bench_fixed_total_mode():
