@@ -82,6 +82,15 @@ def _load() -> C.CDLL:
             f"{_LIB} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback."
         )
+    # PyTorch-ROCm wheels carry their OWN libamdhip64 / HSA runtime.  Two HIP runtimes in one process do not share the device: whichever
+    # loads second reports "No HIP GPUs are available".  A process that uses torch for device memory (tests, bench.py) must therefore load
+    # torch's runtime first; libeg_hip.so then binds to the copy that is already there.  (A host without torch is unaffected.)
+    import sys
+    if "torch" not in sys.modules and not os.environ.get("EG_NO_TORCH_PRELOAD"):
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = C.CDLL(str(_LIB))
     vp, cp, sz = C.c_void_p, C.c_char_p, C.c_size_t
     sig = {
@@ -102,6 +111,12 @@ def _load() -> C.CDLL:
         "eg_vartime_double_mul_generator_batch": (C.c_int, [vp, sz, cp, cp, cp, cp, cp]),
         "eg_vartime_multi_mul_batch": (C.c_int, [vp, sz, sz, cp, cp, cp, cp]),
         "eg_msm_scratch_bytes": (sz, [sz, sz]),
+        "eg_choice_prepare_wide_tables": (C.c_int, [vp]),
+        "eg_qv_prepare_wide_tables": (C.c_int, [vp]),
+        "eg_combine_shares": (C.c_int, [vp, C.c_uint64, C.c_uint64, sz, C.POINTER(C.c_uint64), cp, cp, C.POINTER(C.c_int)]),
+        "eg_dlog_table_create": (C.c_int, [vp, sz, C.POINTER(C.c_uint64), C.POINTER(vp)]),
+        "eg_dlog_table_destroy": (None, [vp]),
+        "eg_dlog_table_get": (C.c_int, [vp, sz, cp, C.POINTER(C.c_uint64), cp]),
         "eg_vartime_multi_mul_batch_device": (C.c_int, [vp, sz, sz, vp, vp, vp, vp, vp, vp, vp]),
         "eg_choice_params_create": (C.c_int, [vp, cp, C.c_int, C.c_int, C.POINTER(vp)]),
         "eg_choice_params_destroy": (None, [vp]),
@@ -174,11 +189,20 @@ def pack_json(text, n_options: int, single: bool | None = None, credits: int | N
     data = text.encode() if isinstance(text, str) else bytes(text)
     if not threads:
         threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    if not max_objects:
-        max_objects = data.count(b'"range_proof"') + 1 if credits is None else data.count(b'"credit_equivalence_proof"') + 1
     size = lib.eg_qv_ballot_size_for(n_options, credits) if credits is not None else lib.eg_choice_ballot_size(n_options, int(bool(single)))
     if not size:
         raise EgError("bad election parameters")
+    if not max_objects:
+        # the library counts the objects itself (max_objects = 0: nothing is written, *n_objects says how many there are); counting a
+        # key word instead would undercount texts that hold junk objects, and one voter's junk must never block the others' ballots
+        n0 = sz_t(0)
+        if credits is not None:
+            rc = lib.eg_qv_pack_json(n_options, credits, data, len(data), threads, 0, None, None, C.byref(n0))
+        else:
+            rc = lib.eg_choice_pack_json(n_options, int(bool(single)), data, len(data), threads, 0, None, None, C.byref(n0))
+        if rc != 0 and n0.value == 0:
+            _check(rc)
+        max_objects = n0.value
     packed = C.create_string_buffer(max(max_objects * size, 1))
     status = (C.c_uint32 * max(max_objects, 1))()
     n = sz_t(0)
@@ -440,7 +464,8 @@ class _BatchParams:
     def verify_json(self, text, max_objects: int = 0, threads: int = 0, with_tally: bool = True):
         """JSON text (serde's layout; one array or objects back to back) -> (status words, tally of this call) through the
         native entry point: host threads pack piece k+1 while the GPU verifies piece k.  Objects that do not deserialise get
-        MALFORMED; objects of another shape than the election's get PACK_RESHAPE (route those through ingest.verify_*_objects)."""
+        MALFORMED; objects of another shape than the election's get the reference's verdict (OptionsLenMismatch / LenMismatch in
+        verify()'s order) from the library's object path."""
         data = text.encode() if isinstance(text, str) else bytes(text)
         if not threads:
             threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -469,6 +494,10 @@ class _BatchParams:
         """Asynchronous device-pointer variant (torch tensors' data_ptr()); tally accumulates on the device."""
         fn = getattr(_load(), f"eg_verify_{self._prefix}_batch_device")
         _check(fn(self._h, n, d_ballots, d_status, stream))
+
+    def prepare_wide_tables(self):
+        """Build the wide fixed-base comb tables now instead of inside the first large verify call (eg_*_prepare_wide_tables)."""
+        _check(self._fn("prepare_wide_tables")(self._h))
 
     def tally_reset(self, stream: int = 0):
         if stream:

@@ -16,6 +16,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/eg_hip.h"
@@ -45,6 +46,11 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
       return fail(EG_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_) + " (" + __FILE__ + ":" + std::to_string(__LINE__) + ")"); \
   } while (0)
 
+// runs at scope exit, on every path (early returns of HIPCHK included)
+struct ScopeExit {
+  std::function<void()> fn;
+  ~ScopeExit() { if (fn) fn(); }
+};
 enum { PROF_CALL = 0, PROF_MSM = 1, PROF_TABLES = 2 };
 struct ProfSpan { hipEvent_t a, b; int kind; };
 
@@ -612,24 +618,30 @@ static int engine_verify_host(Engine* e, size_t n, const uint8_t* ballots, uint3
     HIPCHK(hipMalloc((void**)&e->d_status, std::max<size_t>(n, 1) * sizeof(u32)));
     e->staging_ballots = n;
   }
+  // fallible set-up comes BEFORE the running tally is set aside, and a scope guard puts it back on EVERY exit path (round 2 merged it
+  // only on the explicit error paths: an early HIPCHK return in between lost the running tally)
+  if (n && !e->copy_stream) HIPCHK(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
   // tally_out is the tally of THIS batch; the running tally keeps accumulating across calls (only eg_*_tally_reset clears
   // it).  The running tally is set aside, the batch is tallied from the identity, and the two are merged afterwards.
+  bool set_aside = false;
+  ScopeExit restore{[&]() {   // running tally = saved + this batch
+    if (!set_aside) return;
+    hipLaunchKernelGGL(k_tally_add_points, dim3(blocks_of((size_t)ns)), dim3(NT), 0, s, e->tally_saved, ns, e->tally);
+    (void)hipStreamSynchronize(s);
+  }};
   if (tally_out && ns) {
     HIPCHK(hipMemcpyAsync(e->tally_saved, e->tally, (size_t)ns * PT_WORDS * sizeof(u32), hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(k_tally_init, dim3(blocks_of((size_t)ns)), dim3(NT), 0, s, e->tally, ns);
+    set_aside = true;
   }
-  auto merge_saved = [&]() {   // running tally = saved + this batch (also on the error paths: nothing is lost)
-    if (tally_out && ns) hipLaunchKernelGGL(k_tally_add_points, dim3(blocks_of((size_t)ns)), dim3(NT), 0, s, e->tally_saved, ns, e->tally);
-  };
   if (n && e->items_seen + n >= e->ctx->big_min) {     // the whole batch counts: its first piece already reads the wide comb tables
     const int rc = ensure_big_tables(e, s);
-    if (rc) { merge_saved(); (void)hipStreamSynchronize(s); return rc; }
+    if (rc) return rc;
   }
   if (n) {
     // Pipeline: the copy stream uploads piece k+1 while piece k is verified (host staging, not the kernels, is
     // the scaling risk when ballots arrive in host memory).  The first piece is small so that the exposed upload is short;
     // the rest are as large as the engine's chunks (large chunks waste less of each kernel's last round).
-    if (!e->copy_stream) HIPCHK(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
     std::vector<std::pair<size_t, size_t>> pieces;   // (offset, count)
     {
       const size_t lanes = (size_t)e->ctx->resident_blocks * NT;
@@ -661,15 +673,10 @@ static int engine_verify_host(Engine* e, size_t n, const uint8_t* ballots, uint3
     (void)hipStreamSynchronize(e->copy_stream);
     (void)hipStreamSynchronize(s);
     for (hipEvent_t ev : uploaded) if (ev) (void)hipEventDestroy(ev);
-    if (rc) { merge_saved(); (void)hipStreamSynchronize(s); return rc; }
+    if (rc) return rc;
   }
   HIPCHK(hipStreamSynchronize(s));
-  if (tally_out) {
-    const int rc = engine_tally_encode(e, tally_out);
-    merge_saved();
-    HIPCHK(hipStreamSynchronize(s));
-    return rc;
-  }
+  if (tally_out) return engine_tally_encode(e, tally_out);      // (the guard merges the running tally back after the encoding)
   return EG_OK;
 }
 
@@ -963,24 +970,49 @@ int eg_point_add_batch(eg_ctx* c, size_t n, const uint8_t* a_, const uint8_t* b_
 // terms in all should still cover the chip (a lone 2^16-term product in chunks of 8 keeps only 8192 lanes busy: 3.1 ms; in chunks of 1
 // it is 65 536 independent ladders, ~1 ms): the chunk shrinks until the call has ~2 waves per SIMD worth of lanes.
 static void msm_plan(size_t n, size_t terms, int* chunk, int* n_chunks) {
-  const size_t lanes_wanted = (size_t)1 << 17;
+  size_t lanes_wanted = (size_t)1 << 17;
+  if (const char* v = getenv("EG_MSM_LANES")) lanes_wanted = std::max<size_t>(1, strtoull(v, nullptr, 10));   // tests: 1 = always full chunks
   size_t c = std::min<size_t>(std::max<size_t>(terms, 1), MSM_CHUNK);
   c = std::min(c, std::max<size_t>(1, n * terms / lanes_wanted));
   *chunk = (int)c;
   *n_chunks = (int)std::max<size_t>(1, (terms + c - 1) / c);
 }
-// out[i] = enc( sum_t [k_it]P_it + [r_i]G ) on device pointers (kernels.cuh: k_prim_msm + k_prim_msm_reduce); asynchronous on s
-static int prim_msm_launch(eg_ctx* c, size_t n, size_t terms, const u32* d_scalars, const u32* d_points, const u32* d_r, u32* d_partial,
-                           unsigned char* d_ok_partial, u32* d_out, unsigned char* d_ok, hipStream_t s) {
+// scratch of a call that is cut into several chunks per problem: two areas (the folds ping-pong between them), each holding the partial
+// sums (PT_WORDS words) and the decode flags (one byte) of up to `count` chunks
+struct MsmScratch { u32* part[2]; unsigned char* ok[2]; };
+static size_t msm_area_bytes(size_t count) { return (count * PT_WORDS * sizeof(u32) + 255) / 256 * 256 + (count + 255) / 256 * 256; }
+static size_t msm_scratch_total(size_t n, size_t nc) { return nc > 1 ? msm_area_bytes(n * nc) + msm_area_bytes(n * ((nc + 63) / 64)) : 0; }
+static MsmScratch msm_scratch_at(void* base, size_t n, size_t nc) {
+  MsmScratch m{{nullptr, nullptr}, {nullptr, nullptr}};
+  if (nc <= 1 || !base) return m;
+  char* p = static_cast<char*>(base);
+  const size_t c0 = n * nc, c1 = n * ((nc + 63) / 64);
+  m.part[0] = reinterpret_cast<u32*>(p); m.ok[0] = reinterpret_cast<unsigned char*>(p + (c0 * PT_WORDS * sizeof(u32) + 255) / 256 * 256);
+  p += msm_area_bytes(c0);
+  m.part[1] = reinterpret_cast<u32*>(p); m.ok[1] = reinterpret_cast<unsigned char*>(p + (c1 * PT_WORDS * sizeof(u32) + 255) / 256 * 256);
+  return m;
+}
+// out[i] = enc( sum_t [k_it]P_it + [r_i]G ) on device pointers (kernels.cuh: k_prim_msm, k_prim_msm_fold, k_prim_msm_reduce); asynchronous on s
+static int prim_msm_launch(eg_ctx* c, size_t n, size_t terms, const u32* d_scalars, const u32* d_points, const u32* d_r, void* d_scratch,
+                           u32* d_out, unsigned char* d_ok, hipStream_t s) {
   int chunk, n_chunks;
   msm_plan(n, terms, &chunk, &n_chunks);
+  const MsmScratch m = msm_scratch_at(d_scratch, n, (size_t)n_chunks);
   // every lane owns `chunk` tables in the per-lane workspace: the grid shrinks accordingly (the workspace is msm_blocks x one table)
   const int grid = grid_for(n * (size_t)n_chunks, std::max(1, c->msm_blocks / chunk));
   hipLaunchKernelGGL(k_prim_msm, dim3(grid), dim3(NT), (size_t)chunk * 8 * NT * sizeof(u32), s, n, (int)terms, chunk, n_chunks, d_scalars,
-                     d_points, d_r, c->tabG, c->ws, d_partial, d_ok_partial, d_out, d_ok);
-  if (n_chunks > 1)
-    hipLaunchKernelGGL(k_prim_msm_reduce, dim3((unsigned)((n * 64 + NT - 1) / NT)), dim3(NT), 0, s, n, n_chunks, d_partial, d_ok_partial,
+                     d_points, d_r, c->tabG, c->ws, m.part[0], m.ok[0], d_out, d_ok);
+  if (n_chunks > 1) {
+    int cur = 0, count = n_chunks;
+    while (count > 64) {                 // 64-fold per pass, one wavefront per 64 partial sums
+      const int next = (count + 63) / 64;
+      hipLaunchKernelGGL(k_prim_msm_fold, dim3((unsigned)((n * (size_t)next * 64 + NT - 1) / NT)), dim3(NT), 0, s, n, count, next,
+                         m.part[cur], m.ok[cur], m.part[cur ^ 1], m.ok[cur ^ 1]);
+      cur ^= 1; count = next;
+    }
+    hipLaunchKernelGGL(k_prim_msm_reduce, dim3((unsigned)((n * 64 + NT - 1) / NT)), dim3(NT), 0, s, n, count, m.part[cur], m.ok[cur],
                        d_r, c->tabG, d_out, d_ok);
+  }
   HIPCHK(hipGetLastError());
   return EG_OK;
 }
@@ -991,13 +1023,12 @@ static int prim_msm(eg_ctx* c, size_t n, size_t terms, const uint8_t* scalars, c
   if (n == 0) return EG_OK;
   if (terms > ((size_t)1 << 24) || n > ((size_t)1 << 32)) return fail(EG_ERR_BAD_ARG, "at most 2^24 terms per problem");
   const size_t nc = msm_chunks(n, terms);
-  void *sc, *pt, *rr, *o, *k, *part, *okp;
-  TRY(prim_bufs(c, {n * terms * 32, n * terms * 32, n * 32, n * 32, n, nc > 1 ? n * nc * PT_WORDS * sizeof(u32) : 0, nc > 1 ? n * nc : 0},
-                {&sc, &pt, &rr, &o, &k, &part, &okp}));
+  void *sc, *pt, *rr, *o, *k, *scratch;
+  TRY(prim_bufs(c, {n * terms * 32, n * terms * 32, n * 32, n * 32, n, msm_scratch_total(n, nc)}, {&sc, &pt, &rr, &o, &k, &scratch}));
   TRY(h2d(sc, scalars, n * terms * 32, c->stream)); TRY(h2d(pt, points, n * terms * 32, c->stream));
   if (r) TRY(h2d(rr, r, n * 32, c->stream));
-  TRY(prim_msm_launch(c, n, terms, (const u32*)sc, (const u32*)pt, r ? (const u32*)rr : (const u32*)nullptr, (u32*)part,
-                      (unsigned char*)okp, (u32*)o, (unsigned char*)k, c->stream));
+  TRY(prim_msm_launch(c, n, terms, (const u32*)sc, (const u32*)pt, r ? (const u32*)rr : (const u32*)nullptr, nc > 1 ? scratch : nullptr,
+                      (u32*)o, (unsigned char*)k, c->stream));
   TRY(d2h(out, o, n * 32, c->stream));
   if (ok) TRY(d2h(ok, k, n, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -1020,10 +1051,7 @@ int eg_vartime_multi_mul_batch(eg_ctx* c, size_t n, size_t terms, const uint8_t*
 }
 // the same on DEVICE buffers, asynchronous on `stream` (a caller that keeps its operands in HBM pays no copies and no synchronisation;
 // what bench.py --workload msm times).  d_scratch must hold eg_msm_scratch_bytes(n, terms) bytes (0 for <= 8 terms).
-size_t eg_msm_scratch_bytes(size_t n, size_t terms) {
-  const size_t nc = msm_chunks(n, terms);
-  return nc > 1 ? n * nc * (PT_WORDS * sizeof(u32) + 1) + 256 : 0;
-}
+size_t eg_msm_scratch_bytes(size_t n, size_t terms) { return msm_scratch_total(n, msm_chunks(n, terms)); }
 int eg_vartime_multi_mul_batch_device(eg_ctx* c, size_t n, size_t terms, const void* d_scalars, const void* d_points, const void* d_r,
                                       void* d_scratch, void* d_out, void* d_ok, void* stream) { EG_LOCK(c);
   if (!c || (n && !d_out) || (n && terms && (!d_scalars || !d_points)) || (n && !terms && !d_r)) return fail(EG_ERR_BAD_ARG, "bad argument");
@@ -1032,10 +1060,83 @@ int eg_vartime_multi_mul_batch_device(eg_ctx* c, size_t n, size_t terms, const v
   if (n && nc > 1 && !d_scratch) return fail(EG_ERR_BAD_ARG, "this call is cut into several chunks per problem and needs d_scratch (eg_msm_scratch_bytes)");
   if (n == 0) return EG_OK;
   HIPCHK(hipSetDevice(c->device));
-  u32* part = (u32*)d_scratch;
-  unsigned char* okp = nc > 1 ? (unsigned char*)d_scratch + (n * nc * PT_WORDS * sizeof(u32) + 255) / 256 * 256 : nullptr;
-  return prim_msm_launch(c, n, terms, (const u32*)d_scalars, (const u32*)d_points, (const u32*)d_r, part, okp, (u32*)d_out,
+  return prim_msm_launch(c, n, terms, (const u32*)d_scalars, (const u32*)d_points, (const u32*)d_r, nc > 1 ? d_scratch : nullptr, (u32*)d_out,
                          (unsigned char*)d_ok, (hipStream_t)stream);
+}
+
+// ---- tally stage (examples/voting.rs:122-177) --------------------------------------------------------------------------
+// Params::combine_shares (src/sharing/mod.rs:302-325) with lagrange_coefficients (:139-170): the first `threshold` shares are combined
+// by Lagrange interpolation in the exponent.  Every scalar operation (products of the index differences, the batched inversion, the
+// scaling) and the multi-scalar multiplication run on the GPU primitives; the host only feeds small integers.
+int eg_combine_shares(eg_ctx* c, uint64_t shares, uint64_t threshold, size_t n, const uint64_t* indexes, const uint8_t* dh_elements,
+                      uint8_t out[32], int* combined) { EG_LOCK(c);
+  if (!c || !combined || !out || (n && (!indexes || !dh_elements)) || threshold < 1 || threshold > shares)
+    return fail(EG_ERR_BAD_ARG, "bad argument");
+  *combined = 0;
+  if (n < threshold) return EG_OK;                         // None: the number of shares is insufficient
+  const size_t t = (size_t)threshold;                      // .take(self.threshold)
+  for (size_t i = 0; i < t; ++i) {
+    if (indexes[i] >= shares) return fail(EG_ERR_BAD_ARG, "share index exceeds the number of participants");   // the reference panics
+    for (size_t j = 0; j < i; ++j)
+      if (indexes[i] == indexes[j]) return fail(EG_ERR_BAD_ARG, "duplicate share index");
+  }
+  auto u64_scalar = [](uint64_t v, uint8_t* dst) { memset(dst, 0, 32); memcpy(dst, &v, 8); };
+  std::vector<uint8_t> prod(32 * (t + 1)), factor(32 * (t + 1)), zero(32 * (t + 1), 0), tmp(32 * (t + 1));
+  // lanes 0..t-1: denominators |prod_j d_ij| with d_ii = index_i + 1; lane t: the scale prod_i (index_i + 1)
+  for (size_t i = 0; i <= t; ++i) u64_scalar(1, prod.data() + 32 * i);
+  std::vector<int> negative(t, 0);
+  for (size_t j = 0; j < t; ++j) {
+    for (size_t i = 0; i < t; ++i) {
+      const uint64_t a = indexes[i], b = indexes[j];
+      if (a > b) negative[i] ^= 1;                         // Ordering::Greater => (true, index - other_index)
+      u64_scalar(a == b ? a + 1 : (a > b ? a - b : b - a), factor.data() + 32 * i);
+    }
+    u64_scalar(indexes[j] + 1, factor.data() + 32 * t);
+    TRY(eg_scalar_muladd_batch(c, t + 1, prod.data(), factor.data(), zero.data(), tmp.data()));
+    prod.swap(tmp);
+  }
+  for (size_t i = 0; i < t; ++i)
+    if (negative[i]) TRY(eg_scalar_neg_batch(c, 1, prod.data() + 32 * i, prod.data() + 32 * i));
+  std::vector<uint8_t> inv(32 * t), coeff(32 * t), scale(32 * t);
+  TRY(eg_scalar_invert_batch(c, t, prod.data(), inv.data()));                              // G::invert_scalars
+  for (size_t i = 0; i < t; ++i) memcpy(scale.data() + 32 * i, prod.data() + 32 * t, 32);
+  TRY(eg_scalar_muladd_batch(c, t, inv.data(), scale.data(), zero.data(), coeff.data()));  // [scale](sum [d_i^-1] S_i) = sum [scale d_i^-1] S_i
+  uint8_t ok = 0;
+  TRY(eg_vartime_multi_mul_batch(c, 1, t, coeff.data(), dh_elements, out, &ok));
+  if (!ok) return fail(EG_ERR_BAD_ARG, "a decryption share is not a valid ristretto255 encoding");
+  *combined = 1;
+  return EG_OK;
+}
+
+// DiscreteLogTable (src/encryption.rs:260-298): [v]G (canonical encoding) -> v for the given values; the products come from the GPU,
+// the lookups are a host hash map like the reference's HashMap<Vec<u8>, u64>.
+struct eg_dlog_table { std::unordered_map<std::string, uint64_t> map; };
+int eg_dlog_table_create(eg_ctx* c, size_t n, const uint64_t* values, eg_dlog_table** out) { EG_LOCK(c);
+  if (!c || !out || (n && !values)) return fail(EG_ERR_BAD_ARG, "bad argument");
+  std::vector<uint64_t> vals;
+  for (size_t i = 0; i < n; ++i) if (values[i] != 0) vals.push_back(values[i]);           // .filter(|&value| value != 0)
+  std::vector<uint8_t> sc(32 * vals.size(), 0), enc(32 * vals.size());
+  for (size_t i = 0; i < vals.size(); ++i) memcpy(sc.data() + 32 * i, &vals[i], 8);
+  if (!vals.empty()) TRY(eg_mul_generator_batch(c, vals.size(), sc.data(), enc.data()));
+  std::unique_ptr<eg_dlog_table> t(new eg_dlog_table());
+  t->map.reserve(vals.size() * 2);
+  for (size_t i = 0; i < vals.size(); ++i) t->map.emplace(std::string(reinterpret_cast<const char*>(enc.data()) + 32 * i, 32), vals[i]);
+  *out = t.release();
+  return EG_OK;
+}
+void eg_dlog_table_destroy(eg_dlog_table* t) { delete t; }
+// values[i] = discrete log of elements[i] if it is in the table (found[i] = 1); the identity (32 zero bytes) is always 0
+int eg_dlog_table_get(const eg_dlog_table* t, size_t n, const uint8_t* elements, uint64_t* values, uint8_t* found) {
+  if (!t || (n && (!elements || !values || !found))) return fail(EG_ERR_BAD_ARG, "bad argument");
+  static const char zero[32] = {0};
+  for (size_t i = 0; i < n; ++i) {
+    const char* e = reinterpret_cast<const char*>(elements) + 32 * i;
+    if (memcmp(e, zero, 32) == 0) { values[i] = 0; found[i] = 1; continue; }
+    auto it = t->map.find(std::string(e, 32));
+    found[i] = it != t->map.end();
+    values[i] = found[i] ? it->second : 0;
+  }
+  return EG_OK;
 }
 
 // ---- batch tier: choice ---------------------------------------------------------------------------------------------------
@@ -1087,6 +1188,17 @@ int eg_points_sum_device(eg_ctx* c, int n_ranks, int n_points, const void* d_in,
   HIPCHK(hipGetLastError());
   return EG_OK;
 }
+// builds the wide comb tables now (synchronously, ~12 GB each for G and K) instead of inside the first large verify call
+static int prepare_wide(Engine* e) {
+  HIPCHK(hipSetDevice(e->ctx->device));
+  HIPCHK(hipDeviceSynchronize());
+  const int rc = ensure_big_tables(e, e->ctx->stream);
+  if (rc) return rc;
+  if (e->ctx->big_bits && (!e->ctx->tabG_big || !e->d_tabK_big)) return fail(EG_ERR_NOMEM, "the wide comb tables do not fit the device memory");
+  return EG_OK;
+}
+int eg_choice_prepare_wide_tables(eg_choice_params* p) { EG_LOCK_P(p); return p ? prepare_wide(p->eng) : fail(EG_ERR_BAD_ARG, "null"); }
+int eg_qv_prepare_wide_tables(eg_qv_params* p) { EG_LOCK_P(p); return p ? prepare_wide(p->eng) : fail(EG_ERR_BAD_ARG, "null"); }
 int eg_choice_tally_reset(eg_choice_params* p) { EG_LOCK_P(p); return p ? tally_reset(p->eng, p->eng->ctx->stream, true) : fail(EG_ERR_BAD_ARG, "null"); }
 int eg_choice_tally_reset_async(eg_choice_params* p, void* stream) { EG_LOCK_P(p); return p ? tally_reset(p->eng, (hipStream_t)stream, false) : fail(EG_ERR_BAD_ARG, "null"); }
 int eg_choice_tally_add(eg_choice_params* p, const uint8_t* in) { EG_LOCK_P(p);
@@ -1282,8 +1394,34 @@ int eg_qv_pack_json(int n_options, uint64_t credits, const char* json, size_t js
 // pipelines the upload inside a window).  Objects that do not pack keep their pack verdict; their zeroed slots are verified like
 // any other ballot (an all-zero ballot never verifies, so nothing of it reaches the tally) and the verdict is overwritten afterwards.
 typedef std::function<void(const char*, const std::vector<std::pair<size_t, size_t>>&, int, uint8_t*, uint32_t*)> PackPieceFn;
+// verdicts of the objects that deserialise but do not have the election's shape (egwire::resolve_*_objects): false = a GPU call failed
+typedef std::function<bool(const char*, const std::vector<std::pair<size_t, size_t>>&, std::vector<uint32_t>&)> ReshapeFn;
+// the two GPU services of the object path (wire_json.hpp): validity of 32-byte items, and the batch verifier on substitute ballots
+static egwire::CheckItemsFn make_check_items(eg_ctx* c) {
+  return [c](const std::string& kinds, const egwire::Bytes& data, std::vector<uint8_t>& ok) {
+    egwire::Bytes pts, scs;
+    for (size_t i = 0; i < kinds.size(); ++i) {
+      egwire::Bytes& dst = kinds[i] == 'P' ? pts : scs;
+      dst.insert(dst.end(), data.begin() + 32 * i, data.begin() + 32 * (i + 1));
+    }
+    std::vector<uint8_t> pok(pts.size() / 32), sok(scs.size() / 32), tmp(pts.size());
+    if (!pok.empty() && eg_point_roundtrip_batch(c, pok.size(), pts.data(), tmp.data(), pok.data())) return false;
+    if (!sok.empty() && eg_scalar_is_canonical_batch(c, sok.size(), scs.data(), sok.data())) return false;
+    ok.resize(kinds.size());
+    size_t pi = 0, si = 0;
+    for (size_t i = 0; i < kinds.size(); ++i) ok[i] = kinds[i] == 'P' ? pok[pi++] : sok[si++];
+    return true;
+  };
+}
+static int engine_verify_host(Engine* e, size_t n, const uint8_t* ballots, uint32_t* status, uint8_t* tally_out);
+static egwire::VerifyPackedFn make_verify_packed(Engine* e) {
+  return [e](size_t n, const egwire::Bytes& packed, std::vector<uint32_t>& status) {
+    status.assign(n, 0);
+    return engine_verify_host(e, n, packed.data(), status.data(), nullptr) == EG_OK;
+  };
+}
 static int verify_json_common(Engine* e, const char* json, size_t json_len, int threads, size_t max_objects, uint32_t* status,
-                              size_t* n_objects, uint8_t* tally_out, const PackPieceFn& pack_piece) {
+                              size_t* n_objects, uint8_t* tally_out, const PackPieceFn& pack_piece, const ReshapeFn& reshape) {
   if ((json_len && !json) || (max_objects && !status)) return fail(EG_ERR_BAD_ARG, "bad argument");
   if (n_objects) *n_objects = 0;
   HIPCHK(hipSetDevice(e->ctx->device));
@@ -1291,9 +1429,16 @@ static int verify_json_common(Engine* e, const char* json, size_t json_len, int 
   const int ns = (int)e->plan.tally_slots.size();
   hipStream_t s = e->ctx->stream;
   HIPCHK(hipDeviceSynchronize());
+  bool set_aside = false;
+  ScopeExit restore{[&]() {     // running tally = saved + this call, on every exit path
+    if (!set_aside) return;
+    hipLaunchKernelGGL(k_tally_add_points, dim3(blocks_of((size_t)ns)), dim3(NT), 0, s, e->tally_saved2, ns, e->tally);
+    (void)hipStreamSynchronize(s);
+  }};
   if (tally_out && ns) {        // tally_out = the tally of THIS call; the running tally keeps accumulating (eg_hip.h)
     HIPCHK(hipMemcpyAsync(e->tally_saved2, e->tally, (size_t)ns * PT_WORDS * sizeof(u32), hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(k_tally_init, dim3(blocks_of((size_t)ns)), dim3(NT), 0, s, e->tally, ns);
+    set_aside = true;
     HIPCHK(hipStreamSynchronize(s));
   }
   // windows: a small first one (its split + parse is the only one nothing overlaps with), doubling up to ~2^18 single-choice ballots'
@@ -1339,21 +1484,25 @@ static int verify_json_common(Engine* e, const char* json, size_t json_len, int 
     const size_t m = spans[b].size(), first = first_index[b];
     if (m) {
       rc = engine_verify_host(e, m, e->json_stage[b], status + first, nullptr);
-      if (rc == EG_OK)
-        for (size_t i = 0; i < m; ++i)
+      if (rc == EG_OK) {
+        std::vector<std::pair<size_t, size_t>> odd;
+        std::vector<size_t> odd_at;
+        for (size_t i = 0; i < m; ++i) {
           if (pack_status[b][i] != EG_ST_OK) status[first + i] = pack_status[b][i];
+          if (pack_status[b][i] == EG_PACK_RESHAPE) { odd.push_back(spans[b][i]); odd_at.push_back(first + i); }
+        }
+        if (!odd.empty()) {        // OptionsLenMismatch / LenMismatch territory: the object path, in the reference's order of checks
+          std::vector<uint32_t> verdicts;
+          if (!reshape(json, odd, verdicts)) rc = g_err.empty() ? fail(EG_ERR_HIP, "object path: a GPU call failed") : EG_ERR_HIP;
+          else for (size_t i = 0; i < odd.size(); ++i) status[odd_at[i]] = verdicts[i];
+        }
+      }
     }
     if (producer.joinable()) producer.join();
     if (last) break;
   }
   if (n_objects) *n_objects = cur.count;
-  if (tally_out && ns) {
-    int rc2 = EG_OK;
-    if (rc == EG_OK) rc2 = engine_tally_encode(e, tally_out);
-    hipLaunchKernelGGL(k_tally_add_points, dim3(blocks_of((size_t)ns)), dim3(NT), 0, s, e->tally_saved2, ns, e->tally);
-    (void)hipStreamSynchronize(s);
-    if (rc == EG_OK) rc = rc2;
-  }
+  if (tally_out && ns && rc == EG_OK) rc = engine_tally_encode(e, tally_out);      // (the guard merges the running tally back afterwards)
   return rc;
 }
 int eg_verify_choice_json(eg_choice_params* p, const char* json, size_t json_len, int threads, size_t max_objects, uint32_t* status,
@@ -1361,11 +1510,16 @@ int eg_verify_choice_json(eg_choice_params* p, const char* json, size_t json_len
   if (!p) return fail(EG_ERR_BAD_ARG, "bad argument");
   const int n_options = p->n_options, single = p->single;
   const size_t stride = p->eng->plan.stride;
+  Engine* e = p->eng;
   return verify_json_common(p->eng, json, json_len, threads, max_objects, status, n_objects, tally_out,
                             [=](const char* text, const std::vector<std::pair<size_t, size_t>>& sub, int th, uint8_t* dst, uint32_t* st) {
                               egwire::pack_parallel(text, sub, stride, th, dst, st, [&](egwire::Cursor& c, uint8_t* d) {
                                 return egwire::pack_choice(c, n_options, single != 0, d);
                               });
+                            },
+                            [=](const char* text, const std::vector<std::pair<size_t, size_t>>& odd, std::vector<uint32_t>& out) {
+                              return egwire::resolve_choice_objects(text, odd, n_options, single != 0, stride, make_check_items(e->ctx),
+                                                                    make_verify_packed(e), out);
                             });
 }
 int eg_verify_qv_json(eg_qv_params* p, const char* json, size_t json_len, int threads, size_t max_objects, uint32_t* status,
@@ -1375,11 +1529,16 @@ int eg_verify_qv_json(eg_qv_params* p, const char* json, size_t json_len, int th
   const eghost::QvShape sh = p->shape;
   const egwire::RangeShape vote{sh.vote_range.rings.size(), (size_t)sh.vote_range.rings_size()};
   const egwire::RangeShape credit{sh.credit_range.rings.size(), (size_t)sh.credit_range.rings_size()};
+  Engine* e = p->eng;
   return verify_json_common(p->eng, json, json_len, threads, max_objects, status, n_objects, tally_out,
                             [=](const char* text, const std::vector<std::pair<size_t, size_t>>& sub, int th, uint8_t* dst, uint32_t* st) {
                               egwire::pack_parallel(text, sub, sh.ballot_size, th, dst, st, [&](egwire::Cursor& c, uint8_t* d) {
                                 return egwire::pack_qv(c, n_options, vote, credit, sh.ballot_size, d);
                               });
+                            },
+                            [=](const char* text, const std::vector<std::pair<size_t, size_t>>& odd, std::vector<uint32_t>& out) {
+                              return egwire::resolve_qv_objects(text, odd, n_options, vote, credit, sh.ballot_size, make_check_items(e->ctx),
+                                                                make_verify_packed(e), out);
                             });
 }
 size_t eg_qv_ballot_size_for(int n_options, uint64_t credits) {

@@ -924,6 +924,38 @@ __device__ __forceinline__ void wave_reduce_points(ge& acc) {
     acc = sum;
   }
 }
+// one wavefront per 64 partial sums of a problem: folds them into one (lane = partial, shuffle reduction).  Long products (2^16 single-term
+// chunks) are folded 64-fold per pass until at most 64 partial sums per problem are left for k_prim_msm_reduce.
+__global__ void __launch_bounds__(NT, 2) k_prim_msm_fold(size_t n, int n_in, int n_out, const u32* in, const unsigned char* ok_in, u32* out,
+                                                         unsigned char* ok_out) {
+  const size_t wave = ((size_t)blockIdx.x * NT + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (wave >= n * (size_t)n_out) return;                  // whole wavefronts leave together
+  const size_t i = wave / n_out;
+  const int c = (int)(wave % n_out) * 64 + lane;
+  ge acc; ge_identity(acc);
+  bool okk = true;
+  if (c < n_in) {
+    const size_t j = i * (size_t)n_in + c;
+    u32 w[PT_WORDS];
+#pragma unroll
+    for (int q = 0; q < PT_QUADS; ++q) {
+      const uint4 v = reinterpret_cast<const uint4*>(in)[j * PT_QUADS + q];
+      w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+    }
+    words_to_ge(acc, w);
+    okk = ok_in[j] != 0;
+  }
+  wave_reduce_points(acc);
+  const bool all_ok = __all(okk ? 1 : 0) != 0;
+  if (lane == 0) {
+    u32 w[PT_WORDS];
+    ge_to_words(w, acc);
+#pragma unroll
+    for (int q = 0; q < PT_QUADS; ++q) reinterpret_cast<uint4*>(out)[wave * PT_QUADS + q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+    ok_out[wave] = all_ok ? 1 : 0;
+  }
+}
 // one wavefront per problem: sums the problem's partial sums, adds the generator term, encodes
 __global__ void __launch_bounds__(NT, 2) k_prim_msm_reduce(size_t n, int n_chunks, const u32* partial, const unsigned char* ok_partial,
                                                            const u32* r, const uint4* tabG, u32* out, unsigned char* ok) {

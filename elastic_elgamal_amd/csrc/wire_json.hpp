@@ -21,6 +21,7 @@
 #pragma once
 #include <cstdint>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <thread>
 #include <vector>
@@ -47,12 +48,44 @@ struct B64Table {
 };
 static constexpr B64Table kB64{};
 
-// a JSON string holding exactly 32 bytes of unpadded base64url (43 characters, the 2 trailing bits zero) -> out.
-// Anything else in the string - another alphabet, padding, a backslash escape, another length - fails.
-inline bool parse_b64_32(Cursor& c, uint8_t out[32]) {
+// A JSON string, unescaped into buf (serde_json unescapes every string and key before it is looked at, so a ballot whose emitter wrote
+// "\u0041" for "A" or "\/" for "/" is as valid as the plain one): at most cap - 1 bytes; code points above 0x7f come out as 0xff
+// (never part of a field name or of the base64url alphabet).  The slow path of parse_b64_32 / parse_key.
+inline bool read_json_string(Cursor& c, char* buf, size_t cap, size_t& len) {
+  len = 0;
   if (!c.eat('"')) return false;
-  if (c.end - c.p < 44) return false;
-  const unsigned char* s = reinterpret_cast<const unsigned char*>(c.p);
+  auto hex = [](char ch) { return ch >= '0' && ch <= '9' ? ch - '0' : ch >= 'a' && ch <= 'f' ? ch - 'a' + 10 : ch >= 'A' && ch <= 'F' ? ch - 'A' + 10 : -1; };
+  while (c.p < c.end) {
+    unsigned char ch = (unsigned char)*c.p++;
+    if (ch == '"') { buf[len] = '\0'; return true; }
+    if (ch < 0x20) return false;                         // control characters must be escaped in JSON
+    if (ch == '\\') {
+      if (c.p >= c.end) return false;
+      const char e = *c.p++;
+      switch (e) {
+        case '"': ch = '"'; break;   case '\\': ch = '\\'; break;   case '/': ch = '/'; break;
+        case 'b': ch = '\b'; break;  case 'f': ch = '\f'; break;    case 'n': ch = '\n'; break;
+        case 'r': ch = '\r'; break;  case 't': ch = '\t'; break;
+        case 'u': {
+          if (c.end - c.p < 4) return false;
+          int v = 0;
+          for (int i = 0; i < 4; ++i) { const int h = hex(c.p[i]); if (h < 0) return false; v = v * 16 + h; }
+          c.p += 4;
+          ch = v < 0x80 ? (unsigned char)v : 0xff;
+          break;
+        }
+        default: return false;
+      }
+    }
+    if (len + 1 >= cap) return false;
+    buf[len++] = (char)ch;
+  }
+  return false;
+}
+
+// a JSON string holding exactly 32 bytes of unpadded base64url (43 characters, the 2 trailing bits zero) -> out.
+// Anything else in the string - another alphabet, padding, another length - fails.  Escaped characters take the slow path.
+inline bool decode_b64_43(const unsigned char* s, uint8_t out[32]) {
   uint32_t bad = 0;
   for (int g = 0; g < 10; ++g) {                       // 40 characters -> 30 bytes
     const uint32_t a = kB64.v[s[4 * g]], b = kB64.v[s[4 * g + 1]], d = kB64.v[s[4 * g + 2]], e = kB64.v[s[4 * g + 3]];
@@ -64,8 +97,23 @@ inline bool parse_b64_32(Cursor& c, uint8_t out[32]) {
   bad |= a | b | d;
   const uint32_t w = (a << 12) | (b << 6) | d;
   out[30] = (uint8_t)(w >> 10); out[31] = (uint8_t)(w >> 2);
-  if ((bad & 0x80u) || (w & 3u) || s[43] != '"') return false;
-  c.p += 44;
+  return !(bad & 0x80u) && !(w & 3u);
+}
+inline bool parse_b64_32(Cursor& c, uint8_t out[32]) {
+  c.ws();
+  if (c.p >= c.end || *c.p != '"') return false;
+  if (c.end - c.p >= 45 && c.p[44] == '"' && decode_b64_43(reinterpret_cast<const unsigned char*>(c.p + 1), out)) { c.p += 45; return true; }
+  // not the plain form: either invalid, or a valid string with escapes - look only if a backslash comes before the closing quote
+  const char* q = c.p + 1;
+  bool escaped = false;
+  while (q < c.end && *q != '"') { if (*q == '\\') { escaped = true; break; } ++q; }
+  if (!escaped) return false;
+  char buf[48];
+  size_t len = 0;
+  Cursor t = c;
+  if (!read_json_string(t, buf, sizeof buf, len) || len != 43) return false;
+  if (!decode_b64_43(reinterpret_cast<const unsigned char*>(buf), out)) return false;
+  c.p = t.p;
   return true;
 }
 
@@ -101,7 +149,8 @@ inline bool skip_value(Cursor& c, int depth = 0) {
   return c.p > s;
 }
 
-// field name of an object member, without escapes (every name of the wire format is plain ASCII); longer names are unknown fields
+// field name of an object member (every name of the wire format is plain ASCII; an escaped spelling of one is unescaped like
+// serde_json does); longer names are unknown fields
 inline bool parse_key(Cursor& c, char name[32]) {
   c.ws();
   if (c.p >= c.end || *c.p != '"') return false;
@@ -111,7 +160,20 @@ inline bool parse_key(Cursor& c, char name[32]) {
   while (q < c.end && *q != '"') { if (*q == '\\') { escaped = true; ++q; if (q >= c.end) return false; } ++q; }
   if (q >= c.end) return false;
   const size_t len = (size_t)(q - s);
-  if (escaped || len > 31) name[0] = '\0';
+  if (escaped) {
+    char buf[200];
+    size_t n = 0;
+    Cursor t = c;
+    if (!read_json_string(t, buf, sizeof buf, n)) {       // a well-formed but very long escaped key is an unknown field
+      if (!skip_string(c)) return false;
+      name[0] = '\0';
+      return c.eat(':');
+    }
+    if (n > 31) name[0] = '\0'; else { memcpy(name, buf, n); name[n] = '\0'; }
+    c.p = t.p;
+    return c.eat(':');
+  }
+  if (len > 31) name[0] = '\0';
   else { memcpy(name, s, len); name[len] = '\0'; }
   c.p = q + 1;
   return c.eat(':');
@@ -280,6 +342,222 @@ inline uint32_t pack_qv(Cursor& c, int n_options, const RangeShape& vote, const 
   memcpy(d, proof_r.data(), proof_r.size()); d += proof_r.size();
   memcpy(d, proof_s.data(), 32);
   return ST_OK;
+}
+
+// ---- object path: ballots that deserialise but do not have the election's shape -----------------------------------------------------
+// In the reference such a ballot reaches verify(), which reports OptionsLenMismatch (choice.rs:149-158, quadratic_voting.rs:295) or the
+// LenMismatch of the first ill-shaped proof (ring.rs:310-315, range.rs:555-559, mul.rs:197-202) - unless an EARLIER proof fails first,
+// or deserialisation already failed on a non-canonical scalar / invalid element (serde.rs:191-206,254-269).  The order is kept here:
+//   1. every 32-byte item of the object, in the order of the struct's fields, is checked (GPU: `check_items`); the first bad one wins;
+//   2. the options count; 3. the proofs in verify()'s order: the well-shaped ones before the first ill-shaped one ARE verified on the
+//   GPU - the object is re-packed with an all-zero proof (which cannot verify) in place of every ill-shaped part (`verify_packed`) and
+//   the verdict is read off the status word; if nothing earlier fails, the LenMismatch of the first ill-shaped proof is the verdict.
+// Nothing here computes group or field arithmetic; the two callbacks run the product's GPU entry points.
+struct AnyItems {                 // 32-byte items in struct-field order, tagged 'P' (group element) or 'S' (scalar)
+  std::string kinds;
+  Bytes data;
+  size_t count() const { return kinds.size(); }
+  void add(char kind, const uint8_t* b, size_t n_items) { kinds.append(n_items, kind); data.insert(data.end(), b, b + 32 * n_items); }
+};
+struct ChoiceAny { size_t n_choices = 0, n_resp = 0; bool sum_null = false; Bytes choices, e0, resp, sum; };
+inline bool parse_choice_any(Cursor& c, ChoiceAny& o) {
+  static const char* const F[] = {"choices", "range_proof", "sum_proof"};
+  static const char* const RING[] = {"common_challenge", "ring_responses"};
+  static const char* const LOGEQ[] = {"challenge", "response"};
+  return parse_object(c, F, 3, [&](int i) {
+    if (i == 0) return parse_ciphertexts(c, o.choices, o.n_choices);
+    if (i == 1) return parse_object(c, RING, 2, [&](int k) { return k == 0 ? parse_item(c, o.e0) : parse_items(c, o.resp, o.n_resp, 2); });
+    c.ws();
+    if (c.end - c.p >= 4 && memcmp(c.p, "null", 4) == 0) { c.p += 4; o.sum_null = true; return true; }
+    uint8_t ch[32], rs[32];
+    if (!parse_object(c, LOGEQ, 2, [&](int k) { return parse_b64_32(c, k == 0 ? ch : rs); })) return false;
+    o.sum.assign(ch, ch + 32); o.sum.insert(o.sum.end(), rs, rs + 32);
+    return true;
+  });
+}
+struct RangeAny { Bytes ct, partials, e0, resp; size_t n_partials = 0, n_resp = 0; };
+inline bool parse_range_any(Cursor& c, RangeAny& r) {
+  static const char* const F[] = {"ciphertext", "range_proof"};
+  static const char* const RP[] = {"partial_ciphertexts", "common_challenge", "ring_responses"};
+  return parse_object(c, F, 2, [&](int i) {
+    if (i == 0) return parse_ciphertext(c, r.ct);
+    return parse_object(c, RP, 3, [&](int k) {
+      if (k == 0) return parse_ciphertexts(c, r.partials, r.n_partials);
+      if (k == 1) return parse_item(c, r.e0);
+      return parse_items(c, r.resp, r.n_resp, 2);
+    });
+  });
+}
+struct QvAny { std::vector<RangeAny> votes; RangeAny credit; Bytes c, resp, s; size_t n_resp = 0; };
+inline bool parse_qv_any(Cursor& c, QvAny& o) {
+  static const char* const F[] = {"votes", "credit", "credit_equivalence_proof"};
+  static const char* const SQ[] = {"challenge", "ciphertext_responses", "sum_response"};
+  return parse_object(c, F, 3, [&](int i) {
+    if (i == 0) {
+      if (!c.eat('[')) return false;
+      if (!c.peek(']')) {
+        for (;;) {
+          o.votes.emplace_back();
+          if (!parse_range_any(c, o.votes.back())) return false;
+          if (c.eat(',')) continue;
+          break;
+        }
+      }
+      return c.eat(']');
+    }
+    if (i == 1) return parse_range_any(c, o.credit);
+    return parse_object(c, SQ, 3, [&](int k) {
+      if (k == 0) return parse_item(c, o.c);
+      if (k == 1) return parse_items(c, o.resp, o.n_resp, 2);
+      return parse_item(c, o.s);
+    });
+  });
+}
+
+enum : uint32_t { ST_BAD_SCALAR = 1, ST_BAD_POINT = 2, ST_OPTIONS_LEN = 3, ST_SUM_CHALLENGE = 4, ST_RANGE_LEN = 5, ST_QV_VARIANT_LEN = 7,
+                  ST_QV_VARIANT_CHALLENGE = 8, ST_QV_CREDIT_RANGE_LEN = 9, ST_QV_CREDIT_RANGE_CHALLENGE = 10, ST_QV_CREDIT_EQUIV_LEN = 11 };
+// check_items(kinds, data, ok): ok[i] = item i is a canonical scalar / valid element (one batched GPU call per kind);
+// verify_packed(n, packed, status): the batch verifier on n packed ballots of the election's stride (substitutes never verify).
+using CheckItemsFn = std::function<bool(const std::string& kinds, const Bytes& data, std::vector<uint8_t>& ok)>;
+using VerifyPackedFn = std::function<bool(size_t n, const Bytes& packed, std::vector<uint32_t>& status)>;
+
+// first bad item of every object (item counts in `counts`), or 0 when all are good: BAD_SCALAR / BAD_POINT | index << 8
+inline bool first_invalid(const std::vector<AnyItems>& items, const CheckItemsFn& check, std::vector<uint32_t>& out) {
+  std::string kinds; Bytes data;
+  for (auto& it : items) { kinds += it.kinds; data.insert(data.end(), it.data.begin(), it.data.end()); }
+  std::vector<uint8_t> ok;
+  if (!kinds.empty() && !check(kinds, data, ok)) return false;
+  out.assign(items.size(), 0);
+  size_t pos = 0;
+  for (size_t k = 0; k < items.size(); ++k) {
+    for (size_t i = 0; i < items[k].count(); ++i)
+      if (!ok[pos + i] && !out[k]) out[k] = (items[k].kinds[i] == 'P' ? ST_BAD_POINT : ST_BAD_SCALAR) | ((uint32_t)i << 8);
+    pos += items[k].count();
+  }
+  return true;
+}
+
+// verdicts of EncryptedChoice objects whose shape is not the election's (text spans `odd`); status[k] for each of them
+inline bool resolve_choice_objects(const char* json, const std::vector<std::pair<size_t, size_t>>& odd, int n_options, bool single,
+                                   size_t stride, const CheckItemsFn& check, const VerifyPackedFn& verify, std::vector<uint32_t>& status) {
+  const size_t n = (size_t)n_options;
+  std::vector<ChoiceAny> objs(odd.size());
+  std::vector<AnyItems> items(odd.size());
+  status.assign(odd.size(), ST_MALFORMED);
+  std::vector<char> parsed(odd.size(), 0);
+  for (size_t k = 0; k < odd.size(); ++k) {
+    Cursor c{json + odd[k].first, json + odd[k].first + odd[k].second};
+    ChoiceAny& o = objs[k];
+    if (!parse_choice_any(c, o) || o.sum_null == single) continue;
+    c.ws();
+    if (c.p != c.end) continue;
+    parsed[k] = 1;
+    AnyItems& it = items[k];
+    it.add('P', o.choices.data(), 2 * o.n_choices);
+    it.add('S', o.e0.data(), 1);
+    it.add('S', o.resp.data(), o.n_resp);
+    if (!o.sum_null) it.add('S', o.sum.data(), 2);
+  }
+  std::vector<uint32_t> bad;
+  if (!first_invalid(items, check, bad)) return false;
+  Bytes subs; std::vector<size_t> sub_for;
+  for (size_t k = 0; k < odd.size(); ++k) {
+    if (!parsed[k]) continue;
+    const ChoiceAny& o = objs[k];
+    if (bad[k]) status[k] = bad[k];
+    else if (o.n_choices != n) status[k] = ST_OPTIONS_LEN;
+    else if (!single || o.n_resp == 2 * n) status[k] = ST_RANGE_LEN;     // (a well-shaped object never comes here)
+    else {                       // the sum proof is verified before the ring proof's length check (choice.rs:363-379)
+      const size_t at = subs.size();
+      subs.resize(at + stride, 0);
+      memcpy(subs.data() + at, o.choices.data(), 64 * n);
+      memcpy(subs.data() + at + 64 * n + 32 * (1 + 2 * n), o.sum.data(), 64);
+      sub_for.push_back(k);
+    }
+  }
+  if (!sub_for.empty()) {
+    std::vector<uint32_t> st;
+    if (!verify(sub_for.size(), subs, st)) return false;
+    for (size_t i = 0; i < sub_for.size(); ++i) status[sub_for[i]] = (st[i] & 0xffu) == ST_SUM_CHALLENGE ? st[i] : (uint32_t)ST_RANGE_LEN;
+  }
+  return true;
+}
+
+inline bool resolve_qv_objects(const char* json, const std::vector<std::pair<size_t, size_t>>& odd, int n_options, const RangeShape& vote,
+                               const RangeShape& credit, size_t stride, const CheckItemsFn& check, const VerifyPackedFn& verify,
+                               std::vector<uint32_t>& status) {
+  const size_t n = (size_t)n_options;
+  std::vector<QvAny> objs(odd.size());
+  std::vector<AnyItems> items(odd.size());
+  status.assign(odd.size(), ST_MALFORMED);
+  std::vector<char> parsed(odd.size(), 0);
+  auto add_range = [](AnyItems& it, const RangeAny& r) {
+    it.add('P', r.ct.data(), 2); it.add('P', r.partials.data(), 2 * r.n_partials); it.add('S', r.e0.data(), 1); it.add('S', r.resp.data(), r.n_resp);
+  };
+  for (size_t k = 0; k < odd.size(); ++k) {
+    Cursor c{json + odd[k].first, json + odd[k].first + odd[k].second};
+    QvAny& o = objs[k];
+    if (!parse_qv_any(c, o)) continue;
+    c.ws();
+    if (c.p != c.end) continue;
+    parsed[k] = 1;
+    for (auto& v : o.votes) add_range(items[k], v);
+    add_range(items[k], o.credit);
+    items[k].add('S', o.c.data(), 1); items[k].add('S', o.resp.data(), o.n_resp); items[k].add('S', o.s.data(), 1);
+  }
+  std::vector<uint32_t> bad;
+  if (!first_invalid(items, check, bad)) return false;
+  auto shape_ok = [](const RangeAny& r, const RangeShape& sh) { return r.n_partials == sh.rings - 1 && r.n_resp == sh.responses; };
+  auto put_range = [](Bytes& out, const RangeAny& r, const RangeShape& sh, bool good) {
+    out.insert(out.end(), r.ct.begin(), r.ct.end());
+    if (good) {
+      out.insert(out.end(), r.partials.begin(), r.partials.end());
+      out.insert(out.end(), r.e0.begin(), r.e0.end());
+      out.insert(out.end(), r.resp.begin(), r.resp.end());
+    } else {
+      out.insert(out.end(), 64 * (sh.rings - 1) + 32 * (1 + sh.responses), 0);
+    }
+  };
+  Bytes subs; std::vector<std::pair<size_t, size_t>> sub_for;      // (object, first ill-shaped proof: 0..n-1 votes, n credit, n+1 equivalence)
+  for (size_t k = 0; k < odd.size(); ++k) {
+    if (!parsed[k]) continue;
+    const QvAny& o = objs[k];
+    if (bad[k]) { status[k] = bad[k]; continue; }
+    if (o.votes.size() != n) { status[k] = ST_OPTIONS_LEN; continue; }
+    std::vector<char> good(n + 2);
+    for (size_t v = 0; v < n; ++v) good[v] = shape_ok(o.votes[v], vote);
+    good[n] = shape_ok(o.credit, credit);
+    good[n + 1] = o.n_resp == 2 * n;
+    size_t first_bad = 0;
+    while (first_bad < n + 2 && good[first_bad]) ++first_bad;
+    if (first_bad == n + 2) { status[k] = ST_MALFORMED; continue; }    // well-shaped after all: cannot happen for a RESHAPE verdict
+    if (first_bad == 0) { status[k] = ST_QV_VARIANT_LEN; continue; }   // nothing is verified before the first vote's length check
+    const size_t at = subs.size();
+    for (size_t v = 0; v < n; ++v) put_range(subs, o.votes[v], vote, good[v]);
+    put_range(subs, o.credit, credit, good[n]);
+    if (good[n + 1]) {
+      subs.insert(subs.end(), o.c.begin(), o.c.end()); subs.insert(subs.end(), o.resp.begin(), o.resp.end()); subs.insert(subs.end(), o.s.begin(), o.s.end());
+    } else {
+      subs.insert(subs.end(), 32 * (2 + 2 * n), 0);
+    }
+    if (subs.size() != at + stride) return false;
+    sub_for.push_back({k, first_bad});
+  }
+  if (!sub_for.empty()) {
+    std::vector<uint32_t> st;
+    if (!verify(sub_for.size(), subs, st)) return false;
+    for (size_t i = 0; i < sub_for.size(); ++i) {
+      const size_t k = sub_for[i].first, first_bad = sub_for[i].second;
+      const uint32_t kind = st[i] & 0xffu, detail = st[i] >> 8;
+      // position of the reported failure in verify()'s order: votes 0..n-1, credit range, credit equivalence
+      const size_t pos = (kind == ST_QV_VARIANT_LEN || kind == ST_QV_VARIANT_CHALLENGE) ? detail : kind == ST_QV_CREDIT_RANGE_CHALLENGE ? n : n + 1;
+      if (kind != ST_OK && pos < first_bad) status[k] = st[i];            // an earlier, well-shaped proof fails first
+      else if (first_bad < n) status[k] = ST_QV_VARIANT_LEN | ((uint32_t)first_bad << 8);
+      else if (first_bad == n) status[k] = ST_QV_CREDIT_RANGE_LEN;
+      else status[k] = ST_QV_CREDIT_EQUIV_LEN;
+    }
+  }
+  return true;
 }
 
 // Start offsets of the top-level values of a stream: either one JSON array of objects, or objects back to back / one per line.

@@ -277,51 +277,15 @@ def unpack_qv_ballot(packed: bytes, n_options: int, credits: int) -> dict:
 
 
 # ------------------------------------------------------------------------------------------------ ballots as JSON text
-def _load_objects(text):
-    """The objects of a JSON array, or of a stream of objects back to back / one per line."""
-    import json
-
-    text = text.decode() if isinstance(text, (bytes, bytearray)) else text
-    if text.lstrip().startswith("["):
-        return json.loads(text)
-    dec, objs, i = json.JSONDecoder(), [], 0
-    while True:
-        while i < len(text) and text[i] in " \t\r\n":
-            i += 1
-        if i >= len(text):
-            return objs
-        obj, i = dec.raw_decode(text, i)
-        objs.append(obj)
-
-
-def _verify_json(params, grp, text, object_path, **pack_kw):
-    """Fast path: the native packer (csrc/wire_json.hpp) turns every well-shaped ballot of the text into packed bytes and the GPU
-    verifies them in one batch; objects that do not deserialise are `Malformed`; the few whose shape differs from the election's
-    go through the object path, which applies the reference's order of checks."""
-    from . import PACK_RESHAPE, pack_json
-
-    packed, st = pack_json(text, params.n_options, **pack_kw)
-    size = params.ballot_size
-    good = [k for k, s in enumerate(st) if s == ST_OK]
-    batch = packed if len(good) == len(st) else b"".join(packed[k * size : (k + 1) * size] for k in good)
-    verdicts, tally = params.verify_batch(batch)
-    statuses = list(st)
-    for k, v in zip(good, verdicts):
-        statuses[k] = v
-    odd = [k for k, s in enumerate(st) if s == PACK_RESHAPE]
-    if odd:
-        objs = _load_objects(text)
-        for k, v in zip(odd, object_path(params, grp, [objs[k] for k in odd])[0]):
-            statuses[k] = v
-    return statuses, tally
-
-
 def verify_choice_json(params, grp, text):
     """`EncryptedChoice::verify` for ballots given as JSON text in the reference's serde layout (what examples/voting.rs:195-198
-    prints): (status words, tally of the accepted ballots)."""
-    return _verify_json(params, grp, text, verify_choice_objects, single=params.single)
+    prints): (status words, tally of the accepted ballots).  The whole path runs below the C ABI (`eg_verify_choice_json`): the native
+    packer, the GPU batch, and for objects whose shape is not the election's the object path of csrc/wire_json.hpp, which applies the
+    reference's order of checks exactly like `verify_choice_objects` above (the tests compare the two).  One voter's junk - an object
+    that is not JSON, lacks a field, repeats one - is `Malformed` for that voter only."""
+    return params.verify_json(text)
 
 
 def verify_qv_json(params, grp, text):
-    """`QuadraticVotingBallot::verify` for ballots given as JSON text."""
-    return _verify_json(params, grp, text, verify_qv_objects, credits=params.credits)
+    """`QuadraticVotingBallot::verify` for ballots given as JSON text (`eg_verify_qv_json`)."""
+    return params.verify_json(text)

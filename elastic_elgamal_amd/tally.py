@@ -1,47 +1,29 @@
-"""Tally stage on top of the GPU primitives (examples/voting.rs:122-177): combine verified
-decryption shares by Lagrange interpolation in the exponent and read the vote counts off a discrete-log table.
+"""Tally stage (examples/voting.rs:122-177): combine verified decryption shares by Lagrange interpolation
+in the exponent and read the vote counts off a discrete-log table.
 
-Host code only schedules; every group operation runs on the GPU through :class:`elastic_elgamal_amd.Ristretto`.
-Mirrors ``lagrange_coefficients`` / ``Params::combine_shares`` (src/sharing/mod.rs:139-170,302-325) and
-``DiscreteLogTable`` (src/encryption.rs:260-298).
+Thin ctypes mirror of the C entry points (`eg_combine_shares`, `eg_dlog_table_*`, include/eg_hip.h), which mirror
+``lagrange_coefficients`` / ``Params::combine_shares`` (src/sharing/mod.rs:139-170,302-325) and ``DiscreteLogTable``
+(src/encryption.rs:260-298).  All scalar and group arithmetic runs on the GPU primitives inside the library.
 """
 from __future__ import annotations
 
-L = 2**252 + 27742317777372353535851937790883648493
+import ctypes as C
+
+from . import _check, _load
 
 
-def _sc(x: int) -> bytes:
-    return (x % L).to_bytes(32, "little")
-
-
-def lagrange_coefficients(indexes):
-    """(denominators^-1, scale) exactly as src/sharing/mod.rs:139-170 (zero-based indexes, points index + 1)."""
-    inv = []
-    for i in indexes:
-        d = 1
-        for j in indexes:
-            d = d * ((i + 1) if i == j else (j - i)) % L      # sign folded in: (j - i) mod l
-        inv.append(pow(d, L - 2, L))
-    scale = 1
-    for i in indexes:
-        scale = scale * (i + 1) % L
-    return inv, scale
-
-
-def combine_shares(group, threshold: int, shares):
-    """``Params::combine_shares``: shares = [(participant index, dh_element bytes)], at least `threshold` of them.
-    Returns the combined dh element [x]R, or None if there are too few shares."""
-    shares = list(shares)[:threshold]
-    if len(shares) < threshold:
-        return None
-    idx = [i for i, _ in shares]
-    inv, scale = lagrange_coefficients(idx)
-    # restored = sum_i [denominator_i^-1] share_i ; result = [scale] restored
-    scalars = b"".join(_sc(c * scale) for c in inv)
-    out, ok = group.vartime_multi_mul(len(shares), scalars, b"".join(s for _, s in shares))
-    if ok != b"\x01":
-        raise ValueError("invalid decryption share element")
-    return out
+def combine_shares(group, threshold: int, shares, n_shares: int | None = None):
+    """``Params::combine_shares``: shares = [(participant index, dh_element bytes)]; the first `threshold` are used.
+    Returns the combined dh element [x]R, or None if there are too few shares.  `n_shares` = participants of the key set
+    (default: large enough for the indexes given)."""
+    shares = list(shares)
+    n = len(shares)
+    total = n_shares if n_shares is not None else max([i for i, _ in shares] + [threshold - 1]) + 1
+    idx = (C.c_uint64 * max(n, 1))(*[i for i, _ in shares])
+    out = C.create_string_buffer(32)
+    combined = C.c_int(0)
+    _check(_load().eg_combine_shares(group.ctx._h, total, threshold, n, idx, b"".join(s for _, s in shares), out, C.byref(combined)))
+    return out.raw if combined.value else None
 
 
 class DiscreteLogTable:
@@ -49,11 +31,25 @@ class DiscreteLogTable:
 
     def __init__(self, group, values):
         values = list(values)
-        enc = group.mul_generator(b"".join(_sc(v) for v in values))
-        self.table = {enc[32 * k : 32 * k + 32]: v for k, v in enumerate(values)}
+        arr = (C.c_uint64 * max(len(values), 1))(*values)
+        self._h = C.c_void_p()
+        _check(_load().eg_dlog_table_create(group.ctx._h, len(values), arr, C.byref(self._h)))
 
     def get(self, element: bytes):
-        return self.table.get(element)
+        v, found = C.c_uint64(0), C.create_string_buffer(1)
+        _check(_load().eg_dlog_table_get(self._h, 1, element, C.byref(v), found))
+        return int(v.value) if found.raw[0] else None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _load().eg_dlog_table_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def decrypt_total(group, table: DiscreteLogTable, ciphertext: bytes, combined_dh: bytes):

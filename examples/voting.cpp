@@ -35,19 +35,19 @@ int main(int argc, char** argv) {
   for (size_t i = 0; i < verdict.results.size(); ++i)
     if (verdict.results[i]) printf("  voter #%zu rejected: %s\n", i + 1, verdict.results[i]->to_string().c_str());
 
-  // tally(): decrypt each total = blinded - [sk]random, then look the element up in {[m]G} (DiscreteLogTable)
+  // tally(): decrypt each total = blinded - [sk]random, then look the element up in DiscreteLogTable::new(0..=votes)
+  // (examples/voting.rs:130-131,166-172; the table's products come from the GPU in one batch)
+  std::vector<uint64_t> range(votes + 1);
+  for (uint64_t m = 0; m <= votes; ++m) range[m] = m;
+  const DiscreteLogTable lookup(ctx, range);
   size_t sum = 0;
   for (size_t k = 0; k < options; ++k) {
     const Element dh = group.vartime_multi_mul({sk}, {verdict.totals[k].random_element});
     const Element m_g = group.sub(verdict.totals[k].blinded_element, dh);
-    long found = -1;
-    for (uint64_t m = 0; m <= votes && found < 0; ++m) {
-      Scalar ms{}; memcpy(ms.data(), &m, 8);
-      if (group.mul_generator(ms) == m_g) found = (long)m;
-    }
-    printf("  option #%zu: %ld votes\n", k + 1, found);
-    if (found < 0) { printf("decryption failed\n"); return 1; }
-    sum += (size_t)found;
+    const std::optional<uint64_t> found = lookup.get(m_g);
+    if (!found) { printf("decryption failed\n"); return 1; }
+    printf("  option #%zu: %llu votes\n", k + 1, (unsigned long long)*found);
+    sum += (size_t)*found;
   }
   const bool ok = sum == verdict.accepted();
   printf("%s: decrypted totals sum to %zu, %zu ballots were accepted\n", ok ? "OK" : "MISMATCH", sum, verdict.accepted());

@@ -124,6 +124,21 @@ size_t eg_msm_scratch_bytes(size_t n, size_t terms);
 int eg_vartime_multi_mul_batch_device(eg_ctx*, size_t n, size_t terms, const void* d_scalars, const void* d_points, const void* d_r,
                                       void* d_scratch, void* d_out, void* d_ok, void* stream);
 
+/* ---- tally stage (examples/voting.rs:122-177) -------------------------------------------------------------------------------
+ * Params::combine_shares (src/sharing/mod.rs:302-325, lagrange_coefficients :139-170): combines the FIRST `threshold` of the n given
+ * decryption shares (zero-based participant indexes, dh elements of 32 bytes; verify them first: eg_share_params_create) into the
+ * decryption [x]R of the shared key.  *combined = 0 (and EG_OK) when fewer than `threshold` shares are given (the reference
+ * returns None); an index >= shares or a duplicate index is EG_ERR_BAD_ARG (the reference panics on the former).  All scalar and
+ * group arithmetic runs on the GPU primitives. */
+int eg_combine_shares(eg_ctx*, uint64_t shares, uint64_t threshold, size_t n, const uint64_t* indexes, const uint8_t* dh_elements,
+                      uint8_t out[32], int* combined);
+/* DiscreteLogTable (src/encryption.rs:260-298): new(values) computes [v]G for every non-zero value on the GPU; get() looks decrypted
+ * elements up (found[i] = 0: not among the values; the identity is always 0).  The table itself lives in host memory. */
+typedef struct eg_dlog_table eg_dlog_table;
+int eg_dlog_table_create(eg_ctx*, size_t n, const uint64_t* values, eg_dlog_table** out);
+void eg_dlog_table_destroy(eg_dlog_table*);
+int eg_dlog_table_get(const eg_dlog_table*, size_t n, const uint8_t* elements /*32n*/, uint64_t* values, uint8_t* found);
+
 /* ---- batch tier: EncryptedChoice --------------------------------------------------------------------------------
  * wire layout of one ballot (stride = eg_choice_ballot_size):
  *   n_options x Ciphertext::to_bytes (R || B, encryption.rs:155-160)
@@ -140,8 +155,18 @@ size_t eg_choice_ballot_size(int n_options, int single);
  * of THIS call's batch alone, n_options x 64 bytes (R || B); it never disturbs the running tally. */
 int eg_verify_choice_batch(eg_choice_params*, size_t n, const uint8_t* ballots, uint32_t* status, uint8_t* tally_out);
 /* device-resident variant: d_ballots / d_status are device pointers; the running tally stays on the device
- * inside `params` until eg_choice_tally_* is called.  Asynchronous on `stream`. */
+ * inside `params` until eg_choice_tally_* is called.  Asynchronous on `stream` (internally the work forks onto two streams of the
+ * params object and joins `stream` again before the call returns control of it), with TWO exceptions that block the host once:
+ *  - the first call of a params object (and any later call with a larger batch) allocates the chunk workspace
+ *    (hipDeviceSynchronize + hipMalloc; ~45 KB per ballot of a chunk for 5 options, two chunks of up to 2^19 ballots);
+ *  - the call with which a params object has seen 2^19 ballots in total builds the WIDE fixed-base comb tables inline: about
+ *    12 GB each for the generator (once per context) and the election key (once per params object), ~40 ms, with a
+ *    hipStreamSynchronize on `stream`.  A host that needs strict asynchrony (or wants the memory accounted for up front) calls
+ *    eg_choice_prepare_wide_tables / eg_qv_prepare_wide_tables right after creating the params; EG_COMB_BIG_BITS=0 switches the
+ *    wide tables off (-1..2 % throughput).  If the wide tables do not fit the device memory the narrow ones stay in use. */
 int eg_verify_choice_batch_device(eg_choice_params*, size_t n, const void* d_ballots, void* d_status, void* stream);
+/* builds the wide comb tables now (synchronous); EG_ERR_NOMEM if they do not fit, EG_OK when they exist or are switched off */
+int eg_choice_prepare_wide_tables(eg_choice_params*);
 int eg_choice_tally_reset(eg_choice_params*);
 int eg_choice_tally_encode(eg_choice_params*, uint8_t* out /* n_options*64 */);
 /* running tally += the ciphertexts encoded in `in` (n_options*64 bytes, as eg_choice_tally_encode writes them): resume
@@ -168,6 +193,7 @@ void eg_qv_params_destroy(eg_qv_params*);
 size_t eg_qv_ballot_size(const eg_qv_params*);
 int eg_verify_qv_batch(eg_qv_params*, size_t n, const uint8_t* ballots, uint32_t* status, uint8_t* tally_out);
 int eg_verify_qv_batch_device(eg_qv_params*, size_t n, const void* d_ballots, void* d_status, void* stream);
+int eg_qv_prepare_wide_tables(eg_qv_params*);      /* as eg_choice_prepare_wide_tables */
 int eg_qv_tally_reset(eg_qv_params*);
 int eg_qv_tally_encode(eg_qv_params*, uint8_t* out);
 int eg_qv_tally_add(eg_qv_params*, const uint8_t* in);

@@ -245,4 +245,31 @@ struct Ristretto {
   Scalar scalar_neg(const Scalar& a) const { Scalar o; check(eg_scalar_neg_batch(ctx.raw(), 1, a.data(), o.data())); return o; }
 };
 
+// ---- tally stage (examples/voting.rs:122-177) ------------------------------------------------------------------------------------
+// Params::combine_shares (sharing/mod.rs:302-325): the first `threshold` of the given (participant index, dh element) pairs ->
+// the combined decryption [x]R, or nullopt when there are too few shares.  Verify the shares first (eg_share_params_create).
+inline std::optional<Element> combine_shares(const Context& ctx, uint64_t shares, uint64_t threshold,
+                                             const std::vector<std::pair<uint64_t, Element>>& given) {
+  std::vector<uint64_t> idx; Bytes dh;
+  for (auto& g : given) { idx.push_back(g.first); dh.insert(dh.end(), g.second.begin(), g.second.end()); }
+  Element out; int combined = 0;
+  check(eg_combine_shares(ctx.raw(), shares, threshold, idx.size(), idx.data(), dh.data(), out.data(), &combined));
+  return combined ? std::optional<Element>(out) : std::nullopt;
+}
+// DiscreteLogTable (encryption.rs:260-298)
+class DiscreteLogTable {
+ public:
+  DiscreteLogTable(const Context& ctx, const std::vector<uint64_t>& values) { check(eg_dlog_table_create(ctx.raw(), values.size(), values.data(), &t_)); }
+  ~DiscreteLogTable() { eg_dlog_table_destroy(t_); }
+  DiscreteLogTable(const DiscreteLogTable&) = delete;
+  DiscreteLogTable& operator=(const DiscreteLogTable&) = delete;
+  std::optional<uint64_t> get(const Element& decrypted_element) const {
+    uint64_t v = 0; uint8_t found = 0;
+    check(eg_dlog_table_get(t_, 1, decrypted_element.data(), &v, &found));
+    return found ? std::optional<uint64_t>(v) : std::nullopt;
+  }
+ private:
+  eg_dlog_table* t_ = nullptr;
+};
+
 }  // namespace elastic_elgamal_hip

@@ -3,6 +3,7 @@
 // uploads and its index check) and the native wire ingest (csrc/wire_json.hpp).  The product never loads this library.
 #include <stdint.h>
 #include <string.h>
+#include <functional>
 #include <string>
 #include "../../elastic_elgamal_amd/csrc/host_plan.hpp"
 #include "../../elastic_elgamal_amd/csrc/wire_json.hpp"
@@ -74,4 +75,58 @@ int pc_split_windows(const char* json, size_t len, size_t window, int threads) {
   return 1;
 }
 unsigned long long pc_qv_size(int n_options, unsigned long long credits) { return qv_shape(n_options, credits).ballot_size; }
+
+// The whole JSON entry point of the library (eg_verify_*_json) with its two GPU services replaced by callbacks, so that the object
+// path of wire_json.hpp (OptionsLenMismatch / LenMismatch in verify()'s order) can be checked against oracle/objects.c without a GPU:
+// check(n, kinds, data, ok): validity of n 32-byte items; verify(n, packed, stride, status): the batch verifier.
+typedef int (*pc_check_cb)(size_t n_items, const char* kinds, const uint8_t* data, uint8_t* ok);
+typedef int (*pc_verify_cb)(size_t n, const uint8_t* packed, size_t stride, uint32_t* status);
+static int resolve_common(const char* json, size_t len, size_t stride, uint32_t* status, size_t max, pc_check_cb check, pc_verify_cb verify,
+                          const std::function<uint32_t(egwire::Cursor&, uint8_t*)>& pack_one,
+                          const std::function<bool(const std::vector<std::pair<size_t, size_t>>&, const egwire::CheckItemsFn&,
+                                                   const egwire::VerifyPackedFn&, std::vector<uint32_t>&)>& resolve) {
+  std::vector<std::pair<size_t, size_t>> spans;
+  if (!egwire::split_objects(json, len, spans) || spans.size() > max) return -1;
+  std::vector<uint8_t> packed(spans.size() * stride + 1);
+  std::vector<uint32_t> st(spans.size() + 1);
+  egwire::pack_parallel(json, spans, stride, 2, packed.data(), st.data(), pack_one);
+  std::vector<uint32_t> verdict(spans.size() + 1);
+  if (!spans.empty() && verify(spans.size(), packed.data(), stride, verdict.data())) return -2;
+  std::vector<std::pair<size_t, size_t>> odd; std::vector<size_t> at;
+  for (size_t k = 0; k < spans.size(); ++k) {
+    status[k] = st[k] == egwire::ST_OK ? verdict[k] : st[k];
+    if (st[k] == egwire::PACK_RESHAPE) { odd.push_back(spans[k]); at.push_back(k); }
+  }
+  const egwire::CheckItemsFn ck = [&](const std::string& kinds, const egwire::Bytes& data, std::vector<uint8_t>& ok) {
+    ok.assign(kinds.size(), 0);
+    return check(kinds.size(), kinds.data(), data.data(), ok.data()) == 0;
+  };
+  const egwire::VerifyPackedFn vf = [&](size_t n, const egwire::Bytes& pk, std::vector<uint32_t>& out) {
+    out.assign(n, 0);
+    return verify(n, pk.data(), stride, out.data()) == 0;
+  };
+  std::vector<uint32_t> res;
+  if (!odd.empty()) {
+    if (!resolve(odd, ck, vf, res)) return -3;
+    for (size_t i = 0; i < odd.size(); ++i) status[at[i]] = res[i];
+  }
+  return (int)spans.size();
+}
+int pc_resolve_choice(int n_options, int single, const char* json, size_t len, pc_check_cb check, pc_verify_cb verify, uint32_t* status, size_t max) {
+  const size_t stride = choice_ballot_size(n_options, single != 0);
+  return resolve_common(json, len, stride, status, max, check, verify,
+                        [&](egwire::Cursor& c, uint8_t* dst) { return egwire::pack_choice(c, n_options, single != 0, dst); },
+                        [&](const std::vector<std::pair<size_t, size_t>>& odd, const egwire::CheckItemsFn& ck, const egwire::VerifyPackedFn& vf,
+                            std::vector<uint32_t>& out) { return egwire::resolve_choice_objects(json, odd, n_options, single != 0, stride, ck, vf, out); });
+}
+int pc_resolve_qv(int n_options, unsigned long long credits, const char* json, size_t len, pc_check_cb check, pc_verify_cb verify, uint32_t* status,
+                  size_t max) {
+  const QvShape sh = qv_shape(n_options, credits);
+  const egwire::RangeShape vote{sh.vote_range.rings.size(), (size_t)sh.vote_range.rings_size()};
+  const egwire::RangeShape credit{sh.credit_range.rings.size(), (size_t)sh.credit_range.rings_size()};
+  return resolve_common(json, len, sh.ballot_size, status, max, check, verify,
+                        [&](egwire::Cursor& c, uint8_t* dst) { return egwire::pack_qv(c, n_options, vote, credit, sh.ballot_size, dst); },
+                        [&](const std::vector<std::pair<size_t, size_t>>& odd, const egwire::CheckItemsFn& ck, const egwire::VerifyPackedFn& vf,
+                            std::vector<uint32_t>& out) { return egwire::resolve_qv_objects(json, odd, n_options, vote, credit, sh.ballot_size, ck, vf, out); });
+}
 }

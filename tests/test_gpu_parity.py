@@ -126,10 +126,18 @@ def test_multi_scalar_mul_any_size(eg, ctx, grp, oracle):
     identity points, zero and edge scalars inside; an undecodable point anywhere flags the problem.  Host and device entry points agree."""
     import torch
 
+    import os
+
     rnd = random.Random(77)
     pool = [oracle.point_mul_generator(sc(rnd.randrange(L))) for _ in range(40)] + [b"\0" * 32]
     edge = [0, 1, L - 1, 2**252, 8, 0x0888888888888888888888888888888888888888888888888888888888888888]
-    for terms, m in ((8, 5), (9, 4), (16, 4), (255, 2), (256, 2), (65536, 1)):
+    # a call with few terms in all is cut into single-term chunks so that it covers the chip; EG_MSM_LANES=1 keeps the chunks of 8
+    # terms (one shared doubling chain each) that large batches get: both cuts are checked for every size
+    for lanes, terms, m in [(l, t, k) for l in ("1", None) for t, k in ((8, 5), (9, 4), (16, 4), (255, 2), (256, 2), (65536, 1))]:
+        if lanes is None:
+            os.environ.pop("EG_MSM_LANES", None)
+        else:
+            os.environ["EG_MSM_LANES"] = lanes
         scal = [[sc(edge[(i + t) % len(edge)]) if t % 5 == 0 else sc(rnd.randrange(L)) for t in range(terms)] for i in range(m)]
         pp = [[pool[rnd.randrange(len(pool))] for _ in range(terms)] for _ in range(m)]
         sb, pb = b"".join(b"".join(x) for x in scal), b"".join(b"".join(x) for x in pp)
@@ -158,6 +166,7 @@ def test_multi_scalar_mul_any_size(eg, ctx, grp, oracle):
             bad[(1 * terms + terms - 1) * 32 : (1 * terms + terms) * 32] = b"\xff" * 32
             _, ok = grp.vartime_multi_mul(terms, sb, bytes(bad))
             assert list(ok) == [1, 0] + [1] * (m - 2)
+    os.environ.pop("EG_MSM_LANES", None)
     assert grp.vartime_multi_mul(0, b"", b"") == (b"", b"")
 
 
@@ -714,11 +723,25 @@ def test_threshold_tally_end_to_end(eg, ctx, oracle):
             assert verifiers[i].verify_batch(bytes(bad)) == [eg.SUM_CHALLENGE]
             assert verifiers[(i + 1) % shares_n].verify_batch(item) == [eg.SUM_CHALLENGE]     # other participant's key
             verified.append((i, share[:32]))
-        assert T.combine_shares(grp, threshold, verified[: threshold - 1]) is None
-        dh = T.combine_shares(grp, threshold, verified)
+        assert T.combine_shares(grp, threshold, verified[: threshold - 1], n_shares=shares_n) is None
+        dh = T.combine_shares(grp, threshold, verified, n_shares=shares_n)
+        assert dh == T.combine_shares(grp, threshold, list(reversed(verified[:threshold])), n_shares=shares_n)   # any order of the same shares
         assert dh == oracle.point_multi_mul(sc(coeffs[0]), ct[:32])                       # [x]R for the shared secret x
         got.append(T.decrypt_total(grp, table, ct, dh))
     assert got == expected and sum(got) == votes
+    # Params::combine_shares panics on an index beyond the key set; duplicates cannot be interpolated: both are refused
+    with pytest.raises(eg.EgError):
+        T.combine_shares(grp, threshold, [(shares_n, verified[0][1])] + verified[1:], n_shares=shares_n)
+    with pytest.raises(eg.EgError):
+        T.combine_shares(grp, threshold, [verified[0]] * threshold, n_shares=shares_n)
+    # DiscreteLogTable: zero is always found (identity), values outside the table are not
+    assert table.get(b"\0" * 32) == 0
+    assert table.get(oracle.point_mul_generator(sc(votes))) == votes
+    assert table.get(oracle.point_mul_generator(sc(votes + 1))) is None
+    # the wide comb tables on request (eg_*_prepare_wide_tables): same verdicts afterwards
+    params.prepare_wide_tables()
+    assert ctx.comb_table_bits()[1] != 0
+    assert params.verify_batch(ballots)[0] == [0] * votes
 
 
 # ------------------------------------------------------------------ unusual election shapes
@@ -1030,8 +1053,10 @@ def test_json_text_ingest_matches_object_path(eg, ctx, oracle, pk, kind):
 @pytest.mark.parametrize("kind", ["single", "qv"])
 def test_native_json_verify_entry(eg, ctx, oracle, pk, kind):
     """eg_verify_*_json: JSON text -> verdicts + tally inside the library (host threads pack piece k+1 while the GPU verifies
-    piece k).  Verdicts equal the Python recipe's (ingest.verify_*_json) except that reshaped objects stay PACK_RESHAPE; the
-    tally is the call's own and the running tally accumulates; several pieces (300 000 objects) agree with the packed path."""
+    piece k).  Objects whose shape is not the election's get the reference's verdict below the C ABI (OptionsLenMismatch /
+    LenMismatch in verify()'s order, csrc/wire_json.hpp: resolve_*_objects): every verdict equals the Python object path's
+    (ingest.verify_*_objects, pinned by oracle/objects.c in the CPU tests) and the scenario table's expectation; the tally is the
+    call's own and the running tally accumulates; several pieces (300 000 objects) agree with the packed path."""
     import json
     from elastic_elgamal_amd import ingest, serde
     from ingest_cases import choice_cases, qv_cases
@@ -1044,8 +1069,8 @@ def test_native_json_verify_entry(eg, ctx, oracle, pk, kind):
         packed = op.generate_batch(21, 0, 64, threads=8)
         sz = len(packed) // 64
         objs = [ingest.unpack_qv_ballot(packed[i * sz : (i + 1) * sz], n, credits) for i in range(64)]
-        cases = [c[1] for c in qv_cases(objs[:8])]
-        recipe = ingest.verify_qv_json
+        table = qv_cases(objs[:8])
+        recipe = ingest.verify_qv_objects
     else:
         n = 3
         op = oracle.ChoiceParams(pk, n, True)
@@ -1053,19 +1078,30 @@ def test_native_json_verify_entry(eg, ctx, oracle, pk, kind):
         packed = op.generate_batch(22, 0, 64, threads=8)
         sz = len(packed) // 64
         objs = [serde.unpack_encrypted_choice(packed[i * sz : (i + 1) * sz], n, True) for i in range(64)]
-        cases = [c[1] for c in choice_cases(objs[:8], True)]
-        recipe = ingest.verify_choice_json
+        table = choice_cases(objs[:8], True)
+    cases = [c[1] for c in table]
+    if kind == "single":
+        recipe = ingest.verify_choice_objects
     batch = objs[8:30] + cases + [{"votes": 1, "choices": 2}] + objs[30:]
     text = json.dumps(batch)
-    want, want_tally = recipe(p, grp, text)
+    want, want_tally = recipe(p, grp, batch)          # the Python object path on the parsed objects (pinned by oracle/objects.c on the CPU)
     p.tally_reset()
     got, tally = p.verify_json(text)
     packer_status = eg.pack_json(text, n, single=True)[1] if kind == "single" else eg.pack_json(text, n, credits=credits)[1]
     assert len(got) == len(want) == len(batch)
-    for g, w, ps in zip(got, want, packer_status):
-        assert g == (eg.PACK_RESHAPE if ps == eg.PACK_RESHAPE else w)
+    assert got == want                                                   # reshaped objects included
+    assert got[22 : 22 + len(table)] == [c[2] for c in table], [c[0] for c, g in zip(table, got[22:]) if c[2] != g]
     assert tally == want_tally == p.tally_encode()
-    assert eg.MALFORMED in got and eg.PACK_RESHAPE in got and got.count(0) >= 50
+    assert eg.MALFORMED in got and eg.PACK_RESHAPE in packer_status and eg.PACK_RESHAPE not in got and got.count(0) >= 50
+    # the multi-choice election has no sum proof: a reshaped ballot is Range(LenMismatch) straight away (choice.rs:370-379)
+    if kind == "single":
+        om = oracle.ChoiceParams(pk, n, False)
+        pm = eg.ChoiceParams(ctx, pk, n, False)
+        mp = om.generate_batch(23, 0, 8, n_selected=2)
+        msz = len(mp) // 8
+        mt = choice_cases([serde.unpack_encrypted_choice(mp[i * msz : (i + 1) * msz], n, False) for i in range(8)], False)
+        got_m, _ = pm.verify_json(json.dumps([c[1] for c in mt]))
+        assert got_m == [c[2] for c in mt], [c[0] for c, g in zip(mt, got_m) if c[2] != g]
     if kind == "single":        # many pieces: 300 000 ballots from the GPU prover as one JSON array
         import torch
         m = 300_000

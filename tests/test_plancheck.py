@@ -98,3 +98,85 @@ def test_wire_packer_survives_fuzzed_json(lib):
         assert packed.raw[:736] == serde.pack_encrypted_choice(c)
     """.format(str(ROOT / "tests" / "golden" / "snapshots_serde.json")))
     assert "fuzzed 3000" in out
+
+
+@pytest.mark.parametrize("kind", ["single", "multi", "qv"])
+def test_native_object_path_agrees_with_the_oracle_on_objects(lib, kind):
+    """The object path BELOW the C ABI (csrc/wire_json.hpp: resolve_*_objects, what eg_verify_*_json runs for ballots whose shape is not
+    the election's): the library's JSON entry point with its two GPU services answered by the oracle must give, for the scenario
+    table and for 80 randomly reshaped / tampered objects, the verdicts of oracle/objects.c (the reference's verify() on objects:
+    deserialisation order, check_options_count, every LenMismatch check in the reference's order) - under ASan + UBSan."""
+    out = _run(lib, f"""
+        kind = {kind!r}
+        sys.path.insert(0, {str(ROOT / 'tests')!r})
+        import copy
+        from oracle import oracle
+        from elastic_elgamal_amd import ingest, serde
+        from ingest_cases import BAD_POINT, BAD_SCALAR, choice_cases, flip, qv_cases
+        from test_ingest_cpu import _choice_object_verdict, _qv_object_verdict
+        golden = json.loads(open({str(ROOT / 'tests' / 'golden' / 'snapshots_ristretto.json')!r}).read())
+        import base64
+        s = golden["public_key_b64"]; pk = base64.urlsafe_b64decode(s + "=" * (-len(s) % 4))
+        Lq = 2**252 + 27742317777372353535851937790883648493
+        rnd = random.Random(11)
+        n = 3
+        if kind == "qv":
+            credits = 9
+            op = oracle.QvParams(pk, n, credits)
+            packed = op.generate_batch(12, 0, 8); sz = len(packed) // 8
+            objs = [ingest.unpack_qv_ballot(packed[i * sz:(i + 1) * sz], n, credits) for i in range(8)]
+            cases, verdict = qv_cases(objs), _qv_object_verdict
+        else:
+            single = kind == "single"
+            op = oracle.ChoiceParams(pk, n, single)
+            packed = op.generate_batch(11, 0, 8, n_selected=0 if single else 2); sz = len(packed) // 8
+            objs = [serde.unpack_encrypted_choice(packed[i * sz:(i + 1) * sz], n, single) for i in range(8)]
+            cases, verdict = choice_cases(objs, single), _choice_object_verdict
+        fuzzed = []
+        for k in range(80):
+            o = copy.deepcopy(objs[k % 8])
+            for _ in range(rnd.randrange(1, 4)):
+                lists = []
+                def walk(x):
+                    if isinstance(x, dict):
+                        for v in x.values(): walk(v)
+                    elif isinstance(x, list):
+                        lists.append(x)
+                        for v in x: walk(v)
+                walk(o)
+                target = rnd.choice(lists); action = rnd.randrange(4)
+                if action == 0 and target: target.pop(rnd.randrange(len(target)))
+                elif action == 1 and target: target.append(copy.deepcopy(rnd.choice(target)))
+                elif action == 2 and target and isinstance(target[0], str):
+                    i = rnd.randrange(len(target)); target[i] = rnd.choice([flip(target[i]), BAD_SCALAR])
+                elif target and isinstance(target[0], dict) and "random_element" in target[0]:
+                    rnd.choice(target)["blinded_element"] = BAD_POINT
+            fuzzed.append(o)
+        batch = [c[1] for c in cases] + fuzzed + [{{"choices": "junk"}}]
+        want = [verdict(op, o) for o in batch]
+        CHECK = C.CFUNCTYPE(C.c_int, C.c_size_t, C.c_char_p, C.POINTER(C.c_ubyte), C.POINTER(C.c_ubyte))
+        VERIFY = C.CFUNCTYPE(C.c_int, C.c_size_t, C.POINTER(C.c_ubyte), C.c_size_t, C.POINTER(C.c_uint32))
+        def check(cnt, kinds, data, ok):
+            raw = bytes(data[: 32 * cnt])
+            for i in range(cnt):
+                item = raw[32 * i: 32 * i + 32]
+                ok[i] = (oracle.point_roundtrip(item) is not None) if kinds[i: i + 1] == b"P" else int.from_bytes(item, "little") < Lq
+            return 0
+        def verify(cnt, packed_ptr, stride, status):
+            st = op.verify_batch(bytes(packed_ptr[: cnt * stride]))
+            for i in range(cnt): status[i] = st[i]
+            return 0
+        text = json.dumps(batch).encode()
+        status = (C.c_uint32 * (len(batch) + 1))()
+        if kind == "qv":
+            got_n = L.pc_resolve_qv(n, C.c_ulonglong(credits), text, C.c_size_t(len(text)), CHECK(check), VERIFY(verify), status, C.c_size_t(len(batch)))
+        else:
+            got_n = L.pc_resolve_choice(n, int(single), text, C.c_size_t(len(text)), CHECK(check), VERIFY(verify), status, C.c_size_t(len(batch)))
+        assert got_n == len(batch), got_n
+        got = list(status[: got_n])
+        bad = [(i, g, w) for i, (g, w) in enumerate(zip(got, want)) if g != w]
+        assert not bad, bad[:5]
+        assert [c[2] for c in cases] == got[: len(cases)]
+        print("kinds", len({{w & 0xFF for w in want}}))
+    """)
+    assert int(out.split()[-1]) >= 4

@@ -169,3 +169,33 @@ def test_cpp_mirror_packs_json(tmp_path, objs):
     assert out.returncode == 0, out.stderr
     qsize = len(serde.pack_qv_ballot(objs["qv-ballot"]))
     assert out.stdout.strip() == f"3 0 0 13 {2 * 736} | 2 0 0 {2 * qsize} | 1"
+
+
+def test_escaped_strings_and_keys_are_unescaped_like_serde_json(objs, golden):
+    """serde_json unescapes strings and keys before base64 decoding / field matching: a ballot whose emitter wrote a
+    character as \\uXXXX or '/' as '\\/' is the same ballot; a bad escape, an escape to another character or to a non-ASCII code
+    point is Malformed for that object only."""
+    c = objs["encrypted-choice"]
+    plain = json.dumps(c)
+    want = golden["encrypted-choice"]["packed"]
+    e0 = c["range_proof"]["common_challenge"]
+    esc_first = "\\u%04x" % ord(e0[0]) + e0[1:]
+    esc_mid = e0[:20] + "\\u%04X" % ord(e0[20]) + e0[21:]
+    for variant in (plain.replace('"' + e0 + '"', '"' + esc_first + '"'),
+                    plain.replace('"' + e0 + '"', '"' + esc_mid + '"'),
+                    plain.replace('"choices"', '"ch\\u006fices"'),
+                    plain.replace('"random_element"', '"random\\u005felement"', 1),
+                    plain.replace('"sum_proof"', '"sum\\u005Fproof"')):
+        assert variant != plain
+        packed, st = eg.pack_json("[" + variant + "," + plain + "]", 5, single=True)
+        assert st == [0, 0] and packed.hex() == want * 2, variant[:80]
+    for variant in (plain.replace('"' + e0 + '"', '"' + "\\u0021" + e0[1:] + '"'),            # '!' is not in the alphabet
+                    plain.replace('"' + e0 + '"', '"' + "\\u00e9" + e0[1:] + '"'),            # non-ASCII code point
+                    plain.replace('"' + e0 + '"', '"' + "\\x41" + e0[1:] + '"'),              # not a JSON escape
+                    plain.replace('"' + e0 + '"', '"' + "\\u00" + e0[1:] + '"'),              # truncated \u
+                    plain.replace('"' + e0 + '"', '"' + e0 + "\\n" + '"')):                   # 44 characters after unescaping
+        _, st = eg.pack_json("[" + variant + "," + plain + "]", 5, single=True)
+        assert st == [MAL, 0], variant[:80]
+    # an escaped spelling of an unknown field is still an unknown field; of a duplicate field, a duplicate
+    assert eg.pack_json(plain[:-1] + ', "\\u0065xtra": 1}', 5, single=True)[1] == [0]
+    assert eg.pack_json(plain[:-1] + ', "ch\\u006fices": []}', 5, single=True)[1] == [MAL]
