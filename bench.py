@@ -350,12 +350,22 @@ def main():
     # memory-side bytes per ballot and launch of the dominant kernel, measured by the PMC passes of the last profile round
     traffic_src = None
     try:
+        import hashlib
+        h = hashlib.sha256()
+        for f in sorted((ROOT / "elastic_elgamal_amd" / "csrc").iterdir()):
+            if f.suffix in (".cuh", ".hip", ".hpp", ".h"):
+                h.update(f.name.encode()); h.update(f.read_bytes())
+        tree_hash = h.hexdigest()[:16]
+    except OSError:
+        tree_hash = None
+    try:
         tj = json.loads(TRAFFIC_JSON.read_text())
         key = f"{args.workload}-{n_opt}" + (f"-{args.credits}" if args.workload == "qv" else "")
         ent = tj["workloads"][key]["kernels"][DOMINANT_KERNEL]
         traffic_bpbl = float(ent["bytes_per_ballot_launch"])
         traffic_src = {"file": "profiles/traffic.json", "round": tj.get("round"), "commit": tj.get("commit"),
-                       "ballots_per_launch": tj["workloads"][key].get("ballots_per_launch")}
+                       "ballots_per_launch": tj["workloads"][key].get("ballots_per_launch"), "source_hash": tj.get("source_hash"),
+                       "tree_hash": tree_hash}
     except (OSError, KeyError, ValueError):
         traffic_bpbl = None
     out = {
@@ -401,6 +411,7 @@ def main():
                         if traffic_bpbl is not None and avg_launch_ms > 0 else None),
             "traffic_bytes_per_launch": traffic_bpbl * units_per_launch if traffic_bpbl is not None else None,
             "traffic_source": traffic_src,
+            "traffic_stale": bool(traffic_src is None or traffic_src.get("source_hash") != tree_hash),   # counters measured on another build of csrc/
             "traffic_note": "GB/s like `achieved`: memory-side bytes per ballot and launch of this kernel from the separate rocprofv3 "
                             "PMC passes of the last profile round (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; "
                             "tools/profile_round.sh -> profiles/traffic.json) x this run's ballots per launch / this run's "

@@ -6,20 +6,21 @@
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
-PMC_BALLOTS=262144
+PMC_BALLOTS=1000000     # the size the bench line quotes: launches of the same 2^19-ballot chunks
 for w in single multi qv; do
   timeout -k 10 300 python3 bench.py --steps 5 --warmup 1 --workload $w > gpurun_out/bench_$w.json 2> gpurun_out/bench_$w.err || exit 1
   tail -c 300 gpurun_out/bench_$w.json; echo
 done
 timeout -k 10 300 python3 bench.py --steps 3 --warmup 1 --total-ballots 10000000 > gpurun_out/bench_10M.json 2> gpurun_out/bench_10M.err || exit 1
 timeout -k 10 300 python3 bench.py --steps 5 --warmup 1 --tampered-percent 1 > gpurun_out/bench_tampered1pct.json 2> gpurun_out/bench_tampered.err || exit 1
+timeout -k 10 300 python3 bench.py --steps 3 --warmup 1 --workload msm > gpurun_out/bench_msm.json 2> gpurun_out/bench_msm.err || exit 1
 for w in single multi qv; do
   rm -rf gpurun_out/prof_stats_$w
   timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_stats_$w -o stats --output-format csv -- \
     python3 bench.py --steps 3 --warmup 1 --workload $w --no-cpu-baseline --no-host-inclusive --no-wire-ingest > gpurun_out/prof_stats_$w.log 2>&1 || exit 1
 done
 [ "$1" = "pmc" ] || exit 0
-export EG_COMB_BIG_MIN=1     # the counter passes run 2^18 ballots: give them the wide comb tables that the 1 M-ballot steps use
+export EG_COMB_BIG_MIN=1     # one step without warm-up: give it the wide comb tables that the timed steps of the bench line use
 for w in single multi qv; do
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf gpurun_out/pmc_${c}_$w

@@ -5,6 +5,7 @@
    usage: profile_summary.py <round-tag, e.g. r02>"""
 import collections
 import csv
+import hashlib
 import json
 import shutil
 import subprocess
@@ -14,11 +15,21 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 OUT = ROOT / "gpurun_out"
 PROF = ROOT / "profiles"
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
-PMC_BALLOTS = 262144
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+PMC_BALLOTS = 1000000      # the size the bench line quotes (tools/profile_round.sh); a step is cut into chunks, one launch per chunk and stage
 WORKLOADS = {"single": "single-5", "multi": "multi-16", "qv": "qv-5-20"}
 DESCR = {"single": "1M single-choice 5-option ballots (BASELINE configs[1])", "multi": "1M multi-choice 3-of-16 ballots (configs[3])",
          "qv": "1M quadratic-voting ballots, 5 options / 20 credits (configs[2])"}
+
+
+def source_hash() -> str:
+    """sha256 over the device and host sources of the library: ties profiles/traffic.json to the build it was measured on (bench.py
+    prints "traffic_stale": true when the tree it runs from hashes differently)."""
+    h = hashlib.sha256()
+    for f in sorted((ROOT / "elastic_elgamal_amd" / "csrc").iterdir()):
+        if f.suffix in (".cuh", ".hip", ".hpp", ".h"):
+            h.update(f.name.encode()); h.update(f.read_bytes())
+    return h.hexdigest()[:16]
 
 
 def kname(name):
@@ -28,7 +39,8 @@ def kname(name):
 
 # ---- bench lines ---------------------------------------------------------------------------------------------------
 for src, dst in (("bench_single.json", "bench_line.json"), ("bench_multi.json", "bench_line_multi16.json"), ("bench_qv.json", "bench_line_qv.json"),
-                 ("bench_10M.json", "bench_line_10M.json"), ("bench_tampered1pct.json", "bench_line_tampered1pct.json")):
+                 ("bench_10M.json", "bench_line_10M.json"), ("bench_tampered1pct.json", "bench_line_tampered1pct.json"),
+                 ("bench_msm.json", "bench_line_msm.json")):
     f = OUT / src
     if f.exists() and f.read_text().strip():
         line = f.read_text().strip().splitlines()[-1]
@@ -53,10 +65,10 @@ for w in WORKLOADS:
 want = ["eg::k_eq_table<false>", "eg::k_eq_table<true>", "eg::k_eq_direct", "eg::k_eq_generic", "eg::k_base_tables", "eg::k_sum_tables", "eg::k_encode_batch", "eg::k_decode_points", "eg::k_hash"]
 text = [f"# rocprofv3 --pmc <counter> -- python3 bench.py --steps 1 --warmup 0 --workload W --no-cpu-baseline --no-host-inclusive --no-wire-ingest --ballots {PMC_BALLOTS}   (MI355X)",
         "# separate passes per counter (FETCH_SIZE, WRITE_SIZE; for the single-choice workload also two groups of SQ counters); values are",
-        "# summed over the launches of the one step (1 chunk).  FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the",
+        "# summed over the launches of the one step (its chunks x stages).  FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the",
         "# bytes of 16-B-per-lane reads (MI355X_MICROARCH.md, HBM section; calibrated for this access shape in <round>_fetch_calibration.txt),",
         "# hence the x2.", ""]
-traffic = {"round": tag, "ballots_per_launch_measured": PMC_BALLOTS, "workloads": {}}
+traffic = {"round": tag, "ballots_per_step_measured": PMC_BALLOTS, "source_hash": source_hash(), "workloads": {}}
 try:
     traffic["commit"] = subprocess.check_output(["git", "-C", str(ROOT), "rev-parse", "--short", "HEAD"], text=True).strip()
 except Exception:
@@ -79,7 +91,9 @@ for w, key in WORKLOADS.items():
     if not found:
         continue
     text.append(f"== workload {w}: {DESCR[w].replace('1M', str(PMC_BALLOTS))}")
-    ent = {"ballots_per_launch": PMC_BALLOTS, "kernels": {}}
+    n_chunks = max(len(launches.get("eg::k_base_tables", ())), 1)          # the table builder runs once per chunk
+    per_launch_ballots = PMC_BALLOTS / n_chunks
+    ent = {"ballots_per_launch": per_launch_ballots, "chunks_per_step": n_chunks, "kernels": {}}
     for k in want:
         c = acc.get(k)
         if not c:
@@ -87,9 +101,9 @@ for w, key in WORKLOADS.items():
         n = max(len(launches[k]), 1)
         per_launch = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024 / n
         ent["kernels"][k] = {"launches": n, "fetch_kib": c["FETCH_SIZE"], "write_kib": c["WRITE_SIZE"],
-                             "bytes_per_launch": per_launch, "bytes_per_ballot_launch": per_launch / PMC_BALLOTS}
+                             "bytes_per_launch": per_launch, "bytes_per_ballot_launch": per_launch / per_launch_ballots}
         text.append(f"{k}: launches={n}  FETCH_SIZE={c['FETCH_SIZE']:.0f} KiB  WRITE_SIZE={c['WRITE_SIZE']:.0f} KiB  "
-                    f"-> per launch (FETCH x2 + WRITE) = {per_launch/1e9:.2f} GB = {per_launch/PMC_BALLOTS/1e3:.1f} KB per ballot")
+                    f"-> per launch (FETCH x2 + WRITE) = {per_launch/1e9:.2f} GB = {per_launch/per_launch_ballots/1e3:.1f} KB per ballot")
         sq = "  ".join(f"{n_}={c[n_]:.3e}" for n_ in sorted(c) if n_.startswith("SQ_"))
         if sq:
             text.append("    " + sq)
