@@ -397,12 +397,12 @@ static int engine_create(eg_ctx* ctx, eghost::Plan&& plan, const uint8_t pk[32],
   // chunk workspace: sized lazily by engine_reserve() for the batches actually seen (up to EG_CHUNK ballots per chunk and work set)
   if (const char* v = getenv("EG_STREAMS")) e->n_sets = atoi(v) >= 2 ? 2 : 1;
   const char* env = getenv("EG_CHUNK");
-  // Two work sets whose kernels fill each other's launch tails (profiles/r03_ab_experiments.txt, block 3; M single-choice ballots/s):
-  // one set of 2^20 ballots 6.06 (45 GB of workspace), one set of 2^18 5.81 (-4 %), two sets of 2^18 6.05 (24 GB), two sets of 2^19
-  // 6.13 (+1 %, 47 GB: the default), two sets of 2^17 5.90.  EG_CHUNK=262144 halves the memory for 1 % of the throughput.
-  e->max_cap = env ? (u32)strtoul(env, nullptr, 10) : (e->n_sets == 2 ? 524288u : 1048576u);
+  // Two work sets whose kernels fill each other's launch tails (profiles/r03_ab_experiments.txt, block 3; M single-choice ballots/s and
+  // workspace at 57.6 KB per ballot and set): one set of 2^20 ballots 6.06 (60 GB: round 2's arrangement), one set of 2^18 5.81 (-4 %),
+  // two sets of 2^18 6.05 (30 GB: the default), two sets of 2^19 6.13 (+1 %, 60 GB: EG_CHUNK=524288), two sets of 2^17 5.90 (15 GB).
+  e->max_cap = env ? (u32)strtoul(env, nullptr, 10) : (e->n_sets == 2 ? 262144u : 1048576u);
   {
-    // Large elections keep the workspace within half of the free device memory (~45 KB per ballot and set for 5 options).
+    // Large elections keep the workspace within half of the free device memory (~58 KB per ballot and set for 5 options, 150 KB for 16).
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
     const size_t per = engine_bytes_per_ballot(e.get()) * (size_t)e->n_sets;
@@ -1344,11 +1344,12 @@ int eg_plan_describe(int kind, int n_options, uint64_t credits_or_bound, char* b
            "\"combs\": %zu, \"deferred\": %zu, \"plain_encodes\": %zu, \"inversion_groups\": %zu, "
            "\"single_table_jobs\": %zu, \"chains\": %zu, \"chain_extra_terms\": %zu, \"loose_table_terms\": %zu, \"direct_terms\": %zu, "
            "\"sum_tables\": %zu, \"sum_table_members\": %zu, "
-           "\"hash_programs\": %zu, \"prefixes\": %d, \"flags\": %d, \"rules\": %zu, \"tally_slots\": %zu}",
+           "\"hash_programs\": %zu, \"prefixes\": %d, \"flags\": %d, \"rules\": %zu, \"tally_slots\": %zu, "
+           "\"pt_slots\": %d, \"cmp_slots\": %d, \"chal_slots\": %d, \"state_slots\": %d, \"tables\": %zu}",
            P.stride, P.pt_items.size(), P.sc_items.size(), derived, derive_terms, P.base_slots.size(), P.stages.size(), jobs, per_stage.c_str(),
            var_terms, table_terms, combs, deferred, plain_encodes, inversion_groups, jobs_table1, chains, chain_extra_terms,
            loose_table_terms, direct_terms, P.sum_bases.size(), P.sum_members.size(), insts, P.n_prefixes, P.n_flag_slots, P.rules.size(),
-           P.tally_slots.size());
+           P.tally_slots.size(), P.n_pt_slots, P.n_cmp_slots, P.n_chal_slots, P.n_state_slots, (size_t)P.n_tables());
   if (strlen(tmp) + 1 > cap) return fail(EG_ERR_BAD_ARG, "buffer too small");
   memcpy(buf, tmp, strlen(tmp) + 1);
   return EG_OK;
