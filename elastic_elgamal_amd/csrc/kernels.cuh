@@ -769,7 +769,7 @@ __global__ void __launch_bounds__(NT) k_prim_scalar_invert(size_t n, const u32* 
   st8(out + i * 8, o);
 }
 // ElementOps::is_identity on encodings: the identity's only valid encoding is 32 zero bytes
-__global__ void __launch_bounds__(NT) k_prim_point_is_identity(size_t n, const u32* in, unsigned char* is_id, unsigned char* ok) {
+__global__ void __launch_bounds__(NT, 2) k_prim_point_is_identity(size_t n, const u32* in, unsigned char* is_id, unsigned char* ok) {
   const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
   if (i >= n) return;
   u32 w[8]; ld8(w, in + i * 8);
@@ -781,7 +781,7 @@ __global__ void __launch_bounds__(NT) k_prim_point_is_identity(size_t n, const u
   ok[i] = valid ? 1 : 0;
   is_id[i] = (valid && any == 0) ? 1 : 0;
 }
-__global__ void __launch_bounds__(NT) k_prim_point_roundtrip(size_t n, const u32* in, u32* out, unsigned char* ok) {
+__global__ void __launch_bounds__(NT, 2) k_prim_point_roundtrip(size_t n, const u32* in, u32* out, unsigned char* ok) {
   const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
   if (i >= n) return;
   u32 w[8], o[8]; ld8(w, in + i * 8);
@@ -790,7 +790,7 @@ __global__ void __launch_bounds__(NT) k_prim_point_roundtrip(size_t n, const u32
   ristretto_encode(o, p);
   st8(out + i * 8, o);
 }
-__global__ void __launch_bounds__(NT) k_prim_point_add(size_t n, const u32* a, const u32* b, int subtract, u32* out, unsigned char* ok) {
+__global__ void __launch_bounds__(NT, 2) k_prim_point_add(size_t n, const u32* a, const u32* b, int subtract, u32* out, unsigned char* ok) {
   const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
   if (i >= n) return;
   u32 aw[8], bw[8], o[8]; ld8(aw, a + i * 8); ld8(bw, b + i * 8);

@@ -22,6 +22,9 @@
 #include <cstdint>
 #include <cstring>
 #include <functional>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 #include <string>
 #include <thread>
 #include <vector>
@@ -747,55 +750,76 @@ inline bool split_next(const char* s, size_t len, size_t window, int threads, Sp
     const size_t a = cur.pos, b = (window >= len - a) ? len : a + window;
     const size_t T = std::max<size_t>(1, std::min<size_t>((size_t)threads, (b - a) / 256 + 1));
     auto lo = [&](size_t t) { return a + (b - a) * t / T; };
-    auto is_delim = [&](size_t q) { size_t bs = 0; while (q > a + bs && s[q - 1 - bs] == '\\') ++bs; return (bs & 1) == 0; };
     auto run = [&](auto fn) {
       std::vector<std::thread> pool;
       for (size_t t = 1; t < T; ++t) pool.emplace_back(fn, t);
       fn(0);
       for (auto& th : pool) th.join();
     };
+    // ONE pass per chunk (round 3; two passes + a byte loop before: the splitter, not the parser, bounded eg_verify_*_json).  Whether a
+    // chunk starts inside a string is known only after the chunks before it have been counted, so every chunk sorts its brackets by the
+    // PARITY of the string delimiters seen so far: list 0 holds the brackets of the even regions (outside strings if the chunk starts
+    // outside one), list 1 those of the odd regions; the prefix sum of the delimiter counts then picks one list per chunk.  The bytes
+    // are searched 16 at a time (SSE2) for the six characters that matter: " \ { } [ ]
+    // Only the brackets at the LOWEST levels of a chunk can be top-level ones (the absolute depth never goes below zero, so the top
+    // level of a chunk that starts at depth D is its relative level -D <= the lowest level it reaches): a bracket is recorded only when
+    // its level - before an opening one, after a closing one - is at or below the running minimum of its list.  ~2 events per ballot
+    // instead of ~20; every list also keeps its total change of depth for the prefix sum.
+    struct Ev { size_t pos; int step; int level; };      // +1 open, -1 close, 0 stray backslash; level relative to the chunk's start
     std::vector<size_t> quotes(T, 0);
-    run([&](size_t t) {
-      size_t n = 0;
-      const char* p = s + lo(t);
-      const char* e = s + lo(t + 1);
-      while (p < e) {
-        const void* hit = memchr(p, '"', (size_t)(e - p));
-        if (!hit) break;
-        p = (const char*)hit;
-        n += is_delim((size_t)(p - s));
-        ++p;
-      }
-      quotes[t] = n;
-    });
-    std::vector<char> in_str(T, 0);
-    for (size_t t = 1; t < T; ++t) in_str[t] = (char)((in_str[t - 1] + quotes[t - 1]) & 1);
-    struct Ev { size_t pos; int step; };      // +1 open, -1 close, 0 stray backslash
-    std::vector<std::vector<Ev>> events(T);
+    std::vector<std::vector<Ev>> ev2(2 * T);
+    std::vector<long> delta2(2 * T, 0);
     run([&](size_t t) {
       size_t i = lo(t);
       const size_t e = lo(t + 1);
-      bool str = in_str[t] != 0;
-      auto& ev = events[t];
-      while (i < e) {
-        if (str) {
-          const void* hit = memchr(s + i, '"', e - i);
-          if (!hit) return;
-          i = (size_t)((const char*)hit - s);
-          if (is_delim(i)) str = false;
-          ++i;
-          continue;
+      size_t skip = (size_t)-1;                // position of a character escaped by the backslash before it
+      { size_t bs = 0; while (i > a + bs && s[i - 1 - bs] == '\\') ++bs; if (bs & 1) skip = i; }
+      size_t nq = 0;
+      unsigned parity = 0;
+      std::vector<Ev>* lists[2] = {&ev2[2 * t], &ev2[2 * t + 1]};
+      int d[2] = {0, 0}, low[2] = {0, 0};
+      auto special = [&](size_t p) {
+        if (p == skip) return;
+        const char ch = s[p];
+        if (ch == '"') { ++nq; parity ^= 1u; }
+        else if (ch == '\\') { skip = p + 1; lists[parity]->push_back({p, 0, d[parity]}); }
+        else if (ch == '{' || ch == '[') {
+          if (d[parity] <= low[parity]) lists[parity]->push_back({p, +1, d[parity]});
+          ++d[parity];
+        } else {
+          --d[parity];
+          if (d[parity] <= low[parity]) { lists[parity]->push_back({p, -1, d[parity]}); low[parity] = d[parity]; }
         }
-        const char ch = s[i];
-        if (ch == '"') str = true;
-        else if (ch == '{' || ch == '[') ev.push_back({i, +1});
-        else if (ch == '}' || ch == ']') ev.push_back({i, -1});
-        else if (ch == '\\') ev.push_back({i, 0});
-        ++i;
+      };
+#if defined(__SSE2__)
+      const __m128i q = _mm_set1_epi8('"'), b = _mm_set1_epi8('\\'), o1 = _mm_set1_epi8('{'), c1 = _mm_set1_epi8('}'),
+                    o2 = _mm_set1_epi8('['), c2 = _mm_set1_epi8(']');
+      for (; i + 16 <= e; i += 16) {
+        const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i*>(s + i));
+        const __m128i m = _mm_or_si128(_mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(v, q), _mm_cmpeq_epi8(v, b)),
+                                                    _mm_or_si128(_mm_cmpeq_epi8(v, o1), _mm_cmpeq_epi8(v, c1))),
+                                       _mm_or_si128(_mm_cmpeq_epi8(v, o2), _mm_cmpeq_epi8(v, c2)));
+        unsigned bits = (unsigned)_mm_movemask_epi8(m);
+        while (bits) { special(i + (size_t)__builtin_ctz(bits)); bits &= bits - 1; }
       }
+#endif
+      for (; i < e; ++i) {
+        const char ch = s[i];
+        if (ch == '"' || ch == '\\' || ch == '{' || ch == '}' || ch == '[' || ch == ']') special(i);
+      }
+      quotes[t] = nq;
+      delta2[2 * t] = d[0]; delta2[2 * t + 1] = d[1];
     });
-    // sequential walk over the events
-    long depth = 0;
+    std::vector<char> in_str(T, 0);
+    for (size_t t = 1; t < T; ++t) in_str[t] = (char)((in_str[t - 1] + quotes[t - 1]) & 1);
+    std::vector<const std::vector<Ev>*> events_of(T);
+    std::vector<long> depth0(T + 1, 0);          // absolute depth at the start of every chunk (the window starts at the base depth)
+    for (size_t t = 0; t < T; ++t) {
+      events_of[t] = &ev2[2 * t + (size_t)in_str[t]];
+      depth0[t + 1] = depth0[t] + delta2[2 * t + (size_t)in_str[t]];
+    }
+    // sequential walk over the recorded events
+    long depth = depth0[T];                        // depth at the end of the window (used when no event ends the walk early)
     size_t start = 0, prev_end = a, emitted = 0, close_pos = 0;
     bool closed_here = false, bad = false;
     auto separators_ok = [&](size_t from, size_t to, bool before_value) {
@@ -808,21 +832,21 @@ inline bool split_next(const char* s, size_t len, size_t window, int threads, Sp
       return cur.array ? commas == ((cur.count + emitted) ? 1u : 0u) : commas == 0;
     };
     for (size_t t = 0; t < T && !bad && !closed_here; ++t)
-      for (const Ev& e : events[t]) {
-        if (e.step == 0) { if (depth == 0) { bad = true; } else { bad = true; } break; }
+      for (const Ev& e : *events_of[t]) {
+        if (e.step == 0) { bad = true; break; }                    // a backslash outside a string is not JSON
+        const long level = depth0[t] + e.level;                    // absolute: before an opening bracket, after a closing one
         if (e.step > 0) {
-          if (depth == 0) {
+          if (level == 0) {
             if (s[e.pos] != '{' || !separators_ok(prev_end, e.pos, true)) { bad = true; break; }
             start = e.pos;
           }
-          ++depth;
         } else {
-          if (depth == 0) {                       // the closing bracket of a top-level array
+          if (level < 0) {                        // the closing bracket of a top-level array
             if (!cur.array || s[e.pos] != ']' || !separators_ok(prev_end, e.pos, false)) { bad = true; break; }
             closed_here = true; close_pos = e.pos;
             break;
           }
-          if (--depth == 0) { spans.push_back({start, e.pos + 1 - start}); ++emitted; prev_end = e.pos + 1; }
+          if (level == 0) { spans.push_back({start, e.pos + 1 - start}); ++emitted; prev_end = e.pos + 1; }
         }
       }
     if (bad) return false;
