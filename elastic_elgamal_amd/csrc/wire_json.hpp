@@ -88,19 +88,27 @@ inline bool read_json_string(Cursor& c, char* buf, size_t cap, size_t& len) {
 
 // a JSON string holding exactly 32 bytes of unpadded base64url (43 characters, the 2 trailing bits zero) -> out.
 // Anything else in the string - another alphabet, padding, another length - fails.  Escaped characters take the slow path.
+// the four characters of a group looked up already shifted into place (bit 31 = not in the alphabet): three ORs make the 24-bit word
+struct B64Wide {
+  uint32_t t[4][256];
+  constexpr B64Wide() : t() {
+    for (int k = 0; k < 4; ++k)
+      for (int i = 0; i < 256; ++i) t[k][i] = kB64.v[i] == 0x80 ? 0x80000000u : (uint32_t)kB64.v[i] << (18 - 6 * k);
+  }
+};
+static constexpr B64Wide kB64W{};
 inline bool decode_b64_43(const unsigned char* s, uint8_t out[32]) {
   uint32_t bad = 0;
   for (int g = 0; g < 10; ++g) {                       // 40 characters -> 30 bytes
-    const uint32_t a = kB64.v[s[4 * g]], b = kB64.v[s[4 * g + 1]], d = kB64.v[s[4 * g + 2]], e = kB64.v[s[4 * g + 3]];
-    bad |= a | b | d | e;
-    const uint32_t w = (a << 18) | (b << 12) | (d << 6) | e;
+    const uint32_t w = kB64W.t[0][s[4 * g]] | kB64W.t[1][s[4 * g + 1]] | kB64W.t[2][s[4 * g + 2]] | kB64W.t[3][s[4 * g + 3]];
+    bad |= w;
     out[3 * g] = (uint8_t)(w >> 16); out[3 * g + 1] = (uint8_t)(w >> 8); out[3 * g + 2] = (uint8_t)w;
   }
-  const uint32_t a = kB64.v[s[40]], b = kB64.v[s[41]], d = kB64.v[s[42]];   // 3 characters -> 2 bytes + 2 bits that must be zero
-  bad |= a | b | d;
-  const uint32_t w = (a << 12) | (b << 6) | d;
+  // 3 characters -> 2 bytes + 2 bits that must be zero
+  const uint32_t w = kB64W.t[1][s[40]] | kB64W.t[2][s[41]] | kB64W.t[3][s[42]];        // 18 bits: a << 12 | b << 6 | d
+  bad |= w;
   out[30] = (uint8_t)(w >> 10); out[31] = (uint8_t)(w >> 2);
-  return !(bad & 0x80u) && !(w & 3u);
+  return !(bad & 0x80000000u) && !(w & 3u);
 }
 inline bool parse_b64_32(Cursor& c, uint8_t out[32]) {
   c.ws();
@@ -612,119 +620,6 @@ inline bool split_objects(const char* s, size_t len, std::vector<std::pair<size_
   }
 }
 
-// The same result as split_objects, computed by `threads` workers: (1) every chunk counts its unescaped quotes, which tells the
-// next chunks whether they start inside a string; (2) every chunk computes its change of bracket depth; (3) with the absolute
-// depth known at its start, every chunk emits the starts and ends of the values at the base depth.  Three passes over the text,
-// each split `threads` ways, instead of one sequential pass: the splitter, not the per-object parser, is what limits a many-core
-// host.  Falls back to the sequential splitter for small texts.
-inline bool split_objects_parallel(const char* s, size_t len, int threads, std::vector<std::pair<size_t, size_t>>& spans,
-                                   size_t min_len = (size_t)1 << 20) {
-  if (threads < 2 || len < min_len || len < 4 * (size_t)threads) return split_objects(s, len, spans);
-  const size_t T = (size_t)threads;
-  auto lo = [&](size_t t) { return len * t / T; };
-  // a quote is a delimiter unless an odd run of backslashes precedes it (the run may begin in the previous chunk)
-  auto is_delim = [&](size_t q) { size_t bs = 0; while (q > bs && s[q - 1 - bs] == '\\') ++bs; return (bs & 1) == 0; };
-  std::vector<size_t> quotes(T, 0);
-  auto run = [&](auto fn) {
-    std::vector<std::thread> pool;
-    for (size_t t = 1; t < T; ++t) pool.emplace_back(fn, t);
-    fn(0);
-    for (auto& th : pool) th.join();
-  };
-  run([&](size_t t) {
-    size_t n = 0;
-    const char* p = s + lo(t);
-    const char* e = s + lo(t + 1);
-    while (p < e) {
-      const void* hit = memchr(p, '"', (size_t)(e - p));
-      if (!hit) break;
-      p = (const char*)hit;
-      n += is_delim((size_t)(p - s));
-      ++p;
-    }
-    quotes[t] = n;
-  });
-  std::vector<char> in_str(T, 0);
-  for (size_t t = 1; t < T; ++t) in_str[t] = (char)((in_str[t - 1] + quotes[t - 1]) & 1);
-  // scans a chunk outside strings, calling on_open / on_close for brackets
-  auto scan = [&](size_t t, auto on_bracket) {
-    size_t i = lo(t);
-    const size_t e = lo(t + 1);
-    bool str = in_str[t] != 0;
-    while (i < e) {
-      if (str) {
-        const void* hit = memchr(s + i, '"', e - i);
-        if (!hit) return;
-        i = (size_t)((const char*)hit - s);
-        if (is_delim(i)) str = false;
-        ++i;
-        continue;
-      }
-      const char ch = s[i];
-      if (ch == '"') str = true;
-      else if (ch == '{' || ch == '[') on_bracket(i, +1);
-      else if (ch == '}' || ch == ']') on_bracket(i, -1);
-      else if (ch == '\\') on_bracket(i, 0);             // a backslash outside a string is not JSON
-      ++i;
-    }
-  };
-  std::vector<long> delta(T, 0);
-  std::vector<char> bad(T, 0);
-  run([&](size_t t) { long d = 0; scan(t, [&](size_t, int step) { d += step; if (!step) bad[t] = 1; }); delta[t] = d; });
-  for (size_t t = 0; t < T; ++t) if (bad[t]) return false;
-  // base depth: 1 inside a top-level array, 0 for a stream of objects
-  size_t first = 0;
-  while (first < len && (s[first] == ' ' || s[first] == '\n' || s[first] == '\t' || s[first] == '\r')) ++first;
-  if (first >= len) return true;
-  const bool array = s[first] == '[';
-  if (!array && s[first] != '{') return false;
-  const long base = array ? 1 : 0;
-  std::vector<long> depth0(T, 0);
-  for (size_t t = 1; t < T; ++t) depth0[t] = depth0[t - 1] + delta[t - 1];
-  if (depth0[T - 1] + delta[T - 1] != 0) return false;
-  std::vector<std::vector<size_t>> starts(T), ends(T);
-  run([&](size_t t) {
-    long d = depth0[t];
-    scan(t, [&](size_t pos, int step) {
-      if (step == 0) bad[t] = 1;
-      else if (step > 0) { if (d == base) { if (s[pos] != '{') bad[t] = 1; starts[t].push_back(pos); } ++d; }
-      else { --d; if (d == base) ends[t].push_back(pos + 1); if (d < 0) bad[t] = 1; }
-    });
-  });
-  std::vector<size_t> st, en;
-  for (size_t t = 0; t < T; ++t) {
-    if (bad[t]) return false;
-    st.insert(st.end(), starts[t].begin(), starts[t].end());
-    en.insert(en.end(), ends[t].begin(), ends[t].end());
-  }
-  if (array) {           // the array's own brackets are at depth 0 -> 1: its '[' is not an object start; drop nothing, but check
-    if (en.size() != st.size()) return false;
-  } else if (en.size() != st.size()) return false;
-  spans.reserve(st.size());
-  size_t prev_end = array ? first + 1 : 0;
-  for (size_t k = 0; k < st.size(); ++k) {
-    if (en[k] <= st[k]) return false;
-    // between two values only white space (and one comma inside an array) may appear
-    size_t commas = 0;
-    for (size_t i = prev_end; i < st[k]; ++i) {
-      const char ch = s[i];
-      if (ch == ',') ++commas;
-      else if (!(ch == ' ' || ch == '\n' || ch == '\t' || ch == '\r')) return false;
-    }
-    if (array ? commas != (k ? 1u : 0u) : commas != 0) return false;
-    spans.push_back({st[k], en[k] - st[k]});
-    prev_end = en[k];
-  }
-  // tail: white space, and the closing bracket of an array
-  bool closed = !array;
-  for (size_t i = prev_end; i < len; ++i) {
-    const char ch = s[i];
-    if (ch == ']' && !closed) closed = true;
-    else if (!(ch == ' ' || ch == '\n' || ch == '\t' || ch == '\r')) return false;
-  }
-  return closed;
-}
-
 // ---- streaming splitter: the text is cut window by window, so that parsing and GPU verification of the first ballots start before
 // the last bytes have been looked at (eg_verify_*_json).  Same verdicts as split_objects on the whole text.
 struct SplitCursor {
@@ -864,6 +759,16 @@ inline bool split_next(const char* s, size_t len, size_t window, int threads, Sp
     if (emitted) { cur.count += emitted; cur.pos = prev_end; return true; }
     window *= 2;                                  // no complete value in the window: look further
   }
+}
+
+// The same result as split_objects, computed by `threads` workers: the streaming splitter with one window that spans the whole text
+// (round 2 had a three-pass splitter of its own here; the fuzz tests hold both against the sequential split_objects).
+inline bool split_objects_parallel(const char* s, size_t len, int threads, std::vector<std::pair<size_t, size_t>>& spans,
+                                   size_t min_len = (size_t)1 << 20) {
+  if (threads < 2 || len < min_len || len < 4 * (size_t)threads) return split_objects(s, len, spans);
+  SplitCursor cur;
+  bool done = false;
+  return split_next(s, len, len, threads, cur, spans, done) && done;
 }
 
 template <class PackOne>
