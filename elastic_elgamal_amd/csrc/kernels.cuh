@@ -438,18 +438,37 @@ __global__ void __launch_bounds__(NT) k_status(EngineBufs B, const egplan::Statu
 }
 
 // ---- tally: totals[k] += vote[k] over accepted ballots (examples/voting.rs:199-203) ---------------------------------------------------------
-__device__ __forceinline__ void block_reduce_points(ge& acc, u32* lds /* [PT_WORDS][NT] */) {
-  u32 w[PT_WORDS];
+// acc = sum over the 64 lanes of a wavefront, in lane 0: wavefront-shuffle point accumulation (six rounds of 36 shuffles + one addition)
+__device__ __forceinline__ void wave_reduce_points(ge& acc) {
 #pragma unroll 1
-  for (int s = NT / 2; s >= 1; s >>= 1) {
+  for (int off = 32; off >= 1; off >>= 1) {
+    u32 w[PT_WORDS];
     ge_to_words(w, acc);
-    __syncthreads();
 #pragma unroll
-    for (int i = 0; i < PT_WORDS; ++i) lds[i * NT + threadIdx.x] = w[i];
-    __syncthreads();
-    if ((int)threadIdx.x < s) {
+    for (int k = 0; k < PT_WORDS; ++k) w[k] = (u32)__shfl_down((int)w[k], off, 64);
+    ge other, sum;
+    words_to_ge(other, w);
+    ge_add_full(sum, acc, other);
+    acc = sum;
+  }
+}
+// acc = sum over the block, in thread 0: every wavefront folds its 64 lanes with shuffles, the four wavefront sums meet in LDS
+__device__ __forceinline__ void block_reduce_points(ge& acc, u32* lds /* [NT / 64][PT_WORDS] */) {
+  wave_reduce_points(acc);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) {
+    u32 w[PT_WORDS];
+    ge_to_words(w, acc);
 #pragma unroll
-      for (int i = 0; i < PT_WORDS; ++i) w[i] = lds[i * NT + threadIdx.x + s];
+    for (int i = 0; i < PT_WORDS; ++i) lds[wave * PT_WORDS + i] = w[i];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll 1
+    for (int k = 1; k < NT / 64; ++k) {
+      u32 w[PT_WORDS];
+#pragma unroll
+      for (int i = 0; i < PT_WORDS; ++i) w[i] = lds[k * PT_WORDS + i];
       ge other, sum;
       words_to_ge(other, w);
       ge_add_full(sum, acc, other);
@@ -460,7 +479,7 @@ __device__ __forceinline__ void block_reduce_points(ge& acc, u32* lds /* [PT_WOR
 
 // grid (G, n_slots): block (x, k) sums point slot tally_slots[k] over its share of accepted ballots
 __global__ void __launch_bounds__(NT) k_tally_partial(EngineBufs B, const u32* tally_slots, u32* partial /* [n_slots][G][PT_WORDS] */) {
-  __shared__ u32 lds[PT_WORDS * NT];
+  __shared__ u32 lds[PT_WORDS * (NT / 64)];
   const u32 slot = tally_slots[blockIdx.y];
   ge acc;
   ge_identity(acc);
@@ -480,7 +499,7 @@ __global__ void __launch_bounds__(NT) k_tally_partial(EngineBufs B, const u32* t
 }
 // one block per slot: tally[k] += sum_x partial[k][x]
 __global__ void __launch_bounds__(NT) k_tally_final(const u32* partial, int G, u32* tally /* [n_slots][PT_WORDS] */) {
-  __shared__ u32 lds[PT_WORDS * NT];
+  __shared__ u32 lds[PT_WORDS * (NT / 64)];
   ge acc;
   ge_identity(acc);
   for (int x = threadIdx.x; x < G; x += NT) {
@@ -908,20 +927,6 @@ __global__ void __launch_bounds__(NT, 2) k_prim_msm(size_t n, int terms, int chu
         reinterpret_cast<uint4*>(partial)[j * PT_QUADS + q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
       ok_partial[j] = okk ? 1 : 0;
     }
-  }
-}
-// acc = sum over the 64 lanes of a wavefront, in lane 0: wavefront-shuffle point accumulation (six rounds of 36 shuffles + one addition)
-__device__ __forceinline__ void wave_reduce_points(ge& acc) {
-#pragma unroll 1
-  for (int off = 32; off >= 1; off >>= 1) {
-    u32 w[PT_WORDS];
-    ge_to_words(w, acc);
-#pragma unroll
-    for (int k = 0; k < PT_WORDS; ++k) w[k] = (u32)__shfl_down((int)w[k], off, 64);
-    ge other, sum;
-    words_to_ge(other, w);
-    ge_add_full(sum, acc, other);
-    acc = sum;
   }
 }
 // one wavefront per 64 partial sums of a problem: folds them into one (lane = partial, shuffle reduction).  Long products (2^16 single-term
