@@ -6,20 +6,11 @@
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
-PMC_BALLOTS=1000000     # the size the bench line quotes: launches of the same 2^19-ballot chunks
-for w in single multi qv; do
-  timeout -k 10 300 python3 bench.py --steps 5 --warmup 1 --workload $w > gpurun_out/bench_$w.json 2> gpurun_out/bench_$w.err || exit 1
-  tail -c 300 gpurun_out/bench_$w.json; echo
-done
-timeout -k 10 300 python3 bench.py --steps 3 --warmup 1 --total-ballots 10000000 > gpurun_out/bench_10M.json 2> gpurun_out/bench_10M.err || exit 1
-timeout -k 10 300 python3 bench.py --steps 5 --warmup 1 --tampered-percent 1 > gpurun_out/bench_tampered1pct.json 2> gpurun_out/bench_tampered.err || exit 1
-timeout -k 10 300 python3 bench.py --steps 3 --warmup 1 --workload msm > gpurun_out/bench_msm.json 2> gpurun_out/bench_msm.err || exit 1
-for w in single multi qv; do
-  rm -rf gpurun_out/prof_stats_$w
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_stats_$w -o stats --output-format csv -- \
-    python3 bench.py --steps 3 --warmup 1 --workload $w --no-cpu-baseline --no-host-inclusive --no-wire-ingest > gpurun_out/prof_stats_$w.log 2>&1 || exit 1
-done
-[ "$1" = "pmc" ] || exit 0
+PMC_BALLOTS=1000000     # the size the bench line quotes: launches of the same 2^18-ballot chunks
+if [ "$1" = "pmc" ]; then
+# counters FIRST, then profiles/traffic.json is rewritten on the box from them (with the hash of this tree), so that the bench lines below
+# print a roofline.traffic that belongs to the build they measure ("traffic_stale": false)
+(
 export EG_COMB_BIG_MIN=1     # one step without warm-up: give it the wide comb tables that the timed steps of the bench line use
 for w in single multi qv; do
   for c in FETCH_SIZE WRITE_SIZE; do
@@ -33,4 +24,19 @@ timeout -k 10 300 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_VA
   python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-host-inclusive --no-wire-ingest --ballots $PMC_BALLOTS > gpurun_out/pmc_SQ1.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_WAVES -d gpurun_out/pmc_SQ2_single -o pmc --output-format csv -- \
   python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-host-inclusive --no-wire-ingest --ballots $PMC_BALLOTS > gpurun_out/pmc_SQ2.log 2>&1 || exit 1
+) || exit 1
+python3 tools/profile_summary.py --traffic-only > gpurun_out/traffic_summary.log 2>&1 || exit 1
+fi
+for w in single multi qv; do
+  timeout -k 10 300 python3 bench.py --steps 5 --warmup 1 --workload $w > gpurun_out/bench_$w.json 2> gpurun_out/bench_$w.err || exit 1
+  tail -c 300 gpurun_out/bench_$w.json; echo
+done
+timeout -k 10 300 python3 bench.py --steps 3 --warmup 1 --total-ballots 10000000 > gpurun_out/bench_10M.json 2> gpurun_out/bench_10M.err || exit 1
+timeout -k 10 300 python3 bench.py --steps 5 --warmup 1 --tampered-percent 1 > gpurun_out/bench_tampered1pct.json 2> gpurun_out/bench_tampered.err || exit 1
+timeout -k 10 300 python3 bench.py --steps 3 --warmup 1 --workload msm > gpurun_out/bench_msm.json 2> gpurun_out/bench_msm.err || exit 1
+for w in single multi qv; do
+  rm -rf gpurun_out/prof_stats_$w
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_stats_$w -o stats --output-format csv -- \
+    python3 bench.py --steps 3 --warmup 1 --workload $w --no-cpu-baseline --no-host-inclusive --no-wire-ingest > gpurun_out/prof_stats_$w.log 2>&1 || exit 1
+done
 echo "profile round done"

@@ -2,7 +2,9 @@
 """Turns the outputs of tools/profile_round.sh (under gpurun_out/) into the summaries kept under profiles/:
    <round>_bench_line*.json, <round>_kernel_stats_<workload>.txt, <round>_pmc_counters.txt and traffic.json (the memory-side
    bytes per ballot and launch of every profiled kernel, which bench.py reads for `roofline.traffic`).
-   usage: profile_summary.py <round-tag, e.g. r02>"""
+   usage: profile_summary.py [--traffic-only] <round-tag, e.g. r03>
+   --traffic-only (what tools/profile_round.sh runs on the GPU box between the counter passes and the bench lines): only the PMC summary and
+   traffic.json, so that the bench lines printed afterwards carry the traffic of the build they measure."""
 import collections
 import csv
 import hashlib
@@ -15,7 +17,9 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 OUT = ROOT / "gpurun_out"
 PROF = ROOT / "profiles"
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+TRAFFIC_ONLY = "--traffic-only" in sys.argv[1:]
+tag = args[0] if args else "r03"
 PMC_BALLOTS = 1000000      # the size the bench line quotes (tools/profile_round.sh); a step is cut into chunks, one launch per chunk and stage
 WORKLOADS = {"single": "single-5", "multi": "multi-16", "qv": "qv-5-20"}
 DESCR = {"single": "1M single-choice 5-option ballots (BASELINE configs[1])", "multi": "1M multi-choice 3-of-16 ballots (configs[3])",
@@ -38,7 +42,7 @@ def kname(name):
 
 
 # ---- bench lines ---------------------------------------------------------------------------------------------------
-for src, dst in (("bench_single.json", "bench_line.json"), ("bench_multi.json", "bench_line_multi16.json"), ("bench_qv.json", "bench_line_qv.json"),
+for src, dst in () if TRAFFIC_ONLY else (("bench_single.json", "bench_line.json"), ("bench_multi.json", "bench_line_multi16.json"), ("bench_qv.json", "bench_line_qv.json"),
                  ("bench_10M.json", "bench_line_10M.json"), ("bench_tampered1pct.json", "bench_line_tampered1pct.json"),
                  ("bench_msm.json", "bench_line_msm.json")):
     f = OUT / src
@@ -48,7 +52,7 @@ for src, dst in (("bench_single.json", "bench_line.json"), ("bench_multi.json", 
         (PROF / f"{tag}_{dst}").write_text(line + "\n")
 
 # ---- kernel stats --------------------------------------------------------------------------------------------------
-for w in WORKLOADS:
+for w in () if TRAFFIC_ONLY else WORKLOADS:
     f = OUT / f"prof_stats_{w}" / "stats_kernel_stats.csv"
     if not f.exists():
         continue
