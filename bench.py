@@ -47,6 +47,12 @@ MAD_PEAK_T = 36.8              # profiles/r03_ubench_valu_rates.txt: v_mad_u64_u
                                # clock (4.2 issue cycles per wave64 instruction; 32.8 T at the two or three waves per SIMD the kernels hold)
 FMUL_PEAK_G = 275.0            # profiles/r03_ubench_field_bench.txt: the shipped field multiplication in a bare chain, G/s chip-wide
 SQ_WEIGHT = 0.74               # a squaring in the same bench: 372 G/s
+FMUL_SUSTAINED_G = 252.0       # profiles/r03_ubench_field_sustained.txt: the same chain run back to back for seconds (3 waves per SIMD): the power
+                               # management holds 2.25 GHz at 1.24 kW under it, not the burst clock
+MAD_PEAK_SCLK_MHZ = 2420.0     # shader clock the chip held in that micro-benchmark (same file, s_memtime / s_memrealtime) ...
+FMUL_PEAK_SCLK_MHZ = 2270.0    # ... and in the field-multiplication chain: both are bursts of tens of milliseconds.  Back-to-back verification
+                               # steps run at the clock the power management settles on (about 2.08 GHz at 1.31 kW of the 1.4 kW cap on the
+                               # boxes measured, `clock` in the JSON line), so the fractions are also given against the peaks scaled to it
 DOMINANT_KERNEL = "eg::k_eq_table<false>"   # one table-backed base + fixed-base combs: every ring equation (kernels.cuh)
 
 
@@ -72,6 +78,57 @@ def plan_field_ops(desc: dict, wide_combs: bool = False):
                mul(OPS["enc_batch_inversion"], desc["inversion_groups"]),
                mul(OPS["encode"], desc["plain_encodes"]))
 # algorithmic bytes per ballot = packed ballot + 4-byte status word: 740 (single 5), 2084 (multi 16), 2148 (qv 5/20)
+
+
+class ClockSampler:
+    """Shader clock and package power of one GPU while the timed region runs, read from the hwmon files of its PCI function
+    (freq1_input in Hz, power1_input in microwatts: what rocm-smi prints).  Measurement only; absent files give an empty result."""
+
+    def __init__(self, torch, device_index: int, period_s: float = 0.01):
+        import glob
+        import threading
+        self.files, self.samples, self.cap_w = None, [], None
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            addr = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            for dev in glob.glob("/sys/class/drm/card*/device"):
+                if os.path.basename(os.path.realpath(dev)) == addr:
+                    for h in glob.glob(dev + "/hwmon/hwmon*"):
+                        if os.path.exists(h + "/freq1_input") and os.path.exists(h + "/power1_input"):
+                            self.files = (h + "/freq1_input", h + "/power1_input")
+                            try:
+                                self.cap_w = int(open(h + "/power1_cap").read()) / 1e6
+                            except (OSError, ValueError):
+                                pass
+        except (AttributeError, OSError):
+            pass
+        self.period, self._stop, self._thread = period_s, threading.Event(), None
+        self._threading = threading
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                self.samples.append((int(open(self.files[0]).read()) / 1e6, int(open(self.files[1]).read()) / 1e6))
+            except (OSError, ValueError):
+                pass
+            self._stop.wait(self.period)
+
+    def start(self):
+        if self.files:
+            self._thread = self._threading.Thread(target=self._run, daemon=True)
+            self._thread.start()
+
+    def stop(self):
+        if self._thread:
+            self._stop.set()
+            self._thread.join()
+        if not self.samples:
+            return None
+        f = sorted(x[0] for x in self.samples)
+        w = [x[1] for x in self.samples]
+        return {"sclk_mhz": sum(f) / len(f), "sclk_mhz_median": f[len(f) // 2], "sclk_mhz_min": f[0], "sclk_mhz_max": f[-1],
+                "power_w": sum(w) / len(w), "power_cap_w": self.cap_w, "samples": len(f),
+                "source": "hwmon freq1_input / power1_input of the device, sampled every 10 ms over the timed region"}
 
 
 def parse():
@@ -305,12 +362,16 @@ def main():
     ctx.profile_enable(True)
     ctx.profile_read()
     ctx.profile_read_tables()
+    sampler = ClockSampler(torch, dev.index if dev.index is not None else 0) if rank == 0 else None
     barrier()
+    if sampler:
+        sampler.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    clock = sampler.stop() if sampler else None
     msm_ms, msm_launches, all_ms = ctx.profile_read()
     tables_ms, tables_launches = ctx.profile_read_tables()
     ctx.profile_enable(False)
@@ -444,9 +505,18 @@ def main():
             "unit": "T v_mad_u64_u32 lane-ops/s per GPU",
             "frac": value / world * mads / 1e12 / MAD_PEAK_T,
             "fmul_equiv_frac": value / world * (fm + SQ_WEIGHT * fs) / 1e9 / FMUL_PEAK_G,
+            "fmul_equiv_frac_sustained": value / world * (fm + SQ_WEIGHT * fs) / 1e9 / FMUL_SUSTAINED_G,
             "note": "the multiply-adds of the field operations only (no carries, adds, selects, hashing); peaks measured on this chip: the "
-                    "instruction alone at 8 waves per SIMD, and the field multiplication in a bare chain (fmul_equiv_frac)",
+                    "instruction alone at 8 waves per SIMD, and the field multiplication in a bare chain, in a burst (fmul_equiv_frac) and "
+                    "sustained for seconds (fmul_equiv_frac_sustained); the *_at_sclk fractions scale the burst peaks to the clock this "
+                    "run held",
         }
+        if clock:
+            vr = out["valu_roofline"]
+            vr["frac_at_sclk"] = vr["frac"] * MAD_PEAK_SCLK_MHZ / clock["sclk_mhz"]
+            vr["fmul_equiv_frac_at_sclk"] = vr["fmul_equiv_frac"] * FMUL_PEAK_SCLK_MHZ / clock["sclk_mhz"]
+    if clock:
+        out["clock"] = clock
 
     # ---- PCIe-inclusive rate (first H2D byte to last status byte D2H): the same batch from a pinned host buffer
     # through the host-pointer entry point (pipelined uploads, eg_verify_*_batch).  Reported beside `value`, never as it.

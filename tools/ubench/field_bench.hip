@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstdint>
 #include <vector>
+#include <string>
 #include <algorithm>
 #include "ge25519.cuh"     // the shipped representation (namespace eg)
 #include "fe10.cuh"       // the representation of rounds 1-2 (namespace eg10)
@@ -213,7 +214,7 @@ int main(int argc, char** argv) {
   CK(hipSetDevice(0));
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
   const int cus = prop.multiProcessorCount;
-  const int scale = argc > 1 ? atoi(argv[1]) : 1;
+  const int scale = argc > 1 && atoi(argv[1]) > 0 ? atoi(argv[1]) : 1;
   printf("device %s, %d CUs; cycles from s_memtime (median over waves), clock from s_memrealtime\n", prop.name, cus);
   u32* d_out; Stamp* d_st;
   CK(hipMalloc(&d_out, (size_t)cus * 8 * 256 * 24 * 4));
@@ -237,6 +238,44 @@ int main(int argc, char** argv) {
     {"comb column (4S+11M) regs for 3", k_columns10<3>, k_columns9<3>, 2500 * scale, 1, 24, 3},
     {"comb column (4S+11M) regs for 4", k_columns10<4>, k_columns9<4>, 2500 * scale, 1, 24, 4},
   };
+  if (argc > 1 && std::string(argv[1]) == "sustained") {
+    // The comparison below uses bursts of 20-50 ms.  The verifier runs this arithmetic for seconds, and the clock the power management
+    // settles on under it is lower than in a burst (and lower than under tools/ubench/valu_rates, whose multiplier operands never
+    // change): the same kernels of the shipped representation launched back to back for `seconds`, rate and clock over the second half.
+    const double seconds = argc > 2 ? atof(argv[2]) : 4.0;
+    printf("sustained mode (shipped 9-limb representation): back to back for %.1f s; rate and clock over the second half\n", seconds);
+    printf("%-34s | w/SIMD | Gop/s first launches (GHz) | Gop/s sustained (GHz)\n", "loop");
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (const Case& c : cases) {
+      if (c.w != 2 && c.w != 3) continue;
+      const int w = c.w, blocks = cus * w, waves = blocks * 4;
+      const size_t lds = lds_for(w);
+      CK(hipFuncSetAttribute(reinterpret_cast<const void*>(c.k9), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      const double ops = (double)c.iters * c.ops_per_iter, lanes = (double)blocks * 256;
+      auto burst = [&](int launches, double& gops, double& ghz_med) {
+        CK(hipEventRecord(e0));
+        for (int l = 0; l < launches; ++l) hipLaunchKernelGGL(c.k9, dim3(blocks), dim3(256), lds, 0, d_out, d_st, 12345u + l, c.iters);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        std::vector<Stamp> st(waves);
+        CK(hipMemcpy(st.data(), d_st, sizeof(Stamp) * waves, hipMemcpyDeviceToHost));
+        std::vector<double> ghz(waves);
+        for (int i = 0; i < waves; ++i) ghz[i] = (double)st[i].cyc / ((double)st[i].rt * 10.0);
+        std::sort(ghz.begin(), ghz.end());
+        ghz_med = ghz[waves / 2]; gops = ops * lanes * launches / (ms * 1e6);
+      };
+      CK(hipDeviceSynchronize());
+      double g1, c1, g2, c2, g3, c3;
+      burst(1, g1, c1);
+      const float one_ms = (float)(ops * lanes / (g1 * 1e6));
+      const int half = (int)(seconds * 500.0 / one_ms) + 1;
+      burst(half, g2, c2);
+      burst(half, g3, c3);
+      printf("%-34s | %6d | %9.2f (%4.2f)           | %9.2f (%4.2f)\n", c.name, w, g1, c1, g3, c3);
+      fflush(stdout);
+    }
+    return 0;
+  }
   printf("cyc/op = cycles of the LAST wave to finish / operations / waves per SIMD (issue cycles per operation and SIMD); Gop/s from the wall clock, best of 3\n");
   for (const Case& c : cases) {
     const int w = c.w;

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstdint>
 #include <vector>
+#include <string>
 #include <algorithm>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
 typedef unsigned long long u64;
@@ -172,6 +173,48 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&out, sizeof(uint32_t) * cus * 8 * 256));
   CK(hipMalloc(&d_st, sizeof(Stamp) * cus * 8 * 4));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  if (argc > 1 && std::string(argv[1]) == "sustained") {
+    // The table above comes from bursts of tens of milliseconds, which the power management lets run near the top clock.  The verifier
+    // issues multiply-adds for seconds on end, so its roof is the rate the chip SUSTAINS: the same kernels launched back to back for
+    // `seconds`, rate and clock taken over the second half (by then the clock has settled).
+    const double seconds = argc > 2 ? atof(argv[2]) : 3.0;
+    printf("sustained mode: each instruction back to back for %.1f s; rate and clock over the second half\n", seconds);
+    printf("%-30s | w/SIMD | T-op/s first 50 ms (GHz) | T-op/s sustained (GHz) | cycles per wave64 instruction, sustained\n", "instruction");
+    for (auto& e : es) {
+      const std::string nm = e.name;
+      if (nm != "v_mad_u64_u32 v,v,v64" && nm != "fmul mix (5 mad, 2 x64)" && nm != "v_add_u32 (VOP2)" && nm != "v_fma_f32 v,v,v") continue;
+      for (int w : {2, 8}) {
+        const int blocks = cus * w;
+        const double per_iter = (double)UNROLL * CHAINS * e.instr_per_step * w * 4.0 / 2.0e9;
+        const int iters = (int)(25e-3 / per_iter) + 1;
+        const int waves = blocks * 4;
+        const double n_instr = (double)iters * UNROLL * CHAINS * e.instr_per_step;
+        auto run = [&](int launches, double& tops, double& ghz_med) {
+          CK(hipEventRecord(e0));
+          for (int l = 0; l < launches; ++l) hipLaunchKernelGGL(e.k, dim3(blocks), dim3(256), 0, 0, out, d_st, 12345u, 6789u, iters);
+          CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+          float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+          std::vector<Stamp> st(waves);
+          CK(hipMemcpy(st.data(), d_st, sizeof(Stamp) * waves, hipMemcpyDeviceToHost));     // the stamps of the last launch
+          std::vector<double> ghz(waves);
+          for (int i = 0; i < waves; ++i) ghz[i] = (double)st[i].cyc / ((double)st[i].rt * 10.0);
+          std::sort(ghz.begin(), ghz.end());
+          ghz_med = ghz[waves / 2];
+          tops = n_instr * w * 64.0 * cus * 4 * launches / (ms * 1e-3) / 1e12;
+        };
+        CK(hipDeviceSynchronize());
+        double t_first, g_first, t_half, g_half, t_sus, g_sus;
+        run(2, t_first, g_first);
+        const int half = (int)(seconds / 2 / 25e-3) + 1;
+        run(half, t_half, g_half);
+        run(half, t_sus, g_sus);
+        printf("%-30s | %6d | %8.2f (%4.2f)          | %8.2f (%4.2f)        | %5.2f\n", e.name, w, t_first, g_first, t_sus, g_sus,
+               (double)cus * 4 * 64 * g_sus * 1e9 / (t_sus * 1e12));
+        fflush(stdout);
+      }
+    }
+    return 0;
+  }
   printf("%-30s", "instruction");
   const int wlist[] = {1, 2, 4, 8};
   for (int w : wlist) printf(" | w/SIMD=%d: cyc  T-op/s (wave cyc, GHz)", w);
