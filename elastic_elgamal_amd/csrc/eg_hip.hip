@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -16,6 +17,9 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <condition_variable>
+#include <deque>
+#include <list>
 #include <unordered_map>
 #include <vector>
 
@@ -192,8 +196,11 @@ struct Engine {
   u32* tally = nullptr;        // [2n][PT_WORDS] running tally (extended points) = set[0].tally
   u32* tally_saved = nullptr;  // [2n][PT_WORDS] the running tally set aside while a host call computes its per-batch tally
   u32* tally_saved2 = nullptr; // the same for the JSON entry points, which call the host form piece by piece
-  uint8_t* json_stage[2] = {nullptr, nullptr};     // pinned staging of the JSON entry points (two windows in flight)
-  size_t json_stage_bytes[2] = {0, 0};
+  uint8_t* json_ring = nullptr;        // pinned staging of the JSON entry points: a ring of packed ballots that the parser threads fill
+  size_t json_ring_bytes = 0;          // window by window while earlier windows are uploaded and verified
+  u32* json_status_ring = nullptr;     // pinned verdicts of the ballots in the ring
+  size_t json_ring_ballots = 0;
+  hipStream_t json_ctl[2] = {nullptr, nullptr};   // control streams of consecutive windows (fork / join of a window's chunks)
   // staging for the host-pointer API
   hipStream_t copy_stream = nullptr;
   unsigned char* d_wire = nullptr;
@@ -239,7 +246,9 @@ static void engine_free(Engine* e) {
   if (e->fork) (void)hipEventDestroy(e->fork);
   comb_table_free(e->d_tabK); comb_table_free(e->d_tabK_big);
   if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
-  for (uint8_t* p : e->json_stage) if (p) (void)hipHostFree(p);
+  if (e->json_ring) (void)hipHostFree(e->json_ring);
+  if (e->json_status_ring) (void)hipHostFree(e->json_status_ring);
+  for (hipStream_t st : e->json_ctl) if (st) (void)hipStreamDestroy(st);
   delete e;
 }
 
@@ -460,7 +469,11 @@ static int ensure_big_tables(Engine* e, hipStream_t s) {
 }
 
 // verify n ballots (device pointers), accumulating accepted ciphertexts into the running tally
-static int engine_verify_device(Engine* e, size_t n, const void* d_ballots, void* d_status, hipStream_t s) {
+// flags (the streaming JSON entry points overlap consecutive calls on different control streams `s`):
+//   VD_FORCE_SETS     always run on the work sets' own streams (never on `s` with set 0's buffers), whatever the size of the batch;
+//   VD_KEEP_SET_TALLY leave set 1's share of the tally in its accumulator at the join (the caller merges once, when everything has landed).
+enum { VD_FORCE_SETS = 1, VD_KEEP_SET_TALLY = 2 };
+static int engine_verify_device(Engine* e, size_t n, const void* d_ballots, void* d_status, hipStream_t s, int flags = 0) {
   eg_ctx* ctx = e->ctx;     // s may be the null stream: a NULL hipStream_t means what it means everywhere in HIP
   const eghost::Plan& P = e->plan;
   size_t all_idx = 0;
@@ -471,7 +484,7 @@ static int engine_verify_device(Engine* e, size_t n, const void* d_ballots, void
   if ((rc = prof_begin(ctx, s, PROF_CALL, &all_idx))) return rc;
   // equal-sized chunks (each a multiple of the block size) so that the persistent grids stay balanced on the last chunk; with two
   // work sets a batch that is worth splitting gets an even number of chunks, so that both streams carry the same load
-  const bool two = e->n_sets == 2 && n >= (size_t)ctx->resident_blocks * NT / 2;
+  const bool two = e->n_sets == 2 && ((flags & VD_FORCE_SETS) || n >= (size_t)ctx->resident_blocks * NT / 2);
   auto chunks_for = [&](size_t cap) {
     size_t k = (n + cap - 1) / cap;
     if (two) k = std::max<size_t>(2, (k + 1) / 2 * 2);
@@ -562,7 +575,7 @@ static int engine_verify_device(Engine* e, size_t n, const void* d_ballots, void
       HIPCHK(hipStreamWaitEvent(s, e->set[k].done, 0));
     }
     const int ns = (int)P.tally_slots.size();
-    if (ns) {
+    if (ns && !(flags & VD_KEEP_SET_TALLY)) {
       hipLaunchKernelGGL(k_tally_add_points, dim3(blocks_of((size_t)ns)), dim3(NT), 0, s, e->set[1].tally, ns, e->set[0].tally);
       hipLaunchKernelGGL(k_tally_init, dim3(blocks_of((size_t)ns)), dim3(NT), 0, s, e->set[1].tally, ns);
     }
@@ -603,6 +616,18 @@ static int engine_tally_add(Engine* e, const uint8_t* in) {
   return bad ? fail(EG_ERR_BAD_ARG, "tally contains an invalid ristretto255 encoding") : EG_OK;
 }
 
+// device-side staging of the host forms: room for n packed ballots and their verdicts
+static int engine_stage_reserve(Engine* e, size_t n) {
+  if (n <= e->staging_ballots) return EG_OK;
+  if (e->d_wire) (void)hipFree(e->d_wire);
+  if (e->d_status) (void)hipFree(e->d_status);
+  e->d_wire = nullptr; e->d_status = nullptr; e->staging_ballots = 0;
+  HIPCHK(hipMalloc((void**)&e->d_wire, std::max<size_t>(n, 1) * e->plan.stride));
+  HIPCHK(hipMalloc((void**)&e->d_status, std::max<size_t>(n, 1) * sizeof(u32)));
+  e->staging_ballots = n;
+  return EG_OK;
+}
+
 static int engine_verify_host(Engine* e, size_t n, const uint8_t* ballots, uint32_t* status, uint8_t* tally_out) {
   hipStream_t s = e->ctx->stream;
   HIPCHK(hipSetDevice(e->ctx->device));
@@ -610,14 +635,7 @@ static int engine_verify_host(Engine* e, size_t n, const uint8_t* ballots, uint3
   // `_device` calls enqueued on caller streams: wait for them, like the other host forms do.
   HIPCHK(hipDeviceSynchronize());
   const int ns = (int)e->plan.tally_slots.size();
-  if (n > e->staging_ballots) {
-    if (e->d_wire) (void)hipFree(e->d_wire);
-    if (e->d_status) (void)hipFree(e->d_status);
-    e->d_wire = nullptr; e->d_status = nullptr;
-    HIPCHK(hipMalloc((void**)&e->d_wire, std::max<size_t>(n, 1) * e->plan.stride));
-    HIPCHK(hipMalloc((void**)&e->d_status, std::max<size_t>(n, 1) * sizeof(u32)));
-    e->staging_ballots = n;
-  }
+  { const int rc = engine_stage_reserve(e, n); if (rc) return rc; }
   // fallible set-up comes BEFORE the running tally is set aside, and a scope guard puts it back on EVERY exit path (round 2 merged it
   // only on the explicit error paths: an early HIPCHK return in between lost the running tally)
   if (n && !e->copy_stream) HIPCHK(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
@@ -1391,10 +1409,11 @@ int eg_qv_pack_json(int n_options, uint64_t credits, const char* json, size_t js
   return EG_OK;
 }
 // JSON text -> verdicts + tally in one call.  The text is cut into windows (egwire::split_next); a producer thread splits and packs
-// window k+1 on `threads` host threads into pinned staging while window k is uploaded and verified on the GPU (engine_verify_host
-// pipelines the upload inside a window).  Objects that do not pack keep their pack verdict; their zeroed slots are verified like
-// any other ballot (an all-zero ballot never verifies, so nothing of it reaches the tally) and the verdict is overwritten afterwards.
-typedef std::function<void(const char*, const std::vector<std::pair<size_t, size_t>>&, int, uint8_t*, uint32_t*)> PackPieceFn;
+// them on a pool of `threads` host threads into a pinned ring of packed ballots, while this thread uploads the finished windows and
+// enqueues their verification, two submissions in flight (verify_json_common below).  Objects that do not pack keep their pack verdict;
+// their zeroed slots are verified like any other ballot (an all-zero ballot never verifies, so nothing of it reaches the tally) and the
+// verdict is overwritten afterwards.
+typedef std::function<void(const char*, const std::vector<std::pair<size_t, size_t>>&, int, uint8_t*, uint32_t*, egwire::WorkerPool*)> PackPieceFn;
 // verdicts of the objects that deserialise but do not have the election's shape (egwire::resolve_*_objects): false = a GPU call failed
 typedef std::function<bool(const char*, const std::vector<std::pair<size_t, size_t>>&, std::vector<uint32_t>&)> ReshapeFn;
 // the two GPU services of the object path (wire_json.hpp): validity of 32-byte items, and the batch verifier on substitute ballots
@@ -1442,65 +1461,201 @@ static int verify_json_common(Engine* e, const char* json, size_t json_len, int 
     set_aside = true;
     HIPCHK(hipStreamSynchronize(s));
   }
-  // windows: a small first one (its split + parse is the only one nothing overlaps with), doubling up to ~2^18 single-choice ballots'
-  // worth of text: the host threads parse only ~1.4x as fast as the GPU verifies, so a window may grow only as fast as the GPU falls behind
-  const size_t big_window = std::max<size_t>((size_t)384 << 20, 64 * stride), first_window = big_window / 8;
-  size_t next_window = first_window * 2;
-  egwire::SplitCursor cur;
-  std::vector<std::pair<size_t, size_t>> spans[2];
-  std::vector<uint32_t> pack_status[2];
-  size_t first_index[2] = {0, 0};
-  bool done = false, split_ok = true, too_many = false, nomem = false;
-  const int device = e->ctx->device;
-  auto produce = [&](int b, size_t window) {
-    (void)hipSetDevice(device);                  // runs on a producer thread: HIP's current device is per thread
-    spans[b].clear();
-    first_index[b] = cur.count;
-    if (!egwire::split_next(json, json_len, window, threads, cur, spans[b], done)) { split_ok = false; return; }
-    if (cur.count > max_objects) { too_many = true; return; }
-    const size_t need = spans[b].size() * stride;
-    if (need > e->json_stage_bytes[b]) {          // pinned staging, kept with the engine across calls
-      if (e->json_stage[b]) (void)hipHostFree(e->json_stage[b]);
-      e->json_stage[b] = nullptr; e->json_stage_bytes[b] = 0;
-      // for the largest window of this text at once (an object takes >= 4/3 of its packed size as JSON)
-      const size_t want = std::max(need, std::min(big_window, json_len) * 3 / 4 + stride);
-      if (hipHostMalloc((void**)&e->json_stage[b], want, hipHostMallocPortable) != hipSuccess) { nomem = true; return; }
-      e->json_stage_bytes[b] = want;
+  // Pipeline (round 3, second form).  A producer thread cuts the text window by window and packs each window on `threads` workers into a
+  // pinned RING of packed ballots; this thread uploads every finished window, enqueues its verification and the download of its
+  // verdicts, and only then looks at what has completed - so the GPU always holds the next window's work while it finishes the current
+  // one (the first form verified window k with a blocking host call while window k+1 was parsed: every window paid an exposed upload and
+  // a drained GPU, 0.85 of the HBM-resident rate).  Consecutive windows go through two control streams, so that the chunks of window
+  // k+1 queue behind those of window k on the work sets' streams without waiting for window k's join; the sets' shares of the tally
+  // are merged once at the end.  Ballots of another shape (EG_PACK_RESHAPE) are collected and resolved after the last window.
+  const size_t env_ring = getenv("EG_JSON_RING_KB") ? (size_t)atol(getenv("EG_JSON_RING_KB")) << 10 : 0;        // test knobs
+  const size_t env_window = getenv("EG_JSON_WINDOW_KB") ? (size_t)atol(getenv("EG_JSON_WINDOW_KB")) << 10 : 0;
+  const size_t ring_max = env_ring ? env_ring : (size_t)1 << 30;
+  const size_t ring_bytes = std::max(std::min(json_len / 4 * 3 + stride, ring_max), 64 * stride);
+  const size_t cap = ring_bytes / stride;                          // ballots in the ring
+  const size_t max_values = std::max<size_t>(1, cap / 4);          // per window: at least four windows fit
+  const size_t window_bytes = env_window ? env_window : (size_t)96 << 20, first_window = std::max<size_t>(window_bytes / 4, 1);
+  if (cap * stride > e->json_ring_bytes || cap > e->json_ring_ballots) {
+    if (e->json_ring) (void)hipHostFree(e->json_ring);
+    if (e->json_status_ring) (void)hipHostFree(e->json_status_ring);
+    e->json_ring = nullptr; e->json_status_ring = nullptr; e->json_ring_bytes = 0; e->json_ring_ballots = 0;
+    if (hipHostMalloc((void**)&e->json_ring, cap * stride, hipHostMallocPortable) != hipSuccess ||
+        hipHostMalloc((void**)&e->json_status_ring, cap * sizeof(u32), hipHostMallocPortable) != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(EG_ERR_NOMEM, "pinned staging allocation failed");
     }
-    pack_status[b].resize(spans[b].size());
-    if (!spans[b].empty()) pack_piece(json, spans[b], threads, e->json_stage[b], pack_status[b].data());
+    e->json_ring_bytes = cap * stride; e->json_ring_ballots = cap;
+  }
+  TRY(engine_stage_reserve(e, cap));
+  if (!e->copy_stream) HIPCHK(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+  const int n_ctl = e->n_sets == 2 ? 2 : 1;            // one work set: its buffers serve one window at a time
+  for (int k = 0; k < n_ctl; ++k)
+    if (!e->json_ctl[k]) HIPCHK(hipStreamCreateWithFlags(&e->json_ctl[k], hipStreamNonBlocking));
+  {   // no regrowth of the chunk workspace while windows are in flight (engine_reserve waits for the device and frees the old buffers)
+    const size_t per_set = (std::min(max_values, cap) + e->n_sets - 1) / e->n_sets + NT;
+    const int rr = engine_reserve(e, (u32)std::min<size_t>(per_set, e->max_cap));
+    if (rr != EG_OK && rr != EG_ERR_NOMEM) return rr;         // out of memory: engine_verify_device falls back to smaller chunks
+  }
+  if (e->items_seen + json_len / (2 * stride) >= e->ctx->big_min) TRY(ensure_big_tables(e, s));   // the text is worth the wide comb tables
+  HIPCHK(hipStreamSynchronize(s));
+
+  struct Region {
+    size_t first = 0, off = 0, m = 0;                 // index of its first ballot in the text, offset in the ring, ballots
+    std::vector<std::pair<size_t, size_t>> spans;
+    std::vector<uint32_t> pack_status;
+    bool ready = false, submitted = false;
   };
-  int rc = EG_OK;
-  produce(0, first_window);
-  for (int b = 0; rc == EG_OK; b ^= 1) {
-    if (!split_ok) { rc = fail(EG_ERR_BAD_ARG, "the text is neither a JSON array of objects nor a sequence of JSON objects"); break; }
-    if (too_many) { rc = fail(EG_ERR_BAD_ARG, "more objects in the text than max_objects"); break; }
-    if (nomem) { rc = fail(EG_ERR_NOMEM, "pinned staging allocation failed"); break; }
-    const bool last = done;
-    std::thread producer;
-    if (!last) {
-      producer = std::thread(produce, b ^ 1, next_window);               // split + parse the next window meanwhile
-      next_window = std::min(big_window, next_window * 2);
-    }
-    const size_t m = spans[b].size(), first = first_index[b];
-    if (m) {
-      rc = engine_verify_host(e, m, e->json_stage[b], status + first, nullptr);
-      if (rc == EG_OK) {
-        std::vector<std::pair<size_t, size_t>> odd;
-        std::vector<size_t> odd_at;
-        for (size_t i = 0; i < m; ++i) {
-          if (pack_status[b][i] != EG_ST_OK) status[first + i] = pack_status[b][i];
-          if (pack_status[b][i] == EG_PACK_RESHAPE) { odd.push_back(spans[b][i]); odd_at.push_back(first + i); }
+  std::list<Region> regions;                           // in text order; the front is the oldest one not yet retired
+  std::mutex mu;
+  std::condition_variable cv_ready, cv_space;
+  egwire::SplitCursor cur;
+  bool producer_done = false, abort_all = false, split_ok = true, too_many = false;
+  const int device = e->ctx->device;
+  std::thread producer([&]() {
+    (void)hipSetDevice(device);                  // HIP's current device is per thread
+    egwire::WorkerPool pool(std::max(threads, 1));      // the parser's threads, for the length of the call
+    bool done = false;
+    size_t window = first_window;
+    while (!done) {
+      Region r;
+      r.first = cur.count;
+      const bool ok = egwire::split_next(json, json_len, window, threads, cur, r.spans, done, max_values, &pool);
+      window = window_bytes;
+      Region* slot = nullptr;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        if (!ok) { split_ok = false; break; }
+        if (cur.count > max_objects) { too_many = true; break; }
+        r.m = r.spans.size();
+        if (r.m == 0) continue;
+        // room in the ring: behind the newest region, or from the start again once the oldest regions there have been retired
+        for (;;) {
+          if (abort_all) break;
+          if (regions.empty()) { r.off = 0; break; }
+          const size_t head = regions.back().off + regions.back().m, tail = regions.front().off;
+          if (head > tail) {                            // the occupied part does not wrap
+            if (head + r.m <= cap) { r.off = head; break; }
+            if (r.m <= tail) { r.off = 0; break; }
+          } else if (head + r.m <= tail) { r.off = head; break; }
+          cv_space.wait(lk);
         }
-        if (!odd.empty()) {        // OptionsLenMismatch / LenMismatch territory: the object path, in the reference's order of checks
-          std::vector<uint32_t> verdicts;
-          if (!reshape(json, odd, verdicts)) rc = g_err.empty() ? fail(EG_ERR_HIP, "object path: a GPU call failed") : EG_ERR_HIP;
-          else for (size_t i = 0; i < odd.size(); ++i) status[odd_at[i]] = verdicts[i];
+        if (abort_all) break;
+        regions.push_back(std::move(r));
+        slot = &regions.back();
+      }
+      slot->pack_status.resize(slot->m);
+      pack_piece(json, slot->spans, threads, e->json_ring + slot->off * stride, slot->pack_status.data(), &pool);
+      std::lock_guard<std::mutex> lk(mu);
+      slot->ready = true;
+      cv_ready.notify_all();
+    }
+    std::lock_guard<std::mutex> lk(mu);
+    producer_done = true;
+    cv_ready.notify_all();
+  });
+  int rc = EG_OK;
+  std::vector<std::pair<size_t, size_t>> odd;
+  std::vector<size_t> odd_at;
+  // A submission = the run of finished windows that has piled up (contiguous in the ring): one upload, one verification, one download.
+  // At most two are in flight: while the GPU works through them the parser's windows accumulate, so submissions grow to the size at which
+  // the kernels run well exactly when the GPU is the slower side, and stay small (and early) when the parser is.
+  struct Group { size_t n_regions, first, off, m; hipEvent_t uploaded, done; };
+  std::deque<Group> groups;
+  const size_t growth = getenv("EG_JSON_GROWTH") ? (size_t)atol(getenv("EG_JSON_GROWTH")) : 150;   // per cent (measurement knob; A/B block 6)
+  const bool trace = getenv("EG_JSON_TRACE") != nullptr;             // developer aid: the timeline of the submissions on stderr
+  const auto t_start = std::chrono::steady_clock::now();
+  auto ms_now = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
+  size_t n_submitted = 0;
+  auto retire_oldest = [&]() {         // the oldest submission has landed: verdicts to the caller, its part of the ring back to the producer
+    const Group g = groups.front();
+    groups.pop_front();
+    if (trace) fprintf(stderr, "[json] %8.2f ms  landed    %zu ballots from %zu\n", ms_now(), g.m, g.first);
+    std::memcpy(status + g.first, e->json_status_ring + g.off, g.m * sizeof(u32));
+    for (size_t k = 0; k < g.n_regions; ++k) {
+      Region* r;
+      { std::lock_guard<std::mutex> lk(mu); r = &regions.front(); }
+      for (size_t i = 0; i < r->m; ++i) {
+        if (r->pack_status[i] != EG_ST_OK) status[r->first + i] = r->pack_status[i];
+        if (r->pack_status[i] == EG_PACK_RESHAPE) { odd.push_back(r->spans[i]); odd_at.push_back(r->first + i); }
+      }
+      std::lock_guard<std::mutex> lk(mu);
+      regions.pop_front();
+    }
+    (void)hipEventDestroy(g.uploaded); (void)hipEventDestroy(g.done);
+    std::lock_guard<std::mutex> lk(mu);
+    cv_space.notify_all();
+  };
+  for (;;) {
+    while (!groups.empty() && hipEventQuery(groups.front().done) == hipSuccess) retire_oldest();
+    (void)hipGetLastError();                           // a submission still running reads as hipErrorNotReady: not an error to keep
+    Group g{0, 0, 0, 0, nullptr, nullptr};
+    bool finished = false, wait_gpu = false, again = false;
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      if (split_ok && !too_many) {
+        for (Region& r : regions) {                    // the run of finished windows behind the submitted ones
+          if (r.submitted) continue;
+          if (!r.ready || (g.n_regions && r.off != g.off + g.m)) break;
+          if (!g.n_regions) { g.first = r.first; g.off = r.off; }
+          ++g.n_regions; g.m += r.m;
+        }
+        // nothing in flight: whatever is ready goes now.  One in flight: a second one joins it once it is 1.5x as large (the upload
+        // and the first kernels of the second overlap the tail of the first, and sizes can only grow) or the text has ended.
+        const bool submit = g.n_regions && (groups.empty() || (groups.size() < 2 && (g.m * 100 >= groups.back().m * growth || producer_done)));
+        if (submit) {
+          size_t k = 0;
+          for (Region& r : regions) { if (r.submitted) continue; if (k++ == g.n_regions) break; r.submitted = true; }
+        } else {
+          const bool pending = g.n_regions != 0;
+          g.n_regions = 0;
+          if (groups.empty()) {
+            if (producer_done && regions.empty()) finished = true;
+            else { cv_ready.wait(lk); again = true; }
+          } else if (groups.size() >= 2 || (producer_done && !pending)) wait_gpu = true;
+          else { cv_ready.wait_for(lk, std::chrono::microseconds(200)); again = true; }     // a window may finish, or the submission land
         }
       }
     }
-    if (producer.joinable()) producer.join();
-    if (last) break;
+    if (again) continue;
+    if (!split_ok) { rc = fail(EG_ERR_BAD_ARG, "the text is neither a JSON array of objects nor a sequence of JSON objects"); break; }
+    if (too_many) { rc = fail(EG_ERR_BAD_ARG, "more objects in the text than max_objects"); break; }
+    if (finished) break;
+    if (g.n_regions) {
+      hipStream_t ctl = e->json_ctl[n_submitted % (size_t)n_ctl];
+      hipError_t he = hipEventCreateWithFlags(&g.uploaded, hipEventDisableTiming);
+      if (he == hipSuccess) he = hipEventCreateWithFlags(&g.done, hipEventDisableTiming | hipEventBlockingSync);   // the waiting thread must not take a core from the parser
+      if (he == hipSuccess) he = hipMemcpyAsync(e->d_wire + g.off * stride, e->json_ring + g.off * stride, g.m * stride, hipMemcpyHostToDevice,
+                                                e->copy_stream);
+      if (he == hipSuccess) he = hipEventRecord(g.uploaded, e->copy_stream);
+      if (he == hipSuccess) he = hipStreamWaitEvent(ctl, g.uploaded, 0);
+      if (he != hipSuccess) { rc = fail(EG_ERR_HIP, std::string("window upload: ") + hipGetErrorString(he)); break; }
+      rc = engine_verify_device(e, g.m, e->d_wire + g.off * stride, e->d_status + g.off, ctl, VD_FORCE_SETS | VD_KEEP_SET_TALLY);
+      if (rc) break;
+      he = hipMemcpyAsync(e->json_status_ring + g.off, e->d_status + g.off, g.m * sizeof(u32), hipMemcpyDeviceToHost, ctl);
+      if (he == hipSuccess) he = hipEventRecord(g.done, ctl);
+      if (he != hipSuccess) { rc = fail(EG_ERR_HIP, std::string("verdict download: ") + hipGetErrorString(he)); break; }
+      groups.push_back(g);
+      ++n_submitted;
+      if (trace) fprintf(stderr, "[json] %8.2f ms  submitted %zu windows, %zu ballots from %zu (%zu in flight)\n", ms_now(), g.n_regions, g.m, g.first, groups.size());
+    } else if (wait_gpu) {                               // two in flight, or nothing left to add: wait for the oldest submission
+      const hipError_t he = hipEventSynchronize(groups.front().done);
+      if (he != hipSuccess) { rc = fail(EG_ERR_HIP, std::string("window: ") + hipGetErrorString(he)); break; }
+      retire_oldest();
+    }
+  }
+  { std::lock_guard<std::mutex> lk(mu); abort_all = true; cv_space.notify_all(); }
+  producer.join();
+  (void)hipDeviceSynchronize();                         // also on the error paths: nothing may still read the ring or the work sets
+  for (Group& g : groups) { if (g.uploaded) (void)hipEventDestroy(g.uploaded); if (g.done) (void)hipEventDestroy(g.done); }
+  if (ns && e->n_sets == 2) {                           // the sets' shares of the tally, once
+    hipLaunchKernelGGL(k_tally_add_points, dim3(blocks_of((size_t)ns)), dim3(NT), 0, s, e->set[1].tally, ns, e->set[0].tally);
+    hipLaunchKernelGGL(k_tally_init, dim3(blocks_of((size_t)ns)), dim3(NT), 0, s, e->set[1].tally, ns);
+    HIPCHK(hipStreamSynchronize(s));
+  }
+  if (rc == EG_OK && !odd.empty()) {   // OptionsLenMismatch / LenMismatch territory: the object path, in the reference's order of checks
+    std::vector<uint32_t> verdicts;
+    if (!reshape(json, odd, verdicts)) rc = g_err.empty() ? fail(EG_ERR_HIP, "object path: a GPU call failed") : EG_ERR_HIP;
+    else for (size_t i = 0; i < odd.size(); ++i) status[odd_at[i]] = verdicts[i];
   }
   if (n_objects) *n_objects = cur.count;
   if (tally_out && ns && rc == EG_OK) rc = engine_tally_encode(e, tally_out);      // (the guard merges the running tally back afterwards)
@@ -1513,10 +1668,11 @@ int eg_verify_choice_json(eg_choice_params* p, const char* json, size_t json_len
   const size_t stride = p->eng->plan.stride;
   Engine* e = p->eng;
   return verify_json_common(p->eng, json, json_len, threads, max_objects, status, n_objects, tally_out,
-                            [=](const char* text, const std::vector<std::pair<size_t, size_t>>& sub, int th, uint8_t* dst, uint32_t* st) {
+                            [=](const char* text, const std::vector<std::pair<size_t, size_t>>& sub, int th, uint8_t* dst, uint32_t* st,
+                                egwire::WorkerPool* pool) {
                               egwire::pack_parallel(text, sub, stride, th, dst, st, [&](egwire::Cursor& c, uint8_t* d) {
                                 return egwire::pack_choice(c, n_options, single != 0, d);
-                              });
+                              }, pool);
                             },
                             [=](const char* text, const std::vector<std::pair<size_t, size_t>>& odd, std::vector<uint32_t>& out) {
                               return egwire::resolve_choice_objects(text, odd, n_options, single != 0, stride, make_check_items(e->ctx),
@@ -1532,10 +1688,11 @@ int eg_verify_qv_json(eg_qv_params* p, const char* json, size_t json_len, int th
   const egwire::RangeShape credit{sh.credit_range.rings.size(), (size_t)sh.credit_range.rings_size()};
   Engine* e = p->eng;
   return verify_json_common(p->eng, json, json_len, threads, max_objects, status, n_objects, tally_out,
-                            [=](const char* text, const std::vector<std::pair<size_t, size_t>>& sub, int th, uint8_t* dst, uint32_t* st) {
+                            [=](const char* text, const std::vector<std::pair<size_t, size_t>>& sub, int th, uint8_t* dst, uint32_t* st,
+                                egwire::WorkerPool* pool) {
                               egwire::pack_parallel(text, sub, sh.ballot_size, th, dst, st, [&](egwire::Cursor& c, uint8_t* d) {
                                 return egwire::pack_qv(c, n_options, vote, credit, sh.ballot_size, d);
-                              });
+                              }, pool);
                             },
                             [=](const char* text, const std::vector<std::pair<size_t, size_t>>& odd, std::vector<uint32_t>& out) {
                               return egwire::resolve_qv_objects(text, odd, n_options, vote, credit, sh.ballot_size, make_check_items(e->ctx),

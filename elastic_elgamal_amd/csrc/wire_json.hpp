@@ -26,6 +26,9 @@
 #include <emmintrin.h>
 #endif
 #include <string>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -620,6 +623,69 @@ inline bool split_objects(const char* s, size_t len, std::vector<std::pair<size_
   }
 }
 
+// ---- worker pool: eg_verify_*_json cuts and packs a text window by window; starting and joining `threads` std::threads twice per window
+// cost several per cent of the call and left the join waiting for whichever thread shared its core with the GPU-driving thread.  The pool
+// keeps threads - 1 workers for the length of a call; run() hands out [0, n) in grains from one atomic counter (the caller works too).
+class WorkerPool {
+ public:
+  explicit WorkerPool(int threads) {
+    for (int t = 1; t < threads; ++t) workers_.emplace_back([this]() { loop(); });
+  }
+  ~WorkerPool() {
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+    cv_job_.notify_all();
+    for (auto& th : workers_) th.join();
+  }
+  WorkerPool(const WorkerPool&) = delete;
+  WorkerPool& operator=(const WorkerPool&) = delete;
+  int threads() const { return (int)workers_.size() + 1; }
+  // fn(lo, hi) over [0, n) in pieces of `grain`; returns when every piece is done.  One run() at a time.
+  void run(size_t n, size_t grain, const std::function<void(size_t, size_t)>& fn) {
+    if (n == 0) return;
+    if (grain < 1) grain = 1;
+    if (workers_.empty() || n <= grain) { fn(0, n); return; }
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      fn_ = &fn; n_ = n; grain_ = grain; next_.store(0); active_ = workers_.size(); ++generation_;
+    }
+    cv_job_.notify_all();
+    drain();
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_done_.wait(lk, [this]() { return active_ == 0; });
+    fn_ = nullptr;
+  }
+
+ private:
+  void drain() {
+    for (;;) {
+      const size_t lo = next_.fetch_add(grain_);
+      if (lo >= n_) return;
+      (*fn_)(lo, std::min(n_, lo + grain_));
+    }
+  }
+  void loop() {
+    size_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_job_.wait(lk, [&]() { return stop_ || generation_ != seen; });
+        if (stop_) return;
+        seen = generation_;
+      }
+      drain();
+      std::lock_guard<std::mutex> lk(mu_);
+      if (--active_ == 0) cv_done_.notify_all();
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex mu_;
+  std::condition_variable cv_job_, cv_done_;
+  const std::function<void(size_t, size_t)>* fn_ = nullptr;
+  size_t n_ = 0, grain_ = 1, active_ = 0, generation_ = 0;
+  std::atomic<size_t> next_{0};
+  bool stop_ = false;
+};
+
 // ---- streaming splitter: the text is cut window by window, so that parsing and GPU verification of the first ballots start before
 // the last bytes have been looked at (eg_verify_*_json).  Same verdicts as split_objects on the whole text.
 struct SplitCursor {
@@ -628,11 +694,12 @@ struct SplitCursor {
   bool started = false, array = false, closed = false;
 };
 // Emits the complete values that start in s[cur.pos, cur.pos + window) and advances the cursor past them; `done` = end of text
-// reached (then the tail has been checked as well).  A window that holds no complete value is grown.  false = not a sequence of
-// JSON objects.  Work inside a window: every chunk counts unescaped quotes (-> string state of the next chunks), then records its
+// reached (then the tail has been checked as well).  A window that holds no complete value is grown; at most `max_values` values are
+// emitted per call (the caller's staging is finite, and a window of `{}` junk holds millions).  false = not a sequence of JSON objects.  Work inside a window: every chunk counts unescaped quotes (-> string state of the next chunks), then records its
 // bracket events outside strings; a short sequential walk over the events (about 1 % of the bytes) finds the values.
 inline bool split_next(const char* s, size_t len, size_t window, int threads, SplitCursor& cur,
-                       std::vector<std::pair<size_t, size_t>>& spans, bool& done) {
+                       std::vector<std::pair<size_t, size_t>>& spans, bool& done, size_t max_values = (size_t)-1,
+                       WorkerPool* pool = nullptr) {
   auto is_ws = [](char ch) { return ch == ' ' || ch == '\n' || ch == '\t' || ch == '\r'; };
   done = false;
   if (!cur.started) {
@@ -643,13 +710,14 @@ inline bool split_next(const char* s, size_t len, size_t window, int threads, Sp
   if (threads < 1) threads = 1;
   for (;;) {
     const size_t a = cur.pos, b = (window >= len - a) ? len : a + window;
-    const size_t T = std::max<size_t>(1, std::min<size_t>((size_t)threads, (b - a) / 256 + 1));
+    const size_t T = std::max<size_t>(1, std::min<size_t>((size_t)threads * (pool ? 4 : 1), (b - a) / 256 + 1));   // pool: pieces are handed out
     auto lo = [&](size_t t) { return a + (b - a) * t / T; };
     auto run = [&](auto fn) {
-      std::vector<std::thread> pool;
-      for (size_t t = 1; t < T; ++t) pool.emplace_back(fn, t);
+      if (pool) { pool->run(T, 1, [&](size_t lo_t, size_t hi_t) { for (size_t t = lo_t; t < hi_t; ++t) fn(t); }); return; }
+      std::vector<std::thread> spawned;
+      for (size_t t = 1; t < T; ++t) spawned.emplace_back(fn, t);
       fn(0);
-      for (auto& th : pool) th.join();
+      for (auto& th : spawned) th.join();
     };
     // ONE pass per chunk (round 3; two passes + a byte loop before: the splitter, not the parser, bounded eg_verify_*_json).  Whether a
     // chunk starts inside a string is known only after the chunks before it have been counted, so every chunk sorts its brackets by the
@@ -716,7 +784,7 @@ inline bool split_next(const char* s, size_t len, size_t window, int threads, Sp
     // sequential walk over the recorded events
     long depth = depth0[T];                        // depth at the end of the window (used when no event ends the walk early)
     size_t start = 0, prev_end = a, emitted = 0, close_pos = 0;
-    bool closed_here = false, bad = false;
+    bool closed_here = false, bad = false, full = false;
     auto separators_ok = [&](size_t from, size_t to, bool before_value) {
       size_t commas = 0;
       for (size_t i = from; i < to; ++i) {
@@ -726,7 +794,7 @@ inline bool split_next(const char* s, size_t len, size_t window, int threads, Sp
       if (!before_value) return commas == 0;
       return cur.array ? commas == ((cur.count + emitted) ? 1u : 0u) : commas == 0;
     };
-    for (size_t t = 0; t < T && !bad && !closed_here; ++t)
+    for (size_t t = 0; t < T && !bad && !closed_here && !full; ++t)
       for (const Ev& e : *events_of[t]) {
         if (e.step == 0) { bad = true; break; }                    // a backslash outside a string is not JSON
         const long level = depth0[t] + e.level;                    // absolute: before an opening bracket, after a closing one
@@ -741,10 +809,14 @@ inline bool split_next(const char* s, size_t len, size_t window, int threads, Sp
             closed_here = true; close_pos = e.pos;
             break;
           }
-          if (level == 0) { spans.push_back({start, e.pos + 1 - start}); ++emitted; prev_end = e.pos + 1; }
+          if (level == 0) {
+            spans.push_back({start, e.pos + 1 - start}); ++emitted; prev_end = e.pos + 1;
+            if (emitted >= max_values) { full = true; break; }
+          }
         }
       }
     if (bad) return false;
+    if (full) { cur.count += emitted; cur.pos = prev_end; return true; }     // the rest of the window is looked at again by the next call
     if (closed_here) {
       for (size_t i = close_pos + 1; i < len; ++i) if (!is_ws(s[i])) return false;    // nothing but white space after the array
       cur.closed = true; cur.count += emitted; cur.pos = len; done = true;
@@ -773,7 +845,7 @@ inline bool split_objects_parallel(const char* s, size_t len, int threads, std::
 
 template <class PackOne>
 inline void pack_parallel(const char* json, const std::vector<std::pair<size_t, size_t>>& spans, size_t stride, int threads,
-                          uint8_t* packed, uint32_t* status, PackOne pack_one) {
+                          uint8_t* packed, uint32_t* status, PackOne pack_one, WorkerPool* pool = nullptr) {
   const size_t n = spans.size();
   if (threads < 1) threads = 1;
   if ((size_t)threads > n) threads = (int)std::max<size_t>(n, 1);
@@ -787,10 +859,11 @@ inline void pack_parallel(const char* json, const std::vector<std::pair<size_t, 
       status[k] = st;
     }
   };
+  if (pool) { pool->run(n, 128, work); return; }     // grains of 128 objects: the threads that share a core with others take fewer
   if (threads == 1) { work(0, n); return; }
-  std::vector<std::thread> pool;
-  for (int t = 0; t < threads; ++t) pool.emplace_back(work, n * t / threads, n * (t + 1) / threads);
-  for (auto& th : pool) th.join();
+  std::vector<std::thread> spawned;
+  for (int t = 0; t < threads; ++t) spawned.emplace_back(work, n * t / threads, n * (t + 1) / threads);
+  for (auto& th : spawned) th.join();
 }
 
 }  // namespace egwire

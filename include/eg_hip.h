@@ -275,10 +275,14 @@ int eg_choice_pack_json(int n_options, int single, const char* json, size_t json
 int eg_qv_pack_json(int n_options, uint64_t credits, const char* json, size_t json_len, int threads, size_t max_objects,
                     uint8_t* packed, uint32_t* status, size_t* n_objects);
 size_t eg_qv_ballot_size_for(int n_options, uint64_t credits);   /* eg_qv_ballot_size without a params object (host only) */
-/* JSON text -> verdicts and tally in one call (what a service that receives the output of examples/voting.rs:195-198 needs): the
- * objects are packed on `threads` host threads piece by piece while the previous piece is uploaded and verified on the GPU.
- * status[k]: the verify verdict of object k (as eg_verify_*_batch), or EG_ST_MALFORMED / EG_PACK_RESHAPE from the packer for
- * objects that never reach the GPU as themselves; tally semantics as eg_verify_*_batch.  *n_objects = objects found. */
+/* JSON text -> verdicts and tally in one call (what a service that receives the output of examples/voting.rs:195-198 needs).  A pool of
+ * `threads` host threads cuts the text into windows and packs them into a pinned ring (<= 1 GiB) while the calling thread uploads the
+ * finished windows and enqueues their verification, two submissions in flight; memory: the ring, as much device staging, the chunk
+ * workspace of the params object.  status[k]: the verify verdict of object k (as eg_verify_*_batch); EG_ST_MALFORMED for an object that
+ * does not deserialise; for an object that deserialises with another shape than the election's, the reference's verdict from the object
+ * path (EG_ST_OPTIONS_LEN, the LenMismatch variants, or whatever verify() says after them: src/app/choice.rs:358-380,
+ * src/proofs/mod.rs:73-99).  Tally semantics as eg_verify_*_batch.  *n_objects = objects found; EG_ERR_BAD_ARG if the text is not a
+ * sequence of JSON objects or holds more than max_objects (then no verdict of the call is valid). */
 int eg_verify_choice_json(eg_choice_params*, const char* json, size_t json_len, int threads, size_t max_objects, uint32_t* status,
                           size_t* n_objects, uint8_t* tally_out);
 int eg_verify_qv_json(eg_qv_params*, const char* json, size_t json_len, int threads, size_t max_objects, uint32_t* status,

@@ -49,6 +49,14 @@ int pc_pack_choice(int n_options, int single, const char* json, size_t len, int 
   if (!ok || spans.size() > max) return -1;
   egwire::pack_parallel(json, spans, choice_ballot_size(n_options, single != 0), threads, packed, status,
                         [&](egwire::Cursor& c, uint8_t* dst) { return egwire::pack_choice(c, n_options, single != 0, dst); });
+  // the pooled form (what eg_verify_*_json runs) must pack the same bytes and verdicts
+  const size_t stride = choice_ballot_size(n_options, single != 0);
+  std::vector<uint8_t> packed2(spans.size() * stride + 1);
+  std::vector<uint32_t> status2(spans.size() + 1);
+  egwire::WorkerPool pool(threads);
+  egwire::pack_parallel(json, spans, stride, threads, packed2.data(), status2.data(),
+                        [&](egwire::Cursor& c, uint8_t* dst) { return egwire::pack_choice(c, n_options, single != 0, dst); }, &pool);
+  if (memcmp(packed, packed2.data(), spans.size() * stride) || memcmp(status, status2.data(), spans.size() * sizeof(uint32_t))) return -8;
   return (int)spans.size();
 }
 int pc_pack_qv(int n_options, unsigned long long credits, const char* json, size_t len, int threads, uint8_t* packed, uint32_t* status, size_t max) {
@@ -72,6 +80,20 @@ int pc_split_windows(const char* json, size_t len, size_t window, int threads) {
   for (int guard = 0; ok && !done && guard < 1000000; ++guard) ok = egwire::split_next(json, len, window, threads, cur, parts, done);
   if (ok != ok_whole) return 0;
   if (ok && (parts != whole || cur.count != whole.size())) return 0;
+  // and with a cap on the values per call (the ring of eg_verify_*_json is finite): same values, never more than the cap at once
+  egwire::WorkerPool pool(threads);          // the pooled form of the splitter's passes must cut the same values
+  for (size_t cap : {(size_t)1, (size_t)2, (size_t)5}) {
+    egwire::SplitCursor c2;
+    std::vector<std::pair<size_t, size_t>> capped;
+    done = false; ok = true;
+    for (int guard = 0; ok && !done && guard < 1000000; ++guard) {
+      const size_t before = capped.size();
+      ok = egwire::split_next(json, len, window, threads, c2, capped, done, cap, cap == 2 ? &pool : nullptr);
+      if (ok && capped.size() - before > cap) return 0;
+    }
+    if (ok != ok_whole) return 0;
+    if (ok && (capped != whole || c2.count != whole.size())) return 0;
+  }
   return 1;
 }
 unsigned long long pc_qv_size(int n_options, unsigned long long credits) { return qv_shape(n_options, credits).ballot_size; }

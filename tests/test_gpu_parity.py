@@ -1118,6 +1118,51 @@ def test_native_json_verify_entry(eg, ctx, oracle, pk, kind):
         assert got_st == want_st and got_t == want_t and got_st.count(0) == m - 300
 
 
+@pytest.mark.parametrize("ring_kb,window_kb", [(100, 16), (64, 200), (900, 40)])
+def test_json_pipeline_ring_wraps_and_small_windows(eg, ctx, oracle, pk, monkeypatch, ring_kb, window_kb):
+    """The streaming pipeline of eg_verify_*_json with a pinned ring far smaller than the text (test knobs EG_JSON_RING_KB /
+    EG_JSON_WINDOW_KB): windows of a dozen ballots, a ring that wraps hundreds of times, the producer waiting for the GPU and the GPU
+    for the producer.  Verdicts (tampered, junk and reshaped objects among them), the call's tally and the running tally must equal the
+    packed path's."""
+    import json
+    import torch
+    from elastic_elgamal_amd import serde
+    n, m = 3, 6000
+    p = eg.ChoiceParams(ctx, pk, n, True)
+    sz = p.ballot_size
+    d = torch.empty(m * sz, dtype=torch.uint8, device="cuda")
+    p.encrypt_batch_device(77, 0, m, d.data_ptr())
+    ctx.synchronize()
+    raw = bytearray(d.cpu().numpy().tobytes())
+    for i in range(0, m, 97):
+        raw[i * sz + sz - 32] ^= 1
+    raw = bytes(raw)
+    objs = [serde.unpack_encrypted_choice(raw[i * sz : (i + 1) * sz], n, True) for i in range(m)]
+    short = dict(objs[5]); short["choices"] = short["choices"][:2]          # another shape: OptionsLenMismatch through the object path
+    texts = [json.dumps(o) for o in objs]
+    texts[1234] = '{"junk": [1, 2, {"a": "}"}]}'
+    texts[4321] = json.dumps(short)
+    big = "[" + ",\n".join(texts) + "]"
+    p.tally_reset()
+    want_st, want_t = p.verify_json(big, max_objects=m)                   # default windows: one region
+    assert want_st[1234] == eg.MALFORMED and want_st[4321] not in (0, eg.MALFORMED) and want_st.count(0) == m - len(range(0, m, 97)) - 2
+    ref_st, _ = p.verify_batch(raw)
+    assert [a for i, a in enumerate(ref_st) if i not in (1234, 4321)] == [a for i, a in enumerate(want_st) if i not in (1234, 4321)]
+    monkeypatch.setenv("EG_JSON_RING_KB", str(ring_kb))
+    monkeypatch.setenv("EG_JSON_WINDOW_KB", str(window_kb))
+    p.tally_reset()
+    got_st, got_t = p.verify_json(big, max_objects=m)
+    assert got_st == want_st and got_t == want_t == p.tally_encode()
+    got2, t2 = p.verify_json(big, max_objects=m)                          # the running tally keeps accumulating, the call's tally is its own
+    assert got2 == want_st and t2 == want_t and p.tally_encode() != want_t
+    with pytest.raises(eg.EgError):
+        p.verify_json(big, max_objects=m - 1)                             # more objects than the caller made room for
+    with pytest.raises(eg.EgError):
+        p.verify_json(big[: len(big) // 2], max_objects=m)                # a truncated text fails as a whole
+    p.tally_reset()
+    assert p.verify_json(big, max_objects=m) == (want_st, want_t)          # and the engine is in order afterwards
+
+
 @pytest.mark.parametrize("upper_bound", [12, 15, 20, 50])
 def test_range_proof_negative_cases(eg, ctx, oracle, pk, upper_bound):
     """range.rs:708-795 (range_proof_basics): a proof must not verify for another receiver, another ciphertext, a mangled

@@ -87,6 +87,7 @@ def test_wire_packer_survives_fuzzed_json(lib):
             if t == 0: n = L.pc_pack_choice(5, 1, b, C.c_size_t(len(b)), 3, packed, st, C.c_size_t(16))
             else: n = L.pc_pack_qv(5, C.c_ulonglong(15), b, C.c_size_t(len(b)), 5, packed, st, C.c_size_t(16))
             assert n != -7, ("the parallel and the sequential splitter disagree on", b)
+            assert n != -8, ("the pooled and the spawned packer disagree on", b)
             for window in (1, 7, 64, 700, 1500, 5000, 1 << 20):
                 assert L.pc_split_windows(b, C.c_size_t(len(b)), C.c_size_t(window), 1 + window % 4) == 1, ("streaming splitter differs", window, b)
             if n < 0: bad += 1
