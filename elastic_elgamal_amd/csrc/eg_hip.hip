@@ -664,7 +664,10 @@ static int engine_verify_host(Engine* e, size_t n, const uint8_t* ballots, uint3
     {
       const size_t lanes = (size_t)e->ctx->resident_blocks * NT;
       size_t off = 0;
-      if (n > 2 * lanes) { pieces.push_back({0, lanes}); off = lanes; }
+      if (n >= lanes) {       // (a quarter of a mid-sized batch: 262 144 ballots +5 %, 131 072 +2.5 % over uploading them whole; below that the split costs more)
+        const size_t f = std::min(lanes, (n / 4 + NT - 1) / NT * NT);
+        pieces.push_back({0, f}); off = f;
+      }
       const size_t piece_cap = (size_t)e->max_cap * e->n_sets;      // one piece = one chunk per work set
       const size_t rem = n - off, k = (rem + piece_cap - 1) / piece_cap;
       const size_t even = ((rem + k - 1) / k + NT - 1) / NT * NT;
