@@ -1465,12 +1465,12 @@ static int verify_json_common(Engine* e, const char* json, size_t json_len, int 
     HIPCHK(hipStreamSynchronize(s));
   }
   // Pipeline (round 3, second form).  A producer thread cuts the text window by window and packs each window on `threads` workers into a
-  // pinned RING of packed ballots; this thread uploads every finished window, enqueues its verification and the download of its
-  // verdicts, and only then looks at what has completed - so the GPU always holds the next window's work while it finishes the current
-  // one (the first form verified window k with a blocking host call while window k+1 was parsed: every window paid an exposed upload and
-  // a drained GPU, 0.85 of the HBM-resident rate).  Consecutive windows go through two control streams, so that the chunks of window
-  // k+1 queue behind those of window k on the work sets' streams without waiting for window k's join; the sets' shares of the tally
-  // are merged once at the end.  Ballots of another shape (EG_PACK_RESHAPE) are collected and resolved after the last window.
+  // pinned RING of packed ballots; this thread uploads the finished windows, enqueues their verification and the download of their
+  // verdicts, and only then looks at what has completed - so the GPU holds the next submission's work while it finishes the current one
+  // (the first form verified window k with a blocking host call while window k+1 was parsed: every window paid an exposed upload and a
+  // drained GPU, 0.85 of the HBM-resident rate).  Consecutive submissions go through two control streams, so that the chunks of
+  // submission k+1 queue behind those of submission k on the work sets' streams without waiting for k's join; the sets' shares of the
+  // tally are merged once at the end.  Ballots of another shape (EG_PACK_RESHAPE) are collected and resolved after the last window.
   const size_t env_ring = getenv("EG_JSON_RING_KB") ? (size_t)atol(getenv("EG_JSON_RING_KB")) << 10 : 0;        // test knobs
   const size_t env_window = getenv("EG_JSON_WINDOW_KB") ? (size_t)atol(getenv("EG_JSON_WINDOW_KB")) << 10 : 0;
   const size_t ring_max = env_ring ? env_ring : (size_t)1 << 30;
@@ -1494,8 +1494,9 @@ static int verify_json_common(Engine* e, const char* json, size_t json_len, int 
   const int n_ctl = e->n_sets == 2 ? 2 : 1;            // one work set: its buffers serve one window at a time
   for (int k = 0; k < n_ctl; ++k)
     if (!e->json_ctl[k]) HIPCHK(hipStreamCreateWithFlags(&e->json_ctl[k], hipStreamNonBlocking));
-  {   // no regrowth of the chunk workspace while windows are in flight (engine_reserve waits for the device and frees the old buffers)
-    const size_t per_set = (std::min(max_values, cap) + e->n_sets - 1) / e->n_sets + NT;
+  {   // no regrowth of the chunk workspace while submissions are in flight (engine_reserve waits for the device and frees the old buffers):
+      // a submission holds whatever has piled up, at most the ring
+    const size_t per_set = (cap + e->n_sets - 1) / e->n_sets + NT;
     const int rr = engine_reserve(e, (u32)std::min<size_t>(per_set, e->max_cap));
     if (rr != EG_OK && rr != EG_ERR_NOMEM) return rr;         // out of memory: engine_verify_device falls back to smaller chunks
   }
@@ -1625,18 +1626,25 @@ static int verify_json_common(Engine* e, const char* json, size_t json_len, int 
     if (finished) break;
     if (g.n_regions) {
       hipStream_t ctl = e->json_ctl[n_submitted % (size_t)n_ctl];
+      const char* what = "window upload: ";
       hipError_t he = hipEventCreateWithFlags(&g.uploaded, hipEventDisableTiming);
       if (he == hipSuccess) he = hipEventCreateWithFlags(&g.done, hipEventDisableTiming | hipEventBlockingSync);   // the waiting thread must not take a core from the parser
       if (he == hipSuccess) he = hipMemcpyAsync(e->d_wire + g.off * stride, e->json_ring + g.off * stride, g.m * stride, hipMemcpyHostToDevice,
                                                 e->copy_stream);
       if (he == hipSuccess) he = hipEventRecord(g.uploaded, e->copy_stream);
       if (he == hipSuccess) he = hipStreamWaitEvent(ctl, g.uploaded, 0);
-      if (he != hipSuccess) { rc = fail(EG_ERR_HIP, std::string("window upload: ") + hipGetErrorString(he)); break; }
-      rc = engine_verify_device(e, g.m, e->d_wire + g.off * stride, e->d_status + g.off, ctl, VD_FORCE_SETS | VD_KEEP_SET_TALLY);
-      if (rc) break;
-      he = hipMemcpyAsync(e->json_status_ring + g.off, e->d_status + g.off, g.m * sizeof(u32), hipMemcpyDeviceToHost, ctl);
-      if (he == hipSuccess) he = hipEventRecord(g.done, ctl);
-      if (he != hipSuccess) { rc = fail(EG_ERR_HIP, std::string("verdict download: ") + hipGetErrorString(he)); break; }
+      if (he == hipSuccess) {
+        rc = engine_verify_device(e, g.m, e->d_wire + g.off * stride, e->d_status + g.off, ctl, VD_FORCE_SETS | VD_KEEP_SET_TALLY);
+        what = "verdict download: ";
+        if (rc == EG_OK) he = hipMemcpyAsync(e->json_status_ring + g.off, e->d_status + g.off, g.m * sizeof(u32), hipMemcpyDeviceToHost, ctl);
+        if (rc == EG_OK && he == hipSuccess) he = hipEventRecord(g.done, ctl);
+      }
+      if (he != hipSuccess) rc = fail(EG_ERR_HIP, std::string(what) + hipGetErrorString(he));
+      if (rc) {
+        if (g.uploaded) (void)hipEventDestroy(g.uploaded);
+        if (g.done) (void)hipEventDestroy(g.done);
+        break;
+      }
       groups.push_back(g);
       ++n_submitted;
       if (trace) fprintf(stderr, "[json] %8.2f ms  submitted %zu windows, %zu ballots from %zu (%zu in flight)\n", ms_now(), g.n_regions, g.m, g.first, groups.size());
