@@ -156,6 +156,9 @@ def parse():
                     help="skip the wire-ingest leg (JSON text of the same ballots through the native packer on the host cores)")
     ap.add_argument("--no-host-inclusive", action="store_true",
                     help="skip the PCIe-inclusive leg (host buffers through eg_verify_*_batch) that follows the timed loop at N = 1")
+    ap.add_argument("--no-isolated", action="store_true",
+                    help="skip the extra untimed step that measures the dominant kernel alone on one work set (profile runs: the kernel "
+                         "statistics then hold the launches of the warm-up and timed steps only)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even for one rank: exercises the N > 1 code path on a 1-GPU box")
     return ap.parse_args()
@@ -374,6 +377,15 @@ def main():
     clock = sampler.stop() if sampler else None
     msm_ms, msm_launches, all_ms = ctx.profile_read()
     tables_ms, tables_launches = ctx.profile_read_tables()
+    # one more, untimed step with the chunks run one after the other on one work set: in the timed steps a launch shares the chip with the
+    # other work set's kernels (that is what the two streams are for), so its duration is not its cost
+    iso_ms, iso_launches, iso_tables_ms, iso_tables_launches = 0.0, 0, 0.0, 0
+    if not args.no_isolated:
+        ctx.profile_enable(2)
+        step()
+        barrier()
+        iso_ms, iso_launches, _ = ctx.profile_read()
+        iso_tables_ms, iso_tables_launches = ctx.profile_read_tables()
     ctx.profile_enable(False)
     elapsed = egd.max_over_ranks(elapsed, dev)
 
@@ -478,6 +490,13 @@ def main():
                             "tools/profile_round.sh -> profiles/traffic.json) x this run's ballots per launch / this run's "
                             "launch time; it is the per-ballot table lookups, not the ballots",
             "avg_launch_ms": avg_launch_ms,
+            "isolated": ({"avg_launch_ms": iso_ms / iso_launches, "launches": iso_launches,
+                          "units_per_launch": -(-B // max(1, iso_launches // n_stages)),
+                          "achieved": alg_bytes * -(-B // max(1, iso_launches // n_stages)) / (iso_ms / iso_launches * 1e-3) / 1e9,
+                          "frac": alg_bytes * -(-B // max(1, iso_launches // n_stages)) / (iso_ms / iso_launches * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "second_kernel_avg_launch_ms": iso_tables_ms / max(iso_tables_launches, 1),
+                          "note": "one extra untimed step with the chunks run one after the other on ONE work set (eg_profile_enable 2): "
+                                  "the same kernel without the other stream's kernels beside it"} if iso_launches else None),
             "launches_per_step": launches_per_step,
             "units_per_launch": units_per_launch,
             "kernel_share_of_step": msm_ms / max(all_ms, 1e-9),

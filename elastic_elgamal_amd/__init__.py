@@ -320,7 +320,8 @@ class Context:
                                                  chal_label, len(chal_label), out, out_len))
         return [out.raw[i * out_len : (i + 1) * out_len] for i in range(n)]
 
-    def profile_enable(self, on: bool = True):
+    def profile_enable(self, on=True):
+        """on = 2: profile and run the chunks of a call serially on one work set (a launch's duration is then its own)."""
         _check(_load().eg_profile_enable(self._h, int(on)))
 
     def profile_read(self):

@@ -77,6 +77,7 @@ struct eg_ctx {
   void* prim_scratch = nullptr;   // device scratch of the primitive tier, kept between calls and grown on demand (prim_bufs)
   size_t prim_scratch_bytes = 0;
   bool prof = false;
+  bool prof_serial = false;    // eg_profile_enable(ctx, 2): chunks one after the other on one work set, so that a launch's duration is its own
   std::vector<ProfSpan> spans;
   std::vector<hipEvent_t> event_pool;
   double msm_ms = 0, all_ms = 0, tables_ms = 0;
@@ -484,7 +485,7 @@ static int engine_verify_device(Engine* e, size_t n, const void* d_ballots, void
   if ((rc = prof_begin(ctx, s, PROF_CALL, &all_idx))) return rc;
   // equal-sized chunks (each a multiple of the block size) so that the persistent grids stay balanced on the last chunk; with two
   // work sets a batch that is worth splitting gets an even number of chunks, so that both streams carry the same load
-  const bool two = e->n_sets == 2 && ((flags & VD_FORCE_SETS) || n >= (size_t)ctx->resident_blocks * NT / 2);
+  const bool two = e->n_sets == 2 && ((flags & VD_FORCE_SETS) || (n >= (size_t)ctx->resident_blocks * NT / 2 && !ctx->prof_serial));
   auto chunks_for = [&](size_t cap) {
     size_t k = (n + cap - 1) / cap;
     if (two) k = std::max<size_t>(2, (k + 1) / 2 * 2);
@@ -808,6 +809,7 @@ int eg_synchronize(eg_ctx* c) { EG_LOCK(c);
 int eg_profile_enable(eg_ctx* c, int enable) { EG_LOCK(c);
   if (!c) return fail(EG_ERR_BAD_ARG, "ctx is null");
   c->prof = enable != 0;
+  c->prof_serial = enable == 2;
   return EG_OK;
 }
 

@@ -297,7 +297,9 @@ int eg_plan_describe(int kind, int n_options, uint64_t credits_or_bound, char* b
 
 /* ---- measurement hooks (bench.py) ------------------------------------------------------------------------------------------
  * Average duration in milliseconds of the dominant kernel (k_eq_table<false>: the ring equations) over the launches since the last reset,
- * measured with HIP events on the stream the kernel was launched on; launches = number of launches averaged. */
+ * measured with HIP events on the stream the kernel was launched on; launches = number of launches averaged.
+ * enable = 2: also run the chunks of a call one after the other on one work set instead of alternating between two streams, so that a
+ * launch shares the chip with nothing and its duration is its own (a measurement mode: slower, same results). */
 int eg_profile_enable(eg_ctx*, int enable);
 int eg_profile_read(eg_ctx*, double* msm_ms_total, uint64_t* msm_launches, double* all_ms_total);
 /* same for the second kernel (k_base_tables), covering the launches folded in by the last eg_profile_read */

@@ -57,7 +57,7 @@ for w in () if TRAFFIC_ONLY else WORKLOADS:
     if not f.exists():
         continue
     rows = list(csv.DictReader(open(f)))
-    lines = [f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --workload {w} --no-cpu-baseline --no-host-inclusive --no-wire-ingest   (MI355X)",
+    lines = [f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --workload {w} --no-cpu-baseline --no-host-inclusive --no-wire-ingest --no-isolated   (MI355X)",
              f"# 1 warm-up + 3 timed steps of {DESCR[w]}, plus the untimed generator launch",
              f"{'kernel':64s} {'calls':>6s} {'total_ms':>12s} {'avg_ms':>11s} {'min_ms':>9s} {'max_ms':>9s} {'pct':>8s}"]
     for r in rows:
@@ -67,7 +67,7 @@ for w in () if TRAFFIC_ONLY else WORKLOADS:
 
 # ---- PMC passes ----------------------------------------------------------------------------------------------------
 want = ["eg::k_eq_table<false>", "eg::k_eq_table<true>", "eg::k_eq_direct", "eg::k_eq_generic", "eg::k_base_tables", "eg::k_sum_tables", "eg::k_encode_batch", "eg::k_decode_points", "eg::k_hash"]
-text = [f"# rocprofv3 --pmc <counter> -- python3 bench.py --steps 1 --warmup 0 --workload W --no-cpu-baseline --no-host-inclusive --no-wire-ingest --ballots {PMC_BALLOTS}   (MI355X)",
+text = [f"# rocprofv3 --pmc <counter> -- python3 bench.py --steps 1 --warmup 0 --workload W --no-cpu-baseline --no-host-inclusive --no-wire-ingest --no-isolated --ballots {PMC_BALLOTS}   (MI355X)",
         "# separate passes per counter (FETCH_SIZE, WRITE_SIZE; for the single-choice workload also two groups of SQ counters); values are",
         "# summed over the launches of the one step (its chunks x stages).  FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the",
         "# bytes of 16-B-per-lane reads (MI355X_MICROARCH.md, HBM section; calibrated for this access shape in <round>_fetch_calibration.txt),",
