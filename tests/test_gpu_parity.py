@@ -1118,16 +1118,17 @@ def test_native_json_verify_entry(eg, ctx, oracle, pk, kind):
         assert got_st == want_st and got_t == want_t and got_st.count(0) == m - 300
 
 
-@pytest.mark.parametrize("ring_kb,window_kb", [(100, 16), (64, 200), (900, 40)])
-def test_json_pipeline_ring_wraps_and_small_windows(eg, ctx, oracle, pk, monkeypatch, ring_kb, window_kb):
+@pytest.mark.parametrize("ring_kb,window_kb,streams", [(100, 16, 2), (64, 200, 2), (900, 40, 2), (100, 16, 1)])
+def test_json_pipeline_ring_wraps_and_small_windows(eg, ctx, oracle, pk, monkeypatch, ring_kb, window_kb, streams):
     """The streaming pipeline of eg_verify_*_json with a pinned ring far smaller than the text (test knobs EG_JSON_RING_KB /
     EG_JSON_WINDOW_KB): windows of a dozen ballots, a ring that wraps hundreds of times, the producer waiting for the GPU and the GPU
-    for the producer.  Verdicts (tampered, junk and reshaped objects among them), the call's tally and the running tally must equal the
-    packed path's."""
+    for the producer; with two work sets (submissions overlap on two control streams) and with one (EG_STREAMS=1: one after the other).
+    Verdicts (tampered, junk and reshaped objects among them), the call's tally and the running tally must equal the packed path's."""
     import json
     import torch
     from elastic_elgamal_amd import serde
     n, m = 3, 6000
+    monkeypatch.setenv("EG_STREAMS", str(streams))          # read when the params object is made
     p = eg.ChoiceParams(ctx, pk, n, True)
     sz = p.ballot_size
     d = torch.empty(m * sz, dtype=torch.uint8, device="cuda")

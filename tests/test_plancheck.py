@@ -101,6 +101,17 @@ def test_wire_packer_survives_fuzzed_json(lib):
     assert "fuzzed 3000" in out
 
 
+def test_worker_pool_under_thread_sanitizer(tmp_path):
+    """The parser's worker pool (egwire::WorkerPool: split passes and packing of every window of eg_verify_*_json) in a
+    -fsanitize=thread build: 3000 objects cut and packed on 8 threads, windows of 5 kB, five times over; any data race fails the run."""
+    exe = tmp_path / "poolcheck"
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=thread", "-o", str(exe),
+                           str(HERE / "poolcheck.cpp"), str(HERE / "plancheck.cpp")])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600, env={"TSAN_OPTIONS": "halt_on_error=1 exitcode=66", "PATH": "/usr/bin:/bin"})
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-6000:]
+    assert r.stdout.count("n=3000 split=1") == 5
+
+
 @pytest.mark.parametrize("kind", ["single", "multi", "qv"])
 def test_native_object_path_agrees_with_the_oracle_on_objects(lib, kind):
     """The object path BELOW the C ABI (csrc/wire_json.hpp: resolve_*_objects, what eg_verify_*_json runs for ballots whose shape is not
