@@ -35,10 +35,14 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # VALU model: field operations per building block counted by the host-check build
 # (tests/hostcheck: hc_op_counts) as (fe_mul, fe_sq); one fe_mul issues 98 and one fe_sq 62 v_mad_u64_u32 (fe25519.cuh: 81 / 45 limb
 # products + 16 to fold the high columns + 1 for the top carry).
-OPS = {"decode": (27, 257), "direct_table": (64, 0), "direct_mul": (1269, 1008), "comb": (91, 0), "encode": (32, 255),
-       "base_table": (994, 860), "base_mul": (463, 168), "enc_batch_each": (23, 10), "enc_batch_inversion": (11, 254),
-       "multi_first": (470, 168), "multi_extra": (344, 0), "sum_table_first": (296, 0), "sum_table_extra": (48, 0),
-       "comb_wide": (77, 0)}
+OPS = {5: {"decode": (27, 257), "direct_table": (64, 0), "direct_mul": (1269, 1008), "comb": (91, 0), "encode": (32, 255),
+           "base_table": (805, 816), "base_mul": (551, 200), "enc_batch_each": (23, 10), "enc_batch_inversion": (11, 254),
+           "multi_first": (558, 200), "multi_extra": (408, 0), "sum_table_first": (149, 0), "sum_table_extra": (40, 0),
+           "comb_wide": (77, 0)},
+       6: {"decode": (27, 257), "direct_table": (64, 0), "direct_mul": (1269, 1008), "comb": (91, 0), "encode": (32, 255),
+           "base_table": (994, 860), "base_mul": (463, 168), "enc_batch_each": (23, 10), "enc_batch_inversion": (11, 254),
+           "multi_first": (470, 168), "multi_extra": (344, 0), "sum_table_first": (296, 0), "sum_table_extra": (48, 0),
+           "comb_wide": (77, 0)}}      # by comb shape of the plan's per-ballot tables (5 x 51 or 6 x 43: eg_plan_describe "teeth")
 # memory-side traffic per ballot and launch of the profiled kernels comes from profiles/traffic.json, which
 # tools/profile_summary.py writes from the separate rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of tools/profile_round.sh
 TRAFFIC_JSON = ROOT / "profiles" / "traffic.json"
@@ -53,7 +57,8 @@ MAD_PEAK_SCLK_MHZ = 2420.0     # shader clock the chip held in that micro-benchm
 FMUL_PEAK_SCLK_MHZ = 2270.0    # ... and in the field-multiplication chain: both are bursts of tens of milliseconds.  Back-to-back verification
                                # steps run at the clock the power management settles on (about 2.08 GHz at 1.31 kW of the 1.4 kW cap on the
                                # boxes measured, `clock` in the JSON line), so the fractions are also given against the peaks scaled to it
-DOMINANT_KERNEL = "eg::k_eq_table<false>"   # one table-backed base + fixed-base combs: every ring equation (kernels.cuh)
+DOMINANT_KERNEL = "eg::k_eq_table<false, {teeth}>"   # one table-backed base + fixed-base combs: every ring equation (kernels.cuh); the
+                                                     # second template argument is the comb shape of the plan's tables
 
 
 def plan_field_ops(desc: dict, wide_combs: bool = False):
@@ -65,6 +70,7 @@ def plan_field_ops(desc: dict, wide_combs: bool = False):
     def mul(x, k):
         return (x[0] * k, x[1] * k)
 
+    OPS = globals()["OPS"][desc.get("teeth", 6)]
     return add(mul(OPS["decode"], desc["wire_points"]),
                mul(OPS["base_table"], desc["bases"]),
                mul(OPS["base_mul"], desc["single_table_jobs"] + desc["loose_table_terms"]),
@@ -413,6 +419,7 @@ def main():
     kind = {"single": "single", "multi": "multi", "qv": "qv"}[args.workload]
     desc = eg.plan_describe(kind, n_opt, args.credits if args.workload == "qv" else 0)
     n_stages = desc["stages"]   # one launch of the dominant kernel per stage and chunk
+    dominant = DOMINANT_KERNEL.format(teeth=desc.get("teeth", 6))
     launches_per_step = max(1, msm_launches // max(args.steps, 1))
     avg_launch_ms = msm_ms / max(msm_launches, 1)
     n_chunks = max(1, launches_per_step // n_stages)
@@ -434,7 +441,7 @@ def main():
     try:
         tj = json.loads(TRAFFIC_JSON.read_text())
         key = f"{args.workload}-{n_opt}" + (f"-{args.credits}" if args.workload == "qv" else "")
-        ent = tj["workloads"][key]["kernels"][DOMINANT_KERNEL]
+        ent = tj["workloads"][key]["kernels"][dominant]
         traffic_bpbl = float(ent["bytes_per_ballot_launch"])
         traffic_src = {"file": "profiles/traffic.json", "round": tj.get("round"), "commit": tj.get("commit"),
                        "ballots_per_launch": tj["workloads"][key].get("ballots_per_launch"), "source_hash": tj.get("source_hash"),
@@ -475,7 +482,7 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": DOMINANT_KERNEL,
+            "kernel": dominant,
             "achieved": achieved_gbs,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -500,7 +507,7 @@ def main():
             "launches_per_step": launches_per_step,
             "units_per_launch": units_per_launch,
             "kernel_share_of_step": msm_ms / max(all_ms, 1e-9),
-            "second_kernel": {"kernel": "eg::k_base_tables", "avg_launch_ms": tables_ms / max(tables_launches, 1),
+            "second_kernel": {"kernel": f"eg::k_base_tables<{desc.get('teeth', 6)}>", "avg_launch_ms": tables_ms / max(tables_launches, 1),
                               "launches_per_step": tables_launches // max(args.steps, 1),
                               "share_of_step": tables_ms / max(all_ms, 1e-9)},
             "note": "modular-integer VALU work: ~740 algorithmic bytes but ~4.4e4 field multiplications per ballot, so the "

@@ -34,10 +34,11 @@ struct EngineBufs {
   uint4* ws;            // per-lane variable-base tables (direct multiplications)
   uint4* dpt;           // deferred commitments P with out = encode(2P)   [cmp slot][PT_QUADS][cap]
   u32* encw;            // k_encode_batch scratch: prefix products and N   [2 * slot][EG_NL][cap]
-  uint4* btab;          // comb tables of the ring bases [base][cap] x BTAB_QUADS uint4 (32 packed entries of 128 B: 4 KiB)
+  uint4* btab;          // comb tables of the ring bases [base][cap] x btab_quads<T>() uint4 (16 or 32 packed entries of 128 B: 2 or 4 KiB)
 };
 constexpr int BTAB_ENTRY_QUADS = 8;   // packed entries: 4 field elements x 256 bits = 128 bytes = ONE cache line per lookup
-constexpr int BTAB_QUADS = 32 * BTAB_ENTRY_QUADS;
+template <int T> constexpr int btab_quads() { return Teeth<T>::ENTRIES * BTAB_ENTRY_QUADS; }    // T = the plan's comb shape (ge25519.cuh)
+constexpr int btab_quads_of(int teeth) { return (1 << (teeth - 1)) * BTAB_ENTRY_QUADS; }
 
 // ---- SoA accessors ------------------------------------------------------------------------------------
 __device__ __forceinline__ void words_to_fe4(fe& a, fe& b, fe& c, fe& d, const u32 w[PT_WORDS]) {
@@ -141,7 +142,7 @@ struct WsRows {
 // element when an entry is stored, unpacking ~16 per element at every lookup (fe_pack8 / fe_unpack8, fe25519.cuh).  (The measurement-only
 // layouts of round 2 - unpacked 160-byte entries, one-line and shared-entry bounds - are logged in profiles/r02_ab_experiments.txt
 // and no longer live in this header.)
-// comb table of one (base, ballot): 32 cached entries, contiguous (ge_teeth_tables_build / ge_teeth_mul)
+// comb table of one (base, ballot): 2^(T-1) cached entries, contiguous (ge_teeth_tables_build / ge_teeth_mul)
 struct BaseTable {
   uint4* base;
   __device__ __forceinline__ void store(int e, const ge_cached& c) {

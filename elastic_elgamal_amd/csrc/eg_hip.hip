@@ -191,6 +191,7 @@ struct Engine {
     hipEvent_t done = nullptr;
   } set[2];
   int n_sets = 2;
+  int teeth = 6;               // comb shape of the per-ballot tables (plan_teeth: 5 x 51 when a table serves two products, else 6 x 43)
   hipEvent_t fork = nullptr;
   u32 cap = 0, max_cap = 0;
   int tally_blocks = 64;
@@ -277,7 +278,7 @@ static size_t engine_bytes_per_ballot(const Engine* e) {
   const size_t pt = (size_t)PT_WORDS * sizeof(u32);
   return (size_t)std::max(P.n_pt_slots, 1) * pt + (size_t)std::max(P.n_cmp_slots, 1) * (32 + pt) + (size_t)std::max(P.n_chal_slots, 1) * 32 +
          (size_t)std::max(P.n_state_slots, 1) * 208 + (size_t)std::max(P.n_flag_slots, 1) * 4 + 4 +
-         std::max<size_t>(P.n_tables(), 1) * BTAB_QUADS * 16 + (size_t)std::max(e->max_defer, 1) * 2 * EG_NL * sizeof(u32);
+         std::max<size_t>(P.n_tables(), 1) * btab_quads_of(e->teeth) * 16 + (size_t)std::max(e->max_defer, 1) * 2 * EG_NL * sizeof(u32);
 }
 
 // (re)allocate the per-chunk SoA buffers of every work set for chunks of up to `want` ballots
@@ -301,7 +302,7 @@ static int engine_reserve(Engine* e, u32 want) {
                           (size_t)std::max(P.n_state_slots, 1) * 52 * cap * sizeof(u32),
                           (size_t)std::max(P.n_flag_slots, 1) * cap * sizeof(u32),
                           cap * sizeof(u32),
-                          std::max<size_t>(P.n_tables(), 1) * cap * BTAB_QUADS * sizeof(uint4),
+                          std::max<size_t>(P.n_tables(), 1) * cap * btab_quads_of(e->teeth) * sizeof(uint4),
                           (size_t)std::max(P.n_cmp_slots, 1) * PT_QUADS * cap * sizeof(uint4),
                           (size_t)std::max(e->max_defer, 1) * 2 * EG_NL * cap * sizeof(u32)};
   for (int k = 0; k < e->n_sets; ++k) {
@@ -405,12 +406,20 @@ static int engine_create(eg_ctx* ctx, eghost::Plan&& plan, const uint8_t pk[32],
   }
 
   // chunk workspace: sized lazily by engine_reserve() for the batches actually seen (up to EG_CHUNK ballots per chunk and work set)
+  e->teeth = eghost::plan_teeth(e->plan);
+  if (const char* v = getenv("EG_TEETH")) { const int t = atoi(v); if (t == 5 || t == 6) e->teeth = t; }     // measurement knob
   if (const char* v = getenv("EG_STREAMS")) e->n_sets = atoi(v) >= 2 ? 2 : 1;
   const char* env = getenv("EG_CHUNK");
-  // Two work sets whose kernels fill each other's launch tails (profiles/r03_ab_experiments.txt, block 3; M single-choice ballots/s and
-  // workspace at 57.6 KB per ballot and set): one set of 2^20 ballots 6.06 (60 GB: round 2's arrangement), one set of 2^18 5.81 (-4 %),
-  // two sets of 2^18 6.05 (30 GB: the default), two sets of 2^19 6.13 (+1 %, 60 GB: EG_CHUNK=524288), two sets of 2^17 5.90 (15 GB).
-  e->max_cap = env ? (u32)strtoul(env, nullptr, 10) : (e->n_sets == 2 ? 262144u : 1048576u);
+  // Two work sets whose kernels fill each other's launch tails (profiles/r03_ab_experiments.txt, blocks 3 and 9; M single-choice ballots/s):
+  // with 6-tooth tables (57.6 KB per ballot and set) one set of 2^20 ballots 6.06, one set of 2^18 5.81 (-4 %), two sets of 2^18 6.05,
+  // two sets of 2^19 6.13 (+1 %), two sets of 2^17 5.90; with the 5-tooth tables of the choice ballots (33.6 KB) two sets of 2^18 6.28,
+  // of 2^19 6.35.  Default: two sets of 2^19 ballots where that stays within 40 GB (the choice ballots of up to ~6 options: 35 GB),
+  // else of 2^18 (16 options: 44 GB; quadratic voting 5 / 20: 42 GB); EG_CHUNK overrides.
+  {
+    const size_t per = engine_bytes_per_ballot(e.get()) * (size_t)e->n_sets;
+    const u32 two_sets = per * 524288u <= ((size_t)40 << 30) ? 524288u : 262144u;
+    e->max_cap = env ? (u32)strtoul(env, nullptr, 10) : (e->n_sets == 2 ? two_sets : 1048576u);
+  }
   {
     // Large elections keep the workspace within half of the free device memory (~58 KB per ballot and set for 5 options, 150 KB for 16).
     size_t free_b = 0, total_b = 0;
@@ -468,6 +477,9 @@ static int ensure_big_tables(Engine* e, hipStream_t s) {
   }
   return EG_OK;
 }
+
+// the kernels that touch the per-ballot comb tables exist once per comb shape (template parameter T, ge25519.cuh: Teeth<T>)
+#define EG_WITH_TEETH(teeth, ...) do { if ((teeth) == 5) { constexpr int T = 5; __VA_ARGS__; } else { constexpr int T = 6; __VA_ARGS__; } } while (0)
 
 // verify n ballots (device pointers), accumulating accepted ciphertexts into the running tally
 // flags (the streaming JSON entry points overlap consecutive calls on different control streams `s`):
@@ -527,33 +539,33 @@ static int engine_verify_device(Engine* e, size_t n, const void* d_ballots, void
     if (!P.base_slots.empty()) {
       size_t pi = 0;
       if ((rc = prof_begin(ctx, cs, PROF_TABLES, &pi))) return rc;
-      hipLaunchKernelGGL(k_base_tables, dim3(grid_for((size_t)P.base_slots.size() * cn, msm_blocks)), dim3(NT), 0, cs, B,
-                         e->d_base_slots, (int)P.base_slots.size());
+      EG_WITH_TEETH(e->teeth, hipLaunchKernelGGL(k_base_tables<T>, dim3(grid_for((size_t)P.base_slots.size() * cn, msm_blocks)), dim3(NT), 0, cs, B,
+                                                 e->d_base_slots, (int)P.base_slots.size()));
       if ((rc = prof_end(ctx, cs, pi))) return rc;
     }
     if (!P.sum_bases.empty())
-      hipLaunchKernelGGL(k_sum_tables, dim3(grid_for((size_t)P.sum_bases.size() * cn, msm_blocks)), dim3(NT), 0, cs, B,
-                         e->d_sum_bases, e->d_sum_members, (int)P.sum_bases.size());
+      EG_WITH_TEETH(e->teeth, hipLaunchKernelGGL(k_sum_tables<T>, dim3(grid_for((size_t)P.sum_bases.size() * cn, msm_blocks)), dim3(NT), 0, cs, B,
+                                                 e->d_sum_bases, e->d_sum_members, (int)P.sum_bases.size()));
     for (auto& st : e->stages) {
       if (st.fam_count[FAM_TABLE1]) {
         size_t pi = 0;
         if ((rc = prof_begin(ctx, cs, PROF_MSM, &pi))) return rc;
-        hipLaunchKernelGGL(k_eq_table<false>, dim3(grid_for((size_t)st.fam_count[FAM_TABLE1] * cn, msm_blocks)), dim3(NT), 0, cs, B,
-                           e->d_jobs, e->d_vterms, st.fam_first[FAM_TABLE1], st.fam_count[FAM_TABLE1], 1);
+        EG_WITH_TEETH(e->teeth, hipLaunchKernelGGL((k_eq_table<false, T>), dim3(grid_for((size_t)st.fam_count[FAM_TABLE1] * cn, msm_blocks)), dim3(NT), 0, cs,
+                                                   B, e->d_jobs, e->d_vterms, st.fam_first[FAM_TABLE1], st.fam_count[FAM_TABLE1], 1));
         if ((rc = prof_end(ctx, cs, pi))) return rc;
       }
       if (st.fam_count[FAM_TABLEN]) {
         const int group = std::min(st.max_terms, EG_MULTI_GROUP);
-        hipLaunchKernelGGL(k_eq_table<true>, dim3(grid_for((size_t)st.fam_count[FAM_TABLEN] * cn, msm_blocks)), dim3(NT),
-                           (size_t)group * 9 * NT * sizeof(u32), cs, B, e->d_jobs, e->d_vterms, st.fam_first[FAM_TABLEN],
-                           st.fam_count[FAM_TABLEN], group);
+        EG_WITH_TEETH(e->teeth, hipLaunchKernelGGL((k_eq_table<true, T>), dim3(grid_for((size_t)st.fam_count[FAM_TABLEN] * cn, msm_blocks)), dim3(NT),
+                                                   (size_t)group * 9 * NT * sizeof(u32), cs, B, e->d_jobs, e->d_vterms, st.fam_first[FAM_TABLEN],
+                                                   st.fam_count[FAM_TABLEN], group));
       }
       if (st.fam_count[FAM_DIRECT1])
         hipLaunchKernelGGL(k_eq_direct, dim3(grid_for((size_t)st.fam_count[FAM_DIRECT1] * cn, msm_blocks)), dim3(NT), 0, cs, B,
                            e->d_jobs, e->d_vterms, st.fam_first[FAM_DIRECT1], st.fam_count[FAM_DIRECT1]);
       if (st.fam_count[FAM_GENERIC])
-        hipLaunchKernelGGL(k_eq_generic, dim3(grid_for((size_t)st.fam_count[FAM_GENERIC] * cn, msm_blocks)), dim3(NT), 0, cs, B,
-                           e->d_jobs, e->d_vterms, st.fam_first[FAM_GENERIC], st.fam_count[FAM_GENERIC]);
+        EG_WITH_TEETH(e->teeth, hipLaunchKernelGGL(k_eq_generic<T>, dim3(grid_for((size_t)st.fam_count[FAM_GENERIC] * cn, msm_blocks)), dim3(NT), 0, cs, B,
+                           e->d_jobs, e->d_vterms, st.fam_first[FAM_GENERIC], st.fam_count[FAM_GENERIC]));
       if (st.fam_count[FAM_ENCODE])
         hipLaunchKernelGGL(k_encode_plain, dim3(grid_for((size_t)st.fam_count[FAM_ENCODE] * cn, wide)), dim3(NT), 0, cs, B, e->d_jobs,
                            st.fam_first[FAM_ENCODE], st.fam_count[FAM_ENCODE]);
@@ -768,9 +780,11 @@ int eg_init(int device, eg_ctx** out) {
   if (const char* v = getenv("EG_COMB_BIG_MIN")) c->big_min = (size_t)strtoull(v, nullptr, 10);
   if (c->big_bits != 0 && (c->big_bits <= EG_COMB_BITS || c->big_bits > 26)) return fail(EG_ERR_BAD_ARG, "EG_COMB_BIG_BITS must be 0 or in (EG_COMB_BITS, 26]");
   int per_cu = 0;
-  HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_eq_table<false>, NT, 0));
+  HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_eq_table<false, 6>, NT, 0));
   // the shared-chain kernel keeps up to EG_MULTI_GROUP sign vectors per lane in dynamic LDS (9 KiB per term and block)
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_eq_table<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_eq_table<true, 5>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             EG_MULTI_GROUP * 9 * NT * (int)sizeof(u32)));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_eq_table<true, 6>), hipFuncAttributeMaxDynamicSharedMemorySize,
                              EG_MULTI_GROUP * 9 * NT * (int)sizeof(u32)));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_prim_msm), hipFuncAttributeMaxDynamicSharedMemorySize,
                              MSM_CHUNK * 8 * NT * (int)sizeof(u32)));
@@ -1368,11 +1382,11 @@ int eg_plan_describe(int kind, int n_options, uint64_t credits_or_bound, char* b
            "\"single_table_jobs\": %zu, \"chains\": %zu, \"chain_extra_terms\": %zu, \"loose_table_terms\": %zu, \"direct_terms\": %zu, "
            "\"sum_tables\": %zu, \"sum_table_members\": %zu, "
            "\"hash_programs\": %zu, \"prefixes\": %d, \"flags\": %d, \"rules\": %zu, \"tally_slots\": %zu, "
-           "\"pt_slots\": %d, \"cmp_slots\": %d, \"chal_slots\": %d, \"state_slots\": %d, \"tables\": %zu}",
+           "\"pt_slots\": %d, \"cmp_slots\": %d, \"chal_slots\": %d, \"state_slots\": %d, \"tables\": %zu, \"teeth\": %d}",
            P.stride, P.pt_items.size(), P.sc_items.size(), derived, derive_terms, P.base_slots.size(), P.stages.size(), jobs, per_stage.c_str(),
            var_terms, table_terms, combs, deferred, plain_encodes, inversion_groups, jobs_table1, chains, chain_extra_terms,
            loose_table_terms, direct_terms, P.sum_bases.size(), P.sum_members.size(), insts, P.n_prefixes, P.n_flag_slots, P.rules.size(),
-           P.tally_slots.size(), P.n_pt_slots, P.n_cmp_slots, P.n_chal_slots, P.n_state_slots, (size_t)P.n_tables());
+           P.tally_slots.size(), P.n_pt_slots, P.n_cmp_slots, P.n_chal_slots, P.n_state_slots, (size_t)P.n_tables(), eghost::plan_teeth(P));
   if (strlen(tmp) + 1 > cap) return fail(EG_ERR_BAD_ARG, "buffer too small");
   memcpy(buf, tmp, strlen(tmp) + 1);
   return EG_OK;

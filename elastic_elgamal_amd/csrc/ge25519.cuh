@@ -418,11 +418,20 @@ EG_HD void ge_var_mul(ge& acc, TableIO& io, const u32 digits[8]) {
 // used four radix-16 tables of P, 2^64 P, 2^128 P, 2^192 P: 192 + 28 for the tables but 60 + 64 per product; the comb
 // measured +10 % on 2-equation rings and +23 % on the QV ballot.)  Even multipliers use k + l, which changes the
 // product by the 4-torsion point [l]P only - invisible to the Ristretto encoding, like the halving in sc_halve.
-#define EG_TEETH 6
-#define EG_TEETH_COLS 43
-#define EG_TEETH_ENTRIES 32
+// The shape is a property of the PLAN (template parameter T = teeth): a table that serves two products (the rings of two of a choice
+// ballot) is better off with 5 teeth x 51 columns - 16 entries, 2 KiB, 204 doublings + 21 additions to build, 50 + 51 per product -
+// than with 6 x 43; rings of 3 .. 7 members (range proofs) pay the larger table back.  Same-call A/B (r03_ab_experiments.txt, block 9):
+// 5 x 51 +2.4 % on single- and multi-choice ballots and -5.1 % on quadratic voting; 7 x 37: -10 % / -8.6 % / +0.5 %.
+template <int T> struct Teeth {
+  static_assert(T == 5 || T == 6 || T == 7, "comb shapes: 5 x 51, 6 x 43, 7 x 37");
+  static constexpr int N = T;
+  static constexpr int COLS = T == 5 ? 51 : T == 6 ? 43 : 37;       // N x COLS >= 255 signed bits
+  static constexpr int ENTRIES = 1 << (T - 1);
+  static constexpr int TOP = T * COLS - 1;                          // position of the sign that is always +1
+};
 
-// sg = the 258 sign bits of the multiplier (sg bit i <=> s_i = +1): (k_odd >> 1) with bit 257 set, k_odd = k or k + l
+// sg = the N x COLS sign bits of the multiplier (sg bit i <=> s_i = +1): (k_odd >> 1) with the top bit set, k_odd = k or k + l
+template <int T>
 EG_HD void sc_teeth_signs(u32 sg[9], const u32 s[8]) {
   const u32 l[8] = EG_L_WORDS;
   const bool even = (s[0] & 1u) == 0;
@@ -437,54 +446,57 @@ EG_HD void sc_teeth_signs(u32 sg[9], const u32 s[8]) {
 #pragma unroll
   for (int i = 0; i < 7; ++i) sg[i] = (t[i] >> 1) | (t[i + 1] << 31);
   sg[7] = t[7] >> 1;
-  sg[8] = 2u;
+  sg[8] = 0u;
+  sg[Teeth<T>::TOP >> 5] |= 1u << (Teeth<T>::TOP & 31);     // the top sign (6 x 43: bit 257; k_odd < 2^254 leaves it free in every shape)
 }
-// rows[j] = the 43 sign bits of tooth j, left-aligned (bit 63 = column 42)
-EG_HD void sc_recode_teeth(u64 rows[EG_TEETH], const u32 s[8]) {
+// rows[j] = the COLS sign bits of tooth j, left-aligned (bit 63 = the highest column)
+template <int T>
+EG_HD void sc_recode_teeth(u64 rows[T], const u32 s[8]) {
   u32 sg[9];
-  sc_teeth_signs(sg, s);
+  sc_teeth_signs<T>(sg, s);
 #pragma unroll
-  for (int j = 0; j < EG_TEETH; ++j) {
-    const int off = EG_TEETH_COLS * j, wi = off >> 5, sh = off & 31;
+  for (int j = 0; j < T; ++j) {
+    const int off = Teeth<T>::COLS * j, wi = off >> 5, sh = off & 31;
     u64 v = ((u64)sg[wi] | ((u64)sg[wi + 1] << 32)) >> sh;
-    if (sh + EG_TEETH_COLS > 64) v |= (u64)sg[wi + 2] << (64 - sh);
-    rows[j] = (v & ((1ull << EG_TEETH_COLS) - 1ull)) << (64 - EG_TEETH_COLS);
+    if (sh + Teeth<T>::COLS > 64) v |= (u64)sg[wi + 2] << (64 - sh);
+    rows[j] = (v & ((1ull << Teeth<T>::COLS) - 1ull)) << (64 - Teeth<T>::COLS);
   }
 }
 // column c of a sign vector read word by word through `word(i)` (the multi-term kernel keeps the vectors in LDS): table entry
 // index and whether the entry is negated.  Bit positions are the same in every lane, so the word index is wave-uniform.
-template <class WordFn>
+template <int T, class WordFn>
 EG_HD void sc_teeth_column(WordFn word, int c, int& idx, bool& neg) {
   u32 m = 0;
 #pragma unroll
-  for (int j = 0; j < EG_TEETH - 1; ++j) {
-    const int q = EG_TEETH_COLS * j + c;
+  for (int j = 0; j < T - 1; ++j) {
+    const int q = Teeth<T>::COLS * j + c;
     m |= ((word(q >> 5) >> (q & 31)) & 1u) << j;
   }
-  const int qt = EG_TEETH_COLS * (EG_TEETH - 1) + c;
+  const int qt = Teeth<T>::COLS * (T - 1) + c;
   const bool top = ((word(qt >> 5) >> (qt & 31)) & 1u) != 0;
-  idx = (int)(top ? m : (m ^ (EG_TEETH_ENTRIES - 1)));
+  idx = (int)(top ? m : (m ^ (Teeth<T>::ENTRIES - 1)));
   neg = !top;
 }
-// pops the next column (from column 42 downwards): table entry index and whether the entry is negated
-EG_HD void sc_teeth_next(u64 rows[EG_TEETH], int& idx, bool& neg) {
+// pops the next column (from the highest downwards): table entry index and whether the entry is negated
+template <int T>
+EG_HD void sc_teeth_next(u64 rows[T], int& idx, bool& neg) {
   u32 m = 0;
 #pragma unroll
-  for (int j = 0; j < EG_TEETH - 1; ++j) m |= (u32)(rows[j] >> 63) << j;
-  const bool top = (rows[EG_TEETH - 1] >> 63) != 0;
+  for (int j = 0; j < T - 1; ++j) m |= (u32)(rows[j] >> 63) << j;
+  const bool top = (rows[T - 1] >> 63) != 0;
 #pragma unroll
-  for (int j = 0; j < EG_TEETH; ++j) rows[j] <<= 1;
-  idx = (int)(top ? m : (m ^ (EG_TEETH_ENTRIES - 1)));
+  for (int j = 0; j < T; ++j) rows[j] <<= 1;
+  idx = (int)(top ? m : (m ^ (Teeth<T>::ENTRIES - 1)));
   neg = !top;
 }
 
 // io: the 32-entry table of this base; tmp: scratch for the five cached points 2 P_j (entries 0..4)
-template <class TableIO, class TmpIO>
+template <int T, class TableIO, class TmpIO>
 EG_HD void ge_teeth_tables_build(TableIO& io, TmpIO& tmp, const ge& p) {
   ge cur = p, sum;
   ge_identity(sum);
 #pragma unroll 1
-  for (int j = 0; j < EG_TEETH - 1; ++j) {
+  for (int j = 0; j < T - 1; ++j) {
     ge_p1p1 t;
     {
       ge_cached pc; ge_to_cached_lazy(pc, cur);
@@ -502,7 +514,7 @@ EG_HD void ge_teeth_tables_build(TableIO& io, TmpIO& tmp, const ge& p) {
     ge_p2 q;
     q.X = q3.X; q.Y = q3.Y; q.Z = q3.Z;
 #pragma unroll 1
-    for (int r = 0; r < EG_TEETH_COLS - 2; ++r) { ge_dbl(t, q.X, q.Y, q.Z); ge_dbl_to_p2(q, t); }
+    for (int r = 0; r < Teeth<T>::COLS - 2; ++r) { ge_dbl(t, q.X, q.Y, q.Z); ge_dbl_to_p2(q, t); }
     ge_dbl(t, q.X, q.Y, q.Z);
     ge_dbl_to_p3(cur, t);                 // P_(j+1)
   }
@@ -514,7 +526,7 @@ EG_HD void ge_teeth_tables_build(TableIO& io, TmpIO& tmp, const ge& p) {
     io.store(0, e);
   }
 #pragma unroll 1
-  for (int i = 1; i < EG_TEETH_ENTRIES; ++i) {
+  for (int i = 1; i < Teeth<T>::ENTRIES; ++i) {
     int j = 0;
     while (((i >> j) & 1) == 0) ++j;      // Gray code: step i flips tooth ctz(i)
     const int g = i ^ (i >> 1);
@@ -547,12 +559,12 @@ EG_HD void ge_cached_to_p3(ge& p, const ge_cached& c) {
 // src(k, g, entry) loads entry g of member k; io: the table of S; tmp: scratch for the five cached steps (entries 0..4).
 // (Requesting a member's entry one addition ahead of its use, with the walk re-reading its own output, measured slower:
 // the kernel is bound by the scattered two-line reads themselves, not by their latency.)
-template <class SrcFn, class TableIO, class TmpIO>
+template <int T, class SrcFn, class TableIO, class TmpIO>
 EG_HD void ge_teeth_tables_sum(TableIO& io, TmpIO& tmp, int m, SrcFn src) {
   ge sum;
   ge_identity(sum);
 #pragma unroll 1
-  for (int i = 0; i < EG_TEETH_ENTRIES; ++i) {
+  for (int i = 0; i < Teeth<T>::ENTRIES; ++i) {
     const int g = i ^ (i >> 1);
     int j = 0;
     while (i != 0 && ((i >> j) & 1) == 0) ++j;      // Gray code: step i flips tooth ctz(i)
@@ -596,11 +608,11 @@ EG_HD void ge_teeth_tables_sum(TableIO& io, TmpIO& tmp, int m, SrcFn src) {
 // buffer, measured -0.4 % in round 1 and +-0.2 % = nothing in round 2, when the kernel had the 40 registers to spare).
 // The first column is not added to the identity: +-entry = (Y+X, Y-X, 2Z, ..) IS the point (2X : 2Y : 2Z) in projective
 // coordinates, and the operation that follows is a doubling, which does not read T (saves one 8-multiplication addition).
-template <class TableIO>
-EG_HD void ge_teeth_mul(ge& acc, TableIO& io, u64 rows[EG_TEETH]) {
+template <int T, class TableIO>
+EG_HD void ge_teeth_mul(ge& acc, TableIO& io, u64 rows[T]) {
   {
     int idx; bool neg;
-    sc_teeth_next(rows, idx, neg);
+    sc_teeth_next<T>(rows, idx, neg);
     ge_cached cur;
     io.load(cur, idx);
     fe t = cur.YpX; fe_cmov(cur.YpX, cur.YmX, neg); fe_cmov(cur.YmX, t, neg);   // -(x, y) = (-x, y)
@@ -609,9 +621,9 @@ EG_HD void ge_teeth_mul(ge& acc, TableIO& io, u64 rows[EG_TEETH]) {
     acc.Z = cur.Z2;                                       // 2Z [2]
   }
 #pragma unroll 1
-  for (int c = EG_TEETH_COLS - 2; c >= 0; --c) {
+  for (int c = Teeth<T>::COLS - 2; c >= 0; --c) {
     int idx; bool neg;
-    sc_teeth_next(rows, idx, neg);
+    sc_teeth_next<T>(rows, idx, neg);
     ge_cached cur;
     io.load(cur, idx);
     ge_p1p1 t;
@@ -631,13 +643,13 @@ EG_HD void ge_teeth_mul(ge& acc, TableIO& io, u64 rows[EG_TEETH]) {
 // acc = sum_t [k_t]P_t for bases that all have teeth tables, with ONE chain of 42 doublings shared by every term (Straus /
 // interleaved evaluation, the structure dalek uses for vartime_multi_mul, ristretto.rs:139-145): per column one doubling and
 // one addition per term.  column(t, c, idx, neg) yields term t's entry for column c; load(t, idx, entry) fetches it.
-template <class ColumnFn, class LoadFn>
+template <int T, class ColumnFn, class LoadFn>
 EG_HD void ge_teeth_mul_multi(ge& acc, int n_terms, ColumnFn column, LoadFn load) {
   ge_identity(acc);
 #pragma unroll 1
-  for (int c = EG_TEETH_COLS - 1; c >= 0; --c) {
+  for (int c = Teeth<T>::COLS - 1; c >= 0; --c) {
     ge_p1p1 t;
-    if (c != EG_TEETH_COLS - 1) {
+    if (c != Teeth<T>::COLS - 1) {
       ge_dbl(t, acc.X, acc.Y, acc.Z);
       ge_dbl_to_p3(acc, t);
     }

@@ -637,6 +637,16 @@ inline Plan build_share_plan(uint64_t shares, uint64_t threshold, const uint8_t 
 }
 
 // ---- flattening of a plan into the arrays the kernels index (pure host logic, sanitizer-tested in tests/hostcheck) ------------
+// Comb shape of the per-ballot tables (ge25519.cuh: Teeth<T>).  A table costs ~204 doublings + 21 additions with 5 teeth (16 entries,
+// 51 columns) and 215 + 37 with 6 (32 entries, 43 columns); a product 50 + 51 against 42 + 43.  The rings of two of a choice ballot use a
+// table twice: 5 teeth measured +2.4 %; the rings of 3 .. 7 of the range proofs use it 3 .. 7 times: 6 teeth, +5 % (A/B block 9).
+inline int plan_teeth(const Plan& P) {
+  if (P.base_slots.empty()) return 6;
+  size_t uses = 0;
+  for (const VarTerm& t : P.vterms) uses += t.base != 0xffff && t.base < P.base_slots.size();
+  return uses <= 2 * P.base_slots.size() + P.base_slots.size() / 2 ? 5 : 6;          // <= 2.5 products per table
+}
+
 // the equations of a stage, sorted by kernel family (kernels.cuh): FAM_TABLE1 one table-backed base, FAM_TABLEN several
 // table-backed bases on shared doubling chains, FAM_DIRECT1 one base without a table, FAM_GENERIC everything else, FAM_ENCODE plain
 // encodings of point slots

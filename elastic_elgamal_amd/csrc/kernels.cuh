@@ -98,6 +98,7 @@ __global__ void __launch_bounds__(NT) k_derive_points(EngineBufs B, const egplan
 }
 
 // ---- k_base_tables: comb tables of every ring base (once per base and ballot; shared by all equations of the ring) -----------
+template <int T>
 __global__ void __launch_bounds__(NT, EG_TAB_WAVES) k_base_tables(EngineBufs B, const unsigned short* base_slots, int n_bases) {
   const size_t total = (size_t)n_bases * B.n;
   WsRows tmp;
@@ -106,8 +107,8 @@ __global__ void __launch_bounds__(NT, EG_TAB_WAVES) k_base_tables(EngineBufs B, 
     const u32 k = (u32)(j / B.n), b = (u32)(j % B.n);
     ge p;
     load_pt(p, B.pts, B.cap, base_slots[k], b);
-    BaseTable bt{B.btab + ((size_t)k * B.cap + b) * BTAB_QUADS};
-    ge_teeth_tables_build(bt, tmp, p);
+    BaseTable bt{B.btab + ((size_t)k * B.cap + b) * btab_quads<T>()};
+    ge_teeth_tables_build<T>(bt, tmp, p);
   }
 }
 
@@ -115,6 +116,7 @@ __global__ void __launch_bounds__(NT, EG_TAB_WAVES) k_base_tables(EngineBufs B, 
 #ifndef EG_SUM_WAVES
 #define EG_SUM_WAVES 2
 #endif
+template <int T>
 __global__ void __launch_bounds__(NT, EG_SUM_WAVES) k_sum_tables(EngineBufs B, const egplan::SumBase* sums, const unsigned short* members, int n_sums) {
   const size_t total = (size_t)n_sums * B.n;
   WsRows tmp;
@@ -122,9 +124,9 @@ __global__ void __launch_bounds__(NT, EG_SUM_WAVES) k_sum_tables(EngineBufs B, c
   for (size_t j = (size_t)blockIdx.x * NT + threadIdx.x; j < total; j += (size_t)gridDim.x * NT) {
     const u32 k = (u32)(j / B.n), b = (u32)(j % B.n);
     const egplan::SumBase sb = sums[k];
-    BaseTable out{B.btab + ((size_t)sb.out_base * B.cap + b) * BTAB_QUADS};
-    ge_teeth_tables_sum(out, tmp, (int)sb.count, [&](int t, int g, ge_cached& e) {
-      const BaseTable bt{B.btab + ((size_t)members[sb.first + t] * B.cap + b) * BTAB_QUADS};
+    BaseTable out{B.btab + ((size_t)sb.out_base * B.cap + b) * btab_quads<T>()};
+    ge_teeth_tables_sum<T>(out, tmp, (int)sb.count, [&](int t, int g, ge_cached& e) {
+      const BaseTable bt{B.btab + ((size_t)members[sb.first + t] * B.cap + b) * btab_quads<T>()};
       bt.load(e, g);
     });
   }
@@ -156,7 +158,7 @@ __device__ __forceinline__ void eq_fixed_terms(ge& acc, const EngineBufs& B, u32
   }
 }
 
-template <bool MULTI>
+template <bool MULTI, int T>
 __global__ void __launch_bounds__(NT, EG_EQ_WAVES) k_eq_table(EngineBufs B, const egplan::JobClass* classes, const egplan::VarTerm* terms,
                                                     int class_first, int n_classes, int group) {
   extern __shared__ u32 eq_signs[];          // MULTI: [group][9][NT] sign vectors of the multipliers (sc_teeth_signs)
@@ -169,10 +171,10 @@ __global__ void __launch_bounds__(NT, EG_EQ_WAVES) k_eq_table(EngineBufs B, cons
       const egplan::VarTerm vt = terms[jc.term_first];
       u32 s[8];
       load_scalar(s, B, b, vt.s, true);
-      u64 rows[EG_TEETH];
-      sc_recode_teeth(rows, s);
-      BaseTable bt{B.btab + ((size_t)vt.base * B.cap + b) * BTAB_QUADS};
-      ge_teeth_mul(acc, bt, rows);
+      u64 rows[T];
+      sc_recode_teeth<T>(rows, s);
+      BaseTable bt{B.btab + ((size_t)vt.base * B.cap + b) * btab_quads<T>()};
+      ge_teeth_mul<T>(acc, bt, rows);
     } else {
       // groups of up to `group` terms share a doubling chain (the group size is what fits LDS at two blocks per CU)
       const int nt = (int)jc.term_count;
@@ -183,17 +185,17 @@ __global__ void __launch_bounds__(NT, EG_EQ_WAVES) k_eq_table(EngineBufs B, cons
         for (int t = 0; t < m; ++t) {
           u32 s[8], sg[9];
           load_scalar(s, B, b, terms[jc.term_first + t0 + t].s, true);
-          sc_teeth_signs(sg, s);
+          sc_teeth_signs<T>(sg, s);
 #pragma unroll
           for (int w = 0; w < 9; ++w) eq_signs[(t * 9 + w) * NT + threadIdx.x] = sg[w];
         }
         ge part;
-        ge_teeth_mul_multi(part, m,
+        ge_teeth_mul_multi<T>(part, m,
             [&](int t, int col, int& idx, bool& neg) {
-              sc_teeth_column([&](int w) { return eq_signs[(t * 9 + w) * NT + threadIdx.x]; }, col, idx, neg);
+              sc_teeth_column<T>([&](int w) { return eq_signs[(t * 9 + w) * NT + threadIdx.x]; }, col, idx, neg);
             },
             [&](int t, int idx, ge_cached& e) {
-              const BaseTable bt{B.btab + ((size_t)terms[jc.term_first + t0 + t].base * B.cap + b) * BTAB_QUADS};
+              const BaseTable bt{B.btab + ((size_t)terms[jc.term_first + t0 + t].base * B.cap + b) * btab_quads<T>()};
               bt.load(e, idx);
             });
         if (t0 == 0) acc = part;
@@ -228,6 +230,7 @@ __global__ void __launch_bounds__(NT, 2) k_eq_direct(EngineBufs B, const egplan:
   }
 }
 
+template <int T>
 __global__ void __launch_bounds__(NT, 2) k_eq_generic(EngineBufs B, const egplan::JobClass* classes,
                                                       const egplan::VarTerm* terms, int class_first, int n_classes) {
   const size_t total = (size_t)n_classes * B.n;
@@ -245,10 +248,10 @@ __global__ void __launch_bounds__(NT, 2) k_eq_generic(EngineBufs B, const egplan
       load_scalar(s, B, b, vt.s, true);
       ge part;
       if (vt.base != 0xffffu) {
-        BaseTable bt{B.btab + ((size_t)vt.base * B.cap + b) * BTAB_QUADS};
-        u64 rows[EG_TEETH];
-        sc_recode_teeth(rows, s);
-        ge_teeth_mul(part, bt, rows);
+        BaseTable bt{B.btab + ((size_t)vt.base * B.cap + b) * btab_quads<T>()};
+        u64 rows[T];
+        sc_recode_teeth<T>(rows, s);
+        ge_teeth_mul<T>(part, bt, rows);
       } else {
         ge p;
         load_pt(p, B.pts, B.cap, vt.slot, b);

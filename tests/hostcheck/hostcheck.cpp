@@ -18,7 +18,7 @@ struct ArrTable {
 };
 // the comb table of a base, stored the way the device stores it (device_io.cuh BaseTable): packed, 4 x 256 bits per entry
 struct ArrBase {
-  u32 w[32][32];
+  u32 w[64][32];          // up to 2^6 entries (7 teeth)
   void store(int i, const ge_cached& c) {
     fe a = c.YpX, b = c.YmX, z = c.Z2;
     fe_carry(a); fe_carry(b); fe_carry(z);
@@ -69,9 +69,10 @@ static void bytes_from_words(uint8_t* b, const u32* w, int nwords) {
 static ArrNiels g_base_table;
 static void build_fixed(ArrNiels& t, const ge& base) { t.base = base; t.ready = true; }
 
-extern "C" {
+static int g_teeth = 6;      // comb shape the table-backed checks run with (hc_set_teeth): every shape the product instantiates, and 7 x 37
+extern "C" void hc_set_teeth(int t) { g_teeth = t; }
 
-int hc_point_roundtrip(const uint8_t in[32], uint8_t out[32]) {
+extern "C" int hc_point_roundtrip(const uint8_t in[32], uint8_t out[32]) {
   u32 w[8], o[8]; words_from_bytes(w, in, 8);
   ge p; bool ok = ristretto_decode(p, w);
   ristretto_encode(o, p);
@@ -80,7 +81,7 @@ int hc_point_roundtrip(const uint8_t in[32], uint8_t out[32]) {
 }
 
 // out = enc([k]P + [r]G)   (Group::vartime_double_mul_generator)
-int hc_double_mul_generator(const uint8_t k[32], const uint8_t p_enc[32], const uint8_t r[32], uint8_t out[32]) {
+extern "C" int hc_double_mul_generator(const uint8_t k[32], const uint8_t p_enc[32], const uint8_t r[32], uint8_t out[32]) {
   if (!g_base_table.ready) { ge g; ge_generator(g); build_fixed(g_base_table, g); }
   u32 kw[8], rw[8], pw[8], o[8];
   words_from_bytes(kw, k, 8); words_from_bytes(rw, r, 8); words_from_bytes(pw, p_enc, 8);
@@ -95,14 +96,15 @@ int hc_double_mul_generator(const uint8_t k[32], const uint8_t p_enc[32], const 
 }
 
 // same as hc_double_mul_generator but through the per-base comb table (ge_teeth_tables_build / ge_teeth_mul)
-int hc_double_mul_generator_teeth(const uint8_t k[32], const uint8_t p_enc[32], const uint8_t r[32], uint8_t out[32]) {
+template <int T>
+static int hc_double_mul_generator_teeth_t(const uint8_t k[32], const uint8_t p_enc[32], const uint8_t r[32], uint8_t out[32]) {
   if (!g_base_table.ready) { ge g; ge_generator(g); build_fixed(g_base_table, g); }
   u32 kw[8], rw[8], pw[8], o[8];
   words_from_bytes(kw, k, 8); words_from_bytes(rw, r, 8); words_from_bytes(pw, p_enc, 8);
   ge p; if (!ristretto_decode(p, pw)) return 0;
-  ArrBase tab; ArrTable tmp; ge_teeth_tables_build(tab, tmp, p);
-  u64 rows[EG_TEETH]; u32 dr[EG_COMB_WORDS]; sc_recode_teeth(rows, kw); sc_recode_comb(dr, rw);
-  ge acc; ge_teeth_mul(acc, tab, rows);
+  ArrBase tab; ArrTable tmp; ge_teeth_tables_build<T>(tab, tmp, p);
+  u64 rows[T]; u32 dr[EG_COMB_WORDS]; sc_recode_teeth<T>(rows, kw); sc_recode_comb(dr, rw);
+  ge acc; ge_teeth_mul<T>(acc, tab, rows);
   ge_fixed_mul_add(acc, g_base_table, dr);
   ristretto_encode(o, acc);
   bytes_from_words(out, o, 8);
@@ -111,7 +113,8 @@ int hc_double_mul_generator_teeth(const uint8_t k[32], const uint8_t p_enc[32], 
 
 // out = enc(sum_i [k_i]P_i + [r]G) with every base behind a teeth table and ONE shared doubling chain (ge_teeth_mul_multi, what
 // k_eq_table<true> runs); the sign vectors are read word by word, as the kernel reads them from LDS
-int hc_multi_mul_teeth(int n, const uint8_t* ks, const uint8_t* ps, const uint8_t r[32], uint8_t out[32]) {
+template <int T>
+static int hc_multi_mul_teeth_t(int n, const uint8_t* ks, const uint8_t* ps, const uint8_t r[32], uint8_t out[32]) {
   if (!g_base_table.ready) { ge g; ge_generator(g); build_fixed(g_base_table, g); }
   std::vector<ArrBase> tabs(n);
   std::vector<u32> sg(9 * (size_t)n);
@@ -119,12 +122,12 @@ int hc_multi_mul_teeth(int n, const uint8_t* ks, const uint8_t* ps, const uint8_
     u32 kw[8], pw[8];
     words_from_bytes(kw, ks + 32 * i, 8); words_from_bytes(pw, ps + 32 * i, 8);
     ge p; if (!ristretto_decode(p, pw)) return 0;
-    ArrTable tmp; ge_teeth_tables_build(tabs[i], tmp, p);
-    sc_teeth_signs(&sg[9 * i], kw);
+    ArrTable tmp; ge_teeth_tables_build<T>(tabs[i], tmp, p);
+    sc_teeth_signs<T>(&sg[9 * i], kw);
   }
   ge acc;
-  ge_teeth_mul_multi(acc, n,
-      [&](int t, int c, int& idx, bool& neg) { sc_teeth_column([&](int w) { return sg[9 * t + w]; }, c, idx, neg); },
+  ge_teeth_mul_multi<T>(acc, n,
+      [&](int t, int c, int& idx, bool& neg) { sc_teeth_column<T>([&](int w) { return sg[9 * t + w]; }, c, idx, neg); },
       [&](int t, int idx, ge_cached& e) { tabs[t].load(e, idx); });
   u32 rw[8], dr[EG_COMB_WORDS], o[8];
   words_from_bytes(rw, r, 8); sc_recode_comb(dr, rw);
@@ -137,21 +140,22 @@ int hc_multi_mul_teeth(int n, const uint8_t* ks, const uint8_t* ps, const uint8_
 // out = enc([k](P_1 + .. + P_n) + [r]G) through the table that ge_teeth_tables_sum makes from the members' tables (what k_sum_tables +
 // k_eq_table<false> run for the log-equality proof over the sum of the ciphertexts).  Returns 1 when, in addition, every entry of
 // that table is the same curve point as the entry of a table built from the sum itself; 0 when one differs; -1 for a bad encoding.
-int hc_sum_table_mul(int n, const uint8_t* ps, const uint8_t k[32], const uint8_t r[32], uint8_t out[32]) {
+template <int T>
+static int hc_sum_table_mul_t(int n, const uint8_t* ps, const uint8_t k[32], const uint8_t r[32], uint8_t out[32]) {
   if (!g_base_table.ready) { ge g; ge_generator(g); build_fixed(g_base_table, g); }
   std::vector<ArrBase> tabs(n);
   ge total; ge_identity(total);
   for (int i = 0; i < n; ++i) {
     u32 pw[8]; words_from_bytes(pw, ps + 32 * i, 8);
     ge p; if (!ristretto_decode(p, pw)) return -1;
-    ArrTable tmp; ge_teeth_tables_build(tabs[i], tmp, p);
+    ArrTable tmp; ge_teeth_tables_build<T>(tabs[i], tmp, p);
     ge t; ge_add_full(t, total, p); total = t;
   }
   ArrBase sum_tab, ref_tab; ArrTable tmp, tmp2;
-  ge_teeth_tables_sum(sum_tab, tmp, n, [&](int t, int g, ge_cached& e) { tabs[t].load(e, g); });
-  ge_teeth_tables_build(ref_tab, tmp2, total);
+  ge_teeth_tables_sum<T>(sum_tab, tmp, n, [&](int t, int g, ge_cached& e) { tabs[t].load(e, g); });
+  ge_teeth_tables_build<T>(ref_tab, tmp2, total);
   int same = 1;
-  for (int g = 0; g < EG_TEETH_ENTRIES; ++g) {
+  for (int g = 0; g < Teeth<T>::ENTRIES; ++g) {
     ge_cached ea, eb; sum_tab.load(ea, g); ref_tab.load(eb, g);
     ge a, b; ge_cached_to_p3(a, ea); ge_cached_to_p3(b, eb);
     fe az, bz, l, rr;
@@ -162,8 +166,8 @@ int hc_sum_table_mul(int n, const uint8_t* ps, const uint8_t k[32], const uint8_
   }
   u32 kw[8], rw[8], o[8];
   words_from_bytes(kw, k, 8); words_from_bytes(rw, r, 8);
-  u64 rows[EG_TEETH]; u32 dr[EG_COMB_WORDS]; sc_recode_teeth(rows, kw); sc_recode_comb(dr, rw);
-  ge acc; ge_teeth_mul(acc, sum_tab, rows);
+  u64 rows[T]; u32 dr[EG_COMB_WORDS]; sc_recode_teeth<T>(rows, kw); sc_recode_comb(dr, rw);
+  ge acc; ge_teeth_mul<T>(acc, sum_tab, rows);
   ge_fixed_mul_add(acc, g_base_table, dr);
   ristretto_encode(o, acc);
   bytes_from_words(out, o, 8);
@@ -171,7 +175,7 @@ int hc_sum_table_mul(int n, const uint8_t* ps, const uint8_t k[32], const uint8_
 }
 
 // encode(2P) through the batched-inversion path vs the plain encoder; returns 1 when they agree
-int hc_double_encode(const uint8_t p_enc[32], uint8_t out[32]) {
+extern "C" int hc_double_encode(const uint8_t p_enc[32], uint8_t out[32]) {
   u32 pw[8], o[8], ref[8]; words_from_bytes(pw, p_enc, 8);
   ge p; if (!ristretto_decode(p, pw)) return -1;
   fe n; bool zero;
@@ -184,15 +188,16 @@ int hc_double_encode(const uint8_t p_enc[32], uint8_t out[32]) {
   return memcmp(o, ref, 32) == 0 ? 1 : 0;
 }
 // [k]P + [r]G evaluated as 2 * ([k/2]P + [r/2]G) with the doubled encoder (what k_msm_jobs + k_encode_batch do)
-int hc_double_mul_generator_halved(const uint8_t k[32], const uint8_t p_enc[32], const uint8_t r[32], uint8_t out[32]) {
+template <int T>
+static int hc_double_mul_generator_halved_t(const uint8_t k[32], const uint8_t p_enc[32], const uint8_t r[32], uint8_t out[32]) {
   if (!g_base_table.ready) { ge g; ge_generator(g); build_fixed(g_base_table, g); }
   u32 kw[8], rw[8], pw[8], o[8], kh[8], rh[8];
   words_from_bytes(kw, k, 8); words_from_bytes(rw, r, 8); words_from_bytes(pw, p_enc, 8);
   ge p; if (!ristretto_decode(p, pw)) return 0;
   sc_halve(kh, kw); sc_halve(rh, rw);
-  ArrBase tab; ArrTable tmp; ge_teeth_tables_build(tab, tmp, p);
-  u64 rows[EG_TEETH]; u32 dr[EG_COMB_WORDS]; sc_recode_teeth(rows, kh); sc_recode_comb(dr, rh);
-  ge acc; ge_teeth_mul(acc, tab, rows);
+  ArrBase tab; ArrTable tmp; ge_teeth_tables_build<T>(tab, tmp, p);
+  u64 rows[T]; u32 dr[EG_COMB_WORDS]; sc_recode_teeth<T>(rows, kh); sc_recode_comb(dr, rh);
+  ge acc; ge_teeth_mul<T>(acc, tab, rows);
   ge_fixed_mul_add(acc, g_base_table, dr);
   fe n, inv; bool zero;
   ge_double_encode_prepare(n, zero, acc);
@@ -202,7 +207,7 @@ int hc_double_mul_generator_halved(const uint8_t k[32], const uint8_t p_enc[32],
   return 1;
 }
 
-int hc_point_add(const uint8_t a[32], const uint8_t b[32], int sub, uint8_t out[32]) {
+extern "C" int hc_point_add(const uint8_t a[32], const uint8_t b[32], int sub, uint8_t out[32]) {
   u32 aw[8], bw[8], o[8]; words_from_bytes(aw, a, 8); words_from_bytes(bw, b, 8);
   ge p, q, r; if (!ristretto_decode(p, aw) || !ristretto_decode(q, bw)) return 0;
   if (sub) ge_sub_full(r, p, q); else ge_add_full(r, p, q);
@@ -211,23 +216,23 @@ int hc_point_add(const uint8_t a[32], const uint8_t b[32], int sub, uint8_t out[
   return 1;
 }
 
-void hc_sc_from_wide(const uint8_t in[64], uint8_t out[32]) {
+extern "C" void hc_sc_from_wide(const uint8_t in[64], uint8_t out[32]) {
   u32 w[16], o[8]; words_from_bytes(w, in, 16); sc_from_wide(o, w); bytes_from_words(out, o, 8);
 }
-void hc_sc_muladd(const uint8_t a[32], const uint8_t b[32], const uint8_t c[32], uint8_t out[32]) {
+extern "C" void hc_sc_muladd(const uint8_t a[32], const uint8_t b[32], const uint8_t c[32], uint8_t out[32]) {
   u32 aw[8], bw[8], cw[8], o[8]; words_from_bytes(aw, a, 8); words_from_bytes(bw, b, 8); words_from_bytes(cw, c, 8);
   sc_muladd(o, aw, bw, cw); bytes_from_words(out, o, 8);
 }
-void hc_sc_neg(const uint8_t a[32], uint8_t out[32]) {
+extern "C" void hc_sc_neg(const uint8_t a[32], uint8_t out[32]) {
   u32 aw[8], o[8]; words_from_bytes(aw, a, 8); sc_neg(o, aw); bytes_from_words(out, o, 8);
 }
-void hc_sc_invert(const uint8_t a[32], uint8_t out[32]) {
+extern "C" void hc_sc_invert(const uint8_t a[32], uint8_t out[32]) {
   u32 aw[8], o[8]; words_from_bytes(aw, a, 8); sc_invert(o, aw); bytes_from_words(out, o, 8);
 }
-int hc_sc_is_canonical(const uint8_t a[32]) { u32 aw[8]; words_from_bytes(aw, a, 8); return sc_is_canonical(aw) ? 1 : 0; }
+extern "C" int hc_sc_is_canonical(const uint8_t a[32]) { u32 aw[8]; words_from_bytes(aw, a, 8); return sc_is_canonical(aw) ? 1 : 0; }
 
 // transcript: new(label); append(l1, m1); append_u64(l2, x); challenge(l3) -> 64 bytes; also exports pos
-int hc_merlin(const char* label, const char* l1, const uint8_t* m1, int m1_len, const char* l2, uint64_t x,
+extern "C" int hc_merlin(const char* label, const char* l1, const uint8_t* m1, int m1_len, const char* l2, uint64_t x,
               const char* l3, uint8_t out[64]) {
   Transcript<ArrState> t;
   merlin_init(t, label, (int)strlen(label));
@@ -248,7 +253,8 @@ int hc_merlin(const char* label, const char* l1, const uint8_t* m1, int m1_len, 
 // 9: shared-chain product of ONE term (ge_teeth_mul_multi)   10: every further term of it
 // 11: table of a sum base with ONE member (ge_teeth_tables_sum)   12: every further member of it
 // 13: fixed-base comb over a wide (EG_COMB_BITS_BIG) table
-void hc_op_counts(unsigned long long out[28]) {
+template <int T>
+static void hc_op_counts_t(unsigned long long out[28]) {
   if (!g_base_table.ready) { ge g; ge_generator(g); build_fixed(g_base_table, g); }
   u32 gw[8] = {0x0aaef2e2u, 0x714ebc6au, 0x61a984a8u, 0x5f5100c5u, 0x6a0be358u, 0x8ddd82a5u, 0x4559a6b6u, 0x762d8de0u};
   u32 k[8] = {0x12345678u, 0x9abcdef0u, 0x0fedcba9u, 0x87654321u, 0x11111111u, 0x22222222u, 0x33333333u, 0x04444444u};
@@ -266,10 +272,10 @@ void hc_op_counts(unsigned long long out[28]) {
   m0 = g_fe_mul_count; s0 = g_fe_sq_count;
   u32 o[8]; ristretto_encode(o, acc); snap(4, m0, s0);
   m0 = g_fe_mul_count; s0 = g_fe_sq_count;
-  ArrBase st; ArrTable tmp; ge_teeth_tables_build(st, tmp, p); snap(5, m0, s0);
-  u64 rows[EG_TEETH]; sc_recode_teeth(rows, k);
+  ArrBase st; ArrTable tmp; ge_teeth_tables_build<T>(st, tmp, p); snap(5, m0, s0);
+  u64 rows[T]; sc_recode_teeth<T>(rows, k);
   m0 = g_fe_mul_count; s0 = g_fe_sq_count;
-  ge_teeth_mul(acc, st, rows); snap(6, m0, s0);
+  ge_teeth_mul<T>(acc, st, rows); snap(6, m0, s0);
   // 7: doubled encoder per commitment (prepare + prefix/backward products + finish)   8: the shared field inversion
   m0 = g_fe_mul_count; s0 = g_fe_sq_count;
   fe n, inv, t1, t2; bool zero;
@@ -282,20 +288,20 @@ void hc_op_counts(unsigned long long out[28]) {
   m0 = g_fe_mul_count; s0 = g_fe_sq_count;
   ge_double_encode_finish(o, acc, inv, zero);
   out[14] += g_fe_mul_count - m0; out[15] += g_fe_sq_count - s0;
-  u32 sg[9]; sc_teeth_signs(sg, k);
-  auto column = [&](int, int c, int& idx, bool& neg) { sc_teeth_column([&](int w) { return sg[w]; }, c, idx, neg); };
+  u32 sg[9]; sc_teeth_signs<T>(sg, k);
+  auto column = [&](int, int c, int& idx, bool& neg) { sc_teeth_column<T>([&](int w) { return sg[w]; }, c, idx, neg); };
   auto load = [&](int, int idx, ge_cached& e) { st.load(e, idx); };
   m0 = g_fe_mul_count; s0 = g_fe_sq_count;
-  ge_teeth_mul_multi(acc, 1, column, load); snap(9, m0, s0);
+  ge_teeth_mul_multi<T>(acc, 1, column, load); snap(9, m0, s0);
   m0 = g_fe_mul_count; s0 = g_fe_sq_count;
-  ge_teeth_mul_multi(acc, 2, column, load);
+  ge_teeth_mul_multi<T>(acc, 2, column, load);
   out[20] = g_fe_mul_count - m0 - out[18]; out[21] = g_fe_sq_count - s0 - out[19];
   ArrBase sum_tab;
   auto src = [&](int, int g, ge_cached& e) { st.load(e, g); };
   m0 = g_fe_mul_count; s0 = g_fe_sq_count;
-  ge_teeth_tables_sum(sum_tab, tmp, 1, src); snap(11, m0, s0);
+  ge_teeth_tables_sum<T>(sum_tab, tmp, 1, src); snap(11, m0, s0);
   m0 = g_fe_mul_count; s0 = g_fe_sq_count;
-  ge_teeth_tables_sum(sum_tab, tmp, 2, src);
+  ge_teeth_tables_sum<T>(sum_tab, tmp, 2, src);
   out[24] = g_fe_mul_count - m0 - out[22]; out[25] = g_fe_sq_count - s0 - out[23];
   static ArrNiels wide;
   if (!wide.ready) { ge g; ge_generator(g); wide.bits = EG_COMB_BITS_BIG; build_fixed(wide, g); }
@@ -303,7 +309,7 @@ void hc_op_counts(unsigned long long out[28]) {
   ge_fixed_mul_add(acc, wide, dg8); snap(13, m0, s0);
 }
 // enc([r]G) through a comb of the given window width (the wide tables of large batches use EG_COMB_BITS_BIG)
-void hc_mul_generator_bits(int bits, const uint8_t r[32], uint8_t out[32]) {
+extern "C" void hc_mul_generator_bits(int bits, const uint8_t r[32], uint8_t out[32]) {
   static std::map<int, ArrNiels> tabs;
   ArrNiels& t = tabs[bits];
   if (!t.ready) { ge g; ge_generator(g); t.bits = bits; build_fixed(t, g); }
@@ -317,7 +323,7 @@ void hc_mul_generator_bits(int bits, const uint8_t r[32], uint8_t out[32]) {
 
 // pack / unpack of a field element given as EG_NL raw limbs (any class-1 representation, not only the canonical one): returns 1 when
 // the unpacked element equals the input as a field element; out = its canonical bytes
-int hc_fe_pack_roundtrip(const uint32_t limbs[EG_NL], uint8_t out[32]) {
+extern "C" int hc_fe_pack_roundtrip(const uint32_t limbs[EG_NL], uint8_t out[32]) {
   fe f; for (int i = 0; i < EG_NL; ++i) f.v[i] = limbs[i];
   EG_SETCLS(f, 1.0f);
   u32 w[8], o[8]; fe_pack8(w, f);
@@ -325,11 +331,11 @@ int hc_fe_pack_roundtrip(const uint32_t limbs[EG_NL], uint8_t out[32]) {
   fe_to_words(o, g); bytes_from_words(out, o, 8);
   return fe_eq(f, g) ? 1 : 0;
 }
-void hc_fe_roundtrip(const uint8_t in[32], uint8_t out[32]) {
+extern "C" void hc_fe_roundtrip(const uint8_t in[32], uint8_t out[32]) {
   u32 w[8], o[8]; words_from_bytes(w, in, 8); fe f; fe_from_words(f, w); fe_to_words(o, f); bytes_from_words(out, o, 8);
 }
 // (a*b, a^2, 1/a, a+b, a-b) canonical bytes
-void hc_fe_ops(const uint8_t a[32], const uint8_t b[32], uint8_t out[160]) {
+extern "C" void hc_fe_ops(const uint8_t a[32], const uint8_t b[32], uint8_t out[160]) {
   u32 aw[8], bw[8], o[8]; words_from_bytes(aw, a, 8); words_from_bytes(bw, b, 8);
   fe x, y, r; fe_from_words(x, aw); fe_from_words(y, bw);
   fe_mul(r, x, y); fe_to_words(o, r); bytes_from_words(out, o, 8);
@@ -338,4 +344,8 @@ void hc_fe_ops(const uint8_t a[32], const uint8_t b[32], uint8_t out[160]) {
   fe_add(r, x, y); fe_to_words(o, r); bytes_from_words(out + 96, o, 8);
   fe_sub(r, x, y); fe_to_words(o, r); bytes_from_words(out + 128, o, 8);
 }
-}
+extern "C" int hc_double_mul_generator_teeth(const uint8_t k[32], const uint8_t p_enc[32], const uint8_t r[32], uint8_t out[32]) { return g_teeth == 5 ? hc_double_mul_generator_teeth_t<5>(k, p_enc, r, out) : g_teeth == 7 ? hc_double_mul_generator_teeth_t<7>(k, p_enc, r, out) : hc_double_mul_generator_teeth_t<6>(k, p_enc, r, out); }
+extern "C" int hc_multi_mul_teeth(int n, const uint8_t* ks, const uint8_t* ps, const uint8_t r[32], uint8_t out[32]) { return g_teeth == 5 ? hc_multi_mul_teeth_t<5>(n, ks, ps, r, out) : g_teeth == 7 ? hc_multi_mul_teeth_t<7>(n, ks, ps, r, out) : hc_multi_mul_teeth_t<6>(n, ks, ps, r, out); }
+extern "C" int hc_sum_table_mul(int n, const uint8_t* ps, const uint8_t k[32], const uint8_t r[32], uint8_t out[32]) { return g_teeth == 5 ? hc_sum_table_mul_t<5>(n, ps, k, r, out) : g_teeth == 7 ? hc_sum_table_mul_t<7>(n, ps, k, r, out) : hc_sum_table_mul_t<6>(n, ps, k, r, out); }
+extern "C" int hc_double_mul_generator_halved(const uint8_t k[32], const uint8_t p_enc[32], const uint8_t r[32], uint8_t out[32]) { return g_teeth == 5 ? hc_double_mul_generator_halved_t<5>(k, p_enc, r, out) : g_teeth == 7 ? hc_double_mul_generator_halved_t<7>(k, p_enc, r, out) : hc_double_mul_generator_halved_t<6>(k, p_enc, r, out); }
+extern "C" void hc_op_counts(unsigned long long out[28]) { if (g_teeth == 5) hc_op_counts_t<5>(out); else if (g_teeth == 7) hc_op_counts_t<7>(out); else hc_op_counts_t<6>(out); }

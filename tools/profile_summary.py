@@ -66,7 +66,8 @@ for w in () if TRAFFIC_ONLY else WORKLOADS:
     (PROF / f"{tag}_kernel_stats_{w}.txt").write_text("\n".join(lines) + "\n")
 
 # ---- PMC passes ----------------------------------------------------------------------------------------------------
-want = ["eg::k_eq_table<false>", "eg::k_eq_table<true>", "eg::k_eq_direct", "eg::k_eq_generic", "eg::k_base_tables", "eg::k_sum_tables", "eg::k_encode_batch", "eg::k_decode_points", "eg::k_hash"]
+want = [f"eg::k_eq_table<{m}, {t}>" for m in ("false", "true") for t in (5, 6)] + ["eg::k_eq_direct"] + \
+       [f"eg::{k}<{t}>" for k in ("k_eq_generic", "k_base_tables", "k_sum_tables") for t in (5, 6)] + ["eg::k_encode_batch", "eg::k_decode_points", "eg::k_hash"]
 text = [f"# rocprofv3 --pmc <counter> -- python3 bench.py --steps 1 --warmup 0 --workload W --no-cpu-baseline --no-host-inclusive --no-wire-ingest --no-isolated --ballots {PMC_BALLOTS}   (MI355X)",
         "# separate passes per counter (FETCH_SIZE, WRITE_SIZE; for the single-choice workload also two groups of SQ counters); values are",
         "# summed over the launches of the one step (its chunks x stages).  FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the",
@@ -95,7 +96,7 @@ for w, key in WORKLOADS.items():
     if not found:
         continue
     text.append(f"== workload {w}: {DESCR[w].replace('1M', str(PMC_BALLOTS))}")
-    n_chunks = max(len(launches.get("eg::k_base_tables", ())), 1)          # the table builder runs once per chunk
+    n_chunks = max([len(v) for k, v in launches.items() if k.startswith("eg::k_base_tables")] + [1])          # the table builder runs once per chunk
     per_launch_ballots = PMC_BALLOTS / n_chunks
     ent = {"ballots_per_launch": per_launch_ballots, "chunks_per_step": n_chunks, "kernels": {}}
     for k in want:
