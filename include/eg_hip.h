@@ -296,7 +296,7 @@ int eg_range_decomposition(uint64_t upper_bound, char* buf, size_t cap);
 int eg_plan_describe(int kind, int n_options, uint64_t credits_or_bound, char* buf, size_t cap);
 
 /* ---- measurement hooks (bench.py) ------------------------------------------------------------------------------------------
- * Average duration in milliseconds of the dominant kernel (k_eq_table<false>: the ring equations) over the launches since the last reset,
+ * Average duration in milliseconds of the dominant kernel (k_eq_table<false, T>: the ring equations) over the launches since the last reset,
  * measured with HIP events on the stream the kernel was launched on; launches = number of launches averaged.
  * enable = 2: also run the chunks of a call one after the other on one work set instead of alternating between two streams, so that a
  * launch shares the chip with nothing and its duration is its own (a measurement mode: slower, same results). */

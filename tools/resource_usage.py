@@ -21,8 +21,8 @@ for tu in ("eg_hip", "eg_gen"):
         rows.append((name, *m.groups()[1:]))
 seen, out = set(), []
 out.append(f"# hipcc --offload-arch=gfx950 -O3 -std=c++17 -Rpass-analysis=kernel-resource-usage -c eg_hip.hip eg_gen.hip   (tools/resource_usage.py {tag})")
-out.append("# VGPR/AGPR per lane, scratch bytes per lane, waves per SIMD the allocation admits.  The dominant kernel k_eq_table<false> and the")
-out.append("# table builder k_base_tables run without scratch; round 1's single equation kernel (k_msm_jobs) had 159 VGPR spills / 480 B.")
+out.append("# VGPR/AGPR per lane, scratch bytes per lane, waves per SIMD the allocation admits.  The dominant kernel k_eq_table<false, T> and the")
+out.append("# table builder k_base_tables<T> (T = teeth of the comb) run without scratch; round 1's single equation kernel (k_msm_jobs) had 159 VGPR spills / 480 B.")
 out.append(f"{'kernel':72s} {'SGPR':>5s} {'VGPR':>5s} {'AGPR':>5s} {'scratch':>8s} {'occ':>4s} {'sgpr_spill':>10s} {'vgpr_spill':>10s} {'LDS':>7s}")
 for row in rows:
     if row[0] in seen:
