@@ -114,7 +114,7 @@ struct WsTable {
   }
 };
 // The same workspace, word-interleaved across the lanes of the grid ([entry][quad][lane]): for scratch whose entry index is the SAME
-// in every lane (the five steps of a table's Gray-code walk), so that a wave's access is one coalesced 1-KiB row per quad.
+// in every lane (the steps of a table's Gray-code walk), so that a wave's access is one coalesced 1-KiB row per quad.
 struct WsRows {
   uint4* base;     // ws + global lane
   size_t stride;   // lanes of the grid

@@ -409,12 +409,13 @@ EG_HD void ge_var_mul(ge& acc, TableIO& io, const u32 digits[8]) {
 // ---- variable-base multiplication with a per-base signed comb ("teeth" tables) -----------------------------------------
 // A ring base (R or B of one ciphertext) is multiplied by one challenge per equation of its ring (ring.rs:333-361), and
 // equation j+1 cannot start before equation j is hashed.  The doublings are therefore amortised ACROSS equations with a
-// per-base table, arranged as a signed Lim-Lee comb: with P_j = [2^(43 j)] P, j = 0..5, the table holds
-// the 32 points P_5 +- P_4 +- P_3 +- P_2 +- P_1 +- P_0 (entry index = bitmask of the '+' signs of teeth 0..4), and an odd
-// multiplier k < 2^258 is written with 258 signed bits s_i = +-1 (k = sum s_i 2^i: s_i = 2 bit_(i+1)(k) - 1, s_257 = +1).
-// Column c = (s_c, s_(43+c), .., s_(215+c)) selects +-entry, so [k]P = sum_c 2^c D_c costs 42 doublings + 43 additions
-// (every digit is non-zero: no identity select) instead of 252 + 64 for a fresh ladder; the table costs 215 doublings +
-// 37 additions (Gray-code walk, each step adds +-2 P_j), 32 cached entries = 4 KiB per base and ballot (packed, device_io.cuh).  (Round 1 first
+// per-base table, arranged as a signed Lim-Lee comb of t teeth x c columns (Teeth<T> below; numbers in brackets: 6 x 43): with
+// P_j = [2^(c j)] P, j = 0..t-1, the table holds the 2^(t-1) [32] points P_(t-1) +- .. +- P_1 +- P_0 (entry index = bitmask of the '+'
+// signs of the lower teeth), and an odd multiplier k < 2^(t c) is written with t c [258] signed bits s_i = +-1 (k = sum s_i 2^i:
+// s_i = 2 bit_(i+1)(k) - 1, top sign +1).  Column i = (s_i, s_(c+i), ..) selects +-entry, so [k]P = sum_i 2^i D_i costs c - 1 [42]
+// doublings + c [43] additions (every digit is non-zero: no identity select) instead of 252 + 64 for a fresh ladder; the table costs
+// c (t - 1) [215] doublings + 2^(t-1) + t - 1 [37] additions (Gray-code walk, each step adds +-2 P_j), 128-byte cached entries, packed
+// (device_io.cuh).  (Round 1 first
 // used four radix-16 tables of P, 2^64 P, 2^128 P, 2^192 P: 192 + 28 for the tables but 60 + 64 per product; the comb
 // measured +10 % on 2-equation rings and +23 % on the QV ballot.)  Even multipliers use k + l, which changes the
 // product by the 4-torsion point [l]P only - invisible to the Ristretto encoding, like the halving in sc_halve.
@@ -490,7 +491,7 @@ EG_HD void sc_teeth_next(u64 rows[T], int& idx, bool& neg) {
   neg = !top;
 }
 
-// io: the 32-entry table of this base; tmp: scratch for the five cached points 2 P_j (entries 0..4)
+// io: the table of this base (2^(T-1) entries); tmp: scratch for the T - 1 cached points 2 P_j
 template <int T, class TableIO, class TmpIO>
 EG_HD void ge_teeth_tables_build(TableIO& io, TmpIO& tmp, const ge& p) {
   ge cur = p, sum;
@@ -550,13 +551,13 @@ EG_HD void ge_cached_to_p3(ge& p, const ge_cached& c) {
 }
 
 // Comb table of S = B_1 + .. + B_m when every B_i already has its table: the table is LINEAR in the base (entry g of S is the
-// sum of the members' entries g), so no doubling is needed at all.  Only the six entries where the Gray-code walk of
-// ge_teeth_tables_build flips a tooth for the first time (steps 0, 1, 2, 4, 8, 16) are summed over the members; their differences
-// to the walk's previous entry are the steps +-2 P_j of S, and the other 26 entries follow with one addition each:
+// sum of the members' entries g), so no doubling is needed at all.  Only the T entries where the Gray-code walk of
+// ge_teeth_tables_build flips a tooth for the first time (steps 0, 1, 2, 4, ..) are summed over the members; their differences
+// to the walk's previous entry are the steps +-2 P_j of S, and the other entries follow with one addition each (6 teeth:
 // 6 (m - 1) + 5 + 26 additions against 215 doublings + 37 additions for a table built from S itself, or 252 doublings + 71
-// additions for a ladder over S.  Used for the log-equality proof over the sum of a ballot's ciphertexts (choice.rs:363,
+// additions for a ladder over S).  Used for the log-equality proof over the sum of a ballot's ciphertexts (choice.rs:363,
 // log_equality.rs:160-164), whose two bases are the sums of the ring bases.
-// src(k, g, entry) loads entry g of member k; io: the table of S; tmp: scratch for the five cached steps (entries 0..4).
+// src(k, g, entry) loads entry g of member k; io: the table of S; tmp: scratch for the T - 1 cached steps.
 // (Requesting a member's entry one addition ahead of its use, with the walk re-reading its own output, measured slower:
 // the kernel is bound by the scattered two-line reads themselves, not by their latency.)
 template <int T, class SrcFn, class TableIO, class TmpIO>
@@ -640,7 +641,7 @@ EG_HD void ge_teeth_mul(ge& acc, TableIO& io, u64 rows[T]) {
   }
 }
 
-// acc = sum_t [k_t]P_t for bases that all have teeth tables, with ONE chain of 42 doublings shared by every term (Straus /
+// acc = sum_t [k_t]P_t for bases that all have teeth tables, with ONE chain of c - 1 doublings shared by every term (Straus /
 // interleaved evaluation, the structure dalek uses for vartime_multi_mul, ristretto.rs:139-145): per column one doubling and
 // one addition per term.  column(t, c, idx, neg) yields term t's entry for column c; load(t, idx, entry) fetches it.
 template <int T, class ColumnFn, class LoadFn>

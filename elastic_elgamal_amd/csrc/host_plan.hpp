@@ -212,7 +212,7 @@ struct Plan {
 };
 
 // [a](P_1 + .. + P_m) as m table-backed terms with the same multiplier: the equation kernels evaluate all table-backed terms of
-// an equation on ONE doubling chain (k_eq_table<true>), so a term costs 43 additions, against 252 doublings + 71 additions for a
+// an equation on ONE doubling chain (k_eq_table<true>), so a term costs one addition per column (43 with 6 teeth), against 252 doublings + 71 additions for a
 // ladder over the sum itself.  Used where the reference multiplies a ciphertext that is, component-wise, the sum of ring
 // ciphertexts (mul.rs:207-247 on the vote / credit ciphertexts of a range proof).
 inline void push_sum_terms(Plan& P, std::vector<VarTerm>& out, const std::vector<uint16_t>& slots, ScalarSrc sc) {
@@ -347,7 +347,7 @@ inline Plan build_choice_plan(int n, bool single) {
     uint16_t xg, xk;
     if (n <= 2) {
       // [-c](sum R_k) and [-c](sum B_k - G) = sum [-c]B_k + [c]G over the comb tables the rings need anyway, all terms on one
-      // doubling chain (42 doublings + 43 n additions, against 252 + 71 for a ladder over the sum)
+      // doubling chain (6 teeth: 42 doublings + 43 n additions, against 252 + 71 for a ladder over the sum)
       std::vector<VarTerm> tg, tk;
       push_sum_terms(P, tg, R, c);
       push_sum_terms(P, tk, B, c);
