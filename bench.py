@@ -430,13 +430,10 @@ def main():
     # memory-side bytes per ballot and launch of the dominant kernel, measured by the PMC passes of the last profile round
     traffic_src = None
     try:
-        import hashlib
-        h = hashlib.sha256()
-        for f in sorted((ROOT / "elastic_elgamal_amd" / "csrc").iterdir()):
-            if f.suffix in (".cuh", ".hip", ".hpp", ".h"):
-                h.update(f.name.encode()); h.update(f.read_bytes())
-        tree_hash = h.hexdigest()[:16]
-    except OSError:
+        sys.path.insert(0, str(ROOT / "tools"))
+        from srchash import code_hash                   # comments and white space do not count
+        tree_hash = code_hash(ROOT)
+    except (OSError, ImportError):
         tree_hash = None
     try:
         tj = json.loads(TRAFFIC_JSON.read_text())

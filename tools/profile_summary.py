@@ -27,13 +27,11 @@ DESCR = {"single": "1M single-choice 5-option ballots (BASELINE configs[1])", "m
 
 
 def source_hash() -> str:
-    """sha256 over the device and host sources of the library: ties profiles/traffic.json to the build it was measured on (bench.py
-    prints "traffic_stale": true when the tree it runs from hashes differently)."""
-    h = hashlib.sha256()
-    for f in sorted((ROOT / "elastic_elgamal_amd" / "csrc").iterdir()):
-        if f.suffix in (".cuh", ".hip", ".hpp", ".h"):
-            h.update(f.name.encode()); h.update(f.read_bytes())
-    return h.hexdigest()[:16]
+    """Hash of the device and host sources of the library without comments and white space (tools/srchash.py): ties profiles/traffic.json
+    to the build it was measured on (bench.py prints "traffic_stale": true when the tree it runs from hashes differently)."""
+    sys.path.insert(0, str(ROOT / "tools"))
+    from srchash import code_hash
+    return code_hash(ROOT)
 
 
 def kname(name):
