@@ -412,8 +412,8 @@ static int engine_create(eg_ctx* ctx, eghost::Plan&& plan, const uint8_t pk[32],
   const char* env = getenv("EG_CHUNK");
   // Two work sets whose kernels fill each other's launch tails (profiles/r03_ab_experiments.txt, blocks 3 and 9; M single-choice ballots/s):
   // with 6-tooth tables (57.6 KB per ballot and set) one set of 2^20 ballots 6.06, one set of 2^18 5.81 (-4 %), two sets of 2^18 6.05,
-  // two sets of 2^19 6.13 (+1 %), two sets of 2^17 5.90; with the 5-tooth tables of the choice ballots (33.6 KB) two sets of 2^18 6.28,
-  // of 2^19 6.35.  Default: two sets of 2^19 ballots where that stays within 40 GB (the choice ballots of up to ~6 options: 35 GB),
+  // two sets of 2^19 6.13 (+1 %), two sets of 2^17 5.90; with the 5-tooth tables of the choice ballots (32.3 KB) two sets of 2^18 6.28,
+  // of 2^19 6.35.  Default: two sets of 2^19 ballots where that stays within 40 GB (the choice ballots of up to ~6 options: 34 GB),
   // else of 2^18 (16 options: 44 GB; quadratic voting 5 / 20: 42 GB); EG_CHUNK overrides.
   {
     const size_t per = engine_bytes_per_ballot(e.get()) * (size_t)e->n_sets;
