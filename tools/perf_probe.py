@@ -20,7 +20,7 @@ elif mode == "multi":
     p = eg.ChoiceParams(ctx, pk, 16, False); d = torch.empty(n_total * p.ballot_size, dtype=torch.uint8, device="cuda")
     p.encrypt_batch_device(1, 0, n_total, d.data_ptr(), n_selected=3); ctx.synchronize()
 else:
-    p = eg.QuadraticVotingParams(ctx, pk, 5, 20); d = torch.empty(n_total * p.ballot_size, dtype=torch.uint8, device="cuda")
+    p = eg.QuadraticVotingParams(ctx, pk, 5, int(os.environ.get("EG_PROBE_CREDITS", "20"))); d = torch.empty(n_total * p.ballot_size, dtype=torch.uint8, device="cuda")
     p.encrypt_batch_device(1, 0, n_total, d.data_ptr()); ctx.synchronize()
 st = torch.empty(n_total, dtype=torch.int32, device="cuda")
 ctx.profile_enable(True)
