@@ -113,6 +113,11 @@ def test_plan_shapes(lib_path):
     assert b["jobs"] == 70 + 12 + 2 and b["rules"] == 7
     assert eg.plan_describe("zero")["stride"] == 128 and eg.plan_describe("bool")["stride"] == 160
     assert eg.plan_describe("range", 0, 100)["stride"] == 672
+    # comb shape of the per-ballot tables (host_plan.hpp: plan_teeth): 5 teeth where a table serves two products (rings of two), 6 for the
+    # rings of 3 .. 7 of the range proofs
+    assert a["teeth"] == 5 and c["teeth"] == 5 and eg.plan_describe("single", 150)["teeth"] == 5
+    assert b["teeth"] == 6 and eg.plan_describe("qv", 5, 4)["teeth"] == 6 and eg.plan_describe("range", 0, 100)["teeth"] == 6
+    assert eg.plan_describe("bool")["teeth"] in (5, 6)
 
 
 def test_bench_static_sanity():
