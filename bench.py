@@ -165,6 +165,9 @@ def parse():
     ap.add_argument("--no-isolated", action="store_true",
                     help="skip the extra untimed step that measures the dominant kernel alone on one work set (profile runs: the kernel "
                          "statistics then hold the launches of the warm-up and timed steps only)")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="N > 1 ranks that all use device 0 and exchange through gloo: runs the whole multi-rank path of this file on a box "
+                         "with one GPU (the ranks time-share it: the value means nothing, the JSON line and the tally check do)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even for one rank: exercises the N > 1 code path on a 1-GPU box")
     return ap.parse_args()
@@ -298,6 +301,8 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: N > 1 must be launched with torch.distributed.run, "
                          "one rank per GPU, with --gpus equal to the number of ranks")
+    if args.rehearse_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # one explicit stream for everything: the library's launches, torch's copies and RCCL's collective are ordered on it
@@ -308,7 +313,10 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if args.rehearse_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     ctx = eg.Context(local_rank)
     pk = bytes.fromhex(PUBLIC_KEY_HEX)

@@ -29,10 +29,11 @@ def gather_tallies(local: torch.Tensor) -> torch.Tensor:
     world = dist.get_world_size()
     flat = local.contiguous().view(-1)
     out = torch.empty(world * flat.numel(), dtype=local.dtype, device=local.device)
-    if dist.get_backend() == "gloo":      # CPU tests: gloo has no all_gather_into_tensor for this layout
-        parts = [torch.empty_like(flat) for _ in range(world)]
-        dist.all_gather(parts, flat)
-        out = torch.cat(parts)
+    if dist.get_backend() == "gloo":      # CPU tests, and bench.py's one-GPU rehearsal of N > 1: gloo gathers host tensors
+        host = flat.cpu()
+        parts = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(parts, host)
+        out = torch.cat(parts).to(local.device)
     else:
         dist.all_gather_into_tensor(out, flat)
     return out.view(world, flat.numel())
@@ -41,7 +42,7 @@ def gather_tallies(local: torch.Tensor) -> torch.Tensor:
 def max_over_ranks(seconds: float, device) -> float:
     if not dist.is_initialized() or (dist.get_world_size() == 1 and not os.environ.get("EG_DIST_ALWAYS")):
         return seconds
-    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -49,6 +50,6 @@ def max_over_ranks(seconds: float, device) -> float:
 def sum_over_ranks(value: int, device) -> int:
     if not dist.is_initialized() or (dist.get_world_size() == 1 and not os.environ.get("EG_DIST_ALWAYS")):
         return value
-    t = torch.tensor([value], dtype=torch.int64, device=device)
+    t = torch.tensor([value], dtype=torch.int64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return int(t.item())

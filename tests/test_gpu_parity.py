@@ -1322,6 +1322,39 @@ def test_bench_rccl_leg_in_a_fresh_process():
     assert line["host_inclusive"]["verdicts_match_device_path"] is True
 
 
+@pytest.mark.parametrize("mode", ["weak", "strong"])
+def test_bench_two_ranks_rehearsed_on_one_gpu(mode):
+    """bench.py itself with N = 2, launched the way the driver launches it (python -m torch.distributed.run, one JSON line from rank 0):
+    both ranks use the one GPU of the box and exchange through gloo (--rehearse-one-gpu), so the value means nothing, but every line of the
+    multi-rank path runs - sharding, barriers, max over ranks, the tally all-gather and its check on every rank, the extra isolated step,
+    rank 0 alone printing.  weak: 60 000 ballots per rank; strong: 100 001 ballots split 50 000 / 50 001 (BASELINE configs[4] in small)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    size = ["--ballots", "60000"] if mode == "weak" else ["--total-ballots", "100001"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29700 + os.getpid() % 200), str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--rehearse-one-gpu", "--tampered-percent", "1", *size]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(root))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines                                     # rank 0 alone prints, ONE line
+    line = json.loads(lines[0])
+    total = 120000 if mode == "weak" else 100001
+    assert line["n_gpus"] == 2 and line["scaling"] == mode and line["config"]["total_ballots"] == total
+    assert line["config"]["tally_exchange_ok"] is True
+    assert line["config"]["accepted"] == total - line["config"]["tampered"] and line["config"]["tampered"] > 0
+    assert line["config"]["parallelism"] == "shard2" and line["value"] > 1e4 and line["roofline"]["isolated"]["frac"] > 0
+    assert "cpu_baseline" not in line or line["cpu_baseline"] is None or line["n_gpus"] == 1
+
+
 def test_two_ranks_real_gpu_tallies(eg, ctx, pk, tmp_path):
     """N = 2 with REAL GPU tallies (BASELINE configs[4] in small): two fresh child processes, each initialising the GPU itself (both on
     device 0), form a gloo group; each verifies its shard_range slab of one 200 000-ballot batch (1 % tampered) with the HIP engine,
