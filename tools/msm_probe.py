@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Developer probe: one vartime_multi_mul of n terms, device-resident operands (eg_vartime_multi_mul_batch_device), by n."""
+import sys, time
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch
+import elastic_elgamal_amd as eg
+
+ctx = eg.Context(0)
+grp = eg.Ristretto(ctx)
+L = 2**252 + 27742317777372353535851937790883648493
+big = 1 << 20
+g = torch.Generator(device="cpu"); g.manual_seed(1)
+sc = torch.randint(0, 256, (big, 32), dtype=torch.uint8, generator=g); sc[:, 31] &= 0x0f
+sc = sc.cuda()
+# points: [x]G made on the GPU from the same scalars
+pts = torch.empty(big * 32, dtype=torch.uint8, device="cuda")
+grp_pts = grp.mul_generator(bytes(sc[:4096].cpu().numpy().tobytes()))
+base = torch.frombuffer(bytearray(grp_pts), dtype=torch.uint8).cuda()
+pts = base.repeat(big // 4096)
+out = torch.empty(32, dtype=torch.uint8, device="cuda")
+for n in (1 << 12, 1 << 14, 1 << 16, 1 << 18, 1 << 20):
+    scratch = torch.empty(max(grp.msm_scratch_bytes(1, n), 16), dtype=torch.uint8, device="cuda")
+    for _ in range(2):
+        grp.vartime_multi_mul_device(1, n, sc.data_ptr(), pts.data_ptr(), out.data_ptr(), 0, scratch.data_ptr()); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        grp.vartime_multi_mul_device(1, n, sc.data_ptr(), pts.data_ptr(), out.data_ptr(), 0, scratch.data_ptr())
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 5
+    print(f"{n:8d} terms: {dt * 1e3:8.3f} ms  ({n / dt / 1e6:7.1f} M terms/s)", flush=True)
