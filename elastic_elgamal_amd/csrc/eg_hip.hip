@@ -512,10 +512,36 @@ static int engine_verify_device(Engine* e, size_t n, const void* d_ballots, void
     n_chunks = chunks_for(e->max_cap);
   }
   const size_t even = n_chunks ? ((n + n_chunks - 1) / n_chunks + NT - 1) / NT * NT : 0;
+  // join: the caller's stream continues after both sets; set 1's share of the tally moves into the running tally.  It runs on EVERY
+  // way out once the sets have been forked (the scope guard below): an early return between fork and join (a failed launch, event or
+  // allocation) used to leave the caller's stream ahead of work still queued on the sets' streams - the caller would then free or
+  // re-use buffers those kernels still write, and set 1's accumulator would carry a stale share into the next call.
+  bool forked = false, joined = false;
+  auto join = [&]() -> hipError_t {
+    joined = true;
+    hipError_t first = hipSuccess;
+    for (int k = 0; k < 2; ++k) {
+      hipError_t he = hipEventRecord(e->set[k].done, e->set[k].stream);
+      if (he == hipSuccess) he = hipStreamWaitEvent(s, e->set[k].done, 0);
+      if (he != hipSuccess && first == hipSuccess) first = he;
+    }
+    const int ns = (int)P.tally_slots.size();
+    if (ns && !(flags & VD_KEEP_SET_TALLY)) {
+      hipLaunchKernelGGL(k_tally_add_points, dim3(blocks_of((size_t)ns)), dim3(NT), 0, s, e->set[1].tally, ns, e->set[0].tally);
+      hipLaunchKernelGGL(k_tally_init, dim3(blocks_of((size_t)ns)), dim3(NT), 0, s, e->set[1].tally, ns);
+    }
+    return first;
+  };
+  ScopeExit rejoin{[&]() {
+    if (!forked || joined) return;
+    if (join() != hipSuccess) (void)hipDeviceSynchronize();     // the streams could not even be tied together: drain the device instead
+  }};
   if (two) {                 // fork: both work sets start after whatever the caller's stream holds so far
     HIPCHK(hipEventRecord(e->fork, s));
+    forked = true;
     for (int k = 0; k < 2; ++k) HIPCHK(hipStreamWaitEvent(e->set[k].stream, e->fork, 0));
   }
+  const bool inject_failure = two && getenv("EG_TEST_FAIL_AFTER_FORK") != nullptr;     // test knob (tests/test_gpu_parity.py): fail with work queued
   const int msm_blocks = ctx->msm_blocks / (two ? 2 : 1);
   size_t chunk = 0;
   for (size_t off = 0; off < n; off += even, ++chunk) {
@@ -577,22 +603,13 @@ static int engine_verify_device(Engine* e, size_t n, const void* d_ballots, void
                            st.inst_first, st.inst_count);
     }
     hipLaunchKernelGGL(k_status, dim3((cn + NT - 1) / NT), dim3(NT), 0, cs, B, e->d_rules, (int)P.rules.size());
+    if (inject_failure && chunk == 0) return fail(EG_ERR_HIP, "injected failure between fork and join (EG_TEST_FAIL_AFTER_FORK)");
     if (P.tally_slots.empty()) continue;
     const int G = std::min<int>(e->tally_blocks, (int)((cn + NT - 1) / NT));
     hipLaunchKernelGGL(k_tally_partial, dim3(G, (unsigned)P.tally_slots.size()), dim3(NT), 0, cs, B, e->d_tally_slots, w.partial);
     hipLaunchKernelGGL(k_tally_final, dim3((unsigned)P.tally_slots.size()), dim3(NT), 0, cs, w.partial, G, w.tally);
   }
-  if (two) {                 // join: the caller's stream continues after both sets; set 1's share of the tally moves into the running tally
-    for (int k = 0; k < 2; ++k) {
-      HIPCHK(hipEventRecord(e->set[k].done, e->set[k].stream));
-      HIPCHK(hipStreamWaitEvent(s, e->set[k].done, 0));
-    }
-    const int ns = (int)P.tally_slots.size();
-    if (ns && !(flags & VD_KEEP_SET_TALLY)) {
-      hipLaunchKernelGGL(k_tally_add_points, dim3(blocks_of((size_t)ns)), dim3(NT), 0, s, e->set[1].tally, ns, e->set[0].tally);
-      hipLaunchKernelGGL(k_tally_init, dim3(blocks_of((size_t)ns)), dim3(NT), 0, s, e->set[1].tally, ns);
-    }
-  }
+  if (two) HIPCHK(join());
   if ((rc = prof_end(ctx, s, all_idx))) return rc;
   HIPCHK(hipGetLastError());
   return EG_OK;
@@ -1276,6 +1293,82 @@ int eg_qv_tally_reset_async(eg_qv_params* p, void* stream) { EG_LOCK_P(p); retur
 int eg_qv_tally_encode(eg_qv_params* p, uint8_t* out) { EG_LOCK_P(p);
   if (!p || !out) return fail(EG_ERR_BAD_ARG, "bad argument");
   return engine_tally_encode(p->eng, out);
+}
+
+// ---- batch tier, several GPUs in ONE process (the `device_mask` of the batch entry; examples/voting.rs:179-213 is one
+// single-threaded host process) ------------------------------------------------------------------------------------------------
+// per_device[d] is a params object of the same election created on its own context (normally one context per GPU).  The batch is
+// cut into contiguous slabs, slab d = [n d / n_dev, n (d + 1) / n_dev) (the split of elastic_elgamal_amd/distributed.py:
+// shard_range), and one host thread per params object runs the ordinary host entry on its slab: its own device, streams, uploads and
+// running tally.  The per-slab tallies (64 n_options bytes each) are merged on the host side of the ABI with the element addition
+// of the primitive tier on the first context - in one process there is nothing for RCCL to do.
+template <class Params, class VerifyFn>
+static int verify_batch_multi(Params* const* per_device, int n_dev, size_t n, const uint8_t* ballots, uint32_t* status, uint8_t* tally_out,
+                              VerifyFn verify) {
+  if (!per_device || n_dev < 1 || n_dev > 64 || (n && (!ballots || !status))) return fail(EG_ERR_BAD_ARG, "bad argument");
+  for (int d = 0; d < n_dev; ++d) {
+    if (!per_device[d]) return fail(EG_ERR_BAD_ARG, "null params object");
+    for (int k = 0; k < d; ++k)
+      if (per_device[k] == per_device[d]) return fail(EG_ERR_BAD_ARG, "the same params object given twice: one object (and context) per slab");
+    if (per_device[d]->eng->plan.stride != per_device[0]->eng->plan.stride || per_device[d]->n_options != per_device[0]->n_options)
+      return fail(EG_ERR_BAD_ARG, "params objects of different elections");
+  }
+  const size_t stride = per_device[0]->eng->plan.stride;
+  const size_t tally_bytes = (size_t)per_device[0]->eng->plan.tally_slots.size() * 32;
+  std::vector<std::vector<uint8_t>> tallies(n_dev, std::vector<uint8_t>(tally_bytes));
+  std::vector<int> rcs(n_dev, EG_OK);
+  std::vector<std::string> errs(n_dev);
+  auto work = [&](int d) {
+    const size_t b = n * (size_t)d / (size_t)n_dev, e = n * (size_t)(d + 1) / (size_t)n_dev;
+    rcs[d] = verify(per_device[d], e - b, ballots + b * stride, status + b, tally_out ? tallies[d].data() : nullptr);
+    if (rcs[d]) errs[d] = g_err;          // eg_last_error is per thread: carry the text over to the caller's
+  };
+  {
+    std::vector<std::thread> threads;
+    for (int d = 1; d < n_dev; ++d) threads.emplace_back(work, d);
+    work(0);
+    for (auto& t : threads) t.join();
+  }
+  for (int d = 0; d < n_dev; ++d)
+    if (rcs[d]) return fail(rcs[d], "slab " + std::to_string(d) + " of " + std::to_string(n_dev) + ": " + errs[d]);
+  if (tally_out && tally_bytes) {
+    memcpy(tally_out, tallies[0].data(), tally_bytes);
+    std::vector<uint8_t> ok(tally_bytes / 32);
+    for (int d = 1; d < n_dev; ++d) {
+      TRY(eg_point_add_batch(per_device[0]->eng->ctx, tally_bytes / 32, tally_out, tallies[d].data(), 0, tally_out, ok.data()));
+      for (uint8_t o : ok) if (!o) return fail(EG_ERR_HIP, "a slab's tally does not decode");
+    }
+  }
+  return EG_OK;
+}
+// sum of the RUNNING tallies of the params objects (each keeps the tally of the slabs it verified)
+template <class Params, class EncodeFn>
+static int tally_encode_multi(Params* const* per_device, int n_dev, uint8_t* out, EncodeFn encode) {
+  if (!per_device || n_dev < 1 || n_dev > 64 || !out) return fail(EG_ERR_BAD_ARG, "bad argument");
+  for (int d = 0; d < n_dev; ++d) if (!per_device[d]) return fail(EG_ERR_BAD_ARG, "null params object");
+  const size_t tally_bytes = (size_t)per_device[0]->eng->plan.tally_slots.size() * 32;
+  std::vector<uint8_t> t(tally_bytes), ok(tally_bytes / 32 + 1);
+  TRY(encode(per_device[0], out));
+  for (int d = 1; d < n_dev; ++d) {
+    if ((size_t)per_device[d]->eng->plan.tally_slots.size() * 32 != tally_bytes) return fail(EG_ERR_BAD_ARG, "params objects of different elections");
+    TRY(encode(per_device[d], t.data()));
+    TRY(eg_point_add_batch(per_device[0]->eng->ctx, tally_bytes / 32, out, t.data(), 0, out, ok.data()));
+  }
+  return EG_OK;
+}
+int eg_verify_choice_batch_multi(eg_choice_params* const* per_device, int n_dev, size_t n, const uint8_t* ballots, uint32_t* status,
+                                 uint8_t* tally_out) {
+  return verify_batch_multi(per_device, n_dev, n, ballots, status, tally_out, eg_verify_choice_batch);
+}
+int eg_verify_qv_batch_multi(eg_qv_params* const* per_device, int n_dev, size_t n, const uint8_t* ballots, uint32_t* status,
+                             uint8_t* tally_out) {
+  return verify_batch_multi(per_device, n_dev, n, ballots, status, tally_out, eg_verify_qv_batch);
+}
+int eg_choice_tally_encode_multi(eg_choice_params* const* per_device, int n_dev, uint8_t* out) {
+  return tally_encode_multi(per_device, n_dev, out, eg_choice_tally_encode);
+}
+int eg_qv_tally_encode_multi(eg_qv_params* const* per_device, int n_dev, uint8_t* out) {
+  return tally_encode_multi(per_device, n_dev, out, eg_qv_tally_encode);
 }
 
 // ---- PublicKey::verify_zero / verify_bool / verify_range in batches ---------------------------------------

@@ -200,6 +200,23 @@ int eg_qv_tally_add(eg_qv_params*, const uint8_t* in);
 int eg_qv_tally_reset_async(eg_qv_params*, void* stream);
 int eg_qv_tally_encode_device(eg_qv_params*, void* d_out, void* stream);
 
+/* ---- batch tier on several GPUs of ONE process (SURVEY.md 8b `device_mask`; the reference's host is one single-threaded process,
+ * examples/voting.rs:179-213) -----------------------------------------------------------------------------------------------------
+ * per_device[d], d < n_dev: params objects of the SAME election, each created on its own context (eg_init(d, ..): one per GPU; two
+ * contexts on one GPU work too).  The batch is cut into contiguous slabs - slab d = ballots [n d / n_dev, n (d + 1) / n_dev) - and one
+ * host thread per params object inside the library runs eg_verify_*_batch on its slab (its own device, streams, uploads; pin the
+ * ballots with hipHostRegister / hipHostMalloc for full upload speed).  status: n words, in ballot order.  Every params object
+ * adds its slab to its OWN running tally; tally_out (may be NULL) receives the tally of this call's whole batch, the slabs' tallies
+ * merged with the element addition of the primitive tier - the in-process counterpart of the RCCL all-gather of the one-process-per-GPU
+ * path (examples/tally_exchange.cpp).  eg_*_tally_encode_multi = the sum of the running tallies.  An error in any slab fails the call
+ * (eg_last_error names the slab); verdicts of other slabs may have been written. */
+int eg_verify_choice_batch_multi(eg_choice_params* const* per_device, int n_dev, size_t n, const uint8_t* ballots, uint32_t* status,
+                                 uint8_t* tally_out);
+int eg_verify_qv_batch_multi(eg_qv_params* const* per_device, int n_dev, size_t n, const uint8_t* ballots, uint32_t* status,
+                             uint8_t* tally_out);
+int eg_choice_tally_encode_multi(eg_choice_params* const* per_device, int n_dev, uint8_t* out /* n_options*64 */);
+int eg_qv_tally_encode_multi(eg_qv_params* const* per_device, int n_dev, uint8_t* out /* n_options*64 */);
+
 /* ---- batch tier: single-ciphertext proofs --------------------------------------------------------------
  * PublicKey::verify_zero (keys/impls.rs:59-69)   item = ciphertext(64) || challenge || response              128 B
  * PublicKey::verify_bool (keys/impls.rs:100-112) item = ciphertext(64) || e0 || s0 || s1                     160 B

@@ -14,6 +14,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -o tools/ubench/valu_rates tools/ubench/valu_rates.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <cstdint>
 #include <vector>
@@ -101,6 +102,37 @@ KERNEL32(cndmask, I_cndmask)
 #define I_mov(n)          "v_mov_b32 %" #n ", %16\n\t"
 KERNEL32(cndmask_e64, I_cndmask_e64)
 KERNEL32(bfi, I_bfi)
+
+// Round 4: is the 22.9-cycle v_cndmask_b32 (VOP2, vcc) row real?  Variants: vcc set by an s_mov_b64 before the loop,
+// the same select in VOP3 encoding reading vcc, a v_cmp in every block of 16, selects interleaved with plain adds, selects without a
+// dependency chain, and the mask arithmetic that could replace a select.
+#define KERNEL32P(NAME, I, PRE)                                                                    \
+__global__ void __launch_bounds__(256) k_##NAME(uint32_t* out, Stamp* st, uint32_t a0, uint32_t b0, int iters) { \
+  uint32_t r[CHAINS];                                                                              \
+  uint32_t a = a0 + threadIdx.x, b = b0 ^ threadIdx.x; const uint32_t s = a0 | 3u;                 \
+  const u64 m64 = 0x5555aaaa3333ccccull * (u64)(a0 | 1u);                                          \
+  for (int c = 0; c < CHAINS; ++c) r[c] = a * (c + 1) + b;                                         \
+  PROLOGUE                                                                                         \
+  for (int it = 0; it < iters; ++it) {                                                             \
+    _Pragma("unroll") for (int u = 0; u < UNROLL; ++u) {                                           \
+      asm volatile(PRE R16(I) : OUT16(r) : "v"(a), "v"(b), "s"(s), "s"(m64) : "vcc");              \
+    }                                                                                              \
+  }                                                                                                \
+  EPILOGUE                                                                                         \
+  uint32_t x = 0;                                                                                  \
+  for (int c = 0; c < CHAINS; ++c) x ^= r[c];                                                      \
+  out[blockIdx.x * blockDim.x + threadIdx.x] = x;                                                  \
+}
+#define I_cndmask_e64_vcc(n) "v_cndmask_b32_e64 %" #n ", %" #n ", %16, vcc\n\t"
+#define I_cndmask_nodep(n)   "v_cndmask_b32 %" #n ", %16, %17, vcc\n\t"
+#define I_cnd_add_mix(n)     "v_cndmask_b32 %" #n ", %" #n ", %16, vcc\n\tv_add_u32 %" #n ", %" #n ", %17\n\t"
+#define I_xor_and_xor(n)     "v_xor_b32 %" #n ", %" #n ", %16\n\tv_and_b32 %" #n ", %" #n ", %17\n\tv_xor_b32 %" #n ", %" #n ", %16\n\t"
+KERNEL32P(cndmask_smov, I_cndmask, "s_mov_b64 vcc, %19\n\t")
+KERNEL32P(cndmask_cmp, I_cndmask, "v_cmp_lt_u32 vcc, %16, %17\n\t")
+KERNEL32P(cndmask_e64_vcc, I_cndmask_e64_vcc, "s_mov_b64 vcc, %19\n\t")
+KERNEL32P(cndmask_nodep, I_cndmask_nodep, "s_mov_b64 vcc, %19\n\t")
+KERNEL32P(cnd_add_mix, I_cnd_add_mix, "s_mov_b64 vcc, %19\n\t")
+KERNEL32(xor_and_xor, I_xor_and_xor)
 KERNEL32(xor_b32, I_xor)
 KERNEL32(sub_u32, I_sub)
 KERNEL32(lshlrev_b32, I_lshlrev)
@@ -163,7 +195,10 @@ int main(int argc, char** argv) {
     {"v_mad_u32_u24 v,v,v", k_mad_u32_u24_vvv, 1}, {"v_mad_u32_u24 v,19,v", k_mad_u32_u24_vks, 1}, {"v_mul_u32_u24 (VOP2)", k_mul_u32_u24, 1},
     {"v_alignbit_b32 v,v,13", k_alignbit_vvk, 1}, {"v_lshl_add_u32 v,4,v", k_lshl_add_u32, 1}, {"v_and_or_b32 v,v,v", k_and_or_vvv, 1},
     {"v_bfe_u32 v,3,26", k_bfe_u32, 1}, {"v_cndmask_b32 vcc (VOP2)", k_cndmask, 1},
-    {"v_cndmask_b32_e64 v,v,s[2]", k_cndmask_e64, 1}, {"v_bfi_b32 v,v,v", k_bfi, 1}, {"v_xor_b32 (VOP2)", k_xor_b32, 1}, {"v_sub_u32 (VOP2)", k_sub_u32, 1},
+    {"v_cndmask_b32_e64 v,v,s[2]", k_cndmask_e64, 1},
+    {"v_cndmask_b32 vcc<-s_mov per 16", k_cndmask_smov, 1}, {"v_cndmask_b32 vcc<-v_cmp per 16", k_cndmask_cmp, 1},
+    {"v_cndmask_b32_e64 v,v,vcc", k_cndmask_e64_vcc, 1}, {"v_cndmask_b32 vcc, no dep chain", k_cndmask_nodep, 1},
+    {"v_cndmask_b32 + v_add_u32 pairs", k_cnd_add_mix, 2}, {"v_xor + v_and + v_xor", k_xor_and_xor, 3}, {"v_bfi_b32 v,v,v", k_bfi, 1}, {"v_xor_b32 (VOP2)", k_xor_b32, 1}, {"v_sub_u32 (VOP2)", k_sub_u32, 1},
     {"v_lshlrev_b32 (VOP2)", k_lshlrev_b32, 1}, {"v_mov_b32 (VOP1)", k_mov_b32, 1}, {"v_add_co + v_addc_co", k_addc_pair, 2},
     {"v_mad_u64_u32 v,v,v64", k_mad_u64_u32_vvv, 1}, {"v_mad_u64_u32 v,s,v64", k_mad_u64_u32_vsv, 1}, {"v_mad_u64_u32 v,19,v64", k_mad_u64_u32_vkv, 1},
     {"v_fma_f64", k_fma_f64, 1}, {"v_lshl_add_u64", k_lshl_add_u64, 1}, {"v_lshrrev_b64", k_lshrrev_b64, 1}, {"v_pk_fma_f32", k_pk_fma_f32, 1},
@@ -219,7 +254,9 @@ int main(int argc, char** argv) {
   const int wlist[] = {1, 2, 4, 8};
   for (int w : wlist) printf(" | w/SIMD=%d: cyc  T-op/s (wave cyc, GHz)", w);
   printf("\n");
+  const char* only = argc > 2 ? argv[2] : nullptr;         // optional: run only the rows whose name contains this substring
   for (auto& e : es) {
+    if (only && !strstr(e.name, only)) continue;
     printf("%-30s", e.name);
     for (int w : wlist) {
       const int blocks = cus * w;          // 256 threads = one wave per SIMD; w blocks per CU
