@@ -134,6 +134,10 @@ def _load() -> C.CDLL:
         "eg_verify_qv_batch_device": (C.c_int, [vp, sz, vp, vp, vp]),
         "eg_qv_tally_reset": (C.c_int, [vp]),
         "eg_qv_tally_encode": (C.c_int, [vp, cp]),
+        "eg_verify_choice_batch_multi": (C.c_int, [C.POINTER(vp), C.c_int, sz, vp, vp, vp]),
+        "eg_verify_qv_batch_multi": (C.c_int, [C.POINTER(vp), C.c_int, sz, vp, vp, vp]),
+        "eg_choice_tally_encode_multi": (C.c_int, [C.POINTER(vp), C.c_int, cp]),
+        "eg_qv_tally_encode_multi": (C.c_int, [C.POINTER(vp), C.c_int, cp]),
         "eg_choice_tally_reset_async": (C.c_int, [vp, vp]),
         "eg_choice_tally_encode_device": (C.c_int, [vp, vp, vp]),
         "eg_qv_tally_reset_async": (C.c_int, [vp, vp]),
@@ -439,6 +443,36 @@ class Ristretto:
                                  d_ok: int = 0, stream: int = 0):
         """The multi-scalar multiplication on device buffers, asynchronous on `stream` (eg_vartime_multi_mul_batch_device)."""
         _check(_load().eg_vartime_multi_mul_batch_device(self.ctx._h, n, terms, d_scalars, d_points, d_r, d_scratch, d_out, d_ok, stream))
+
+
+def verify_batch_multi(per_device, ballots: bytes, with_tally: bool = True):
+    """``eg_verify_*_batch_multi``: one batch over several params objects of the same election, each on its own context (normally one
+    per GPU of the process): contiguous slabs, one host thread per object inside the library, tallies merged in the library.
+    Returns (status words in ballot order, tally of this batch or None)."""
+    per_device = list(per_device)
+    p0 = per_device[0]
+    if any(type(p) is not type(p0) for p in per_device):
+        raise ValueError("params objects of different kinds")
+    n = len(ballots) // p0.ballot_size
+    if n * p0.ballot_size != len(ballots):
+        raise ValueError("ballots is not a whole number of packed ballots")
+    arr = (C.c_void_p * len(per_device))(*[p._h for p in per_device])
+    st = (C.c_uint32 * max(n, 1))()
+    tally = C.create_string_buffer(64 * p0.n_options) if with_tally else None
+    buf = (C.c_char * max(len(ballots), 1)).from_buffer_copy(ballots or b"\0")
+    fn = getattr(_load(), f"eg_verify_{p0._prefix}_batch_multi")
+    _check(fn(arr, len(per_device), n, buf, st, tally))
+    return list(st[:n]), (tally.raw if with_tally else None)
+
+
+def tally_encode_multi(per_device) -> bytes:
+    """Sum of the running tallies of several params objects of one election (``eg_*_tally_encode_multi``)."""
+    per_device = list(per_device)
+    p0 = per_device[0]
+    arr = (C.c_void_p * len(per_device))(*[p._h for p in per_device])
+    out = C.create_string_buffer(64 * p0.n_options)
+    _check(getattr(_load(), f"eg_{p0._prefix}_tally_encode_multi")(arr, len(per_device), out))
+    return out.raw
 
 
 class _BatchParams:

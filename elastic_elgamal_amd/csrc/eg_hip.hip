@@ -1302,6 +1302,7 @@ int eg_qv_tally_encode(eg_qv_params* p, uint8_t* out) { EG_LOCK_P(p);
 // shard_range), and one host thread per params object runs the ordinary host entry on its slab: its own device, streams, uploads and
 // running tally.  The per-slab tallies (64 n_options bytes each) are merged on the host side of the ABI with the element addition
 // of the primitive tier on the first context - in one process there is nothing for RCCL to do.
+extern "C++" {
 template <class Params, class VerifyFn>
 static int verify_batch_multi(Params* const* per_device, int n_dev, size_t n, const uint8_t* ballots, uint32_t* status, uint8_t* tally_out,
                               VerifyFn verify) {
@@ -1356,6 +1357,7 @@ static int tally_encode_multi(Params* const* per_device, int n_dev, uint8_t* out
   }
   return EG_OK;
 }
+}  // extern "C++"
 int eg_verify_choice_batch_multi(eg_choice_params* const* per_device, int n_dev, size_t n, const uint8_t* ballots, uint32_t* status,
                                  uint8_t* tally_out) {
   return verify_batch_multi(per_device, n_dev, n, ballots, status, tally_out, eg_verify_choice_batch);

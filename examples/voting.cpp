@@ -1,23 +1,71 @@
-// voting.cpp -- the reference's examples/voting.rs:179-213 (`Args::vote`) on the GPU backend, in C++ on top of the
-// C ABI: talliers' key -> voters create ballots -> verify every ballot -> homomorphic totals -> decrypt and
-// compare with the expected counts.  Threshold sharing of the key (examples/voting.rs:105-120) is out of scope
-// (SURVEY 2); a single key pair stands in for the shared key.
+// voting.cpp -- the reference's examples/voting.rs on the GPU backend, in C++ on top of the C ABI:
+//   `Args::vote`            (examples/voting.rs:179-213)  ./voting [votes] [options] [seed]
+//   `Args::quadratic_vote`  (examples/voting.rs:219-269)  ./voting --qv [votes] [options] [credits] [seed]
+// talliers' key -> voters create ballots from their own choices -> verify every ballot -> homomorphic totals -> decrypt and
+// compare with the EXPECTED totals the voters' choices add up to.  Threshold sharing of the key (examples/voting.rs:105-120) is out
+// of scope; a single key pair stands in for the shared key (tests/test_gpu_parity.py::test_threshold_tally_end_to_end
+// runs the 7-of-10 tally stage).  With --devices N the batch goes through the in-process multi-GPU entry
+// (eg_verify_*_batch_multi) over N contexts on the visible GPUs (all on GPU 0 when fewer are visible).
 //
 //   g++ -std=c++17 -Iinclude examples/voting.cpp -Lelastic_elgamal_amd -leg_hip -Wl,-rpath,$PWD/elastic_elgamal_amd -o voting
-//   ./voting [votes=1000] [options=5] [seed=1]
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <string>
 
 #include "elastic_elgamal_hip.hpp"
 
 using namespace elastic_elgamal_hip;
 
+// the voters' randomness (rand::rng() in the reference): splitmix64, so that a run is reproducible from its seed
+struct Rng {
+  uint64_t s;
+  uint64_t next() { uint64_t z = (s += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+  uint64_t below(uint64_t n) { return next() % n; }
+  bool chance(double p) { return (double)(next() >> 11) / 9007199254740992.0 < p; }
+};
+
+// Self::tally (examples/voting.rs:122-177) with one key: decrypt each total = blinded - [sk]random, look it up in
+// DiscreteLogTable::new(0..=max), compare with the expected totals
+static bool tally(const Context& ctx, const Ristretto& group, const Scalar& sk, const std::vector<Ciphertext>& totals,
+                  const std::vector<uint64_t>& expected, uint64_t max_value) {
+  std::vector<uint64_t> range(max_value + 1);
+  for (uint64_t m = 0; m <= max_value; ++m) range[m] = m;
+  const DiscreteLogTable lookup(ctx, range);
+  bool ok = true;
+  for (size_t k = 0; k < totals.size(); ++k) {
+    const Element dh = group.mul(totals[k].random_element, sk);                 // Element * &Scalar
+    const Element m_g = group.sub(totals[k].blinded_element, dh);
+    const std::optional<uint64_t> found = lookup.get(m_g);
+    if (!found) { printf("  variant #%zu: decryption failed\n", k + 1); return false; }
+    printf("  variant #%zu decrypted tally: %llu (expected %llu)\n", k + 1, (unsigned long long)*found, (unsigned long long)expected[k]);
+    ok = ok && *found == expected[k];
+  }
+  return ok;
+}
+
 int main(int argc, char** argv) {
-  const size_t votes = argc > 1 ? strtoul(argv[1], nullptr, 10) : 1000;
-  const size_t options = argc > 2 ? strtoul(argv[2], nullptr, 10) : 5;
-  const uint64_t seed = argc > 3 ? strtoull(argv[3], nullptr, 10) : 1;
-  Context ctx(0);
+  bool qv = false;
+  int devices = 1;
+  std::vector<std::string> pos;
+  for (int i = 1; i < argc; ++i) {
+    if (!strcmp(argv[i], "--qv")) qv = true;
+    else if (!strcmp(argv[i], "--devices") && i + 1 < argc) devices = atoi(argv[++i]);
+    else pos.push_back(argv[i]);
+  }
+  auto arg = [&](size_t k, uint64_t dflt) { return k < pos.size() ? strtoull(pos[k].c_str(), nullptr, 10) : dflt; };
+  const size_t votes = (size_t)arg(0, 1000), options = (size_t)arg(1, 5);
+  const uint64_t credits = qv ? arg(2, 20) : 0, seed = arg(qv ? 3 : 2, 1);
+  if (devices < 1 || devices > 16) { printf("--devices must be in 1..16\n"); return 2; }
+
+  // one context per device slot; slot d uses GPU d when the process sees that many, else GPU 0
+  std::vector<std::unique_ptr<Context>> ctxs;
+  for (int d = 0; d < devices; ++d) {
+    try { ctxs.push_back(std::make_unique<Context>(d)); }
+    catch (const Error&) { if (d == 0) throw; ctxs.push_back(std::make_unique<Context>(0)); }
+  }
+  const Context& ctx = *ctxs[0];
   Ristretto group{ctx};
 
   // Keypair::generate: secret scalar from 64 seed-derived bytes, public key = [sk]G
@@ -25,31 +73,54 @@ int main(int argc, char** argv) {
   for (size_t i = 0; i < 64; ++i) wide[i] = (uint8_t)((seed * 0x9E3779B97F4A7C15ull >> (i % 8 * 8)) + 31 * i);
   const Scalar sk = group.scalar_from_random_bytes(wide);
   const Element pk = group.mul_generator(sk);
+  Rng rng{seed ^ 0xC0FFEEull};
+  std::vector<uint64_t> expected(options, 0);
+  bool ok = true;
 
-  ChoiceParams params = ChoiceParams::single(ctx, pk, options);
-  Bytes ballots = params.encrypt_batch(seed, 0, votes);          // EncryptedChoice::single(&params, choice, rng) per voter
-  if (votes > 3) ballots[3 * params.ballot_size() + 64 * options + 40] ^= 1;   // one forged ballot must be rejected
-
-  auto verdict = params.verify_batch(ballots);                     // encrypted.verify(&params) for every voter
-  printf("%zu of %zu ballots verified\n", verdict.accepted(), votes);
-  for (size_t i = 0; i < verdict.results.size(); ++i)
-    if (verdict.results[i]) printf("  voter #%zu rejected: %s\n", i + 1, verdict.results[i]->to_string().c_str());
-
-  // tally(): decrypt each total = blinded - [sk]random, then look the element up in DiscreteLogTable::new(0..=votes)
-  // (examples/voting.rs:130-131,166-172; the table's products come from the GPU in one batch)
-  std::vector<uint64_t> range(votes + 1);
-  for (uint64_t m = 0; m <= votes; ++m) range[m] = m;
-  const DiscreteLogTable lookup(ctx, range);
-  size_t sum = 0;
-  for (size_t k = 0; k < options; ++k) {
-    const Element dh = group.vartime_multi_mul({sk}, {verdict.totals[k].random_element});
-    const Element m_g = group.sub(verdict.totals[k].blinded_element, dh);
-    const std::optional<uint64_t> found = lookup.get(m_g);
-    if (!found) { printf("decryption failed\n"); return 1; }
-    printf("  option #%zu: %llu votes\n", k + 1, (unsigned long long)*found);
-    sum += (size_t)*found;
+  if (!qv) {
+    std::vector<std::unique_ptr<ChoiceParams>> params;
+    for (auto& c : ctxs) params.push_back(std::make_unique<ChoiceParams>(ChoiceParams::single(*c, pk, options)));
+    std::vector<size_t> choices(votes);
+    for (auto& c : choices) c = (size_t)rng.below(options);                            // rng.random_range(0..options_count)
+    Bytes ballots = params[0]->encrypt_single_choices(seed, 0, choices);               // EncryptedChoice::single(&params, choice, rng)
+    const size_t forged = votes > 3 ? 3 : votes;                                       // one forged ballot must be rejected
+    if (forged < votes) ballots[forged * params[0]->ballot_size() + 64 * options + 40] ^= 1;
+    for (size_t i = 0; i < votes; ++i) if (i != forged) expected[choices[i]] += 1;
+    std::vector<const ChoiceParams*> per;
+    for (auto& p : params) per.push_back(p.get());
+    auto verdict = devices > 1 ? verify_batch_multi(per, ballots) : params[0]->verify_batch(ballots);   // encrypted.verify(&params)
+    printf("%zu of %zu ballots verified\n", verdict.accepted(), votes);
+    for (size_t i = 0; i < verdict.results.size(); ++i)
+      if (verdict.results[i]) printf("  voter #%zu rejected: %s\n", i + 1, verdict.results[i]->to_string().c_str());
+    ok = verdict.accepted() == votes - (forged < votes ? 1 : 0) && tally(ctx, group, sk, verdict.totals, expected, votes);
+  } else {
+    std::vector<std::unique_ptr<QuadraticVotingParams>> params;
+    for (auto& c : ctxs) params.push_back(std::make_unique<QuadraticVotingParams>(*c, pk, options, credits));
+    // the reference's vote draw (examples/voting.rs:235-244): add one vote to a random option with probability 0.8 while the credit lasts
+    std::vector<uint32_t> all(votes * options, 0u);
+    for (size_t i = 0; i < votes; ++i) {
+      uint32_t* v = &all[i * options];
+      while (rng.chance(0.8)) {
+        const size_t k = (size_t)rng.below(options);
+        uint64_t credit = 0;
+        for (size_t j = 0; j < options; ++j) { const uint64_t x = v[j] + (j == k ? 1u : 0u); credit += x * x; }
+        if (credit > credits) break;
+        v[k] += 1;
+      }
+    }
+    Bytes ballots = params[0]->encrypt_votes_batch(seed, 0, all);                      // QuadraticVotingBallot::new(&vote_params, &votes, rng)
+    const size_t forged = votes > 3 ? 3 : votes;
+    if (forged < votes) ballots[forged * params[0]->ballot_size() + params[0]->ballot_size() - 40] ^= 1;
+    for (size_t i = 0; i < votes; ++i) if (i != forged) for (size_t k = 0; k < options; ++k) expected[k] += all[i * options + k];
+    std::vector<const QuadraticVotingParams*> per;
+    for (auto& p : params) per.push_back(p.get());
+    auto verdict = devices > 1 ? verify_batch_multi(per, ballots) : params[0]->verify_batch(ballots);   // encrypted.verify(&vote_params)
+    printf("%zu of %zu quadratic-voting ballots verified\n", verdict.accepted(), votes);
+    for (size_t i = 0; i < verdict.results.size(); ++i)
+      if (verdict.results[i]) printf("  voter #%zu rejected (error kind %d)\n", i + 1, (int)verdict.results[i]->kind);
+    const uint64_t max_votes = votes * params[0]->max_votes();                          // votes_count * vote_params.max_votes()
+    ok = verdict.accepted() == votes - (forged < votes ? 1 : 0) && tally(ctx, group, sk, verdict.totals, expected, max_votes);
   }
-  const bool ok = sum == verdict.accepted();
-  printf("%s: decrypted totals sum to %zu, %zu ballots were accepted\n", ok ? "OK" : "MISMATCH", sum, verdict.accepted());
+  printf("%s: the decrypted totals %s the expected ones\n", ok ? "OK" : "MISMATCH", ok ? "equal" : "differ from");
   return ok ? 0 : 1;
 }

@@ -145,6 +145,20 @@ class ChoiceParams {
     check(eg_choice_encrypt_batch(p_, base_seed, first, n, n_selected, out.data()));
     return out;
   }
+  // EncryptedChoice::single(&params, choice, rng) with the caller's choices (choice.rs:296-311); voter i draws from
+  // ChaChaRng::seed_from_u64(base_seed + first + i).  VARIABLE TIME in the choice (see eg_hip.h): test / synthetic data only.
+  Bytes encrypt_single_choices(uint64_t base_seed, size_t first, const std::vector<size_t>& choices) const {
+    const size_t words = (n_ + 31) / 32;
+    std::vector<uint32_t> sel(choices.size() * words, 0u);
+    for (size_t i = 0; i < choices.size(); ++i) {
+      if (choices[i] >= n_) throw Error(EG_ERR_BAD_ARG, "choice out of range");
+      sel[i * words + choices[i] / 32] |= 1u << (choices[i] % 32);
+    }
+    Bytes out(choices.size() * ballot_size());
+    check(eg_choice_encrypt_selected_batch(p_, base_seed, first, choices.size(), 0, sel.data(), out.data()));
+    return out;
+  }
+  eg_choice_params* raw() const { return p_; }
  private:
   ChoiceParams(const Context& ctx, const Element& pk, size_t n, bool single) : n_(n), single_(single) {
     check(eg_choice_params_create(ctx.raw(), pk.data(), (int)n, single, &p_));
@@ -156,7 +170,7 @@ class ChoiceParams {
 
 class QuadraticVotingParams {
  public:
-  QuadraticVotingParams(const Context& ctx, const Element& receiver, size_t options, uint64_t credits) : n_(options) {
+  QuadraticVotingParams(const Context& ctx, const Element& receiver, size_t options, uint64_t credits) : n_(options), credits_(credits) {
     check(eg_qv_params_create(ctx.raw(), receiver.data(), (int)options, credits, &p_));
   }
   ~QuadraticVotingParams() { eg_qv_params_destroy(p_); }
@@ -164,6 +178,9 @@ class QuadraticVotingParams {
   QuadraticVotingParams& operator=(const QuadraticVotingParams&) = delete;
   size_t options_count() const { return n_; }
   size_t ballot_size() const { return eg_qv_ballot_size(p_); }
+  uint64_t credit_amount() const { return credits_; }
+  // QuadraticVotingParams::max_votes (quadratic_voting.rs:84-87): isqrt(credit_amount)
+  uint64_t max_votes() const { uint64_t r = 0; while ((r + 1) * (r + 1) <= credits_) ++r; return r; }
   BatchVerdict<QuadraticVotingError> verify_batch(const Bytes& packed) const {
     const size_t n = packed.size() / ballot_size();
     if (n * ballot_size() != packed.size()) throw Error(EG_ERR_BAD_ARG, "packed length is not a whole number of ballots");
@@ -175,10 +192,53 @@ class QuadraticVotingParams {
     v.totals = unpack_totals(tally);
     return v;
   }
+  // QuadraticVotingBallot::new(&params, votes, rng) for voters base_seed + first + i (quadratic_voting.rs:234-284); votes:
+  // options_count() numbers per voter with sum(v^2) <= credits.  VARIABLE TIME in the votes (see eg_hip.h): test / synthetic data only.
+  Bytes encrypt_votes_batch(uint64_t base_seed, size_t first, const std::vector<uint32_t>& votes) const {
+    if (votes.size() % n_) throw Error(EG_ERR_BAD_ARG, "votes is not a whole number of ballots");
+    const size_t n = votes.size() / n_;
+    Bytes out(n * ballot_size());
+    check(eg_qv_encrypt_votes_batch(p_, base_seed, first, n, 0, votes.data(), out.data()));
+    return out;
+  }
+  eg_qv_params* raw() const { return p_; }
  private:
   eg_qv_params* p_ = nullptr;
   size_t n_;
+  uint64_t credits_ = 0;
 };
+
+// One batch over several GPUs of this process (eg_verify_*_batch_multi): per_device[d] = the election's params created on the context
+// of GPU d; contiguous slabs, one host thread per GPU inside the library, the slabs' tallies merged in the library.  What a
+// single-process host like examples/voting.rs:179-213 calls when the node has more than one GPU.
+inline BatchVerdict<ChoiceVerificationError> verify_batch_multi(const std::vector<const ChoiceParams*>& per_device, const Bytes& packed) {
+  if (per_device.empty()) throw Error(EG_ERR_BAD_ARG, "no params objects");
+  const size_t bs = per_device[0]->ballot_size(), n = packed.size() / bs;
+  if (n * bs != packed.size()) throw Error(EG_ERR_BAD_ARG, "packed length is not a whole number of ballots for these parameters");
+  std::vector<eg_choice_params*> raw;
+  for (auto* p : per_device) raw.push_back(p->raw());
+  std::vector<uint32_t> st(n);
+  Bytes tally(64 * per_device[0]->options_count());
+  check(eg_verify_choice_batch_multi(raw.data(), (int)raw.size(), n, packed.data(), st.data(), tally.data()));
+  BatchVerdict<ChoiceVerificationError> v;
+  for (uint32_t x : st) v.results.push_back(choice_error_from_status(x));
+  v.totals = unpack_totals(tally);
+  return v;
+}
+inline BatchVerdict<QuadraticVotingError> verify_batch_multi(const std::vector<const QuadraticVotingParams*>& per_device, const Bytes& packed) {
+  if (per_device.empty()) throw Error(EG_ERR_BAD_ARG, "no params objects");
+  const size_t bs = per_device[0]->ballot_size(), n = packed.size() / bs;
+  if (n * bs != packed.size()) throw Error(EG_ERR_BAD_ARG, "packed length is not a whole number of ballots");
+  std::vector<eg_qv_params*> raw;
+  for (auto* p : per_device) raw.push_back(p->raw());
+  std::vector<uint32_t> st(n);
+  Bytes tally(64 * per_device[0]->options_count());
+  check(eg_verify_qv_batch_multi(raw.data(), (int)raw.size(), n, packed.data(), st.data(), tally.data()));
+  BatchVerdict<QuadraticVotingError> v;
+  for (uint32_t x : st) v.results.push_back(qv_error_from_status(x));
+  v.totals = unpack_totals(tally);
+  return v;
+}
 
 // Wire ingest (src/serde.rs:19-80,179-355): ballots as JSON text in the reference's serde layout -> packed ballots, on the host.
 // status[k]: EG_ST_OK (packed[k] valid), EG_ST_MALFORMED (does not deserialise) or EG_PACK_RESHAPE (wrong number of choices /
@@ -235,6 +295,10 @@ struct Ristretto {
     Bytes sb, eb; for (auto& x : s) sb.insert(sb.end(), x.begin(), x.end()); for (auto& x : e) eb.insert(eb.end(), x.begin(), x.end());
     Element o; uint8_t ok; check(eg_vartime_multi_mul_batch(ctx.raw(), 1, s.size(), sb.data(), eb.data(), o.data(), &ok)); valid(ok); return o;
   }
+  // Element * &Scalar (ElementOps::Element: Mul<&Scalar>, group/mod.rs:136-143): one-term vartime_multi_mul.  VARIABLE TIME.
+  Element mul(const Element& p, const Scalar& k) const { return vartime_multi_mul({k}, {p}); }
+  // Scalar::from(u64) (ScalarOps::Scalar: From<u64>, group/mod.rs:70-80): the little-endian integer, canonical by construction
+  static Scalar scalar_from_u64(uint64_t x) { Scalar s{}; for (int i = 0; i < 8; ++i) s[i] = (uint8_t)(x >> (8 * i)); return s; }
   Element add(const Element& a, const Element& b) const { Element o; uint8_t ok = 0; check(eg_point_add_batch(ctx.raw(), 1, a.data(), b.data(), 0, o.data(), &ok)); valid(ok); return o; }
   Element sub(const Element& a, const Element& b) const { Element o; uint8_t ok = 0; check(eg_point_add_batch(ctx.raw(), 1, a.data(), b.data(), 1, o.data(), &ok)); valid(ok); return o; }
   Element neg(const Element& a) const { return sub(identity(), a); }

@@ -543,7 +543,8 @@ def test_range_proofs_various_bounds(eg, ctx, oracle, pk, upper_bound):
 
 # ------------------------------------------------------------------ C++ host mirror + the voting example
 def test_cpp_voting_example(tmp_path):
-    """examples/voting.cpp = examples/voting.rs:179-213 on the GPU backend through include/elastic_elgamal_hip.hpp"""
+    """examples/voting.cpp = examples/voting.rs:179-269 (`vote` and `quadratic_vote`) on the GPU backend through
+    include/elastic_elgamal_hip.hpp"""
     import subprocess
     from pathlib import Path
 
@@ -555,7 +556,17 @@ def test_cpp_voting_example(tmp_path):
     out = subprocess.run([str(exe), "200", "5", "7"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "199 of 200 ballots verified" in out.stdout and "voter #4 rejected" in out.stdout
-    assert "OK: decrypted totals sum to 199" in out.stdout
+    assert "OK: the decrypted totals equal the expected ones" in out.stdout
+    # Args::quadratic_vote (examples/voting.rs:219-269): the voters' own votes, expected totals, max_votes-sized lookup table
+    out = subprocess.run([str(exe), "--qv", "150", "4", "20", "11"], capture_output=True, text=True, timeout=180)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "149 of 150 quadratic-voting ballots verified" in out.stdout and "voter #4 rejected" in out.stdout
+    assert "OK: the decrypted totals equal the expected ones" in out.stdout
+    # the same elections through the in-process multi-GPU entry (two contexts; both on GPU 0 when the box has one GPU)
+    for args in (["--devices", "2", "300", "5", "3"], ["--qv", "--devices", "2", "120", "3", "10", "5"]):
+        out = subprocess.run([str(exe)] + args, capture_output=True, text=True, timeout=240)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert "OK: the decrypted totals equal the expected ones" in out.stdout
 
 
 def test_cpp_tally_exchange_example(tmp_path):
@@ -1439,3 +1450,99 @@ def test_host_buffer_path_matches_device_path(eg, ctx, pk):
     got, tally = p.verify_batch(d.cpu().numpy().tobytes())
     assert got == want and tally == want_tally
     assert sum(1 for s in got if s) == n // 100
+
+
+# ------------------------------------------------------------------ round 4: in-process multi-GPU entry, stream hygiene on failure
+@pytest.mark.parametrize("kind", ["single", "qv"])
+def test_in_process_multi_device_entry(eg, ctx, oracle, pk, kind):
+    """eg_verify_*_batch_multi (SURVEY 8b `device_mask`; the host of examples/voting.rs:179-213 is ONE process): contiguous slabs over
+    several params objects, each on its own context, one host thread per object inside the library, tallies merged in the library.
+    One GPU on the box: two and three contexts on device 0 stand in for two and three GPUs.  Verdicts (1 % tampered), the batch
+    tally and the sum of the running tallies must equal the single-context result and the oracle's."""
+    if kind == "single":
+        op = oracle.ChoiceParams(pk, 5, True)
+        mk = lambda c: eg.ChoiceParams.single_choice(c, pk, 5)
+        n = 3001
+    else:
+        op = oracle.QvParams(pk, 3, 6)
+        mk = lambda c: eg.QuadraticVotingParams(c, pk, 3, 6)
+        n = 1203
+    ballots = bytearray(op.generate_batch(2718, 0, n, threads=8))
+    sz = len(ballots) // n
+    for i in range(0, n, 100):
+        ballots[i * sz + sz - 40] ^= 4
+    ballots = bytes(ballots)
+    want = op.verify_batch(ballots, threads=8)
+    want_tally = op.tally(ballots, want)
+    assert 0 < want.count(0) < n
+    single = mk(ctx)
+    st1, t1 = single.verify_batch(ballots)
+    assert st1 == want and t1 == want_tally
+    extra = [eg.Context(0), eg.Context(0)]
+    try:
+        for n_dev in (2, 3):
+            objs = [single] + [mk(c) for c in extra[: n_dev - 1]]
+            for o in objs:
+                o.tally_reset()
+            st, t = eg.verify_batch_multi(objs, ballots)
+            assert st == want
+            assert t == want_tally
+            assert eg.tally_encode_multi(objs) == want_tally
+            # every object tallied its own slab only (distributed.shard_range's split)
+            b0, e0 = 0, n // n_dev
+            assert objs[0].tally_encode() == op.tally(ballots[: e0 * sz], want[:e0])
+            st_again, t_none = eg.verify_batch_multi(objs, ballots, with_tally=False)       # running tallies accumulate
+            assert st_again == want and t_none is None
+            grp = eg.Ristretto(ctx)
+            assert eg.tally_encode_multi(objs) == grp.element_add(want_tally, want_tally)[0]
+            st_e, t_e = eg.verify_batch_multi(objs, b"")                                      # an empty batch
+            assert st_e == [] and t_e == bytes(64 * single.n_options)
+            for o in objs[1:]:
+                o.close()
+        with pytest.raises(eg.EgError):
+            eg.verify_batch_multi([single, single], ballots)                                  # one object per slab
+    finally:
+        for c in extra:
+            c.close()
+
+
+def test_failure_between_fork_and_join_leaves_a_usable_engine(eg, ctx, oracle, pk, monkeypatch):
+    """an error return between the fork onto the two work sets' streams and the join must still tie the streams
+    back into the caller's.  EG_TEST_FAIL_AFTER_FORK makes engine_verify_device return an error with the first chunk's kernels queued;
+    the same params object must then verify a clean batch with the right verdicts and tally (no stale share of set 1, no kernel
+    of the failed call still writing into the workspace or the status buffer)."""
+    import torch
+
+    op = oracle.ChoiceParams(pk, 5, True)
+    p = eg.ChoiceParams.single_choice(ctx, pk, 5)
+    n = 140000                                           # more than half the resident lanes: the call forks onto both work sets
+    d = torch.empty(n * p.ballot_size, dtype=torch.uint8, device="cuda")
+    p.encrypt_batch_device(99, 0, n, d.data_ptr())
+    ctx.synchronize()
+    st = torch.full((n,), 77, dtype=torch.int32, device="cuda")
+    p.tally_reset()
+    p.verify_batch_device(n, d.data_ptr(), st.data_ptr())
+    ctx.synchronize()
+    assert int((st == 0).sum()) == n
+    good_tally = p.tally_encode()
+    sample = bytes(d[: 64 * p.ballot_size].cpu().numpy().tobytes())
+    assert op.verify_batch(sample) == [0] * 64
+    monkeypatch.setenv("EG_TEST_FAIL_AFTER_FORK", "1")
+    p.tally_reset()
+    with pytest.raises(eg.EgError, match="injected failure"):
+        p.verify_batch_device(n, d.data_ptr(), st.data_ptr())
+    monkeypatch.delenv("EG_TEST_FAIL_AFTER_FORK")
+    # the caller's (null) stream was joined: work enqueued on it now runs after the failed call's kernels, so this fill wins
+    st.fill_(55)
+    torch.cuda.synchronize()
+    ctx.synchronize()
+    assert int((st == 55).sum()) == n, "kernels of the failed call wrote after the caller's stream went on"
+    p.tally_reset()
+    p.verify_batch_device(n, d.data_ptr(), st.data_ptr())
+    ctx.synchronize()
+    assert int((st == 0).sum()) == n
+    assert p.tally_encode() == good_tally
+    ballots = bytearray(sample)
+    ballots[5 * p.ballot_size + 100] ^= 1
+    st_h, t_h = p.verify_batch(bytes(ballots))           # the host form on the same object
+    assert st_h == op.verify_batch(bytes(ballots)) and t_h == op.tally(bytes(ballots), st_h)
