@@ -36,6 +36,9 @@ def gather_tallies(local: torch.Tensor) -> torch.Tensor:
         out = torch.cat(parts).to(local.device)
     else:
         dist.all_gather_into_tensor(out, flat)
+    if os.environ.get("EG_TEST_CORRUPT_GATHER") and dist.get_rank() == 1:     # test knob: what a broken transport would hand back
+        out = out.clone()
+        out[0] ^= 0x5A
     return out.view(world, flat.numel())
 
 

@@ -70,6 +70,36 @@ def test_two_rank_sharded_tally():
     assert res[0][1] == op.tally(whole, op.verify_batch(whole, threads=2))
 
 
+def test_eight_rank_shape_of_configs4():
+    """BASELINE configs[4] is 10 M ballots over EIGHT ranks.  Eight gloo processes (the GPU box admits at most six processes on its
+    card, so eight ranks can only ever be rehearsed on CPU by the builder): contiguous slabs by shard_range, ONE all-gather of 8 x 320
+    bytes, every rank merges the eight tallies itself and all agree with the single-process tally; at the full size the slabs are
+    1.25 M each."""
+    from elastic_elgamal_amd.distributed import shard_range
+    from oracle import oracle as o
+
+    assert [shard_range(10_000_000, r, 8) for r in range(8)] == [(1_250_000 * r, 1_250_000 * (r + 1)) for r in range(8)]
+    world, total = 8, 83
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort()
+    assert [r[4] for r in res] == [shard_range(total, r, world) for r in range(world)]
+    assert len({r[1] for r in res}) == 1                       # all eight ranks hold the same merged tally
+    assert all(r[2] == total for r in res) and all(r[3] == 8.0 for r in res)
+    _, pk, _ = o.keypair_from_seed(12345)
+    op = o.ChoiceParams(pk, 5, True)
+    whole = op.generate_batch(31337, 0, total, threads=4)
+    assert res[0][1] == op.tally(whole, op.verify_batch(whole, threads=4))
+
+
 def test_shard_range_covers_everything():
     from elastic_elgamal_amd.distributed import shard_range
 

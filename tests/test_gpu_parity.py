@@ -1546,3 +1546,46 @@ def test_failure_between_fork_and_join_leaves_a_usable_engine(eg, ctx, oracle, p
     ballots[5 * p.ballot_size + 100] ^= 1
     st_h, t_h = p.verify_batch(bytes(ballots))           # the host form on the same object
     assert st_h == op.verify_batch(bytes(ballots)) and t_h == op.tally(bytes(ballots), st_h)
+
+
+def test_configs4_eight_shards_on_one_gpu(eg, ctx, pk):
+    """BASELINE configs[4] (10 M single-choice ballots over EIGHT GPUs) with the eight ranks played one after the other by the one GPU
+    of the box (eight GPU processes at once are more than the pool admits): rank r's slab [1.25 M r, 1.25 M (r + 1)) is generated,
+    1 % tampered, verified and tallied from a reset tally exactly as bench.py's step does; the eight encoded tallies then go through
+    eg_points_sum_device the way the all-gathered tallies do.  The merged tally must equal the running tally of one engine that
+    verified all ten million (examples/voting.rs:199-203), with 9 900 000 ballots accepted."""
+    import torch
+
+    from elastic_elgamal_amd.distributed import shard_range
+
+    world, total = 8, 10_000_000
+    p = eg.ChoiceParams.single_choice(ctx, pk, 5)          # the eight "ranks"
+    whole = eg.ChoiceParams.single_choice(ctx, pk, 5)      # one engine over everything, never reset
+    whole.tally_reset()
+    gathered = torch.empty(world, 320, dtype=torch.uint8, device="cuda")
+    accepted = 0
+    for r in range(world):
+        lo, hi = shard_range(total, r, world)
+        n = hi - lo
+        assert n == 1_250_000
+        d = torch.empty(n * p.ballot_size, dtype=torch.uint8, device="cuda")
+        p.encrypt_batch_device(20260612, lo, n, d.data_ptr())
+        ctx.synchronize()
+        g = torch.Generator(device="cpu").manual_seed(20260612 + r)
+        bad = torch.randperm(n, generator=g)[: n // 100].to("cuda")
+        d.view(n, p.ballot_size)[bad, p.ballot_size - 32] ^= 1
+        st = torch.empty(n, dtype=torch.int32, device="cuda")
+        p.tally_reset()
+        p.verify_batch_device(n, d.data_ptr(), st.data_ptr())
+        p.tally_encode_device(gathered[r].data_ptr())
+        whole.verify_batch_device(n, d.data_ptr(), st.data_ptr())
+        ctx.synchronize()
+        accepted += int((st == 0).sum().item())
+        del d, st
+    assert accepted == 9_900_000
+    out = torch.empty(320, dtype=torch.uint8, device="cuda")
+    n_bad = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ctx.points_sum_device(world, 10, gathered.data_ptr(), out.data_ptr(), d_bad=n_bad.data_ptr())
+    ctx.synchronize()
+    assert int(n_bad.item()) == 0
+    assert bytes(out.cpu().numpy()) == whole.tally_encode()
