@@ -19,6 +19,17 @@
  * Every function returns EG_OK (0) or a negative eg_error.  Nothing here falls back to the CPU: if no
  * gfx950 device is usable eg_init fails with EG_ERR_NO_DEVICE.
  *
+ * TIMING (the `Group` contract, src/group/mod.rs:65-135,183-255): the reference requires scalar arithmetic, element addition,
+ * `Element * &Scalar`, `mul_generator` and `multi_mul` to be CONSTANT-TIME and lets only the `vartime_*` methods depend on their
+ * operands.  NOTHING in this library is constant-time: every multiplication indexes tables in device memory with digits of its scalar
+ * (2^19-entry comb windows), the provers branch on the voter's choice, and a GPU shared with other processes is not a place for
+ * secrets in the first place.  The library is the VERIFIER-side backend - `EncryptedChoice::verify`, `QuadraticVotingBallot::verify`
+ * and everything under them call `vartime_double_mul_generator` / `vartime_multi_mul` on public data only (src/proofs/ring.rs:342-350,
+ * log_equality.rs:160-164, mul.rs:213-247).  eg_mul_generator_batch, eg_scalar_*_batch, eg_point_add_batch and the
+ * eg_*_encrypt_* provers exist for completeness of the trait, for tests and for making SYNTHETIC ballots (bench.py); a deployment that
+ * encrypts real voters' choices, or multiplies by secret keys, keeps those operations on the CPU's constant-time backend
+ * (curve25519-dalek), which is what the shim of INTEGRATION.md section 3 does.
+ *
  * Threads: entry points may be called from any thread; calls on one context (and on the params objects created on
  * it) are serialised by a lock inside the context, and eg_last_error is per thread.  Host-pointer functions return
  * when the results are in the caller's buffers (they run on a stream owned by the context; the tally reset / encode host
@@ -105,7 +116,8 @@ int eg_point_add_batch(eg_ctx*, size_t n, const uint8_t* a, const uint8_t* b, in
 int eg_merlin_challenge_batch(eg_ctx*, size_t n, const char* proto, size_t proto_len, const char* msg_label, size_t msg_label_len,
                               const uint8_t* msgs /* n x msg_len */, size_t msg_len, const char* chal_label, size_t chal_label_len,
                               uint8_t* out /* n x out_len */, size_t out_len);
-/* Group::mul_generator / vartime_mul_generator (ristretto.rs:105-121) */
+/* Group::mul_generator / vartime_mul_generator (ristretto.rs:105-121); variable time like everything here (see TIMING): this IS
+ * vartime_mul_generator, and stands in for mul_generator only where the scalar is public */
 int eg_mul_generator_batch(eg_ctx*, size_t n, const uint8_t* k /*32n*/, uint8_t* out /*32n*/);
 /* Group::vartime_double_mul_generator(k, P, r) = [k]P + [r]G (ristretto.rs:131-137) */
 int eg_vartime_double_mul_generator_batch(eg_ctx*, size_t n, const uint8_t* k, const uint8_t* p, const uint8_t* r,
@@ -243,6 +255,8 @@ int eg_verify_proof_batch(eg_proof_params*, size_t n, const uint8_t* items, uint
 int eg_verify_proof_batch_device(eg_proof_params*, size_t n, const void* d_items, void* d_status, void* stream);
 
 /* ---- synthetic ballots on the GPU (EncryptedChoice::new / QuadraticVotingBallot::new) ---------
+ * VARIABLE TIME in the choices / votes and in the RNG-drawn secrets (see TIMING at the top): these entry points make test and benchmark
+ * inputs; they are not a voting client.
  * Ballot i of the call is produced from ChaChaRng::seed_from_u64(base_seed + first + i) with the reference's
  * RNG draw order (choice.rs:313-349, ring.rs:54-194, log_equality.rs:114-139, range.rs:462-534, mul.rs:107-181);
  * the voter's selection comes from a second stream seeded with the complemented seed.  n_selected is only

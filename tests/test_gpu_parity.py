@@ -569,6 +569,23 @@ def test_cpp_voting_example(tmp_path):
         assert "OK: the decrypted totals equal the expected ones" in out.stdout
 
 
+def test_cpp_shim_calls(tmp_path):
+    """tests/cpp/shim_calls.cpp: every primitive-tier entry point with n = 1, the way the `Group` shim of INTEGRATION.md section 3 calls
+    them (Element * &Scalar, From<u64>, add / sub / neg, vartime_* ...), checked against each other through group identities
+    (group/mod.rs:183-255); prints the cost of one call (kept in profiles/r04_shim_call_latency.txt)."""
+    import subprocess
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    exe = tmp_path / "shim_calls"
+    subprocess.check_call(["g++", "-std=c++17", "-O2", f"-I{root / 'include'}", str(root / "tests" / "cpp" / "shim_calls.cpp"),
+                           f"-L{root / 'elastic_elgamal_amd'}", "-leg_hip", f"-Wl,-rpath,{root / 'elastic_elgamal_amd'}", "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "OK: every identity holds" in out.stdout and "vartime_double_mul_generator" in out.stdout
+    print(out.stdout)
+
+
 def test_cpp_tally_exchange_example(tmp_path):
     """examples/tally_exchange.cpp: the one collective of the path through librccl directly (eg_*_tally_encode_device -> ncclAllGather
     -> eg_points_sum_device on one stream), the recipe for a host that is not Python; one rank on the box's one GPU."""
