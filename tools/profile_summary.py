@@ -62,6 +62,22 @@ for w in () if TRAFFIC_ONLY else WORKLOADS:
         lines.append(f"{kname(r['Name'])[:64]:64s} {int(r['Calls']):6d} {int(r['TotalDurationNs'])/1e6:12.3f} {float(r['AverageNs'])/1e6:11.4f} "
                      f"{int(r['MinNs'])/1e6:9.3f} {int(r['MaxNs'])/1e6:9.3f} {float(r['Percentage']):8.4g}")
     (PROF / f"{tag}_kernel_stats_{w}.txt").write_text("\n".join(lines) + "\n")
+    # the same command with EG_STREAMS=1 (one work set, one stream): nothing overlaps, so a kernel's total is its share of the step
+    f = OUT / f"prof_serial_{w}" / "stats_kernel_stats.csv"
+    if f.exists():
+        rows = list(csv.DictReader(open(f)))
+        skip = ("encrypt", "k_build_fixed_table", "k_comb_window_bases", "k_setup_points", "k_const_points", "at::")
+        step = sum(int(r["TotalDurationNs"]) for r in rows if not any(x in r["Name"] for x in skip))
+        lines = [f"# EG_STREAMS=1 rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --workload {w} --no-cpu-baseline --no-host-inclusive --no-wire-ingest --no-isolated --no-extra-configs   (MI355X)",
+                 f"# ONE work set on one stream: kernels run one after the other, so total_ms / 4 steps is a kernel's cost per step of {DESCR[w]}",
+                 f"# (share = of the verification kernels; generator and table set-up excluded: {step / 4e6:.1f} ms per step)",
+                 f"{'kernel':64s} {'calls':>6s} {'total_ms':>12s} {'avg_ms':>11s} {'share':>8s}"]
+        for r in rows:
+            if any(x in r["Name"] for x in skip):
+                continue
+            lines.append(f"{kname(r['Name'])[:64]:64s} {int(r['Calls']):6d} {int(r['TotalDurationNs'])/1e6:12.3f} {float(r['AverageNs'])/1e6:11.4f} "
+                         f"{100 * int(r['TotalDurationNs']) / step:7.2f}%")
+        (PROF / f"{tag}_kernel_stats_serial_{w}.txt").write_text("\n".join(lines) + "\n")
 
 # ---- PMC passes ----------------------------------------------------------------------------------------------------
 want = [f"eg::k_eq_table<{m}, {t}>" for m in ("false", "true") for t in (5, 6)] + ["eg::k_eq_direct"] + \
