@@ -79,6 +79,8 @@ def plan_field_ops(desc: dict, wide_combs: bool = False):
                mul(add(OPS["direct_table"], OPS["direct_mul"]), desc["direct_terms"]),
                mul(OPS["sum_table_first"], desc["sum_tables"]),           # tables of sums of ring bases, made from their tables
                mul(OPS["sum_table_extra"], desc["sum_table_members"] - desc["sum_tables"]),
+               # ring-group walk: every further group re-opens and re-stores the T accumulator entries of a sum (one multiplication each way)
+               (2 * desc.get("teeth", 6) * desc["sum_tables"] * max(desc.get("table_groups", 1) - 1, 0) if desc.get("ring_group") else 0, 0),
                mul(OPS["comb_wide" if wide_combs else "comb"], desc["combs"]),   # wide tables: 11 instead of 13 additions per comb
                mul(OPS["enc_batch_each"], desc["deferred"]),
                mul(OPS["enc_batch_inversion"], desc["inversion_groups"]),

@@ -34,7 +34,8 @@ struct EngineBufs {
   uint4* ws;            // per-lane variable-base tables (direct multiplications)
   uint4* dpt;           // deferred commitments P with out = encode(2P)   [cmp slot][PT_QUADS][cap]
   u32* encw;            // k_encode_batch scratch: prefix products and N   [2 * slot][EG_NL][cap]
-  uint4* btab;          // comb tables of the ring bases [base][cap] x btab_quads<T>() uint4 (16 or 32 packed entries of 128 B: 2 or 4 KiB)
+  uint4* btab;          // comb tables of the ring bases [table slot][cap] x btab_quads<T>() uint4 (16 or 32 packed entries of 128 B: 2 or 4 KiB)
+  uint4* sacc;          // ring-group walk: accumulators of the sums of bases [sum][cap] x T packed entries (k_sum_accumulate / k_sum_finish)
 };
 constexpr int BTAB_ENTRY_QUADS = 8;   // packed entries: 4 field elements x 256 bits = 128 bytes = ONE cache line per lookup
 template <int T> constexpr int btab_quads() { return Teeth<T>::ENTRIES * BTAB_ENTRY_QUADS; }    // T = the plan's comb shape (ge25519.cuh)

@@ -161,9 +161,12 @@ struct Engine {
   egplan::HashOp* d_ops = nullptr;
   egplan::StatusRule* d_rules = nullptr;
   u32* d_tally_slots = nullptr;
-  unsigned short* d_base_slots = nullptr;
-  egplan::SumBase* d_sum_bases = nullptr;
+  unsigned short* d_base_slots = nullptr;      // FlatPlan::build_slots: point slots by the stage that builds their tables
+  egplan::SumBase* d_sum_bases = nullptr;      // FlatPlan::sums / sum_members (members as table slots)
   unsigned short* d_sum_members = nullptr;
+  egplan::SumBase* d_acc_sums = nullptr;       // ring-group walk: FlatPlan::acc_sums / acc_members
+  unsigned short* d_acc_members = nullptr;
+  int n_sums = 0;
   unsigned short* d_defer_slots = nullptr;
   int max_defer = 0;
   unsigned char* d_blob = nullptr;
@@ -183,7 +186,7 @@ struct Engine {
   struct WorkSet {
     uint4 *pts = nullptr, *cmp = nullptr, *chal = nullptr;
     u32 *states = nullptr, *flags = nullptr, *bad_item = nullptr;
-    uint4 *btab = nullptr, *dpt = nullptr;
+    uint4 *btab = nullptr, *dpt = nullptr, *sacc = nullptr;
     u32* encw = nullptr;
     u32* partial = nullptr;
     u32* tally = nullptr;      // set 0: the engine's running tally; set 1: this call's share, added to set 0's at the join
@@ -236,11 +239,11 @@ static int gen_workspace(Engine* e, size_t n, unsigned words, int* blocks_out) {
 static void engine_free(Engine* e) {
   if (!e) return;
   void* ptrs[] = {e->d_pt_items, e->d_sc_items, e->d_dclasses, e->d_dterms, e->d_jobs, e->d_vterms, e->d_insts, e->d_ops,
-                  e->d_rules, e->d_tally_slots, e->d_base_slots, e->d_sum_bases, e->d_sum_members, e->d_defer_slots, e->d_blob, e->d_cpts, e->d_prefixes, e->d_key_words,
+                  e->d_rules, e->d_tally_slots, e->d_base_slots, e->d_sum_bases, e->d_sum_members, e->d_acc_sums, e->d_acc_members, e->d_defer_slots, e->d_blob, e->d_cpts, e->d_prefixes, e->d_key_words,
                   e->tally_saved, e->tally_saved2, e->d_wire, e->d_status, e->gen_ws, e->d_gen_desc};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& w : e->set) {
-    void* sp[] = {w.pts, w.cmp, w.chal, w.states, w.flags, w.bad_item, w.btab, w.dpt, w.encw, w.partial, w.tally};
+    void* sp[] = {w.pts, w.cmp, w.chal, w.states, w.flags, w.bad_item, w.btab, w.dpt, w.sacc, w.encw, w.partial, w.tally};
     for (void* p : sp) if (p) (void)hipFree(p);
     if (w.stream) (void)hipStreamDestroy(w.stream);
     if (w.done) (void)hipEventDestroy(w.done);
@@ -267,6 +270,7 @@ static EngineBufs make_bufs(const Engine* e, int set, const void* d_ballots, u32
   // each set works in its own part of the context's per-lane workspace (the grids of its kernels are 1 / n_sets of msm_blocks)
   B.ws = e->ctx->ws + (size_t)set * (e->ctx->msm_blocks / e->n_sets) * WS_QUADS * NT;
   B.btab = w.btab;
+  B.sacc = w.sacc;
   B.dpt = w.dpt;
   B.encw = w.encw;
   return B;
@@ -278,14 +282,15 @@ static size_t engine_bytes_per_ballot(const Engine* e) {
   const size_t pt = (size_t)PT_WORDS * sizeof(u32);
   return (size_t)std::max(P.n_pt_slots, 1) * pt + (size_t)std::max(P.n_cmp_slots, 1) * (32 + pt) + (size_t)std::max(P.n_chal_slots, 1) * 32 +
          (size_t)std::max(P.n_state_slots, 1) * 208 + (size_t)std::max(P.n_flag_slots, 1) * 4 + 4 +
-         std::max<size_t>(P.n_tables(), 1) * btab_quads_of(e->teeth) * 16 + (size_t)std::max(e->max_defer, 1) * 2 * EG_NL * sizeof(u32);
+         std::max<size_t>(P.n_tables(), 1) * btab_quads_of(e->teeth) * 16 + (size_t)std::max(e->max_defer, 1) * 2 * EG_NL * sizeof(u32) +
+         (P.grouped() ? P.sum_bases.size() * (size_t)e->teeth * BTAB_ENTRY_QUADS * 16 : 0);
 }
 
 // (re)allocate the per-chunk SoA buffers of every work set for chunks of up to `want` ballots
 static void engine_release_sets(Engine* e) {
   for (auto& w : e->set) {
     void** bufs[] = {(void**)&w.pts, (void**)&w.cmp, (void**)&w.chal, (void**)&w.states, (void**)&w.flags, (void**)&w.bad_item,
-                     (void**)&w.btab, (void**)&w.dpt, (void**)&w.encw};
+                     (void**)&w.btab, (void**)&w.dpt, (void**)&w.encw, (void**)&w.sacc};
     for (void** b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
   }
   e->cap = 0;
@@ -304,11 +309,12 @@ static int engine_reserve(Engine* e, u32 want) {
                           cap * sizeof(u32),
                           std::max<size_t>(P.n_tables(), 1) * cap * btab_quads_of(e->teeth) * sizeof(uint4),
                           (size_t)std::max(P.n_cmp_slots, 1) * PT_QUADS * cap * sizeof(uint4),
-                          (size_t)std::max(e->max_defer, 1) * 2 * EG_NL * cap * sizeof(u32)};
+                          (size_t)std::max(e->max_defer, 1) * 2 * EG_NL * cap * sizeof(u32),
+                          P.grouped() ? std::max<size_t>(P.sum_bases.size(), 1) * cap * (size_t)e->teeth * BTAB_ENTRY_QUADS * sizeof(uint4) : (size_t)256};
   for (int k = 0; k < e->n_sets; ++k) {
     Engine::WorkSet& w = e->set[k];
     void** bufs[] = {(void**)&w.pts, (void**)&w.cmp, (void**)&w.chal, (void**)&w.states, (void**)&w.flags, (void**)&w.bad_item,
-                     (void**)&w.btab, (void**)&w.dpt, (void**)&w.encw};
+                     (void**)&w.btab, (void**)&w.dpt, (void**)&w.encw, (void**)&w.sacc};
     for (size_t i = 0; i < sizeof(sizes) / sizeof(sizes[0]); ++i) {
       const hipError_t he = hipMalloc(bufs[i], sizes[i]);
       if (he == hipErrorOutOfMemory) {        // the caller retries with smaller chunks
@@ -369,9 +375,12 @@ static int engine_create(eg_ctx* ctx, eghost::Plan&& plan, const uint8_t pk[32],
   if ((rc = upload(&e->d_ops, ops, s))) return rc;
   if ((rc = upload(&e->d_rules, P.rules, s))) return rc;
   if ((rc = upload(&e->d_tally_slots, P.tally_slots, s))) return rc;
-  if ((rc = upload(&e->d_base_slots, P.base_slots, s))) return rc;
-  if ((rc = upload(&e->d_sum_bases, P.sum_bases, s))) return rc;
-  if ((rc = upload(&e->d_sum_members, P.sum_members, s))) return rc;
+  if ((rc = upload(&e->d_base_slots, F.build_slots, s))) return rc;
+  if ((rc = upload(&e->d_sum_bases, F.sums, s))) return rc;
+  if ((rc = upload(&e->d_sum_members, F.sum_members, s))) return rc;
+  if ((rc = upload(&e->d_acc_sums, F.acc_sums, s))) return rc;
+  if ((rc = upload(&e->d_acc_members, F.acc_members, s))) return rc;
+  e->n_sums = (int)F.sums.size();
   if ((rc = upload(&e->d_defer_slots, defer_slots, s))) return rc;
   if ((rc = upload(&e->d_blob, P.blob, s))) return rc;
 
@@ -562,17 +571,25 @@ static int engine_verify_device(Engine* e, size_t n, const void* d_ballots, void
       if (lv.count)
         hipLaunchKernelGGL(k_derive_points, dim3(grid_for((size_t)lv.count * cn, wide)), dim3(NT), 0, cs, B, e->d_dclasses,
                            e->d_dterms, lv.first, lv.count);
-    if (!P.base_slots.empty()) {
-      size_t pi = 0;
-      if ((rc = prof_begin(ctx, cs, PROF_TABLES, &pi))) return rc;
-      EG_WITH_TEETH(e->teeth, hipLaunchKernelGGL(k_base_tables<T>, dim3(grid_for((size_t)P.base_slots.size() * cn, msm_blocks)), dim3(NT), 0, cs, B,
-                                                 e->d_base_slots, (int)P.base_slots.size()));
-      if ((rc = prof_end(ctx, cs, pi))) return rc;
-    }
-    if (!P.sum_bases.empty())
-      EG_WITH_TEETH(e->teeth, hipLaunchKernelGGL(k_sum_tables<T>, dim3(grid_for((size_t)P.sum_bases.size() * cn, msm_blocks)), dim3(NT), 0, cs, B,
-                                                 e->d_sum_bases, e->d_sum_members, (int)P.sum_bases.size()));
     for (auto& st : e->stages) {
+      // the comb tables this stage starts with (host_plan.hpp: Stage): every table of the ballot before stage 0, or - ring-group walk -
+      // the tables of one group of rings in the table slots the previous group has finished with
+      if (st.build_count) {
+        size_t pi = 0;
+        if ((rc = prof_begin(ctx, cs, PROF_TABLES, &pi))) return rc;
+        EG_WITH_TEETH(e->teeth, hipLaunchKernelGGL(k_base_tables<T>, dim3(grid_for((size_t)st.build_count * cn, msm_blocks)), dim3(NT), 0, cs, B,
+                                                   e->d_base_slots + st.build_first, st.build_count));
+        if ((rc = prof_end(ctx, cs, pi))) return rc;
+      }
+      if (st.sums_direct)
+        EG_WITH_TEETH(e->teeth, hipLaunchKernelGGL(k_sum_tables<T>, dim3(grid_for((size_t)e->n_sums * cn, msm_blocks)), dim3(NT), 0, cs, B,
+                                                   e->d_sum_bases, e->d_sum_members, e->n_sums));
+      if (st.acc_count)
+        EG_WITH_TEETH(e->teeth, hipLaunchKernelGGL(k_sum_accumulate<T>, dim3(grid_for((size_t)st.acc_count * T * cn, msm_blocks)), dim3(NT), 0, cs, B,
+                                                   e->d_acc_sums + st.acc_first, e->d_acc_members, st.acc_count));
+      if (st.sum_finish)
+        EG_WITH_TEETH(e->teeth, hipLaunchKernelGGL(k_sum_finish<T>, dim3(grid_for((size_t)e->n_sums * cn, msm_blocks)), dim3(NT), 0, cs, B,
+                                                   e->d_sum_bases, e->n_sums));
       if (st.fam_count[FAM_TABLE1]) {
         size_t pi = 0;
         if ((rc = prof_begin(ctx, cs, PROF_MSM, &pi))) return rc;
@@ -1194,13 +1211,15 @@ int eg_dlog_table_get(const eg_dlog_table* t, size_t n, const uint8_t* elements,
 }
 
 // ---- batch tier: choice ---------------------------------------------------------------------------------------------------
+// rings per group of the ring-group walk: EG_RING_GROUP overrides the plan's default (0 = every table of a ballot at once)
+static int choice_ring_group() { const char* v = getenv("EG_RING_GROUP"); return v ? std::max(0, atoi(v)) : -1; }
 size_t eg_choice_ballot_size(int n_options, int single) { return eghost::choice_ballot_size(n_options, single != 0); }
 
 int eg_choice_params_create(eg_ctx* c, const uint8_t pk[32], int n_options, int single, eg_choice_params** out) { EG_LOCK(c);
   if (!c || !pk || !out) return fail(EG_ERR_BAD_ARG, "bad argument");
   if (n_options < 1 || n_options > 4000) return fail(EG_ERR_BAD_ARG, "n_options must be in 1..4000");
   Engine* e = nullptr;
-  TRY(engine_create(c, eghost::build_choice_plan(n_options, single != 0), pk, n_options, &e));
+  TRY(engine_create(c, eghost::build_choice_plan(n_options, single != 0, choice_ring_group()), pk, n_options, &e));
   *out = new eg_choice_params{e, n_options, single};
   return EG_OK;
 }
@@ -1430,8 +1449,8 @@ int eg_plan_describe(int kind, int n_options, uint64_t credits_or_bound, char* b
   eghost::Plan P;
   size_t item = 0;
   switch (kind) {
-    case 0: P = eghost::build_choice_plan(n_options, true); break;
-    case 1: P = eghost::build_choice_plan(n_options, false); break;
+    case 0: P = eghost::build_choice_plan(n_options, true, choice_ring_group()); break;
+    case 1: P = eghost::build_choice_plan(n_options, false, choice_ring_group()); break;
     case 2: P = eghost::build_qv_plan(n_options, credits_or_bound); break;
     case 3: P = eghost::build_zero_plan(); break;
     case 4: P = eghost::build_bool_plan(); break;
@@ -1477,11 +1496,13 @@ int eg_plan_describe(int kind, int n_options, uint64_t credits_or_bound, char* b
            "\"single_table_jobs\": %zu, \"chains\": %zu, \"chain_extra_terms\": %zu, \"loose_table_terms\": %zu, \"direct_terms\": %zu, "
            "\"sum_tables\": %zu, \"sum_table_members\": %zu, "
            "\"hash_programs\": %zu, \"prefixes\": %d, \"flags\": %d, \"rules\": %zu, \"tally_slots\": %zu, "
-           "\"pt_slots\": %d, \"cmp_slots\": %d, \"chal_slots\": %d, \"state_slots\": %d, \"tables\": %zu, \"teeth\": %d}",
+           "\"pt_slots\": %d, \"cmp_slots\": %d, \"chal_slots\": %d, \"state_slots\": %d, \"tables\": %zu, \"teeth\": %d, "
+           "\"ring_group\": %d, \"table_groups\": %zu}",
            P.stride, P.pt_items.size(), P.sc_items.size(), derived, derive_terms, P.base_slots.size(), P.stages.size(), jobs, per_stage.c_str(),
            var_terms, table_terms, combs, deferred, plain_encodes, inversion_groups, jobs_table1, chains, chain_extra_terms,
            loose_table_terms, direct_terms, P.sum_bases.size(), P.sum_members.size(), insts, P.n_prefixes, P.n_flag_slots, P.rules.size(),
-           P.tally_slots.size(), P.n_pt_slots, P.n_cmp_slots, P.n_chal_slots, P.n_state_slots, (size_t)P.n_tables(), eghost::plan_teeth(P));
+           P.tally_slots.size(), P.n_pt_slots, P.n_cmp_slots, P.n_chal_slots, P.n_state_slots, (size_t)P.n_tables(), eghost::plan_teeth(P),
+           P.ring_group, P.group_stage.size());
   if (strlen(tmp) + 1 > cap) return fail(EG_ERR_BAD_ARG, "buffer too small");
   memcpy(buf, tmp, strlen(tmp) + 1);
   return EG_OK;

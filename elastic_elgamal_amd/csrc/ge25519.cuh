@@ -604,6 +604,33 @@ EG_HD void ge_teeth_tables_sum(TableIO& io, TmpIO& tmp, int m, SrcFn src) {
   }
 }
 
+// ---- the same sum of tables when the members' tables do NOT exist at the same time (ring-group walk) ----------------
+// ge_teeth_tables_sum reads only T entries of every member: the ones where the Gray-code walk flips a tooth for the first time.  They
+// can be summed up group by group into T accumulator entries per sum (ge_teeth_sum_accumulate), and once every member has been added
+// the table of the sum is made from the accumulator alone (ge_teeth_tables_sum with one pseudo-member that answers from it).
+template <int T> EG_HD int teeth_first_flip_entry(int t) { const int i = t == 0 ? 0 : 1 << (t - 1); return i ^ (i >> 1); }   // 0, 1, 3, 6, 12, 24
+template <int T> EG_HD int teeth_first_flip_index(int g) { int t = 0; while ((g >> t) != 0) ++t; return t; }                // its inverse
+// accumulator entry t (+)= sum over the m members of this group of their entries first_flip(t); first: the sum has no contribution yet
+template <int T, class AccIO, class SrcFn>
+EG_HD void ge_teeth_sum_accumulate(AccIO& acc_io, int t, bool first, int m, SrcFn src) {
+  const int g = teeth_first_flip_entry<T>(t);
+  ge acc;
+  int k0 = 0;
+  {
+    ge_cached c;
+    if (first) { src(0, g, c); k0 = 1; } else acc_io.load(c, t);
+    ge_cached_to_p3(acc, c);
+  }
+#pragma unroll 1
+  for (int k = k0; k < m; ++k) {
+    ge_cached c; src(k, g, c);
+    ge_p1p1 r; ge_add(r, acc, c);
+    ge_add_to_p3(acc, r);
+  }
+  ge_cached e; ge_to_cached_lazy(e, acc);       // Z may be [2] when nothing was added: 2Z [4], carried by the store
+  acc_io.store(t, e);
+}
+
 // acc = [k]P from the teeth table; rows = sc_recode_teeth(k) (consumed).  A column's entry is requested before the doubling and
 // used after it, which hides the load without a second entry buffer (requesting it a whole column ahead, in a second register
 // buffer, measured -0.4 % in round 1 and +-0.2 % = nothing in round 2, when the kernel had the 40 registers to spare).

@@ -87,6 +87,11 @@ struct Stage {
   std::vector<std::vector<HashOp>> insts;
   std::vector<uint16_t> deferred;   // output slots encoded by k_encode_batch (one batched inversion per ballot and stage)
 };
+// What happens to the per-ballot comb tables at the START of a stage (filled in by flatten_plan from the plan's base registry):
+//   build       point slots whose tables are built now, into table slots 0, 1, .. (k_base_tables)
+//   sums_direct every table of the ballot exists at once: the tables of the sums of bases follow at once (k_sum_tables)
+//   acc         ring-group walk: this group's members are added into the sums' accumulators (k_sum_accumulate)
+//   sum_finish  ring-group walk: the sums' tables are made from the accumulators (k_sum_finish); the groups' tables are dead by then
 
 struct Plan {
   size_t stride = 0;  // bytes per ballot
@@ -112,33 +117,60 @@ struct Plan {
   std::vector<SumBase> sum_bases;
   std::vector<uint16_t> sum_members;
   bool late_base = false;
+  // Ring-group walk: the rings of a choice ballot are independent chains until the final challenge, so a chunk
+  // can hold the tables of ONE group of rings at a time - tables of group g, its stages, then the same table slots for group g + 1 -
+  // while the tables of the sums of bases are accumulated group by group.  ring_group = rings per group (0: every table of a ballot
+  // exists at once, the layout of rounds 1-3).  A base belongs to the group that was current when it was registered and sits in
+  // table slot base_local[] of that group; group_stage[g] is the stage at whose start group g's tables are built; sum_stage the stage
+  // at whose start the sums' tables must exist.
+  int ring_group = 0, cur_group = 0, sum_stage = 0;
+  std::vector<uint16_t> base_group, base_local;
+  std::vector<int> group_stage{0};
+  size_t table_uses = 0;              // products over ordinary bases' tables (plan_teeth)
+  bool grouped() const { return ring_group > 0; }
+  void begin_group(int g, int first_stage) {
+    cur_group = g;
+    if ((int)group_stage.size() <= g) group_stage.resize(g + 1, first_stage);
+    group_stage[g] = first_stage;
+  }
+  size_t group_size(int g) const { size_t n = 0; for (uint16_t x : base_group) n += x == g; return n; }
   uint16_t base_index(uint16_t slot) {
     auto it = base_index_of.find(slot);
     if (it != base_index_of.end()) return it->second;
-    if (!sum_bases.empty()) late_base = true;
+    if (!sum_bases.empty() && !grouped()) late_base = true;
     const uint16_t i = (uint16_t)base_slots.size();
+    base_local.push_back((uint16_t)group_size(cur_group));
+    base_group.push_back((uint16_t)cur_group);
     base_slots.push_back(slot);
     base_index_of[slot] = i;
     return i;
   }
   bool has_base(uint16_t slot) const { return base_index_of.count(slot) != 0; }
-  VarTerm term(uint16_t slot, ScalarSrc sc) { return VarTerm{slot, has_base(slot) ? base_index_of[slot] : (uint16_t)0xffff, sc}; }
-  VarTerm bterm(uint16_t slot, ScalarSrc sc) { return VarTerm{slot, base_index(slot), sc}; }
+  // VarTerm::base is the TABLE SLOT the kernels index (the base's slot inside its group; without groups = its index)
+  VarTerm term(uint16_t slot, ScalarSrc sc) { return VarTerm{slot, has_base(slot) ? base_local[base_index_of[slot]] : (uint16_t)0xffff, sc}; }
+  VarTerm bterm(uint16_t slot, ScalarSrc sc) { ++table_uses; return VarTerm{slot, base_local[base_index(slot)], sc}; }
   // [sc](sum of the points in `member_slots`), every member a ring base: one table-backed term over the sum's own table.
-  // `slot` is the derived point that holds the sum (not read by the equation kernel).
+  // `slot` is the derived point that holds the sum (not read by the equation kernel).  Members may be registered later (grouped plans
+  // register a ring's bases when the ring is added): sum_members holds POINT SLOTS until flatten_plan resolves them.
   VarTerm sum_term(uint16_t slot, const std::vector<uint16_t>& member_slots, ScalarSrc sc) {
-    std::vector<uint16_t> members;
-    for (uint16_t m : member_slots) members.push_back(base_index(m));
+    if (!grouped()) for (uint16_t m : member_slots) (void)base_index(m);
     SumBase sb;
     sb.first = (uint16_t)sum_members.size();
-    sb.count = (uint16_t)members.size();
-    sb.out_base = (uint16_t)(base_slots.size() + sum_bases.size());
+    sb.count = (uint16_t)member_slots.size();
+    // without groups the sums' tables follow the ordinary bases' tables; with groups they re-use the table slots from 0 on
+    sb.out_base = (uint16_t)(grouped() ? sum_bases.size() : base_slots.size() + sum_bases.size());
     sb.pad = 0;
-    sum_members.insert(sum_members.end(), members.begin(), members.end());
+    sum_members.insert(sum_members.end(), member_slots.begin(), member_slots.end());
     sum_bases.push_back(sb);
     return VarTerm{slot, sb.out_base, sc};
   }
-  size_t n_tables() const { return base_slots.size() + sum_bases.size(); }
+  // table slots a chunk needs per ballot
+  size_t n_tables() const {
+    if (!grouped()) return base_slots.size() + sum_bases.size();
+    size_t m = sum_bases.size();
+    for (size_t g = 0; g < group_stage.size(); ++g) m = std::max(m, group_size((int)g));
+    return m;
+  }
 
   uint32_t ref(const std::string& s) {  // label / constant message in the blob
     auto it = blob_index.find(s);
@@ -254,9 +286,17 @@ inline uint16_t add_ring_proof(Plan& P, const std::vector<HashOp>& setup, const 
   size_t max_size = 0;
   for (auto& r : rings) max_size = std::max(max_size, r.admissible.size());
   std::vector<std::pair<uint16_t, uint16_t>> terminal(rings.size());
+  // ring-group walk: the rings of group g run their equations in stages first_stage + g * max_size + j, after their tables are built
+  const size_t base_stage = first_stage;
+  const size_t n_groups = P.grouped() ? (rings.size() + P.ring_group - 1) / P.ring_group : 1;
   for (size_t ri = 0; ri < rings.size(); ++ri) {
     const RingIn& r = rings[ri];
     const size_t s = r.admissible.size();
+    if (P.grouped()) {
+      const size_t g = ri / P.ring_group;
+      first_stage = base_stage + g * max_size;
+      if (ri % P.ring_group == 0) P.begin_group((int)g, (int)first_stage);
+    }
     uint16_t enc_r = 0, enc_b = 0;
     if (!r.enc_from_wire) {
       enc_r = P.encode_job(first_stage, r.ptR);
@@ -311,15 +351,29 @@ inline uint16_t add_ring_proof(Plan& P, const std::vector<HashOp>& setup, const 
     fin.push_back({OP_APPEND_CMP, P.ref("R_K"), t.second, 0xffff});
   }
   fin.push_back({OP_CHALLENGE_CHECK, P.ref("c"), challenge_item, flag});
-  P.stage(first_stage + max_size - 1).insts.push_back(fin);
+  P.stage(base_stage + (n_groups - 1) * max_size + max_size - 1).insts.push_back(fin);
   return flag;
 }
 
 // ---- EncryptedChoice (choice.rs:358-380) ----------------------------------------------------------------------------
 inline size_t choice_ballot_size(int n, bool single) { return (size_t)n * 64 + 32 * (size_t)(1 + 2 * n) + (single ? 64 : 0); }
 
-inline Plan build_choice_plan(int n, bool single) {
+// ring_group: rings per group of the ring-group walk, 0 = off (a single-choice ballot of 1 or 2 options evaluates its sum proof over the
+// rings' tables on shared chains and needs them all at once: never grouped).  Rings have two members here, so a group takes two stages.
+// The walk trades throughput for memory (profiles/r04_ab_experiments.txt, block 2: workspace per ballot 32.3 -> 16.7 KB for 5 options,
+// 84 -> 26 KB for 16, at -4 % / -0.5 % throughput - a group's launches are a third the size and nothing comes back from the caches), so
+// it is on by default only where all tables at once would squeeze the chunks to a few thousand ballots (2 KiB x 2 n tables per ballot:
+// 1 MiB from 256 options on); EG_RING_GROUP chooses it for any election.
+inline int choice_group_default(int n, bool single) {
+  (void)single;
+  return n >= 256 ? 8 : 0;
+}
+inline Plan build_choice_plan(int n, bool single, int ring_group = -1) {
   Plan P;
+  if (ring_group < 0) ring_group = choice_group_default(n, single);
+  if ((single && n <= 2) || ring_group >= n) ring_group = 0;
+  P.ring_group = ring_group;
+  const size_t tail = ring_group ? (size_t)((n + ring_group - 1) / ring_group) * 2 : 0;   // stage of the sum proof: after the last group
   P.stride = choice_ballot_size(n, single);
   std::vector<uint16_t> R(n), B(n);
   for (int k = 0; k < n; ++k) { R[k] = P.wire_point((uint16_t)(2 * k)); B[k] = P.wire_point((uint16_t)(2 * k + 1)); }
@@ -355,14 +409,16 @@ inline Plan build_choice_plan(int n, bool single) {
       xk = P.job(0, tk, wire_src(sum_items), s);
     } else {
       // more options: the comb tables of sum R_k and sum B_k are summed up from the ring bases' tables (6 (n - 1) + 31 additions,
-      // no doublings: ge_teeth_tables_sum), and the two equations become ordinary one-table equations
-      for (int k = 0; k < n; ++k) { (void)P.base_index(R[k]); (void)P.base_index(B[k]); }   // ring bases first, in ring order
-      xg = P.job(0, {P.sum_term(p0, R, c)}, s, no_src());
-      xk = P.job(0, {P.sum_term(p1, B, c)}, wire_src(sum_items), s);
+      // no doublings: ge_teeth_tables_sum), and the two equations become ordinary one-table equations.  With the ring-group walk the
+      // sums are accumulated group by group and the two equations run after the last group (stage `tail`).
+      if (!P.grouped()) for (int k = 0; k < n; ++k) { (void)P.base_index(R[k]); (void)P.base_index(B[k]); }   // ring bases first, in ring order
+      P.sum_stage = (int)tail;
+      xg = P.job(tail, {P.sum_term(p0, R, c)}, s, no_src());
+      xk = P.job(tail, {P.sum_term(p1, B, c)}, wire_src(sum_items), s);
     }
-    const uint16_t e0 = P.encode_job(0, p0), e1 = P.encode_job(0, p1);
+    const uint16_t e0 = P.encode_job(tail, p0), e1 = P.encode_job(tail, p1);
     sum_flag = P.new_flag();
-    P.stage(0).insts.push_back({{OP_LOAD_PREFIX, 0, pre, 0},
+    P.stage(tail).insts.push_back({{OP_LOAD_PREFIX, 0, pre, 0},
                                 {OP_APPEND_CMP, P.ref("[r]G"), e0, 0xffff},
                                 {OP_APPEND_CMP, P.ref("[r]K"), e1, 0xffff},
                                 {OP_APPEND_CMP, P.ref("[x]G"), xg, 0xffff},
@@ -642,9 +698,7 @@ inline Plan build_share_plan(uint64_t shares, uint64_t threshold, const uint8_t 
 // table twice: 5 teeth measured +2.4 %; the rings of 3 .. 7 of the range proofs use it 3 .. 7 times: 6 teeth, +5 % (A/B block 9).
 inline int plan_teeth(const Plan& P) {
   if (P.base_slots.empty()) return 6;
-  size_t uses = 0;
-  for (const VarTerm& t : P.vterms) uses += t.base != 0xffff && t.base < P.base_slots.size();
-  return uses <= 2 * P.base_slots.size() + P.base_slots.size() / 2 ? 5 : 6;          // <= 2.5 products per table
+  return P.table_uses <= 2 * P.base_slots.size() + P.base_slots.size() / 2 ? 5 : 6;          // <= 2.5 products per table
 }
 
 // the equations of a stage, sorted by kernel family (kernels.cuh): FAM_TABLE1 one table-backed base, FAM_TABLEN several
@@ -659,7 +713,12 @@ inline int job_family(const JobClass& j, const std::vector<VarTerm>& vterms) {
     if (vterms[j.term_first + t].base == 0xffff) return j.term_count == 1 ? FAM_DIRECT1 : FAM_GENERIC;
   return j.term_count == 1 ? FAM_TABLE1 : FAM_TABLEN;
 }
-struct StageDev { int fam_first[N_FAM], fam_count[N_FAM], max_terms, inst_first, inst_count, defer_first, defer_count; };
+struct StageDev {
+  int fam_first[N_FAM], fam_count[N_FAM], max_terms, inst_first, inst_count, defer_first, defer_count;
+  // tables at the start of the stage (see Stage): build_slots[build_first ..) -> table slots 0 ..; sums_direct: k_sum_tables over
+  // F.sums / F.sum_members; acc_count > 0: k_sum_accumulate over F.acc_sums[acc_first ..); sum_finish: k_sum_finish over F.sums
+  int build_first, build_count, sums_direct, acc_first, acc_count, sum_finish;
+};
 struct LevelDev { int first, count; };
 struct FlatPlan {
   std::vector<JobClass> jobs;
@@ -669,12 +728,66 @@ struct FlatPlan {
   std::vector<DeriveClass> dclasses;
   std::vector<StageDev> stages;
   std::vector<LevelDev> levels;
+  std::vector<uint16_t> build_slots;     // point slots, grouped by the stage that builds their tables
+  std::vector<SumBase> sums;             // the sums of bases: members = sum_members[first ..) as TABLE SLOTS (ungrouped plans); out_base = table slot
+  std::vector<uint16_t> sum_members;
+  std::vector<SumBase> acc_sums;         // ring-group walk, per (group, sum) with members in the group: members as table slots of the group,
+  std::vector<uint16_t> acc_members;     //   out_base = index of the sum (its accumulator), pad = 1 for the sum's first contribution
   int max_defer = 0, prefix_inst_first = 0, prefix_inst_count = 0;
 };
 inline FlatPlan flatten_plan(const Plan& P) {
   FlatPlan F;
-  for (auto& st : P.stages) {
-    StageDev sd;
+  const size_t n_stages = std::max(P.stages.size(), (size_t)(P.sum_bases.empty() ? 0 : P.sum_stage + 1));
+  std::vector<StageDev> tab(n_stages);
+  for (auto& t : tab) t.build_first = t.build_count = t.sums_direct = t.acc_first = t.acc_count = t.sum_finish = 0;
+  auto base_of = [&](uint16_t slot) -> int { auto it = P.base_index_of.find(slot); return it == P.base_index_of.end() ? -1 : (int)it->second; };
+  for (size_t g = 0; g < P.group_stage.size(); ++g) {           // tables of group g: built at the start of its first stage, in slot order
+    std::vector<uint16_t> slots(P.group_size((int)g));
+    for (size_t i = 0; i < P.base_slots.size(); ++i)
+      if (P.base_group[i] == g) slots[P.base_local[i]] = P.base_slots[i];
+    if (slots.empty() || (size_t)P.group_stage[g] >= n_stages) continue;
+    StageDev& t = tab[P.group_stage[g]];
+    t.build_first = (int)F.build_slots.size(); t.build_count = (int)slots.size();
+    F.build_slots.insert(F.build_slots.end(), slots.begin(), slots.end());
+  }
+  for (const SumBase& sb : P.sum_bases) {                        // members: point slots -> table slots
+    SumBase r = sb;
+    r.first = (uint16_t)F.sum_members.size();
+    for (unsigned t = 0; t < sb.count; ++t) {
+      const int b = base_of(P.sum_members[sb.first + t]);
+      F.sum_members.push_back(b < 0 ? (uint16_t)0xffff : P.base_local[b]);
+    }
+    F.sums.push_back(r);
+  }
+  if (!P.sum_bases.empty()) {
+    if (!P.grouped()) tab[0].sums_direct = 1;
+    else {
+      std::vector<char> seen(P.sum_bases.size(), 0);
+      for (size_t g = 0; g < P.group_stage.size(); ++g) {
+        if ((size_t)P.group_stage[g] >= n_stages) continue;
+        StageDev& t = tab[P.group_stage[g]];
+        t.acc_first = (int)F.acc_sums.size();
+        for (size_t k = 0; k < P.sum_bases.size(); ++k) {
+          SumBase r;
+          r.first = (uint16_t)F.acc_members.size(); r.count = 0; r.out_base = (uint16_t)k; r.pad = 0;
+          for (unsigned m = 0; m < P.sum_bases[k].count; ++m) {
+            const int b = base_of(P.sum_members[P.sum_bases[k].first + m]);
+            if (b >= 0 && P.base_group[b] == g) { F.acc_members.push_back(P.base_local[b]); ++r.count; }
+          }
+          if (!r.count) continue;
+          r.pad = seen[k] ? 0 : 1;
+          seen[k] = 1;
+          F.acc_sums.push_back(r);
+        }
+        t.acc_count = (int)F.acc_sums.size() - t.acc_first;
+      }
+      tab[P.sum_stage].sum_finish = 1;
+    }
+  }
+  for (size_t si = 0; si < n_stages; ++si) {
+    static const Stage empty_stage;
+    const Stage& st = si < P.stages.size() ? P.stages[si] : empty_stage;
+    StageDev sd = tab[si];
     sd.defer_first = (int)F.defer_slots.size(); sd.defer_count = (int)st.deferred.size();
     F.defer_slots.insert(F.defer_slots.end(), st.deferred.begin(), st.deferred.end());
     F.max_defer = std::max(F.max_defer, std::min(sd.defer_count, 32));
@@ -729,15 +842,57 @@ inline std::string check_flat_plan(const Plan& P, const FlatPlan& F) {
   }
   for (uint16_t b : P.base_slots) if ((int)b >= P.n_pt_slots) return "base slot out of range";
   if (P.late_base) return "ordinary base registered after a sum base";
-  for (size_t i = 0; i < P.sum_bases.size(); ++i) {
-    const SumBase& sb = P.sum_bases[i];
-    if (sb.out_base != P.base_slots.size() + i) return "sum base index out of order";
-    if (sb.count == 0 || (size_t)sb.first + sb.count > P.sum_members.size()) return "sum base members out of range";
-    for (unsigned t = 0; t < sb.count; ++t)
-      if (P.sum_members[sb.first + t] >= P.base_slots.size()) return "sum base member is not an ordinary base";
+  if (P.base_group.size() != P.base_slots.size() || P.base_local.size() != P.base_slots.size()) return "base registry out of step";
+  const size_t n_tab = P.n_tables();
+  if (F.sums.size() != P.sum_bases.size()) return "sums lost in flattening";
+  for (size_t i = 0; i < F.sums.size(); ++i) {
+    const SumBase& sb = F.sums[i];
+    if (sb.out_base != (P.grouped() ? i : P.base_slots.size() + i) || sb.out_base >= n_tab) return "sum base index out of order";
+    if (sb.count == 0 || (size_t)sb.first + sb.count > F.sum_members.size()) return "sum base members out of range";
+    for (unsigned t = 0; t < sb.count; ++t) {
+      const uint16_t m = F.sum_members[sb.first + t];
+      if (m == 0xffff) return "sum base member is not an ordinary base";
+      if (!P.grouped() && m >= P.base_slots.size()) return "sum base member out of range";
+    }
   }
-  size_t counted = 0;
+  {
+    // every ordinary base's table is built exactly once, into its own slot, by the stage its group starts with; accumulators cover
+    // every member of every sum exactly once, the first contribution of a sum carries the `first` mark, and the sums are finished
+    // at a stage after every group's tables
+    size_t built = 0, acc_members = 0;
+    std::vector<char> first_seen(F.sums.size(), 0);
+    int last_acc_stage = -1, finish_stage = -1;
+    for (size_t si = 0; si < F.stages.size(); ++si) {
+      const StageDev& sd = F.stages[si];
+      if (sd.build_count < 0 || (size_t)sd.build_first + sd.build_count > F.build_slots.size() || (size_t)sd.build_count > n_tab) return "table build range out of range";
+      for (int k = 0; k < sd.build_count; ++k) if ((int)F.build_slots[sd.build_first + k] >= P.n_pt_slots) return "table build slot out of range";
+      built += sd.build_count;
+      if (sd.sums_direct && (P.grouped() || si != 0)) return "direct sum tables in a grouped plan";
+      if (sd.acc_count < 0 || (size_t)sd.acc_first + sd.acc_count > F.acc_sums.size()) return "accumulate range out of range";
+      for (int k = 0; k < sd.acc_count; ++k) {
+        const SumBase& a = F.acc_sums[sd.acc_first + k];
+        if (a.out_base >= F.sums.size() || a.count == 0 || (size_t)a.first + a.count > F.acc_members.size()) return "accumulate record out of range";
+        for (unsigned m = 0; m < a.count; ++m) if ((int)F.acc_members[a.first + m] >= sd.build_count) return "accumulate member outside the group's tables";
+        if ((a.pad != 0) != (first_seen[a.out_base] == 0)) return "accumulate first-mark out of order";
+        first_seen[a.out_base] = 1;
+        acc_members += a.count;
+        last_acc_stage = (int)si;
+      }
+      if (sd.sum_finish) { if (finish_stage >= 0) return "sums finished twice"; finish_stage = (int)si; }
+      if (sd.sum_finish && sd.build_count) return "sums finished in a stage that builds tables (they share the table slots)";
+    }
+    if (built != P.base_slots.size()) return "not every base table is built exactly once";
+    if (P.grouped() && !F.sums.empty()) {
+      size_t want = 0;
+      for (auto& sb : F.sums) want += sb.count;
+      if (acc_members != want || finish_stage <= last_acc_stage) return "sum accumulation incomplete or finished too early";
+      for (char c : first_seen) if (!c) return "a sum has no members";
+    } else if (finish_stage >= 0 || last_acc_stage >= 0) return "accumulators in an ungrouped plan";
+  }
+  size_t counted = 0, live = 0;      // live = table slots that hold a table while the stage's equations run
   for (auto& sd : F.stages) {
+    if (sd.build_count) live = (size_t)sd.build_count + (sd.sums_direct ? F.sums.size() : 0);
+    if (sd.sum_finish) live = F.sums.size();
     for (int f = 0; f < N_FAM; ++f) {
       if (sd.fam_first[f] < 0 || (size_t)sd.fam_first[f] + sd.fam_count[f] > F.jobs.size()) return "family range out of range";
       counted += sd.fam_count[f];
@@ -751,7 +906,7 @@ inline std::string check_flat_plan(const Plan& P, const FlatPlan& F) {
         for (unsigned t = 0; t < j.term_count; ++t) {
           const VarTerm& v = P.vterms[j.term_first + t];
           if (!scalar_ok(v.s) || v.s.kind == SRC_NONE) return "term scalar out of range";
-          if (v.base == 0xffff ? (int)v.slot >= P.n_pt_slots : v.base >= P.n_tables()) return "term base out of range";
+          if (v.base == 0xffff ? (int)v.slot >= P.n_pt_slots : (v.base >= n_tab || v.base >= live)) return "term base out of range";
         }
       }
     }

@@ -132,6 +132,36 @@ __global__ void __launch_bounds__(NT, EG_SUM_WAVES) k_sum_tables(EngineBufs B, c
   }
 }
 
+// ---- ring-group walk: the sums' tables when only one group of ring tables exists at a time (ge_teeth_sum_accumulate) ---------------------
+// k_sum_accumulate: one lane = one accumulator entry (sum, first-flip step t) of one ballot: adds the entries of this group's members.
+// recs: per (group, sum) {first, count: members as table slots of the group; out_base: index of the sum; pad: 1 = first contribution}.
+template <int T>
+__global__ void __launch_bounds__(NT, EG_SUM_WAVES) k_sum_accumulate(EngineBufs B, const egplan::SumBase* recs, const unsigned short* members, int n_recs) {
+  const size_t total = (size_t)n_recs * T * B.n;
+  for (size_t j = (size_t)blockIdx.x * NT + threadIdx.x; j < total; j += (size_t)gridDim.x * NT) {
+    const u32 q = (u32)(j / B.n), b = (u32)(j % B.n);
+    const egplan::SumBase rec = recs[q / T];
+    BaseTable acc{B.sacc + ((size_t)rec.out_base * B.cap + b) * (T * BTAB_ENTRY_QUADS)};
+    ge_teeth_sum_accumulate<T>(acc, (int)(q % T), rec.pad != 0, (int)rec.count, [&](int t, int g, ge_cached& e) {
+      const BaseTable bt{B.btab + ((size_t)members[rec.first + t] * B.cap + b) * btab_quads<T>()};
+      bt.load(e, g);
+    });
+  }
+}
+// k_sum_finish: one lane = one sum of one ballot: its table (table slot sums[k].out_base) from its accumulator
+template <int T>
+__global__ void __launch_bounds__(NT, EG_SUM_WAVES) k_sum_finish(EngineBufs B, const egplan::SumBase* sums, int n_sums) {
+  const size_t total = (size_t)n_sums * B.n;
+  WsRows tmp;
+  tmp.init(B.ws);
+  for (size_t j = (size_t)blockIdx.x * NT + threadIdx.x; j < total; j += (size_t)gridDim.x * NT) {
+    const u32 k = (u32)(j / B.n), b = (u32)(j % B.n);
+    BaseTable out{B.btab + ((size_t)sums[k].out_base * B.cap + b) * btab_quads<T>()};
+    const BaseTable acc{B.sacc + ((size_t)k * B.cap + b) * (T * BTAB_ENTRY_QUADS)};
+    ge_teeth_tables_sum<T>(out, tmp, 1, [&](int, int g, ge_cached& e) { acc.load(e, teeth_first_flip_index<T>(g)); });
+  }
+}
+
 // ---- group equations: P = sum_i [a_i]P_i + [g]G + [k]K (halved scalars; k_encode_batch then emits encode(2P)) ------------------
 // One lane = one group equation of one ballot: vartime_double_mul_generator / vartime_multi_mul (ring.rs:342-350,
 // log_equality.rs:160-164, mul.rs:213-247).  Persistent blocks stride over (class, ballot); lanes of a wave share the class, so

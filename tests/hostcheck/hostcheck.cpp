@@ -346,6 +346,47 @@ extern "C" void hc_fe_ops(const uint8_t a[32], const uint8_t b[32], uint8_t out[
 }
 extern "C" int hc_double_mul_generator_teeth(const uint8_t k[32], const uint8_t p_enc[32], const uint8_t r[32], uint8_t out[32]) { return g_teeth == 5 ? hc_double_mul_generator_teeth_t<5>(k, p_enc, r, out) : g_teeth == 7 ? hc_double_mul_generator_teeth_t<7>(k, p_enc, r, out) : hc_double_mul_generator_teeth_t<6>(k, p_enc, r, out); }
 extern "C" int hc_multi_mul_teeth(int n, const uint8_t* ks, const uint8_t* ps, const uint8_t r[32], uint8_t out[32]) { return g_teeth == 5 ? hc_multi_mul_teeth_t<5>(n, ks, ps, r, out) : g_teeth == 7 ? hc_multi_mul_teeth_t<7>(n, ks, ps, r, out) : hc_multi_mul_teeth_t<6>(n, ks, ps, r, out); }
+// the same table of a sum made the way the ring-group walk makes it: members in groups of `group`, whose tables exist only while their
+// group is accumulated (ge_teeth_sum_accumulate), then ge_teeth_tables_sum from the accumulator alone.  Every entry must equal the
+// entry of the table summed directly from all members' tables (same curve point), and the product must be the same encoding.
+template <int T>
+static int hc_sum_table_grouped_t(int n, int group, const uint8_t* ps, const uint8_t k[32], const uint8_t r[32], uint8_t out[32]) {
+  if (!g_base_table.ready) { ge g; ge_generator(g); build_fixed(g_base_table, g); }
+  std::vector<ArrBase> tabs(n);
+  for (int i = 0; i < n; ++i) {
+    u32 pw[8]; words_from_bytes(pw, ps + 32 * i, 8);
+    ge p; if (!ristretto_decode(p, pw)) return -1;
+    ArrTable tmp; ge_teeth_tables_build<T>(tabs[i], tmp, p);
+  }
+  ArrBase direct, acc, viaacc; ArrTable tmp, tmp2;
+  ge_teeth_tables_sum<T>(direct, tmp, n, [&](int t, int g, ge_cached& e) { tabs[t].load(e, g); });
+  for (int g0 = 0; g0 < n; g0 += group) {
+    const int m = std::min(group, n - g0);
+    for (int t = 0; t < T; ++t)
+      ge_teeth_sum_accumulate<T>(acc, t, g0 == 0, m, [&](int i, int g, ge_cached& e) { tabs[g0 + i].load(e, g); });
+  }
+  ge_teeth_tables_sum<T>(viaacc, tmp2, 1, [&](int, int g, ge_cached& e) { acc.load(e, teeth_first_flip_index<T>(g)); });
+  int same = 1;
+  for (int t = 0; t < T; ++t) if (teeth_first_flip_index<T>(teeth_first_flip_entry<T>(t)) != t) same = 0;
+  for (int g = 0; g < Teeth<T>::ENTRIES; ++g) {
+    ge_cached ea, eb; direct.load(ea, g); viaacc.load(eb, g);
+    ge a, b; ge_cached_to_p3(a, ea); ge_cached_to_p3(b, eb);
+    fe az, bz, l, rr;
+    az = a.Z; fe_carry(az); bz = b.Z; fe_carry(bz);
+    fe_mul(l, a.X, bz); fe_mul(rr, b.X, az); if (!fe_eq(l, rr)) same = 0;
+    fe_mul(l, a.Y, bz); fe_mul(rr, b.Y, az); if (!fe_eq(l, rr)) same = 0;
+    fe_mul(l, a.T, bz); fe_mul(rr, b.T, az); if (!fe_eq(l, rr)) same = 0;
+  }
+  u32 kw[8], rw[8], o[8];
+  words_from_bytes(kw, k, 8); words_from_bytes(rw, r, 8);
+  u64 rows[T]; u32 dr[EG_COMB_WORDS]; sc_recode_teeth<T>(rows, kw); sc_recode_comb(dr, rw);
+  ge res; ge_teeth_mul<T>(res, viaacc, rows);
+  ge_fixed_mul_add(res, g_base_table, dr);
+  ristretto_encode(o, res);
+  bytes_from_words(out, o, 8);
+  return same;
+}
+extern "C" int hc_sum_table_grouped(int n, int group, const uint8_t* ps, const uint8_t k[32], const uint8_t r[32], uint8_t out[32]) { return g_teeth == 5 ? hc_sum_table_grouped_t<5>(n, group, ps, k, r, out) : g_teeth == 7 ? hc_sum_table_grouped_t<7>(n, group, ps, k, r, out) : hc_sum_table_grouped_t<6>(n, group, ps, k, r, out); }
 extern "C" int hc_sum_table_mul(int n, const uint8_t* ps, const uint8_t k[32], const uint8_t r[32], uint8_t out[32]) { return g_teeth == 5 ? hc_sum_table_mul_t<5>(n, ps, k, r, out) : g_teeth == 7 ? hc_sum_table_mul_t<7>(n, ps, k, r, out) : hc_sum_table_mul_t<6>(n, ps, k, r, out); }
 extern "C" int hc_double_mul_generator_halved(const uint8_t k[32], const uint8_t p_enc[32], const uint8_t r[32], uint8_t out[32]) { return g_teeth == 5 ? hc_double_mul_generator_halved_t<5>(k, p_enc, r, out) : g_teeth == 7 ? hc_double_mul_generator_halved_t<7>(k, p_enc, r, out) : hc_double_mul_generator_halved_t<6>(k, p_enc, r, out); }
 extern "C" void hc_op_counts(unsigned long long out[28]) { if (g_teeth == 5) hc_op_counts_t<5>(out); else if (g_teeth == 7) hc_op_counts_t<7>(out); else hc_op_counts_t<6>(out); }

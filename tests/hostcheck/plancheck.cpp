@@ -23,8 +23,8 @@ int pc_plan(int kind, int n, unsigned long long v) {
   uint8_t pk[32]; memset(pk, 7, 32);
   size_t item = 0;
   switch (kind) {
-    case 0: return check(build_choice_plan(n, true), pk);
-    case 1: return check(build_choice_plan(n, false), pk);
+    case 0: return check(build_choice_plan(n, true, v ? (int)v - 1 : -1), pk);      // v = rings per group of the ring-group walk + 1 (0: default)
+    case 1: return check(build_choice_plan(n, false, v ? (int)v - 1 : -1), pk);
     case 2: return check(build_qv_plan(n, v), pk);
     case 3: return check(build_zero_plan(), pk);
     case 4: return check(build_bool_plan(), pk);

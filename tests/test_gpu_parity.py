@@ -1606,3 +1606,36 @@ def test_configs4_eight_shards_on_one_gpu(eg, ctx, pk):
     ctx.synchronize()
     assert int(n_bad.item()) == 0
     assert bytes(out.cpu().numpy()) == whole.tally_encode()
+
+
+@pytest.mark.parametrize("single,n_opt,groups", [(True, 5, ("0", "1", "2", "3", "4")), (False, 16, ("0", "3", "4", "8")), (True, 9, ("0", "4", "8"))])
+def test_ring_group_walk_gives_the_same_verdicts(eg, ctx, oracle, pk, monkeypatch, single, n_opt, groups):
+    """The ring-group walk (the comb tables of one group of rings at a time, the sums of bases accumulated group by
+    group) is a schedule, not a different computation: for every group size - EG_RING_GROUP = rings per group, 0 = every table of a
+    ballot at once - verdicts and tally equal the oracle's on a batch with tampered ring responses in different groups, tampered
+    sum proofs, a bad point and a bad scalar (choice.rs:358-380 order of checks)."""
+    op = oracle.ChoiceParams(pk, n_opt, single)
+    n = 700
+    ballots = bytearray(op.generate_batch(777, 0, n, n_selected=0 if single else 3, threads=8))
+    sz = len(ballots) // n
+    ring0 = 64 * n_opt                                     # e0, then 2 responses per ring
+    for i in range(0, n, 9):                               # a response of ring (i mod n_opt): every group gets its share
+        ballots[i * sz + ring0 + 32 * (1 + 2 * (i % n_opt) + (i // 9) % 2) + 5] ^= 0x10
+    if single:
+        for i in range(4, n, 31):                          # the sum proof (verified after the last group)
+            ballots[i * sz + sz - 20] ^= 2
+    ballots[13 * sz + 64 * (n_opt - 1) + 3] ^= 0x80        # a point of the last ring
+    ballots[14 * sz + ring0 + 31] |= 0xf0                  # e0 not canonical
+    ballots = bytes(ballots)
+    want = op.verify_batch(ballots, threads=8)
+    want_tally = op.tally(ballots, want)
+    assert len(set(want)) >= (4 if single else 3)
+    for g in groups:
+        monkeypatch.setenv("EG_RING_GROUP", g)
+        desc = eg.plan_describe("single" if single else "multi", n_opt)
+        assert desc["ring_group"] == (int(g) if int(g) < n_opt else 0)
+        p = eg.ChoiceParams(ctx, pk, n_opt, single)
+        st, tally = p.verify_batch(ballots)
+        assert st == want, g
+        assert tally == want_tally, g
+        p.close()

@@ -213,6 +213,25 @@ def test_sum_of_tables(hc, oracle, teeth):
             assert out.raw == want, (si, trial)
 
 
+def test_sum_of_tables_group_by_group(hc, oracle, teeth):
+    """Ring-group walk (ge_teeth_sum_accumulate + ge_teeth_tables_sum over the accumulator): the table of a sum whose members' tables
+    exist one group at a time holds the same points as the table summed from all members at once, for every group size, including
+    members that cancel (identity partial sums inside and across groups)."""
+    rnd = random.Random(46)
+    pts = [oracle.point_mul_generator(rnd.randrange(L).to_bytes(32, "little")) for _ in range(9)] + [b"\x00" * 32]
+    neg0 = oracle.point_mul_generator((L - 1).to_bytes(32, "little"))
+    g1 = oracle.point_mul_generator((1).to_bytes(32, "little"))
+    sets = [[pts[0]], pts[:2], pts[:5], pts[:9], [g1, neg0], [g1, neg0, pts[4], pts[9]], [pts[3], pts[3], pts[3], pts[3]], pts[:9] + pts[:7]]
+    for si, ps in enumerate(sets):
+        for group in (1, 2, 3, 4, len(ps)):
+            k, r = (rnd.randrange(L) if (si + group) % 3 else [0, 1, L - 1][group % 3]), rnd.randrange(L)
+            out = _b()
+            kb, rb = k.to_bytes(32, "little"), r.to_bytes(32, "little")
+            assert hc.hc_sum_table_grouped(len(ps), group, b"".join(ps), kb, rb, out) == 1, (si, group)
+            want = oracle.point_multi_mul(kb * len(ps) + rb, b"".join(ps) + oracle.const_bytes(4))
+            assert out.raw == want, (si, group)
+
+
 def test_merlin(hc, oracle):
     out = _b(64)
     hc.hc_merlin.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_uint64, C.c_char_p, C.c_char_p]

@@ -43,6 +43,12 @@ def test_every_plan_shape_builds_flattens_and_checks(lib):
         for n in list(range(1, 41)) + [64, 150, 1000, 4000]:
             for kind in (0, 1):
                 j = L.pc_plan(kind, n, C.c_ulonglong(0)); assert j == 4 * n + (4 if kind == 0 else 0), (kind, n, j); total += 1
+        # the ring-group walk with every group size (v - 1 rings per group; 0 = every table at once): same equations, consistent indices
+        for n in (1, 2, 3, 4, 5, 6, 7, 8, 9, 16, 17, 33, 150):
+            for kind in (0, 1):
+                for rg in (0, 1, 2, 3, 4, 5, 8, n - 1, n, n + 1):
+                    if rg < 0: continue
+                    j = L.pc_plan(kind, n, C.c_ulonglong(rg + 1)); assert j == 4 * n + (4 if kind == 0 else 0), (kind, n, rg, j); total += 1
         for n, credits in [(1, 1), (2, 4), (3, 9), (5, 15), (5, 20), (5, 25), (4, 100), (8, 36), (12, 200), (16, 64), (20, 1000), (3, 10000), (256, 100000)]:
             assert L.pc_plan(2, n, C.c_ulonglong(credits)) > 0, (n, credits); total += 1
         for ub in list(range(2, 300)) + [1000, 65536, 777777, 1000000]:

@@ -13,11 +13,12 @@ mode = sys.argv[2] if len(sys.argv) > 2 else "single"
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 pk = bytes.fromhex("a6adb6e9c0ae8d54c26e6e56b5ccd7a16bb0e1951abe4d7ee7028e3d4eca8531")
 ctx = eg.Context(0)
+n_opt = int(os.environ.get("EG_PROBE_OPTIONS", "0"))      # another election size than the BASELINE configs' (single / multi)
 if mode == "single":
-    p = eg.ChoiceParams(ctx, pk, 5, True); d = torch.empty(n_total * p.ballot_size, dtype=torch.uint8, device="cuda")
+    p = eg.ChoiceParams(ctx, pk, n_opt or 5, True); d = torch.empty(n_total * p.ballot_size, dtype=torch.uint8, device="cuda")
     p.encrypt_batch_device(1, 0, n_total, d.data_ptr()); ctx.synchronize()
 elif mode == "multi":
-    p = eg.ChoiceParams(ctx, pk, 16, False); d = torch.empty(n_total * p.ballot_size, dtype=torch.uint8, device="cuda")
+    p = eg.ChoiceParams(ctx, pk, n_opt or 16, False); d = torch.empty(n_total * p.ballot_size, dtype=torch.uint8, device="cuda")
     p.encrypt_batch_device(1, 0, n_total, d.data_ptr(), n_selected=3); ctx.synchronize()
 else:
     p = eg.QuadraticVotingParams(ctx, pk, 5, int(os.environ.get("EG_PROBE_CREDITS", "20"))); d = torch.empty(n_total * p.ballot_size, dtype=torch.uint8, device="cuda")
