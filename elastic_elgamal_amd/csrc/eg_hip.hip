@@ -27,6 +27,7 @@
 #include "host_plan.hpp"
 #include "wire_json.hpp"
 #include "kernels.cuh"
+#include "pippenger.cuh"
 
 using namespace eg;
 
@@ -1063,9 +1064,127 @@ static MsmScratch msm_scratch_at(void* base, size_t n, size_t nc) {
   m.part[1] = reinterpret_cast<u32*>(p); m.ok[1] = reinterpret_cast<unsigned char*>(p + (c1 * PT_WORDS * sizeof(u32) + 255) / 256 * 256);
   return m;
 }
-// out[i] = enc( sum_t [k_it]P_it + [r_i]G ) on device pointers (kernels.cuh: k_prim_msm, k_prim_msm_fold, k_prim_msm_reduce); asynchronous on s
+// `count` partial sums per problem in m.part[0] -> out: 64-fold wavefront-shuffle passes, then one wavefront per problem adds them up, adds the
+// generator term and encodes
+static void msm_fold_reduce(eg_ctx* c, size_t n, int count, const MsmScratch& m, const u32* d_r, u32* d_out, unsigned char* d_ok, hipStream_t s) {
+  int cur = 0;
+  while (count > 64) {                 // 64-fold per pass, one wavefront per 64 partial sums
+    const int next = (count + 63) / 64;
+    hipLaunchKernelGGL(k_prim_msm_fold, dim3((unsigned)((n * (size_t)next * 64 + NT - 1) / NT)), dim3(NT), 0, s, n, count, next,
+                       m.part[cur], m.ok[cur], m.part[cur ^ 1], m.ok[cur ^ 1]);
+    cur ^= 1; count = next;
+  }
+  hipLaunchKernelGGL(k_prim_msm_reduce, dim3((unsigned)((n * 64 + NT - 1) / NT)), dim3(NT), 0, s, n, count, m.part[cur], m.ok[cur],
+                     d_r, c->tabG, d_out, d_ok);
+}
+
+// ---- the bucket method for one very large product (pippenger.cuh) ----------------------------------------------------------------------------
+// Window width by size: 2^(c-1) buckets per window with ~64 terms each.  Measured against the Straus path (tools/msm_probe.py,
+// profiles/r04_msm_by_size.txt): 2^19 terms 3.6 ms against 3.3, 2^20 4.8 against 5.7, 2^21 7.3 against 10.8, 2^22 13.0 against 21.5 - the
+// bucket method takes over from 2^20 terms; EG_MSM_BUCKET_MIN moves the switch (tests force either path at sizes the oracle can follow).
+static size_t pip_bucket_min() {
+  if (const char* v = getenv("EG_MSM_BUCKET_MIN")) return (size_t)strtoull(v, nullptr, 10);
+  return (size_t)1 << 20;
+}
+static int pip_window_bits(size_t terms) {
+  int c = PIP_MIN_C;
+  while (c < PIP_MAX_C && ((size_t)64 << (c - 1)) < terms) ++c;      // 2^17 -> 12, 2^18 -> 13, 2^19 -> 14, >= 2^20 -> 15
+  return c;
+}
+static bool msm_uses_buckets(size_t terms) { return terms >= std::max<size_t>(pip_bucket_min(), (size_t)1 << 12); }
+constexpr int PIP_MAX_LEVELS = PIP_SEQ - 1;
+struct PipLayout {
+  size_t niels, digits, counts, offsets, cursors, idx, pieces[PIP_MAX_LEVELS], piece0[PIP_MAX_LEVELS], totals, tiles, psum[2], flag, part, total;
+  size_t psum_points;       // capacity of each of the two partial-sum buffers
+  int c, W, B, waves, levels;
+};
+static PipLayout pip_layout(size_t terms) {
+  PipLayout L;
+  L.c = pip_window_bits(terms); L.W = pip_windows(L.c); L.B = 1 << (L.c - 1); L.waves = L.W * (L.B / PIP_SEG) / 64;
+  const size_t nb = (size_t)L.W * L.B;
+  // levels: pieces of 128 terms, then of 64 partial sums, until the longest possible bucket (all terms) is down to one sum
+  L.levels = 1;
+  for (size_t n = (terms + PIP_S_TERMS - 1) / PIP_S_TERMS; n > 1; n = (n + PIP_S_POINTS - 1) / PIP_S_POINTS) ++L.levels;
+  L.psum_points = (size_t)L.W * terms / PIP_S_TERMS + nb + 64;      // every bucket adds at most one ragged piece per level
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) / 256 * 256; return at; };
+  L.niels = take(terms * PIP_NIELS_WORDS * sizeof(u32));
+  L.digits = take((size_t)L.W * terms * sizeof(unsigned short));
+  L.counts = take(nb * sizeof(u32));
+  L.offsets = take(nb * sizeof(u32));
+  L.cursors = take(nb * sizeof(u32));
+  L.idx = take((size_t)L.W * terms * sizeof(u32));
+  for (int l = 0; l < PIP_MAX_LEVELS; ++l) { L.pieces[l] = take(nb * sizeof(u32)); L.piece0[l] = take(nb * sizeof(u32)); }
+  L.totals = take(256);
+  L.tiles = take(((nb + 1023) / 1024) * PIP_SEQ * sizeof(u32));
+  L.psum[0] = take(L.psum_points * PT_QUADS * sizeof(uint4));
+  L.psum[1] = take(L.psum_points * PT_QUADS * sizeof(uint4));
+  L.flag = take(256);
+  L.part = take(msm_scratch_total(1, (size_t)L.waves) + 256);
+  L.total = off;
+  return L;
+}
+static int pip_launch(eg_ctx* c, size_t terms, const u32* d_scalars, const u32* d_points, const u32* d_r, void* d_scratch, u32* d_out,
+                      unsigned char* d_ok, hipStream_t s) {
+  const PipLayout L = pip_layout(terms);
+  if (L.levels > PIP_MAX_LEVELS) return fail(EG_ERR_BAD_ARG, "too many terms for the bucket method");
+  char* base = static_cast<char*>(d_scratch);
+  auto at = [&](size_t o) { return reinterpret_cast<u32*>(base + o); };
+  PipBufs P;
+  P.niels = at(L.niels); P.digits = reinterpret_cast<unsigned short*>(base + L.digits);
+  P.counts = at(L.counts); P.offsets = at(L.offsets); P.cursors = at(L.cursors); P.idx = at(L.idx); P.all_ok = at(L.flag);
+  const u32 nb = (u32)((size_t)L.W * L.B);
+  u32* totals = at(L.totals);
+  uint4* psum[2] = {reinterpret_cast<uint4*>(base + L.psum[0]), reinterpret_cast<uint4*>(base + L.psum[1])};
+  HIPCHK(hipMemsetAsync(P.counts, 0, (size_t)nb * sizeof(u32), s));
+  HIPCHK(hipMemsetAsync(P.all_ok, 0x01, sizeof(u32), s));
+  hipLaunchKernelGGL(k_pip_prepare, dim3((unsigned)((terms + NT - 1) / NT)), dim3(NT), 0, s, terms, L.c, d_scalars, d_points, P);
+  {
+    PipScan S;
+    S.offsets = P.offsets; S.cursors = P.cursors; S.totals = totals; S.tile_sums = at(L.tiles);
+    for (int l = 0; l < PIP_SEQ - 1; ++l) { S.pieces[l] = at(L.pieces[l]); S.piece0[l] = at(L.piece0[l]); }
+    const unsigned tiles = (nb + 1023u) / 1024u;
+    hipLaunchKernelGGL(k_pip_scan_tiles, dim3(tiles), dim3(NT), 0, s, (const u32*)P.counts, nb, L.levels, S);
+    hipLaunchKernelGGL(k_pip_scan_tops, dim3(1), dim3(64 * PIP_SEQ), 0, s, tiles, S);
+    hipLaunchKernelGGL(k_pip_scan_apply, dim3(tiles), dim3(NT), 0, s, (const u32*)P.counts, nb, L.levels, S);
+  }
+  hipLaunchKernelGGL(k_pip_fill, dim3(grid_for(terms * (size_t)L.W, c->cus * 64)), dim3(NT), 0, s, terms, L.c, P);
+  // level 0: pieces of the term lists; levels 1 ..: pieces of the partial sums of the level before
+  const u32* cnt = P.counts;
+  const u32* off = P.offsets;
+  size_t bound = L.psum_points;
+  for (int l = 0; l < L.levels; ++l) {
+    u32 *pieces = at(L.pieces[l]), *piece0 = at(L.piece0[l]);
+    const PipLevel lv{cnt, off, pieces, piece0, totals + l};
+    const int grid = grid_for(bound, c->cus * 64);
+    if (l == 0) hipLaunchKernelGGL(k_pip_sum_terms, dim3(grid), dim3(NT), 0, s, P, lv, nb, psum[0]);
+    else hipLaunchKernelGGL(k_pip_sum_points, dim3(grid), dim3(NT), 0, s, (const uint4*)psum[(l - 1) & 1], lv, nb, psum[l & 1]);
+    cnt = pieces; off = piece0;
+    bound = bound / PIP_S_POINTS + nb + 64;
+  }
+  const MsmScratch m = msm_scratch_at(base + L.part, 1, (size_t)L.waves);
+  hipLaunchKernelGGL(k_pip_window, dim3((unsigned)(((size_t)L.waves * 64 + NT - 1) / NT)), dim3(NT), 0, s, L.c, P,
+                     (const uint4*)psum[(L.levels - 1) & 1], cnt, off, m.part[0], m.ok[0]);
+  msm_fold_reduce(c, 1, L.waves, m, d_r, d_out, d_ok, s);
+  HIPCHK(hipGetLastError());
+  return EG_OK;
+}
+
+static size_t msm_chunks(size_t n, size_t terms) { int c, k; msm_plan(n, terms, &c, &k); return (size_t)k; }
+// scratch a call needs on the device (0: none)
+static size_t msm_scratch_for(size_t n, size_t terms) {
+  return msm_uses_buckets(terms) ? pip_layout(terms).total : msm_scratch_total(n, msm_chunks(n, terms));
+}
+// out[i] = enc( sum_t [k_it]P_it + [r_i]G ) on device pointers (kernels.cuh: k_prim_msm, k_prim_msm_fold, k_prim_msm_reduce; very large
+// products: pippenger.cuh, one problem after the other); asynchronous on s
 static int prim_msm_launch(eg_ctx* c, size_t n, size_t terms, const u32* d_scalars, const u32* d_points, const u32* d_r, void* d_scratch,
                            u32* d_out, unsigned char* d_ok, hipStream_t s) {
+  if (msm_uses_buckets(terms)) {
+    for (size_t i = 0; i < n; ++i)
+      TRY(pip_launch(c, terms, d_scalars + i * terms * 8, d_points + i * terms * 8, d_r ? d_r + i * 8 : nullptr, d_scratch, d_out + i * 8,
+                     d_ok ? d_ok + i : nullptr, s));
+    return EG_OK;
+  }
   int chunk, n_chunks;
   msm_plan(n, terms, &chunk, &n_chunks);
   const MsmScratch m = msm_scratch_at(d_scratch, n, (size_t)n_chunks);
@@ -1073,32 +1192,21 @@ static int prim_msm_launch(eg_ctx* c, size_t n, size_t terms, const u32* d_scala
   const int grid = grid_for(n * (size_t)n_chunks, std::max(1, c->msm_blocks / chunk));
   hipLaunchKernelGGL(k_prim_msm, dim3(grid), dim3(NT), (size_t)chunk * 8 * NT * sizeof(u32), s, n, (int)terms, chunk, n_chunks, d_scalars,
                      d_points, d_r, c->tabG, c->ws, m.part[0], m.ok[0], d_out, d_ok);
-  if (n_chunks > 1) {
-    int cur = 0, count = n_chunks;
-    while (count > 64) {                 // 64-fold per pass, one wavefront per 64 partial sums
-      const int next = (count + 63) / 64;
-      hipLaunchKernelGGL(k_prim_msm_fold, dim3((unsigned)((n * (size_t)next * 64 + NT - 1) / NT)), dim3(NT), 0, s, n, count, next,
-                         m.part[cur], m.ok[cur], m.part[cur ^ 1], m.ok[cur ^ 1]);
-      cur ^= 1; count = next;
-    }
-    hipLaunchKernelGGL(k_prim_msm_reduce, dim3((unsigned)((n * 64 + NT - 1) / NT)), dim3(NT), 0, s, n, count, m.part[cur], m.ok[cur],
-                       d_r, c->tabG, d_out, d_ok);
-  }
+  if (n_chunks > 1) msm_fold_reduce(c, n, n_chunks, m, d_r, d_out, d_ok, s);
   HIPCHK(hipGetLastError());
   return EG_OK;
 }
-static size_t msm_chunks(size_t n, size_t terms) { int c, k; msm_plan(n, terms, &c, &k); return (size_t)k; }
 static int prim_msm(eg_ctx* c, size_t n, size_t terms, const uint8_t* scalars, const uint8_t* points, const uint8_t* r,
                     uint8_t* out, uint8_t* ok) {
   HIPCHK(hipSetDevice(c->device));
   if (n == 0) return EG_OK;
   if (terms > ((size_t)1 << 24) || n > ((size_t)1 << 32)) return fail(EG_ERR_BAD_ARG, "at most 2^24 terms per problem");
-  const size_t nc = msm_chunks(n, terms);
+  const size_t need = msm_scratch_for(n, terms);
   void *sc, *pt, *rr, *o, *k, *scratch;
-  TRY(prim_bufs(c, {n * terms * 32, n * terms * 32, n * 32, n * 32, n, msm_scratch_total(n, nc)}, {&sc, &pt, &rr, &o, &k, &scratch}));
+  TRY(prim_bufs(c, {n * terms * 32, n * terms * 32, n * 32, n * 32, n, need}, {&sc, &pt, &rr, &o, &k, &scratch}));
   TRY(h2d(sc, scalars, n * terms * 32, c->stream)); TRY(h2d(pt, points, n * terms * 32, c->stream));
   if (r) TRY(h2d(rr, r, n * 32, c->stream));
-  TRY(prim_msm_launch(c, n, terms, (const u32*)sc, (const u32*)pt, r ? (const u32*)rr : (const u32*)nullptr, nc > 1 ? scratch : nullptr,
+  TRY(prim_msm_launch(c, n, terms, (const u32*)sc, (const u32*)pt, r ? (const u32*)rr : (const u32*)nullptr, need ? scratch : nullptr,
                       (u32*)o, (unsigned char*)k, c->stream));
   TRY(d2h(out, o, n * 32, c->stream));
   if (ok) TRY(d2h(ok, k, n, c->stream));
@@ -1122,16 +1230,16 @@ int eg_vartime_multi_mul_batch(eg_ctx* c, size_t n, size_t terms, const uint8_t*
 }
 // the same on DEVICE buffers, asynchronous on `stream` (a caller that keeps its operands in HBM pays no copies and no synchronisation;
 // what bench.py --workload msm times).  d_scratch must hold eg_msm_scratch_bytes(n, terms) bytes (0 for <= 8 terms).
-size_t eg_msm_scratch_bytes(size_t n, size_t terms) { return msm_scratch_total(n, msm_chunks(n, terms)); }
+size_t eg_msm_scratch_bytes(size_t n, size_t terms) { return msm_scratch_for(n, terms); }
 int eg_vartime_multi_mul_batch_device(eg_ctx* c, size_t n, size_t terms, const void* d_scalars, const void* d_points, const void* d_r,
                                       void* d_scratch, void* d_out, void* d_ok, void* stream) { EG_LOCK(c);
   if (!c || (n && !d_out) || (n && terms && (!d_scalars || !d_points)) || (n && !terms && !d_r)) return fail(EG_ERR_BAD_ARG, "bad argument");
   if (terms > ((size_t)1 << 24)) return fail(EG_ERR_BAD_ARG, "at most 2^24 terms per problem");
-  const size_t nc = msm_chunks(n, terms);
-  if (n && nc > 1 && !d_scratch) return fail(EG_ERR_BAD_ARG, "this call is cut into several chunks per problem and needs d_scratch (eg_msm_scratch_bytes)");
+  const size_t need = msm_scratch_for(n, terms);
+  if (n && need && !d_scratch) return fail(EG_ERR_BAD_ARG, "this call is cut into several chunks per problem (or uses the bucket method) and needs d_scratch (eg_msm_scratch_bytes)");
   if (n == 0) return EG_OK;
   HIPCHK(hipSetDevice(c->device));
-  return prim_msm_launch(c, n, terms, (const u32*)d_scalars, (const u32*)d_points, (const u32*)d_r, nc > 1 ? d_scratch : nullptr, (u32*)d_out,
+  return prim_msm_launch(c, n, terms, (const u32*)d_scalars, (const u32*)d_points, (const u32*)d_r, need ? d_scratch : nullptr, (u32*)d_out,
                          (unsigned char*)d_ok, (hipStream_t)stream);
 }
 

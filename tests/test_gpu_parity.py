@@ -1639,3 +1639,76 @@ def test_ring_group_walk_gives_the_same_verdicts(eg, ctx, oracle, pk, monkeypatc
         assert st == want, g
         assert tally == want_tally, g
         p.close()
+
+
+def test_bucket_method_multi_scalar_mul(eg, ctx, grp, oracle, monkeypatch):
+    """The bucket (Pippenger) path of Group::vartime_multi_mul (pippenger.cuh; ristretto.rs:139-145 -> dalek's Pippenger above 190 terms),
+    forced at small sizes (EG_MSM_BUCKET_MIN) so that the oracle can follow: identity points, zero / edge / non-canonical-width
+    scalars, ONE point repeated thousands of times (a bucket as long as the problem), a point and its negative, duplicates, two
+    problems in one call, a generator term through the device entry point, an undecodable point (flagged, contributes nothing)."""
+    import torch
+
+    rnd = random.Random(2026)
+    pool = [oracle.point_mul_generator(sc(rnd.randrange(L))) for _ in range(300)] + [b"\0" * 32]
+    neg = [oracle.point_add(b"\0" * 32, b"\0" * 32)]          # identity again
+    edge = [0, 1, 2, L - 1, L - 2, 2**252, 2**252 - 1, (1 << 15) - 1, 1 << 15, 1 << 14, (1 << 14) + 1, 8, 0x0888888888888888888888888888888888888888888888888888888888888888]
+    monkeypatch.setenv("EG_MSM_BUCKET_MIN", "4096")
+    for terms, m, mode in ((4096, 1, "random"), (5003, 2, "random"), (4096, 1, "one_point"), (6001, 1, "edge"), (20001, 1, "random")):
+        if mode == "one_point":
+            scal = [[sc(rnd.randrange(1, 9)) for _ in range(terms)] for _ in range(m)]       # digits 1..8 of window 0 only: eight huge buckets
+            pp = [[pool[3]] * terms for _ in range(m)]
+        elif mode == "edge":
+            scal = [[sc(edge[t % len(edge)]) for t in range(terms)] for _ in range(m)]
+            pp = [[pool[t % 7] if t % 3 else pool[-1] for t in range(terms)] for _ in range(m)]
+        else:
+            scal = [[sc(rnd.randrange(L)) for _ in range(terms)] for _ in range(m)]
+            pp = [[pool[rnd.randrange(len(pool))] for _ in range(terms)] for _ in range(m)]
+        sb, pb = b"".join(b"".join(x) for x in scal), b"".join(b"".join(x) for x in pp)
+        got, ok = grp.vartime_multi_mul(terms, sb, pb)
+        assert set(ok) == {1}, (terms, mode)
+        for i in range(m):
+            assert got[32 * i : 32 * i + 32] == oracle.point_multi_mul(b"".join(scal[i]), b"".join(pp[i])), (terms, mode, i)
+        r = b"".join(sc(rnd.randrange(L)) for _ in range(m))
+        ds = torch.frombuffer(bytearray(sb), dtype=torch.uint8).cuda()
+        dp = torch.frombuffer(bytearray(pb), dtype=torch.uint8).cuda()
+        dr = torch.frombuffer(bytearray(r), dtype=torch.uint8).cuda()
+        do = torch.zeros(32 * m, dtype=torch.uint8, device="cuda")
+        dok = torch.zeros(m, dtype=torch.uint8, device="cuda")
+        need = grp.msm_scratch_bytes(m, terms)
+        assert need > 0
+        scratch = torch.zeros(need, dtype=torch.uint8, device="cuda")
+        grp.vartime_multi_mul_device(m, terms, ds.data_ptr(), dp.data_ptr(), do.data_ptr(), d_r=dr.data_ptr(), d_scratch=scratch.data_ptr(), d_ok=dok.data_ptr())
+        ctx.synchronize()
+        out = bytes(do.cpu().numpy())
+        for i in range(m):
+            assert out[32 * i : 32 * i + 32] == oracle.point_add(got[32 * i : 32 * i + 32], oracle.point_mul_generator(r[32 * i : 32 * i + 32])), (terms, mode, i)
+        assert dok.cpu().tolist() == [1] * m
+        with pytest.raises(eg.EgError):          # the bucket path cannot run without its scratch
+            grp.vartime_multi_mul_device(m, terms, ds.data_ptr(), dp.data_ptr(), do.data_ptr())
+        if mode == "random" and m == 2:          # an undecodable point in problem 1: flagged, and it contributes the identity
+            bad = bytearray(pb)
+            bad[(terms + 77) * 32 : (terms + 78) * 32] = b"\xff" * 32
+            out2, ok2 = grp.vartime_multi_mul(terms, sb, bytes(bad))
+            assert list(ok2) == [1, 0] and out2[:32] == got[:32]
+            rest_s = b"".join(scal[1][:77] + scal[1][78:]); rest_p = b"".join(pp[1][:77] + pp[1][78:])
+            assert out2[32:] == oracle.point_multi_mul(rest_s, rest_p)
+    # a size of the order of the default switch (2^20 terms): both paths must give the same encoding on the same operands
+    terms = (1 << 17) + 12345
+    g = torch.Generator(device="cpu").manual_seed(5)
+    s_t = torch.randint(0, 256, (terms, 32), dtype=torch.uint8, generator=g)
+    s_t[:, 31] &= 0x0F
+    base = torch.frombuffer(bytearray(b"".join(pool[:256])), dtype=torch.uint8)
+    p_t = base.view(256, 32)[torch.randint(0, 256, (terms,), generator=g)].contiguous()
+    ds, dp = s_t.reshape(-1).cuda(), p_t.reshape(-1).cuda()
+    outs = []
+    for switch in ("4096", str(1 << 30)):
+        monkeypatch.setenv("EG_MSM_BUCKET_MIN", switch)
+        do = torch.zeros(32, dtype=torch.uint8, device="cuda")
+        scratch = torch.zeros(max(grp.msm_scratch_bytes(1, terms), 16), dtype=torch.uint8, device="cuda")
+        grp.vartime_multi_mul_device(1, terms, ds.data_ptr(), dp.data_ptr(), do.data_ptr(), d_scratch=scratch.data_ptr())
+        ctx.synchronize()
+        outs.append(bytes(do.cpu().numpy()))
+    assert outs[0] == outs[1] != bytes(32)
+    monkeypatch.delenv("EG_MSM_BUCKET_MIN")
+    assert grp.msm_scratch_bytes(1, 1 << 20) > 100 << 20       # by default the bucket path takes over at 2^20 terms (and needs its scratch) ...
+    assert grp.msm_scratch_bytes(1, (1 << 20) - 1) < 16 << 20  # ... and Straus' partial sums are all that is needed below

@@ -9,7 +9,7 @@ import elastic_elgamal_amd as eg
 ctx = eg.Context(0)
 grp = eg.Ristretto(ctx)
 L = 2**252 + 27742317777372353535851937790883648493
-big = 1 << 20
+big = 1 << 22
 g = torch.Generator(device="cpu"); g.manual_seed(1)
 sc = torch.randint(0, 256, (big, 32), dtype=torch.uint8, generator=g); sc[:, 31] &= 0x0f
 sc = sc.cuda()
@@ -19,7 +19,11 @@ grp_pts = grp.mul_generator(bytes(sc[:4096].cpu().numpy().tobytes()))
 base = torch.frombuffer(bytearray(grp_pts), dtype=torch.uint8).cuda()
 pts = base.repeat(big // 4096)
 out = torch.empty(32, dtype=torch.uint8, device="cuda")
-for n in (1 << 12, 1 << 14, 1 << 16, 1 << 18, 1 << 20):
+import os
+sizes = [(n, "default") for n in (1 << 12, 1 << 14, 1 << 16, 1 << 17, 1 << 18, 1 << 19, 1 << 20, 1 << 21, 1 << 22)]
+sizes = [(n, mode) for n, _ in sizes for mode in (("straus", "buckets") if n >= 1 << 14 else ("straus",))]
+for n, mode in sizes:
+    os.environ["EG_MSM_BUCKET_MIN"] = str(1 << 30) if mode == "straus" else "4096"       # force one path or the other
     scratch = torch.empty(max(grp.msm_scratch_bytes(1, n), 16), dtype=torch.uint8, device="cuda")
     for _ in range(2):
         grp.vartime_multi_mul_device(1, n, sc.data_ptr(), pts.data_ptr(), out.data_ptr(), 0, scratch.data_ptr()); torch.cuda.synchronize()
@@ -28,4 +32,4 @@ for n in (1 << 12, 1 << 14, 1 << 16, 1 << 18, 1 << 20):
         grp.vartime_multi_mul_device(1, n, sc.data_ptr(), pts.data_ptr(), out.data_ptr(), 0, scratch.data_ptr())
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 5
-    print(f"{n:8d} terms: {dt * 1e3:8.3f} ms  ({n / dt / 1e6:7.1f} M terms/s)", flush=True)
+    print(f"{n:8d} terms  {mode:8s}: {dt * 1e3:8.3f} ms  ({n / dt / 1e6:7.1f} M terms/s)   result {bytes(out.cpu().numpy()).hex()[:16]}", flush=True)
