@@ -1453,7 +1453,11 @@ static int verify_batch_multi(Params* const* per_device, int n_dev, size_t n, co
   };
   {
     std::vector<std::thread> threads;
-    for (int d = 1; d < n_dev; ++d) threads.emplace_back(work, d);
+    try {
+      for (int d = 1; d < n_dev; ++d) threads.emplace_back(work, d);
+    } catch (const std::exception& ex) {          // no thread for a slab (resource limits): the caller's thread takes it over - nothing may escape the C ABI
+      for (int d = (int)threads.size() + 1; d < n_dev; ++d) work(d);
+    }
     work(0);
     for (auto& t : threads) t.join();
   }
