@@ -160,29 +160,10 @@ EG_HD void fe_neg(fe& h, const fe& f) {  // class 1 in -> class 2 out (0 + 2p - 
   fe_sub(h, z, f);
 }
 
-// 17 column sums of a product -> class 1.  Columns 9..16 sit 255 bits above columns 0..8 (2^255 = 19): the low word of column k
-// goes into column k - 9 times 19, its high word (2^32 = 2^W(k-9) * 2^(32 - W(k-9)) above) into column k - 8 times 19 * 2^(32 - W).
-EG_HD void fe_reduce_columns(fe& h, u64 c[2 * EG_NL - 1]) {
-#pragma unroll
-  for (int k = EG_NL; k < 2 * EG_NL - 1; ++k) {
-    const u32 lo = (u32)c[k], hi = (u32)(c[k] >> 32);
-    c[k - 9] += (u64)lo * 19u;
-    c[k - 8] += (u64)hi * (19u << (32 - fe_w(k - 9)));
-  }
-  u64 t;
-#pragma unroll
-  for (int i = 0; i < EG_NL - 1; ++i) { t = c[i] >> fe_w(i); c[i] &= fe_mask(i); c[i + 1] += t; }
-  t = c[8] >> 28; c[8] &= fe_mask(8); c[0] += 19ull * t;
-  t = c[0] >> 29; c[0] &= fe_mask(0); c[1] += t;
-#pragma unroll
-  for (int i = 0; i < EG_NL; ++i) h.v[i] = (u32)c[i];
-  EG_SETCLS(h, 1.0f);
-}
-
 // One low column, finished: seed + its products are already in acc; adds the folds of the high columns, cuts the limb, returns the carry.
 // The carry of column k is the SEED of column k + 1's multiply-add chain (the addend of its first v_mad_u64_u32), so the carry chain
-// needs no 64-bit additions: per column one 64-bit shift and one mask.  (EG_FE_UNSEEDED: the independent-columns form measured against it.)
-#ifndef EG_FE_UNSEEDED
+// needs no 64-bit additions: per column one 64-bit shift and one mask.  (The independent-columns form it was measured against - 17 column
+// sums, then a carry chain of 64-bit adds: -3.3 %, profiles/r03_ab_experiments.txt - is tools/variants/fe_unseeded.patch.)
 // hipcc reassociates carry + sum of products into (sum of products) + carry, i.e. a chain seeded with 0 and a separate 64-bit add; the
 // empty asm pins "seed + first product" as one value, which selects to ONE v_mad_u64_u32 with the carry as its addend.
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(EG_NO_SEED_FENCE)
@@ -206,7 +187,6 @@ EG_HD void fe_reduce_columns(fe& h, u64 c[2 * EG_NL - 1]) {
     h.v[1] += (u32)(c0 >> 29);                                                                              \
   }                                                                                                         \
   EG_SETCLS(h, 1.0f);
-#endif
 
 EG_HD void fe_mul(fe& h, const fe& f, const fe& g) {
   EG_REQUIRE(EG_GETCLS(f) * EG_GETCLS(g) <= 12.5f, "fe_mul: class product > 12.5");
@@ -217,21 +197,6 @@ EG_HD void fe_mul(fe& h, const fe& f, const fe& g) {
   u32 f2[EG_NL];
 #pragma unroll
   for (int i = 0; i < EG_NL; ++i) f2[i] = (i % 3 != 0) ? fe_twice(f.v[i]) : 0u;
-#ifdef EG_FE_UNSEEDED
-  u64 c[2 * EG_NL - 1];
-#pragma unroll
-  for (int k = 0; k < 2 * EG_NL - 1; ++k) {
-    u64 acc = 0;
-#pragma unroll
-    for (int i = 0; i < EG_NL; ++i) {
-      const int j = k - i;
-      if (j < 0 || j >= EG_NL) continue;
-      acc += (u64)(fe_dbl(i, j) ? f2[i] : f.v[i]) * g.v[j];
-    }
-    c[k] = acc;
-  }
-  fe_reduce_columns(h, c);
-#else
   u64 hc[EG_NL - 1];                        // columns 9..16
 #pragma unroll
   for (int k = EG_NL; k < 2 * EG_NL - 1; ++k) {
@@ -251,7 +216,6 @@ EG_HD void fe_mul(fe& h, const fe& f, const fe& g) {
     )
   }
   h = r;
-#endif
   EG_SCHED_FENCE();
 }
 
@@ -263,22 +227,6 @@ EG_HD void fe_sq(fe& h, const fe& f) {
   u32 d[EG_NL];
 #pragma unroll
   for (int i = 0; i < EG_NL; ++i) d[i] = fe_twice(f.v[i]);
-#ifdef EG_FE_UNSEEDED
-  u64 c[2 * EG_NL - 1];
-#pragma unroll
-  for (int k = 0; k < 2 * EG_NL - 1; ++k) {
-    u64 acc = 0;
-#pragma unroll
-    for (int i = 0; i < EG_NL; ++i) {
-      const int j = k - i;
-      if (j < i || j >= EG_NL) continue;
-      if (i == j) acc += (u64)(fe_dbl(i, i) ? d[i] : f.v[i]) * f.v[i];
-      else acc += (u64)d[i] * (fe_dbl(i, j) ? d[j] : f.v[j]);          // cross terms count twice
-    }
-    c[k] = acc;
-  }
-  fe_reduce_columns(h, c);
-#else
 #define EG_SQ_TERMS(K)                                                                                      \
   _Pragma("unroll") for (int i = 0; i < EG_NL; ++i) {                                                       \
     const int j = (K) - i;                                                                                  \
@@ -301,7 +249,6 @@ EG_HD void fe_sq(fe& h, const fe& f) {
   }
   h = r;
 #undef EG_SQ_TERMS
-#endif
   EG_SCHED_FENCE();
 }
 
