@@ -393,8 +393,9 @@ def main():
             got = egd.gather_tallies(probe)
             torch.cuda.synchronize()
             want = torch.arange(1, world + 1, dtype=torch.uint8, device=dev).view(world, 1).expand(world, 320)
-            if got.dtype != torch.uint8 or tuple(got.shape) != (world, 320) or not torch.equal(got, want):
-                die(3, f"tally all-gather preflight returned wrong data: dtype {got.dtype}, shape {tuple(got.shape)}")
+            wrong = got.dtype != torch.uint8 or tuple(got.shape) != (world, 320) or not torch.equal(got, want)
+            if egd.sum_over_ranks(1 if wrong else 0, dev):        # every rank learns of it and ends here, none is left waiting in a collective
+                die(3, "tally all-gather preflight returned wrong data" + (f" on this rank: dtype {got.dtype}, shape {tuple(got.shape)}" if wrong else " on another rank"))
         except SystemExit:
             raise
         except Exception as e:
@@ -459,10 +460,15 @@ def main():
             ok = exchanged == params.tally_encode()
         else:
             digest = float(int.from_bytes(__import__("hashlib").sha256(exchanged).digest()[:6], "big"))   # exact in a double
-            ok = egd.max_over_ranks(digest, dev) == digest == -egd.max_over_ranks(-digest, dev)
+            # every rank runs every collective, whatever it has seen so far (a rank that skipped one would hang the others)
+            hi = egd.max_over_ranks(digest, dev)
+            lo = -egd.max_over_ranks(-digest, dev)
+            ok = hi == digest == lo
             if world == 1:
                 ok = ok and exchanged == params.tally_encode()
-        return bool(ok and egd.sum_over_ranks(int(bad_terms.item()), dev) == 0)
+        bad = egd.sum_over_ranks(int(bad_terms.item()), dev)
+        verdicts = egd.sum_over_ranks(0 if ok else 1, dev)       # ... and every rank learns whether ANY rank disagreed
+        return bool(ok and bad == 0 and verdicts == 0)
 
     for _ in range(args.warmup):
         step()
