@@ -1712,3 +1712,34 @@ def test_bucket_method_multi_scalar_mul(eg, ctx, grp, oracle, monkeypatch):
     monkeypatch.delenv("EG_MSM_BUCKET_MIN")
     assert grp.msm_scratch_bytes(1, 1 << 20) > 100 << 20       # by default the bucket path takes over at 2^20 terms (and needs its scratch) ...
     assert grp.msm_scratch_bytes(1, (1 << 20) - 1) < 64 << 20  # ... and Straus' partial sums are all that is needed below
+
+
+def test_ring_group_walk_over_many_chunks(eg, ctx, pk, monkeypatch):
+    """The ring-group walk across chunk and work-set boundaries: 300 000 single-choice ballots (1 % tampered) in chunks of 65 536 on the
+    two work sets, grouped (2 rings per group: the accumulators of the sum tables are re-used chunk after chunk) against the ungrouped
+    engine on the same device buffer: identical verdicts and tally."""
+    import torch
+
+    n = 300_000
+    monkeypatch.setenv("EG_CHUNK", "65536")
+    monkeypatch.setenv("EG_RING_GROUP", "0")
+    plain = eg.ChoiceParams.single_choice(ctx, pk, 5)
+    monkeypatch.setenv("EG_RING_GROUP", "2")
+    grouped = eg.ChoiceParams.single_choice(ctx, pk, 5)
+    assert eg.plan_describe("single", 5)["table_groups"] == 3
+    d = torch.empty(n * plain.ballot_size, dtype=torch.uint8, device="cuda")
+    plain.encrypt_batch_device(424242, 0, n, d.data_ptr())
+    ctx.synchronize()
+    g = torch.Generator(device="cpu").manual_seed(7)
+    bad = torch.randperm(n, generator=g)[: n // 100].to("cuda")
+    d.view(n, plain.ballot_size)[bad[: n // 200], plain.ballot_size - 32] ^= 1          # sum proofs ...
+    d.view(n, plain.ballot_size)[bad[n // 200 :], 64 * 5 + 32 * 4 + 7] ^= 4             # ... and a response of ring 1
+    st_a = torch.empty(n, dtype=torch.int32, device="cuda")
+    st_b = torch.empty(n, dtype=torch.int32, device="cuda")
+    for p, st in ((plain, st_a), (grouped, st_b)):
+        p.tally_reset()
+        p.verify_batch_device(n, d.data_ptr(), st.data_ptr())
+    ctx.synchronize()
+    assert torch.equal(st_a, st_b)
+    assert int((st_a == 0).sum()) == n - n // 100
+    assert plain.tally_encode() == grouped.tally_encode()
