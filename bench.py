@@ -8,6 +8,7 @@ shard (weak scaling; ballots are independent, no data-path collective) and the p
 all-gathered over RCCL once per step.
 
     python bench.py --gpus 1 --steps 5 --warmup 1
+    python bench.py --gpus N --steps K --warmup W          # bare: starts the N ranks itself, as a child torch.distributed.run
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -351,8 +352,40 @@ def die(code: int, msg: str):
     raise SystemExit(code)
 
 
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` started bare (no WORLD_SIZE in the environment): start the N ranks as a CHILD
+    `python -m torch.distributed.run ... bench.py <same arguments>` and hand back its exit code.  Runs before this process has imported
+    torch.cuda or loaded the library, so nothing here has touched the GPU; it is a child process, never an exec (a process that has
+    initialised the GPU must not be replaced, and under `rocprofv3 -- python3 bench.py` the profiler's preload has).  The child's stdout
+    is this process's stdout: rank 0's one JSON line stays the last line.  examples/voting.rs:199-203 is the loop the N slabs stand in for."""
+    import socket
+    import subprocess
+
+    if not args.rehearse_one_gpu:
+        import torch                      # device_count() does not initialise the runtime
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            print(f"bench.py: FATAL: --gpus {args.gpus} but this node shows {have} GPU(s) (use --rehearse-one-gpu to time-share device 0 "
+                  "over gloo)", file=sys.stderr, flush=True)
+            return 2
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE"):
+        env.pop(k, None)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, effective_cores() // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    print("bench.py: --gpus %d without a launcher: starting the ranks as a child: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    sys.stdout.flush()
+    return subprocess.call(cmd, env=env, cwd=os.getcwd())
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
     import torch
     import torch.distributed as dist
 
@@ -363,8 +396,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: N > 1 must be launched with torch.distributed.run, "
-                         "one rank per GPU, with --gpus equal to the number of ranks")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: under torch.distributed.run --gpus must equal the number of ranks "
+                         "(started bare, `python bench.py --gpus N` launches the N ranks itself)")
     if args.rehearse_one_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -373,7 +406,7 @@ def main():
     torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     use_dist = world > 1 or args.force_dist
     if args.force_dist:
-        os.environ["EG_DIST_ALWAYS"] = "1"     # the helpers then run their collectives even with one rank
+        egd.ALWAYS_COLLECTIVE = True           # the helpers then run their collectives even with one rank
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")

@@ -8,10 +8,15 @@ RCCL/xGMI; point addition is not an RCCL reduction op, so every rank then sums t
 """
 from __future__ import annotations
 
-import os
-
 import torch
 import torch.distributed as dist
+
+# bench.py --force-dist sets this: the helpers then run their collectives even with one rank (RCCL at world size 1 on a one-GPU box)
+ALWAYS_COLLECTIVE = False
+
+
+def _single() -> bool:
+    return not dist.is_initialized() or (dist.get_world_size() == 1 and not ALWAYS_COLLECTIVE)
 
 
 def shard_range(total: int, rank: int, world: int) -> tuple[int, int]:
@@ -24,7 +29,7 @@ def shard_range(total: int, rank: int, world: int) -> tuple[int, int]:
 def gather_tallies(local: torch.Tensor) -> torch.Tensor:
     """All-gather of the per-rank tally encodings.  local: uint8 [n_options*64] -> uint8 [world, n_options*64],
     rank-major (row r is rank r's tally).  A single collective per batch; no data-path collective elsewhere."""
-    if not dist.is_initialized() or (dist.get_world_size() == 1 and not os.environ.get("EG_DIST_ALWAYS")):
+    if _single():
         return local.reshape(1, -1).clone()
     world = dist.get_world_size()
     flat = local.contiguous().view(-1)
@@ -36,14 +41,11 @@ def gather_tallies(local: torch.Tensor) -> torch.Tensor:
         out = torch.cat(parts).to(local.device)
     else:
         dist.all_gather_into_tensor(out, flat)
-    if os.environ.get("EG_TEST_CORRUPT_GATHER") and dist.get_rank() == 1:     # test knob: what a broken transport would hand back
-        out = out.clone()
-        out[0] ^= 0x5A
     return out.view(world, flat.numel())
 
 
 def max_over_ranks(seconds: float, device) -> float:
-    if not dist.is_initialized() or (dist.get_world_size() == 1 and not os.environ.get("EG_DIST_ALWAYS")):
+    if _single():
         return seconds
     t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -51,7 +53,7 @@ def max_over_ranks(seconds: float, device) -> float:
 
 
 def sum_over_ranks(value: int, device) -> int:
-    if not dist.is_initialized() or (dist.get_world_size() == 1 and not os.environ.get("EG_DIST_ALWAYS")):
+    if _single():
         return value
     t = torch.tensor([value], dtype=torch.int64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)

@@ -20,6 +20,14 @@ def golden():
 
 
 @pytest.fixture(scope="session")
+def rejections():
+    """The reference's own REJECTING inputs for Ristretto (src/serde.rs unit tests), copied by tests/golden/make_golden.py."""
+    import json
+
+    return json.loads((ROOT / "tests" / "golden" / "rejections_ristretto.json").read_text())
+
+
+@pytest.fixture(scope="session")
 def oracle():
     from oracle import oracle as o
 

@@ -8,6 +8,9 @@ Output: tests/golden/snapshots_ristretto.json  (hex of the packed wire layout us
         concatenation of the reference's own to_bytes formats in serde field order, plus the generating
         parameters from tests/snapshots.rs).
 
+        /root/reference/src/serde.rs #[cfg(test)] -- the two REJECTING inputs the reference's tests hold for Ristretto (a string that is
+        not a group element, a non-canonical scalar) with the error text each test expects -> tests/golden/rejections_ristretto.json.
+
 Run in the build container only (the reference tree does not exist on the GPU box); the JSON is committed.
 """
 import base64
@@ -45,7 +48,38 @@ def range_proof(p) -> bytes:
     return b"".join(ct(c) for c in p["partial_ciphertexts"]) + ring_proof(p)
 
 
+def rejections() -> dict:
+    """The reference's own negative vectors: string literals of the unit tests in src/serde.rs (test DATA: an input and the error text
+    the test asserts), looked up by test name so that a moved line does not silently change what is pinned."""
+    import re
+
+    src = Path("/root/reference/src/serde.rs").read_text()
+    lines = src.splitlines()
+
+    def case(test_name: str, which: int = 0):
+        start = next(i for i, l in enumerate(lines) if f"fn {test_name}()" in l)
+        end = next(i for i in range(start + 1, len(lines)) if lines[i].startswith("    }"))
+        body = "\n".join(lines[start:end])
+        # 43-character unpadded base64url strings = 32 bytes; JSON-quoted ("\"...\"") or bare ("...".into())
+        found = [(m.group(1), start + 1 + body[:m.start()].count("\n")) for m in re.finditer(r'"\\?"?([A-Za-z0-9_-]{43})\\?"?"', body)]
+        text, line = found[which]
+        after = body[body.index(text):]
+        err = re.search(r'contains\("([^"]+)"\)', after).group(1)
+        raw = unb64(text)
+        assert len(raw) == 32
+        return {"b64": text, "hex": raw.hex(), "error_contains": err, "source": f"src/serde.rs:{line} ({test_name})"}
+
+    return {
+        "_source": "slowli/elastic-elgamal src/serde.rs unit tests: the inputs the reference itself rejects for Ristretto",
+        "non_element": case("public_key_deserialization_of_non_element"),
+        "non_canonical_scalar": case("secret_key_deserialization_of_invalid_scalar"),
+        "scalar_helper_invalid_scalar": case("scalar_helper_invalid_scalar"),
+        "element_helper_invalid_element": case("element_helper_invalid_element"),
+    }
+
+
 def main() -> None:
+    (OUT.parent / "rejections_ristretto.json").write_text(json.dumps(rejections(), indent=1) + "\n")
     out = {
         "_source": "slowli/elastic-elgamal tests/snapshots/*-ristretto.snap (tests/snapshots.rs, seed 12345)",
         "seed": 12345,

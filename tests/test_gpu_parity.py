@@ -714,6 +714,68 @@ def test_degenerate_points_and_scalars(eg, ctx, oracle, pk):
         assert out[32 * i : 32 * i + 32] == oracle.point_double_mul_generator(ks[i], pts[i], ks[3 - i])
 
 
+def test_reference_rejection_vectors_on_the_hip_path(eg, ctx, grp, oracle, pk, rejections):
+    """The REJECTING inputs of the reference's own unit tests (tests/golden/rejections_ristretto.json <- src/serde.rs:403, :428, :484,
+    :511) on the HIP path: eg_point_roundtrip_batch refuses the non-element (and the all-ones-top-byte string as an element),
+    eg_scalar_is_canonical_batch refuses the non-canonical scalar; a ballot that carries either in ANY of its 32-byte slots gets
+    BAD_POINT / BAD_SCALAR with that slot's index (oracle agrees; serde.rs:197-198, 260-261 refuse it at deserialisation), and the JSON
+    entry gives the same verdicts when the ballots carry the reference's base64url strings themselves."""
+    import json
+    from elastic_elgamal_amd import serde
+
+    bad_pt, bad_sc = bytes.fromhex(rejections["non_element"]["hex"]), bytes.fromhex(rejections["non_canonical_scalar"]["hex"])
+    good_pt = oracle.const_bytes(4)
+    out, ok = grp.element_roundtrip(bad_pt + good_pt + bytes.fromhex(rejections["element_helper_invalid_element"]["hex"]) + bytes(32))
+    assert list(ok) == [0, 1, 0, 1] and out[32:64] == good_pt and out[96:] == bytes(32)
+    assert list(grp.deserialize_scalar_ok(bad_sc + sc(5) + bad_pt + (L - 1).to_bytes(32, "little") + L.to_bytes(32, "little"))) \
+        == [0, 1, 1 if int.from_bytes(bad_pt, "little") < L else 0, 1, 0]
+    _, ok = grp.vartime_double_mul_generator(sc(3) * 2, bad_pt + good_pt, sc(4) * 2)      # a product over the non-element is refused as well
+    assert list(ok) == [0, 1]
+    # single-choice ballots, 5 options: 23 items (10 elements, 13 scalars); ballot i carries the bad value in item i
+    op = oracle.ChoiceParams(pk, 5, True)
+    p = eg.ChoiceParams(ctx, pk, 5, True)
+    sz = op.ballot_size
+    raw = bytearray(op.generate_batch(31, 0, 40))
+    for item in range(23):
+        raw[item * sz + 32 * item : item * sz + 32 * item + 32] = bad_pt if item < 10 else bad_sc
+    raw[23 * sz + 32 * 9 : 23 * sz + 32 * 10] = bad_pt              # two bad items: the FIRST one is reported
+    raw[23 * sz + 32 * 4 : 23 * sz + 32 * 5] = bad_pt
+    raw[24 * sz + 32 * 22 : 24 * sz + 32 * 23] = bad_sc            # a bad element beats a bad scalar that comes later in the ballot ...
+    raw[24 * sz + 32 * 7 : 24 * sz + 32 * 8] = bad_pt
+    raw = bytes(raw)
+    want = op.verify_batch(raw)
+    assert want[:23] == [(eg.BAD_POINT if item < 10 else eg.BAD_SCALAR) | (item << 8) for item in range(23)]
+    assert want[23] == eg.BAD_POINT | (4 << 8) and want[24] == eg.BAD_POINT | (7 << 8) and want[25:] == [0] * 15
+    got, tally = p.verify_batch(raw)
+    assert got == want and tally == op.tally(raw, want)
+    # quadratic voting: a vote ciphertext, a partial ciphertext of the credit proof, a ring response, the sum-of-squares responses
+    oq = oracle.QvParams(pk, 5, 20)
+    q = eg.QuadraticVotingParams(ctx, pk, 5, 20)
+    qsz = oq.ballot_size
+    n_items = qsz // 32
+    qraw = bytearray(oq.generate_batch(32, 0, n_items + 3, threads=8))
+    is_point = []
+    for v in range(5):
+        is_point += [True, True] + [False] * 6            # ciphertext, common challenge + 5 responses (ring of 5, no partials)
+    is_point += [True, True, True, True] + [False] * 11    # credit: ciphertext, one partial ciphertext, challenge + 7 + 3 responses
+    is_point += [False] * 12                               # sum of squares: challenge, 10 responses, sum response
+    assert len(is_point) == n_items
+    for item in range(n_items):
+        qraw[item * qsz + 32 * item : item * qsz + 32 * item + 32] = bad_pt if is_point[item] else bad_sc
+    qraw = bytes(qraw)
+    qwant = oq.verify_batch(qraw)
+    assert qwant[:n_items] == [(eg.BAD_POINT if is_point[i] else eg.BAD_SCALAR) | (i << 8) for i in range(n_items)] and qwant[n_items:] == [0] * 3
+    qgot, qtally = q.verify_batch(qraw)
+    assert qgot == qwant and qtally == oq.tally(qraw, qwant)
+    # the same ballots as JSON text with the reference's strings in place (base64url, unpadded: serde.rs:19-80)
+    objs = [serde.unpack_encrypted_choice(raw[i * sz : (i + 1) * sz], 5, True) for i in range(40)]
+    text = json.dumps(objs)
+    assert text.count(rejections["non_element"]["b64"]) == 10 + 3 and text.count(rejections["non_canonical_scalar"]["b64"]) == 13 + 1
+    p.tally_reset()
+    jgot, jtally = p.verify_json(text)
+    assert jgot == want and jtally == tally
+
+
 # ------------------------------------------------------------------ tally stage: decryption shares (SURVEY 8f row 4)
 def test_threshold_tally_end_to_end(eg, ctx, oracle):
     """examples/voting.rs:122-177 shape with a 7-of-10 key: verify ballots, tally, every tallier's decryption share is

@@ -109,15 +109,50 @@ def test_scalar_arithmetic_vs_bigint(oracle):
     assert not oracle.sc_is_canonical((2**256 - 1).to_bytes(32, "little"))
 
 
-def test_serde_rejection_vectors(oracle):
-    # src/serde.rs:402-404 (scalar with all bits set) and :427-429 (invalid element)
+def test_serde_rejection_vectors(oracle, rejections):
+    """The inputs the reference's own unit tests reject (tests/golden/rejections_ristretto.json, copied from src/serde.rs:403
+    "does not represent a group element", :428 / :484 "bytes do not represent a group scalar", :511 the same 32 bytes as an element):
+    deserialize_element (ristretto.rs:93-95) and deserialize_scalar (:59-62) of the oracle refuse exactly these."""
+    r = rejections
+    assert r["non_element"]["b64"] == "tNDkeYUVQWgh34d-RqaElOk7yFB8d2qCh5f4Vi2euT0"
+    assert r["non_canonical_scalar"]["b64"] == r["scalar_helper_invalid_scalar"]["b64"] == r["element_helper_invalid_element"]["b64"] \
+        == "nN3xf7lSOX0_zs6QPBwWHYi0Dkx2Ln_z1MPwnbzaM_8"
+    for k in ("non_element", "element_helper_invalid_element"):
+        raw = bytes.fromhex(r[k]["hex"])
+        assert raw == unb64(r[k]["b64"]) and len(raw) == 32 and "group element" in r[k]["error_contains"]
+        assert oracle.point_roundtrip(raw) is None
+    for k in ("non_canonical_scalar", "scalar_helper_invalid_scalar"):
+        raw = bytes.fromhex(r[k]["hex"])
+        assert raw == unb64(r[k]["b64"]) and len(raw) == 32 and "group scalar" in r[k]["error_contains"]
+        assert not oracle.sc_is_canonical(raw)
+    # the non-element is a canonical field element (s < p, s even): it fails inside the decoding (no square root), not at the range
+    # check; it is also a canonical SCALAR, so only the element path refuses it
+    s = int.from_bytes(bytes.fromhex(r["non_element"]["hex"]), "little")
+    assert s < P and s % 2 == 0
+    assert oracle.sc_is_canonical(bytes.fromhex(r["non_element"]["hex"])) == (s < L)
+    # further encodings no reference test holds: all-ones, RFC 9496 A.3 style non-canonical field element, negative s
     assert not oracle.sc_is_canonical(b"\xff" * 32)
     assert oracle.point_roundtrip(b"\xff" * 32) is None
-    # RFC 9496 A.3 style invalid encodings: non-canonical field element, negative s
     assert oracle.point_roundtrip((P).to_bytes(32, "little")) is None
     assert oracle.point_roundtrip((1).to_bytes(32, "little")) is None
     # identity encodes as zeros and round-trips
     assert oracle.point_roundtrip(b"\x00" * 32) == b"\x00" * 32
+
+
+def test_rejection_vectors_inside_ballots(oracle, rejections, keys):
+    """A ballot that carries the reference's non-element in a ciphertext slot / its non-canonical scalar in a response slot: the
+    reference refuses such a ballot when it is deserialised (serde.rs:197-198, 260-261); here that is BAD_POINT / BAD_SCALAR with the
+    index of the first bad 32-byte item, for every position."""
+    _, pk = keys
+    op = oracle.ChoiceParams(pk, 5, True)
+    sz = op.ballot_size
+    base = op.generate_batch(31, 0, 23)
+    bad_pt, bad_sc = bytes.fromhex(rejections["non_element"]["hex"]), bytes.fromhex(rejections["non_canonical_scalar"]["hex"])
+    raw = bytearray(base)
+    for item in range(23):                       # items 0..9 ciphertext elements, 10..22 scalars (challenge, responses, sum proof)
+        raw[item * sz + 32 * item : item * sz + 32 * item + 32] = bad_pt if item < 10 else bad_sc
+    st = op.verify_batch(bytes(raw))
+    assert st == [(2 if item < 10 else 1) | (item << 8) for item in range(23)]
 
 
 def test_ristretto_rfc9496_multiples(oracle):
