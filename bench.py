@@ -174,6 +174,10 @@ def parse():
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip the short runs of the other BASELINE configs (multi-choice 3-of-16, quadratic voting 5 / 20, the primitive "
                          "tier) that follow the headline measurement at N = 1 and are printed as extra.configs")
+    ap.add_argument("--in-process-devices", type=int, default=0, metavar="N",
+                    help="the same step over N GPUs through ONE process (eg_verify_*_batch_multi_device: one context, one resident slab and "
+                         "one stream per GPU, the slabs' tallies merged inside the library - no torch.distributed, no collective); with "
+                         "--rehearse-one-gpu the N contexts all sit on device 0.  A second scaling measurement beside the ranked path")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even for one rank: exercises the N > 1 code path on a 1-GPU box")
     return ap.parse_args()
@@ -301,36 +305,51 @@ def bench_msm(args, ctx, eg, torch, dev, world):
     print(json.dumps(line))
 
 
-def extra_configs(args, ctx, eg, torch, dev, pk, stream, steps: int = 3):
-    """Short runs of the BASELINE configs that are not the headline (configs[3] multi-choice 3-of-16, configs[2] quadratic voting
-    5 options / 20 credits) and of the primitive tier, on the same GPU, ballots resident in HBM; a step is what a step of the headline
-    is (tally reset, verify, tally encode).  The headline's params object has been closed by the caller."""
+def extra_configs(args, ctx, eg, torch, dev, pk, stream, steps: int = 10):
+    """Short runs of the BASELINE configs that are not the headline - configs[3] multi-choice 3-of-16, configs[2] quadratic voting
+    5 options / 20 credits, configs[4]'s 10 M single-choice batch on this one GPU, configs[1] with 1 % tampered ballots -
+    and of the primitive tier, on the same GPU, ballots resident in HBM; a step is what a step of the headline is (tally reset, verify,
+    tally encode).  10 timed steps each (3 for the 10 M batch: 1.6 s a step), one warm-up.  The headline's params object has been closed
+    by the caller."""
     res = {}
     n = args.ballots
-    for name, make, gen_kw in (("multi16", lambda: eg.ChoiceParams.multi_choice(ctx, pk, 16), {"n_selected": 3}),
-                               ("qv", lambda: eg.QuadraticVotingParams(ctx, pk, 5, args.credits), {})):
+    runs = (("multi16", lambda: eg.ChoiceParams.multi_choice(ctx, pk, 16), {"n_selected": 3}, n, 0.0, steps),
+            ("qv", lambda: eg.QuadraticVotingParams(ctx, pk, 5, args.credits), {}, n, 0.0, steps),
+            ("single10M", lambda: eg.ChoiceParams.single_choice(ctx, pk, 5), {}, 10 * n, 0.0, 3),
+            ("tampered1pct", lambda: eg.ChoiceParams.single_choice(ctx, pk, 5), {}, n, 1.0, steps))
+    for name, make, gen_kw, m, tampered, k in runs:
         try:
             p = make()
-            b = torch.empty(n * p.ballot_size, dtype=torch.uint8, device=dev)
-            st = torch.empty(n, dtype=torch.int32, device=dev)
+            b = torch.empty(m * p.ballot_size, dtype=torch.uint8, device=dev)
+            st = torch.empty(m, dtype=torch.int32, device=dev)
             tl = torch.empty(64 * p.n_options, dtype=torch.uint8, device=dev)
-            p.encrypt_batch_device(args.seed, 0, n, b.data_ptr(), stream=stream, **gen_kw)
+            p.encrypt_batch_device(args.seed, 0, m, b.data_ptr(), stream=stream, **gen_kw)
+            n_t = int(m * tampered / 100.0)
+            if n_t:
+                g = torch.Generator(device="cpu").manual_seed(args.seed)
+                bad = torch.randperm(m, generator=g)[:n_t].to(dev)
+                b.view(m, p.ballot_size)[bad, p.ballot_size - 32] ^= 1       # last response scalar stays canonical
 
             def one():
                 p.tally_reset(stream)
-                p.verify_batch_device(n, b.data_ptr(), st.data_ptr(), stream)
+                p.verify_batch_device(m, b.data_ptr(), st.data_ptr(), stream)
                 p.tally_encode_device(tl.data_ptr(), stream)
 
             one()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(steps):
+            for _ in range(k):
                 one()
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-            res[name] = {"value": n * steps / dt, "ms_per_step": dt / steps * 1e3, "accepted": int((st == 0).sum().item()), "ballots": n,
-                         "ballot_bytes": p.ballot_size, "steps": steps,
+            accepted = int((st == 0).sum().item())
+            res[name] = {"value": m * k / dt, "ms_per_step": dt / k * 1e3, "accepted": accepted, "ballots": m, "tampered": n_t,
+                         "ballot_bytes": p.ballot_size, "steps": k, "accepted_is_all_but_tampered": accepted == m - n_t,
                          "tally_matches_engine": bytes(tl.cpu().numpy()) == p.tally_encode()}
+            if p.kind_name != "single":
+                desc = eg.plan_describe(p.kind_name, p.n_options, args.credits if p.kind_name == "qv" else 0)
+                fm, fs = plan_field_ops(desc, wide_combs=ctx.comb_table_bits()[1] != 0)
+                res[name]["fmul_equiv_frac_sustained"] = m * k / dt * (fm + SQ_WEIGHT * fs) / 1e9 / FMUL_SUSTAINED_G
             del b, st, tl
             p.close()
             torch.cuda.empty_cache()
@@ -382,8 +401,117 @@ def launch_ranks(args) -> int:
     return subprocess.call(cmd, env=env, cwd=os.getcwd())
 
 
+def bench_in_process(args):
+    """--in-process-devices N: what a single-process host (examples/voting.rs:179-213 is one) does on a node with N GPUs.  One context, one
+    params object, one resident slab and one stream per GPU; a step = tally reset on every GPU, eg_verify_*_batch_multi_device (one host
+    thread per GPU inside the library enqueues the slab's verification and waits for its stream), eg_*_tally_encode_multi (the running
+    tallies merged in the library).  Same JSON line as the ranked path; `parallelism` says which one ran."""
+    import torch
+
+    import elastic_elgamal_amd as eg
+    from elastic_elgamal_amd import distributed as egd
+
+    N = args.in_process_devices
+    have = torch.cuda.device_count()
+    if not args.rehearse_one_gpu and have < N:
+        die(2, f"--in-process-devices {N} but this node shows {have} GPU(s) (use --rehearse-one-gpu to put the N contexts on device 0)")
+    if args.workload == "msm":
+        die(2, "--in-process-devices times the ballot workloads")
+    devs = [0] * N if args.rehearse_one_gpu else list(range(N))
+    pk = bytes.fromhex(PUBLIC_KEY_HEX)
+    n_opt = args.options or {"single": 5, "multi": 16, "qv": 5}[args.workload]
+    strong = args.total_ballots > 0
+    total = args.total_ballots if strong else args.ballots * N
+    ctxs, params, ballots, status, streams, counts = [], [], [], [], [], []
+    t0 = time.time()
+    for d, dev_i in enumerate(devs):
+        torch.cuda.set_device(dev_i)
+        dev = torch.device("cuda", dev_i)
+        c = eg.Context(dev_i)
+        if args.workload == "single":
+            p = eg.ChoiceParams.single_choice(c, pk, n_opt)
+        elif args.workload == "multi":
+            p = eg.ChoiceParams.multi_choice(c, pk, n_opt)
+        else:
+            p = eg.QuadraticVotingParams(c, pk, n_opt, args.credits)
+        first, last = egd.shard_range(total, d, N)           # GPU d owns the contiguous slab of voters [first, last)
+        B = last - first
+        b = torch.empty(max(B, 1) * p.ballot_size, dtype=torch.uint8, device=dev)
+        s = torch.cuda.Stream(device=dev)
+        kw = {"n_selected": 3} if args.workload == "multi" else {}
+        p.encrypt_batch_device(args.seed, first, B, b.data_ptr(), stream=s.cuda_stream, **kw)
+        n_t = int(B * args.tampered_percent / 100.0)
+        if n_t:
+            with torch.cuda.stream(s):
+                g = torch.Generator(device="cpu").manual_seed(args.seed + d)
+                bad = torch.randperm(B, generator=g)[:n_t].to(dev)
+                b.view(-1, p.ballot_size)[bad, p.ballot_size - 32] ^= 1
+        ctxs.append(c); params.append(p); ballots.append(b); streams.append(s); counts.append(B)
+        status.append(torch.empty(max(B, 1), dtype=torch.int32, device=dev))
+    for dev_i in set(devs):
+        torch.cuda.synchronize(dev_i)
+    gen_s = time.time() - t0
+    ptr_b, ptr_s, ptr_q = [x.data_ptr() for x in ballots], [x.data_ptr() for x in status], [x.cuda_stream for x in streams]
+    merged = [None]
+
+    def step():
+        for p in params:
+            p.tally_reset()
+        eg.verify_batch_multi_device(params, counts, ptr_b, ptr_s, ptr_q)
+        merged[0] = eg.tally_encode_multi(params)
+
+    for _ in range(args.warmup):
+        step()
+    sampler = ClockSampler(torch, devs[0])
+    sampler.start()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    for dev_i in set(devs):
+        torch.cuda.synchronize(dev_i)
+    elapsed = time.perf_counter() - t0
+    clock = sampler.stop()
+    accepted = sum(int((st[:c] == 0).sum().item()) for st, c in zip(status, counts))
+    n_tampered = sum(int(c * args.tampered_percent / 100.0) for c in counts)
+    # the merged tally is the sum of the per-GPU running tallies, each of which is the tally of its own slab: re-merge them with the
+    # primitive tier one by one, and (one GPU's worth of work, untimed) let ONE engine verify every slab and compare its running tally
+    grp = eg.Ristretto(ctxs[0])
+    again = bytes(64 * n_opt)
+    for p in params:
+        again = grp.element_add(again, p.tally_encode())[0]
+    tally_ok = merged[0] == again and accepted == total - n_tampered
+    check_one_engine = total <= 4_000_000
+    if check_one_engine:
+        one = params[0]
+        one.tally_reset()
+        scratch = torch.empty(max(counts) if counts else 1, dtype=torch.int32, device=torch.device("cuda", devs[0]))
+        for d, (b, c) in enumerate(zip(ballots, counts)):
+            src = b if devs[d] == devs[0] else b.to(torch.device("cuda", devs[0]))
+            torch.cuda.set_device(devs[0])
+            one.verify_batch_device(c, src.data_ptr(), scratch.data_ptr(), 0)
+        tally_ok = tally_ok and one.tally_encode() == merged[0]
+    out = {
+        "metric": "EncryptedChoice ballot verifications/sec" if args.workload != "qv" else "QuadraticVotingBallot verifications/sec",
+        "value": total * args.steps / elapsed, "unit": "ballots/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+        "dtype": "u32", "data": "synthetic",
+        "config": {"workload": f"{counts[0]} {args.workload} {n_opt}-option ballots per GPU per step, resident in HBM; verify + homomorphic tally "
+                               f"+ in-library tally merge over {N} GPUs of ONE process (eg_verify_*_batch_multi_device)",
+                   "ballots_per_gpu": counts[0], "total_ballots": total, "options": n_opt, "ballot_bytes": params[0].ballot_size,
+                   "seed": args.seed, "accepted": accepted, "tampered": n_tampered, "tally_exchange_ok": bool(tally_ok),
+                   "tally_checked_against_one_engine": check_one_engine, "generator_s": round(gen_s, 3),
+                   "parallelism": f"in-process{N}" + ("-on-one-gpu" if args.rehearse_one_gpu else ""), "devices": devs},
+        "clock": clock,
+    }
+    print(json.dumps(out), flush=True)
+    if not tally_ok:
+        raise SystemExit(5)
+
+
 def main():
     args = parse()
+    if args.in_process_devices:
+        return bench_in_process(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args))
     import torch
@@ -808,8 +936,8 @@ def main():
         params.close()                         # frees the chunk workspace and the key's comb tables before the next election's are made
         torch.cuda.empty_cache()
         out["extra"] = {"configs": extra_configs(args, ctx, eg, torch, dev, pk, stream),
-                        "note": "3 timed steps each (1 warm-up), same process and GPU, after the headline measurement; value in ballots/s "
-                                "(msm: vartime_double_mul_generator operations/s); NOT part of `value`"}
+                        "note": "10 timed steps each (3 for the 10 M batch; 1 warm-up), same process and GPU, after the headline measurement; value "
+                                "in ballots/s (msm: vartime_double_mul_generator operations/s); NOT part of `value`"}
     sys.stdout.flush()
     print(json.dumps(out), flush=True)
     if use_dist:

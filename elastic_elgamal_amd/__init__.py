@@ -110,7 +110,7 @@ def _load() -> C.CDLL:
         "eg_mul_generator_batch": (C.c_int, [vp, sz, cp, cp]),
         "eg_vartime_double_mul_generator_batch": (C.c_int, [vp, sz, cp, cp, cp, cp, cp]),
         "eg_vartime_multi_mul_batch": (C.c_int, [vp, sz, sz, cp, cp, cp, cp]),
-        "eg_msm_scratch_bytes": (sz, [sz, sz]),
+        "eg_msm_scratch_bytes": (sz, [vp, sz, sz]),
         "eg_choice_prepare_wide_tables": (C.c_int, [vp]),
         "eg_qv_prepare_wide_tables": (C.c_int, [vp]),
         "eg_combine_shares": (C.c_int, [vp, C.c_uint64, C.c_uint64, sz, C.POINTER(C.c_uint64), cp, cp, C.POINTER(C.c_int)]),
@@ -136,6 +136,8 @@ def _load() -> C.CDLL:
         "eg_qv_tally_encode": (C.c_int, [vp, cp]),
         "eg_verify_choice_batch_multi": (C.c_int, [C.POINTER(vp), C.c_int, sz, vp, vp, vp]),
         "eg_verify_qv_batch_multi": (C.c_int, [C.POINTER(vp), C.c_int, sz, vp, vp, vp]),
+        "eg_verify_choice_batch_multi_device": (C.c_int, [C.POINTER(vp), C.c_int, C.POINTER(sz), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp]),
+        "eg_verify_qv_batch_multi_device": (C.c_int, [C.POINTER(vp), C.c_int, C.POINTER(sz), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp]),
         "eg_choice_tally_encode_multi": (C.c_int, [C.POINTER(vp), C.c_int, cp]),
         "eg_qv_tally_encode_multi": (C.c_int, [C.POINTER(vp), C.c_int, cp]),
         "eg_choice_tally_reset_async": (C.c_int, [vp, vp]),
@@ -437,7 +439,7 @@ class Ristretto:
         return out.raw[: 32 * n], ok.raw[:n]
 
     def msm_scratch_bytes(self, n: int, terms: int) -> int:
-        return int(_load().eg_msm_scratch_bytes(n, terms))
+        return int(_load().eg_msm_scratch_bytes(self.ctx._h, n, terms))
 
     def vartime_multi_mul_device(self, n: int, terms: int, d_scalars: int, d_points: int, d_out: int, d_r: int = 0, d_scratch: int = 0,
                                  d_ok: int = 0, stream: int = 0):
@@ -463,6 +465,27 @@ def verify_batch_multi(per_device, ballots: bytes, with_tally: bool = True):
     fn = getattr(_load(), f"eg_verify_{p0._prefix}_batch_multi")
     _check(fn(arr, len(per_device), n, buf, st, tally))
     return list(st[:n]), (tally.raw if with_tally else None)
+
+
+def verify_batch_multi_device(per_device, counts, d_ballots, d_status, streams=None, with_tally: bool = False):
+    """``eg_verify_*_batch_multi_device``: slab d (counts[d] ballots at device pointer d_ballots[d], verdicts to d_status[d]) is already
+    resident on the GPU of per_device[d]; streams[d] a stream of that device (None: the null streams).  Returns when every verdict is
+    written; with_tally: the tally of this call's batch alone (the running tallies advance either way)."""
+    per_device = list(per_device)
+    p0, k = per_device[0], len(per_device)
+    if any(type(p) is not type(p0) for p in per_device):
+        raise ValueError("params objects of different kinds")
+    if not (len(counts) == len(d_ballots) == len(d_status) == k) or (streams is not None and len(streams) != k):
+        raise ValueError("one count, ballot pointer, status pointer (and stream) per params object")
+    arr = (C.c_void_p * k)(*[p._h for p in per_device])
+    cnt = (C.c_size_t * k)(*counts)
+    db = (C.c_void_p * k)(*d_ballots)
+    ds = (C.c_void_p * k)(*d_status)
+    ss = (C.c_void_p * k)(*streams) if streams is not None else None
+    tally = C.create_string_buffer(64 * p0.n_options) if with_tally else None
+    fn = getattr(_load(), f"eg_verify_{p0._prefix}_batch_multi_device")
+    _check(fn(arr, k, cnt, db, ds, ss, tally))
+    return tally.raw if with_tally else None
 
 
 def tally_encode_multi(per_device) -> bytes:
@@ -567,6 +590,11 @@ class ChoiceParams(_BatchParams):
         _check(_load().eg_choice_params_create(ctx._h, public_key, options_count, int(single), C.byref(self._h)))
         self.ballot_size = _load().eg_choice_ballot_size(options_count, int(single))
 
+    @property
+    def kind_name(self) -> str:
+        """The name plan_describe() knows this election's plan by."""
+        return "single" if self.single else "multi"
+
     @classmethod
     def single_choice(cls, ctx, public_key, options_count):
         return cls(ctx, public_key, options_count, True)
@@ -668,6 +696,7 @@ class QuadraticVotingParams(_BatchParams):
     """``QuadraticVotingParams::new(pk, options, credits)`` (quadratic_voting.rs:63-76)."""
 
     _prefix = "qv"
+    kind_name = "qv"
 
     def __init__(self, ctx: Context, public_key: bytes, options_count: int, credits: int):
         self.ctx, self.public_key, self.n_options, self.credits = ctx, public_key, options_count, credits

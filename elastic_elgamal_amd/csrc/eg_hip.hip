@@ -56,11 +56,56 @@ struct ScopeExit {
   std::function<void()> fn;
   ~ScopeExit() { if (fn) fn(); }
 };
+// Every run-time knob of the library, read from the environment in ONE place and at two moments only: eg_init (the context keeps a copy)
+// and the creation of a params object (the engine keeps its own copy, so a host may change the environment between two elections).  No
+// entry point reads the environment per call.  The table in include/eg_hip.h ("Run-time knobs") is the documentation; keep it in step.
+struct Knobs {
+  int teeth = 0;                    // EG_TEETH            0 = by plan (5 or 6)
+  int streams = 2;                  // EG_STREAMS          work sets (1 or 2)
+  size_t chunk = 0;                 // EG_CHUNK            0 = by plan and memory
+  int ring_group = -1;              // EG_RING_GROUP       -1 = by plan (off below 256 options), 0 = off, g = rings per group
+  int comb_big_bits = -1;           // EG_COMB_BIG_BITS    -1 = EG_COMB_BITS_BIG
+  long long comb_big_min = -1;      // EG_COMB_BIG_MIN     -1 = 2^19 items
+  int msm_blocks_per_cu = 32;       // EG_MSM_BLOCKS_PER_CU
+  size_t msm_lanes = (size_t)1 << 17;       // EG_MSM_LANES
+  size_t msm_bucket_min = (size_t)1 << 20;  // EG_MSM_BUCKET_MIN
+  size_t json_ring_kb = 0, json_window_kb = 0;   // EG_JSON_RING_KB, EG_JSON_WINDOW_KB   0 = 1 GiB ring, 96 MiB windows
+  size_t json_growth = 150;         // EG_JSON_GROWTH      per cent
+  bool json_trace = false;          // EG_JSON_TRACE
+  bool allow_any_arch = false;      // EG_ALLOW_ANY_ARCH
+};
+static Knobs read_knobs() {
+  Knobs k;
+  auto num = [](const char* name, long long dflt) { const char* v = getenv(name); return v && *v ? strtoll(v, nullptr, 10) : dflt; };
+  { const long long t = num("EG_TEETH", 0); if (t == 5 || t == 6) k.teeth = (int)t; }
+  if (getenv("EG_STREAMS")) k.streams = num("EG_STREAMS", 2) >= 2 ? 2 : 1;
+  k.chunk = (size_t)std::max<long long>(0, num("EG_CHUNK", 0));
+  if (getenv("EG_RING_GROUP")) k.ring_group = (int)std::max<long long>(0, num("EG_RING_GROUP", 0));
+  if (getenv("EG_COMB_BIG_BITS")) k.comb_big_bits = (int)num("EG_COMB_BIG_BITS", -1);
+  if (getenv("EG_COMB_BIG_MIN")) k.comb_big_min = std::max<long long>(0, num("EG_COMB_BIG_MIN", -1));
+  k.msm_blocks_per_cu = (int)std::max<long long>(1, num("EG_MSM_BLOCKS_PER_CU", 32));
+  k.msm_lanes = (size_t)std::max<long long>(1, num("EG_MSM_LANES", 1 << 17));
+  k.msm_bucket_min = (size_t)std::max<long long>(0, num("EG_MSM_BUCKET_MIN", 1 << 20));
+  k.json_ring_kb = (size_t)std::max<long long>(0, num("EG_JSON_RING_KB", 0));
+  k.json_window_kb = (size_t)std::max<long long>(0, num("EG_JSON_WINDOW_KB", 0));
+  k.json_growth = (size_t)std::max<long long>(0, num("EG_JSON_GROWTH", 150));
+  k.json_trace = getenv("EG_JSON_TRACE") != nullptr;
+  k.allow_any_arch = getenv("EG_ALLOW_ANY_ARCH") != nullptr;
+  return k;
+}
+// Fault points: places where a TEST build can make a call fail on purpose.  The shipped library has none - the macro is the constant
+// false - and holds no name of a switch; tests/faultlib builds a second library with -DEG_FAULT_POINTS_H=<its header>, which defines the macro.
+#ifdef EG_FAULT_POINTS_H
+#include EG_FAULT_POINTS_H
+#else
+#define EG_FAULT_POINT(name) false
+#endif
 enum { PROF_CALL = 0, PROF_MSM = 1, PROF_TABLES = 2 };
 struct ProfSpan { hipEvent_t a, b; int kind; };
 
 struct eg_ctx {
   std::recursive_mutex mu;   // serialises the C entry points of one context (and of the params created on it)
+  Knobs knobs;               // the environment as eg_init found it (read_knobs)
   std::atomic<int> refs{1};  // the caller's reference + one per live params object
   int device = 0;
   hipStream_t stream = nullptr;
@@ -195,6 +240,8 @@ struct Engine {
     hipEvent_t done = nullptr;
   } set[2];
   int n_sets = 2;
+  Knobs knobs;                 // the environment as the creation of this params object found it (read_knobs)
+  uint8_t key_bytes[32] = {0}; // the election key as given (canonical encoding): two params objects belong to one election if these agree
   int teeth = 6;               // comb shape of the per-ballot tables (plan_teeth: 5 x 51 when a table serves two products, else 6 x 43)
   hipEvent_t fork = nullptr;
   u32 cap = 0, max_cap = 0;
@@ -417,9 +464,10 @@ static int engine_create(eg_ctx* ctx, eghost::Plan&& plan, const uint8_t pk[32],
 
   // chunk workspace: sized lazily by engine_reserve() for the batches actually seen (up to EG_CHUNK ballots per chunk and work set)
   e->teeth = eghost::plan_teeth(e->plan);
-  if (const char* v = getenv("EG_TEETH")) { const int t = atoi(v); if (t == 5 || t == 6) e->teeth = t; }     // measurement knob
-  if (const char* v = getenv("EG_STREAMS")) e->n_sets = atoi(v) >= 2 ? 2 : 1;
-  const char* env = getenv("EG_CHUNK");
+  e->knobs = read_knobs();
+  memcpy(e->key_bytes, pk, 32);
+  if (e->knobs.teeth) e->teeth = e->knobs.teeth;     // measurement knob
+  e->n_sets = e->knobs.streams;
   // Two work sets whose kernels fill each other's launch tails (profiles/r03_ab_experiments.txt, blocks 3 and 9; M single-choice ballots/s):
   // with 6-tooth tables (57.6 KB per ballot and set) one set of 2^20 ballots 6.06, one set of 2^18 5.81 (-4 %), two sets of 2^18 6.05,
   // two sets of 2^19 6.13 (+1 %), two sets of 2^17 5.90; with the 5-tooth tables of the choice ballots (32.3 KB) two sets of 2^18 6.28,
@@ -428,7 +476,7 @@ static int engine_create(eg_ctx* ctx, eghost::Plan&& plan, const uint8_t pk[32],
   {
     const size_t per = engine_bytes_per_ballot(e.get()) * (size_t)e->n_sets;
     const u32 two_sets = per * 524288u <= ((size_t)40 << 30) ? 524288u : 262144u;
-    e->max_cap = env ? (u32)strtoul(env, nullptr, 10) : (e->n_sets == 2 ? two_sets : 1048576u);
+    e->max_cap = e->knobs.chunk ? (u32)std::min<size_t>(e->knobs.chunk, 1u << 30) : (e->n_sets == 2 ? two_sets : 1048576u);
   }
   {
     // Large elections keep the workspace within half of the free device memory (~58 KB per ballot and set for 5 options, 150 KB for 16).
@@ -551,7 +599,7 @@ static int engine_verify_device(Engine* e, size_t n, const void* d_ballots, void
     forked = true;
     for (int k = 0; k < 2; ++k) HIPCHK(hipStreamWaitEvent(e->set[k].stream, e->fork, 0));
   }
-  const bool inject_failure = two && getenv("EG_TEST_FAIL_AFTER_FORK") != nullptr;     // test knob (tests/test_gpu_parity.py): fail with work queued
+  const bool inject_failure = two && EG_FAULT_POINT(after_fork);     // constant false in the shipped library (see EG_FAULT_POINT above)
   const int msm_blocks = ctx->msm_blocks / (two ? 2 : 1);
   size_t chunk = 0;
   for (size_t off = 0; off < n; off += even, ++chunk) {
@@ -621,7 +669,7 @@ static int engine_verify_device(Engine* e, size_t n, const void* d_ballots, void
                            st.inst_first, st.inst_count);
     }
     hipLaunchKernelGGL(k_status, dim3((cn + NT - 1) / NT), dim3(NT), 0, cs, B, e->d_rules, (int)P.rules.size());
-    if (inject_failure && chunk == 0) return fail(EG_ERR_HIP, "injected failure between fork and join (EG_TEST_FAIL_AFTER_FORK)");
+    if (inject_failure && chunk == 0) return fail(EG_ERR_HIP, "injected failure between fork and join (fault point of a test build)");
     if (P.tally_slots.empty()) continue;
     const int G = std::min<int>(e->tally_blocks, (int)((cn + NT - 1) / NT));
     hipLaunchKernelGGL(k_tally_partial, dim3(G, (unsigned)P.tally_slots.size()), dim3(NT), 0, cs, B, e->d_tally_slots, w.partial);
@@ -783,7 +831,9 @@ static void params_destroy(Params* p) {
 }
 
 
-#define EG_LOCK(c) std::unique_lock<std::recursive_mutex> lk_; if (c) lk_ = std::unique_lock<std::recursive_mutex>((c)->mu)
+// every entry point runs under its context's lock AND on its context's device (hipSetDevice is per thread and cheap): a process that holds
+// contexts on several GPUs may call any function of any of them from any thread
+#define EG_LOCK(c) std::unique_lock<std::recursive_mutex> lk_; if (c) { lk_ = std::unique_lock<std::recursive_mutex>((c)->mu); (void)hipSetDevice((c)->device); }
 #define EG_LOCK_P(p) EG_LOCK((p) ? (p)->eng->ctx : (eg_ctx*)nullptr)
 
 extern "C" {
@@ -802,7 +852,8 @@ int eg_init(int device, eg_ctx** out) {
   c->device = device;
   c->cus = prop.multiProcessorCount;
   c->name = std::string(prop.name) + " (" + prop.gcnArchName + ")";
-  if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos && !getenv("EG_ALLOW_ANY_ARCH"))
+  c->knobs = read_knobs();
+  if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos && !c->knobs.allow_any_arch)
     return fail(EG_ERR_NO_DEVICE, "device is " + c->name + ", this library is built for gfx950 (MI355X) only");
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIPCHK(hipMalloc((void**)&c->gen_words, 2 * PT_WORDS * sizeof(u32)));
@@ -811,8 +862,8 @@ int eg_init(int device, eg_ctx** out) {
     const int rc = comb_table_build(c->gen_words, EG_COMB_BITS, c->stream, &c->tabG);
     if (rc) return rc;
   }
-  if (const char* v = getenv("EG_COMB_BIG_BITS")) c->big_bits = atoi(v);
-  if (const char* v = getenv("EG_COMB_BIG_MIN")) c->big_min = (size_t)strtoull(v, nullptr, 10);
+  if (c->knobs.comb_big_bits >= 0) c->big_bits = c->knobs.comb_big_bits;
+  if (c->knobs.comb_big_min >= 0) c->big_min = (size_t)c->knobs.comb_big_min;
   if (c->big_bits != 0 && (c->big_bits <= EG_COMB_BITS || c->big_bits > 26)) return fail(EG_ERR_BAD_ARG, "EG_COMB_BIG_BITS must be 0 or in (EG_COMB_BITS, 26]");
   int per_cu = 0;
   HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_eq_table<false, 6>, NT, 0));
@@ -829,9 +880,7 @@ int eg_init(int device, eg_ctx** out) {
   // last round runs part-empty; 32 blocks per CU, handed out as others finish, measured +1.5 % (single) / +1.8 % (QV) in one
   // call in round 2 (2 -> 4 -> 8 -> 16 -> 32 -> 64 blocks per CU: 5.33 / 5.38 / 5.41 / 5.39 / 5.40 / 5.44 M ballots/s).  The price is the
   // per-lane workspace: 2.4 GB.
-  per_cu = 32;
-  const char* env = getenv("EG_MSM_BLOCKS_PER_CU");
-  if (env) per_cu = std::max(1, atoi(env));
+  per_cu = c->knobs.msm_blocks_per_cu;      // 32
   c->msm_blocks = per_cu * c->cus;
   HIPCHK(hipMalloc((void**)&c->ws, (size_t)c->msm_blocks * WS_QUADS * NT * sizeof(uint4)));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -1041,9 +1090,8 @@ int eg_point_add_batch(eg_ctx* c, size_t n, const uint8_t* a_, const uint8_t* b_
 // How the terms of a problem are cut: chunks of up to MSM_CHUNK terms share a doubling chain (less work per term), but a call with few
 // terms in all should still cover the chip (a lone 2^16-term product in chunks of 8 keeps only 8192 lanes busy: 3.1 ms; in chunks of 1
 // it is 65 536 independent ladders, ~1 ms): the chunk shrinks until the call has ~2 waves per SIMD worth of lanes.
-static void msm_plan(size_t n, size_t terms, int* chunk, int* n_chunks) {
-  size_t lanes_wanted = (size_t)1 << 17;
-  if (const char* v = getenv("EG_MSM_LANES")) lanes_wanted = std::max<size_t>(1, strtoull(v, nullptr, 10));   // tests: 1 = always full chunks
+static void msm_plan(const eg_ctx* ctx, size_t n, size_t terms, int* chunk, int* n_chunks) {
+  const size_t lanes_wanted = ctx->knobs.msm_lanes;     // 2^17 (EG_MSM_LANES; tests: 1 = always full chunks)
   size_t c = std::min<size_t>(std::max<size_t>(terms, 1), MSM_CHUNK);
   c = std::min(c, std::max<size_t>(1, n * terms / lanes_wanted));
   *chunk = (int)c;
@@ -1082,16 +1130,12 @@ static void msm_fold_reduce(eg_ctx* c, size_t n, int count, const MsmScratch& m,
 // Window width by size: 2^(c-1) buckets per window with ~64 terms each.  Measured against the Straus path (tools/msm_probe.py,
 // profiles/r04_msm_by_size.txt): 2^19 terms 3.6 ms against 3.3, 2^20 4.8 against 5.7, 2^21 7.3 against 10.8, 2^22 13.0 against 21.5 - the
 // bucket method takes over from 2^20 terms; EG_MSM_BUCKET_MIN moves the switch (tests force either path at sizes the oracle can follow).
-static size_t pip_bucket_min() {
-  if (const char* v = getenv("EG_MSM_BUCKET_MIN")) return (size_t)strtoull(v, nullptr, 10);
-  return (size_t)1 << 20;
-}
 static int pip_window_bits(size_t terms) {
   int c = PIP_MIN_C;
   while (c < PIP_MAX_C && ((size_t)64 << (c - 1)) < terms) ++c;      // 2^17 -> 12, 2^18 -> 13, 2^19 -> 14, >= 2^20 -> 15
   return c;
 }
-static bool msm_uses_buckets(size_t terms) { return terms >= std::max<size_t>(pip_bucket_min(), (size_t)1 << 12); }
+static bool msm_uses_buckets(const eg_ctx* ctx, size_t terms) { return terms >= std::max<size_t>(ctx->knobs.msm_bucket_min, (size_t)1 << 12); }
 constexpr int PIP_MAX_LEVELS = PIP_SEQ - 1;
 struct PipLayout {
   size_t niels, digits, counts, offsets, cursors, idx, pieces[PIP_MAX_LEVELS], piece0[PIP_MAX_LEVELS], totals, tiles, psum[2], flag, part, total;
@@ -1170,23 +1214,23 @@ static int pip_launch(eg_ctx* c, size_t terms, const u32* d_scalars, const u32* 
   return EG_OK;
 }
 
-static size_t msm_chunks(size_t n, size_t terms) { int c, k; msm_plan(n, terms, &c, &k); return (size_t)k; }
+static size_t msm_chunks(const eg_ctx* ctx, size_t n, size_t terms) { int c, k; msm_plan(ctx, n, terms, &c, &k); return (size_t)k; }
 // scratch a call needs on the device (0: none)
-static size_t msm_scratch_for(size_t n, size_t terms) {
-  return msm_uses_buckets(terms) ? pip_layout(terms).total : msm_scratch_total(n, msm_chunks(n, terms));
+static size_t msm_scratch_for(const eg_ctx* ctx, size_t n, size_t terms) {
+  return msm_uses_buckets(ctx, terms) ? pip_layout(terms).total : msm_scratch_total(n, msm_chunks(ctx, n, terms));
 }
 // out[i] = enc( sum_t [k_it]P_it + [r_i]G ) on device pointers (kernels.cuh: k_prim_msm, k_prim_msm_fold, k_prim_msm_reduce; very large
 // products: pippenger.cuh, one problem after the other); asynchronous on s
 static int prim_msm_launch(eg_ctx* c, size_t n, size_t terms, const u32* d_scalars, const u32* d_points, const u32* d_r, void* d_scratch,
                            u32* d_out, unsigned char* d_ok, hipStream_t s) {
-  if (msm_uses_buckets(terms)) {
+  if (msm_uses_buckets(c, terms)) {
     for (size_t i = 0; i < n; ++i)
       TRY(pip_launch(c, terms, d_scalars + i * terms * 8, d_points + i * terms * 8, d_r ? d_r + i * 8 : nullptr, d_scratch, d_out + i * 8,
                      d_ok ? d_ok + i : nullptr, s));
     return EG_OK;
   }
   int chunk, n_chunks;
-  msm_plan(n, terms, &chunk, &n_chunks);
+  msm_plan(c, n, terms, &chunk, &n_chunks);
   const MsmScratch m = msm_scratch_at(d_scratch, n, (size_t)n_chunks);
   // every lane owns `chunk` tables in the per-lane workspace: the grid shrinks accordingly (the workspace is msm_blocks x one table)
   const int grid = grid_for(n * (size_t)n_chunks, std::max(1, c->msm_blocks / chunk));
@@ -1201,7 +1245,7 @@ static int prim_msm(eg_ctx* c, size_t n, size_t terms, const uint8_t* scalars, c
   HIPCHK(hipSetDevice(c->device));
   if (n == 0) return EG_OK;
   if (terms > ((size_t)1 << 24) || n > ((size_t)1 << 32)) return fail(EG_ERR_BAD_ARG, "at most 2^24 terms per problem");
-  const size_t need = msm_scratch_for(n, terms);
+  const size_t need = msm_scratch_for(c, n, terms);
   void *sc, *pt, *rr, *o, *k, *scratch;
   TRY(prim_bufs(c, {n * terms * 32, n * terms * 32, n * 32, n * 32, n, need}, {&sc, &pt, &rr, &o, &k, &scratch}));
   TRY(h2d(sc, scalars, n * terms * 32, c->stream)); TRY(h2d(pt, points, n * terms * 32, c->stream));
@@ -1229,13 +1273,13 @@ int eg_vartime_multi_mul_batch(eg_ctx* c, size_t n, size_t terms, const uint8_t*
   return prim_msm(c, n, terms, scalars, points, nullptr, out, ok);
 }
 // the same on DEVICE buffers, asynchronous on `stream` (a caller that keeps its operands in HBM pays no copies and no synchronisation;
-// what bench.py --workload msm times).  d_scratch must hold eg_msm_scratch_bytes(n, terms) bytes (0 for <= 8 terms).
-size_t eg_msm_scratch_bytes(size_t n, size_t terms) { return msm_scratch_for(n, terms); }
+// what bench.py --workload msm times).  d_scratch must hold eg_msm_scratch_bytes(ctx, n, terms) bytes (0 for <= 8 terms).
+size_t eg_msm_scratch_bytes(eg_ctx* c, size_t n, size_t terms) { return c ? msm_scratch_for(c, n, terms) : 0; }
 int eg_vartime_multi_mul_batch_device(eg_ctx* c, size_t n, size_t terms, const void* d_scalars, const void* d_points, const void* d_r,
                                       void* d_scratch, void* d_out, void* d_ok, void* stream) { EG_LOCK(c);
   if (!c || (n && !d_out) || (n && terms && (!d_scalars || !d_points)) || (n && !terms && !d_r)) return fail(EG_ERR_BAD_ARG, "bad argument");
   if (terms > ((size_t)1 << 24)) return fail(EG_ERR_BAD_ARG, "at most 2^24 terms per problem");
-  const size_t need = msm_scratch_for(n, terms);
+  const size_t need = msm_scratch_for(c, n, terms);
   if (n && need && !d_scratch) return fail(EG_ERR_BAD_ARG, "this call is cut into several chunks per problem (or uses the bucket method) and needs d_scratch (eg_msm_scratch_bytes)");
   if (n == 0) return EG_OK;
   HIPCHK(hipSetDevice(c->device));
@@ -1320,7 +1364,7 @@ int eg_dlog_table_get(const eg_dlog_table* t, size_t n, const uint8_t* elements,
 
 // ---- batch tier: choice ---------------------------------------------------------------------------------------------------
 // rings per group of the ring-group walk: EG_RING_GROUP overrides the plan's default (0 = every table of a ballot at once)
-static int choice_ring_group() { const char* v = getenv("EG_RING_GROUP"); return v ? std::max(0, atoi(v)) : -1; }
+static int choice_ring_group() { return read_knobs().ring_group; }     // at the creation of a params object (the plan is built before the engine)
 size_t eg_choice_ballot_size(int n_options, int single) { return eghost::choice_ballot_size(n_options, single != 0); }
 
 int eg_choice_params_create(eg_ctx* c, const uint8_t pk[32], int n_options, int single, eg_choice_params** out) { EG_LOCK(c);
@@ -1430,63 +1474,162 @@ int eg_qv_tally_encode(eg_qv_params* p, uint8_t* out) { EG_LOCK_P(p);
 // running tally.  The per-slab tallies (64 n_options bytes each) are merged on the host side of the ABI with the element addition
 // of the primitive tier on the first context - in one process there is nothing for RCCL to do.
 extern "C++" {
-template <class Params, class VerifyFn>
-static int verify_batch_multi(Params* const* per_device, int n_dev, size_t n, const uint8_t* ballots, uint32_t* status, uint8_t* tally_out,
-                              VerifyFn verify) {
-  if (!per_device || n_dev < 1 || n_dev > 64 || (n && (!ballots || !status))) return fail(EG_ERR_BAD_ARG, "bad argument");
+// the checks every multi entry shares: n_dev objects, all different, all of one election
+template <class Params>
+static int multi_check(Params* const* per_device, int n_dev) {
+  if (!per_device || n_dev < 1 || n_dev > 64) return fail(EG_ERR_BAD_ARG, "bad argument");
   for (int d = 0; d < n_dev; ++d) {
     if (!per_device[d]) return fail(EG_ERR_BAD_ARG, "null params object");
     for (int k = 0; k < d; ++k)
       if (per_device[k] == per_device[d]) return fail(EG_ERR_BAD_ARG, "the same params object given twice: one object (and context) per slab");
-    if (per_device[d]->eng->plan.stride != per_device[0]->eng->plan.stride || per_device[d]->n_options != per_device[0]->n_options)
+    const eghost::Plan &A = per_device[0]->eng->plan, &B = per_device[d]->eng->plan;
+    if (B.stride != A.stride || per_device[d]->n_options != per_device[0]->n_options || B.tally_slots.size() != A.tally_slots.size() ||
+        memcmp(per_device[d]->eng->key_bytes, per_device[0]->eng->key_bytes, 32) != 0)
       return fail(EG_ERR_BAD_ARG, "params objects of different elections");
   }
+  return EG_OK;
+}
+// One host thread per slab (the caller's thread takes slab 0), nothing escapes the C ABI: an exception inside a slab's work becomes that
+// slab's error code.
+template <class Work>
+static void multi_run(int n_dev, std::vector<int>& rcs, std::vector<std::string>& errs, Work work) {
+  auto guarded = [&](int d) {
+    try {
+      rcs[d] = work(d);
+      if (rcs[d]) errs[d] = g_err;          // eg_last_error is per thread: carry the text over to the caller's
+    } catch (const std::bad_alloc&) { rcs[d] = EG_ERR_NOMEM; errs[d] = "out of host memory";
+    } catch (const std::exception& ex) { rcs[d] = EG_ERR_HIP; errs[d] = std::string("exception: ") + ex.what();
+    } catch (...) { rcs[d] = EG_ERR_HIP; errs[d] = "unknown exception"; }
+  };
+  std::vector<std::thread> threads;
+  int started = 0;
+  try {
+    for (int d = 1; d < n_dev; ++d) { threads.emplace_back(guarded, d); started = d; }
+  } catch (const std::exception&) {          // no thread for a slab (resource limits): the caller's thread takes it over
+    for (int d = started + 1; d < n_dev; ++d) guarded(d);
+  }
+  guarded(0);
+  for (auto& t : threads) t.join();
+}
+// The running tallies before a multi call, as encodings on the host (64 n_options bytes each), and the way back to them: a multi call that
+// fails in ANY slab leaves every running tally as it found it (a host that retries the batch must not count slabs twice).
+template <class Params>
+struct TallyRollback {
+  Params* const* per_device; int n_dev; size_t bytes;
+  std::vector<std::vector<uint8_t>> saved;
+  int save() {
+    saved.assign(n_dev, std::vector<uint8_t>(bytes));
+    if (!bytes) return EG_OK;
+    for (int d = 0; d < n_dev; ++d) { std::lock_guard<std::recursive_mutex> g(per_device[d]->eng->ctx->mu); HIPCHK(hipSetDevice(per_device[d]->eng->ctx->device)); TRY(engine_tally_encode(per_device[d]->eng, saved[d].data())); }
+    return EG_OK;
+  }
+  int restore() {
+    if (!bytes) return EG_OK;
+    int first = EG_OK;
+    for (int d = 0; d < n_dev; ++d) {
+      std::lock_guard<std::recursive_mutex> g(per_device[d]->eng->ctx->mu);
+      Engine* e = per_device[d]->eng;
+      int rc = hipSetDevice(e->ctx->device) == hipSuccess ? EG_OK : EG_ERR_HIP;
+      if (!rc) rc = tally_reset(e, e->ctx->stream, true);
+      if (!rc) rc = engine_tally_add(e, saved[d].data());
+      if (rc && !first) first = rc;
+    }
+    return first;
+  }
+};
+template <class Params>
+static int multi_fail(Params* const* per_device, int n_dev, const std::vector<int>& rcs, const std::vector<std::string>& errs, TallyRollback<Params>& rb) {
+  for (int d = 0; d < n_dev; ++d)
+    if (rcs[d]) {
+      const bool back = rb.restore() == EG_OK;
+      return fail(rcs[d], "slab " + std::to_string(d) + " of " + std::to_string(n_dev) + ": " + errs[d] +
+                              (back ? " (every running tally is as it was before the call)" : " (AND the running tallies could not be restored: reset them)"));
+    }
+  return EG_OK;
+}
+// merges per-slab tally encodings (host) into out with the element addition of the primitive tier on the first context
+template <class Params>
+static int multi_merge(Params* const* per_device, int n_dev, const std::vector<std::vector<uint8_t>>& tallies, size_t tally_bytes, uint8_t* out) {
+  if (!tally_bytes) return EG_OK;
+  memcpy(out, tallies[0].data(), tally_bytes);
+  std::vector<uint8_t> ok(tally_bytes / 32);
+  for (int d = 1; d < n_dev; ++d) {
+    TRY(eg_point_add_batch(per_device[0]->eng->ctx, tally_bytes / 32, out, tallies[d].data(), 0, out, ok.data()));
+    for (uint8_t o : ok) if (!o) return fail(EG_ERR_HIP, "the tally of slab " + std::to_string(d) + " does not decode");
+  }
+  return EG_OK;
+}
+template <class Params, class VerifyFn>
+static int verify_batch_multi(Params* const* per_device, int n_dev, size_t n, const uint8_t* ballots, uint32_t* status, uint8_t* tally_out,
+                              VerifyFn verify) {
+  TRY(multi_check(per_device, n_dev));
+  if (n && (!ballots || !status)) return fail(EG_ERR_BAD_ARG, "bad argument");
   const size_t stride = per_device[0]->eng->plan.stride;
   const size_t tally_bytes = (size_t)per_device[0]->eng->plan.tally_slots.size() * 32;
   std::vector<std::vector<uint8_t>> tallies(n_dev, std::vector<uint8_t>(tally_bytes));
   std::vector<int> rcs(n_dev, EG_OK);
   std::vector<std::string> errs(n_dev);
-  auto work = [&](int d) {
+  TallyRollback<Params> rb{per_device, n_dev, tally_bytes, {}};
+  TRY(rb.save());
+  multi_run(n_dev, rcs, errs, [&](int d) {
     const size_t b = n * (size_t)d / (size_t)n_dev, e = n * (size_t)(d + 1) / (size_t)n_dev;
-    rcs[d] = verify(per_device[d], e - b, ballots + b * stride, status + b, tally_out ? tallies[d].data() : nullptr);
-    if (rcs[d]) errs[d] = g_err;          // eg_last_error is per thread: carry the text over to the caller's
-  };
-  {
-    std::vector<std::thread> threads;
-    try {
-      for (int d = 1; d < n_dev; ++d) threads.emplace_back(work, d);
-    } catch (const std::exception& ex) {          // no thread for a slab (resource limits): the caller's thread takes it over - nothing may escape the C ABI
-      for (int d = (int)threads.size() + 1; d < n_dev; ++d) work(d);
-    }
-    work(0);
-    for (auto& t : threads) t.join();
-  }
-  for (int d = 0; d < n_dev; ++d)
-    if (rcs[d]) return fail(rcs[d], "slab " + std::to_string(d) + " of " + std::to_string(n_dev) + ": " + errs[d]);
+    return verify(per_device[d], e - b, ballots + b * stride, status + b, tally_out ? tallies[d].data() : nullptr);
+  });
+  TRY(multi_fail(per_device, n_dev, rcs, errs, rb));
   if (tally_out && tally_bytes) {
-    memcpy(tally_out, tallies[0].data(), tally_bytes);
+    const int rc = multi_merge(per_device, n_dev, tallies, tally_bytes, tally_out);
+    if (rc) { const std::string why = g_err; (void)rb.restore(); return fail(rc, why); }
+  }
+  return EG_OK;
+}
+// The same with every slab ALREADY RESIDENT on its GPU: d_ballots[d] / d_status[d] are device pointers on per_device[d]'s device, n_per_dev[d]
+// ballots each, streams[d] (may be NULL = all null streams) a stream of that device.  One host thread per slab enqueues
+// eg_verify_*_batch_device and waits for its stream, so that the call returns with every verdict written and every running tally advanced;
+// no byte of a ballot crosses PCIe or xGMI.
+template <class Params, class VerifyDevFn>
+static int verify_batch_multi_device(Params* const* per_device, int n_dev, const size_t* n_per_dev, const void* const* d_ballots,
+                                     void* const* d_status, void* const* streams, uint8_t* tally_out, VerifyDevFn verify_dev) {
+  TRY(multi_check(per_device, n_dev));
+  if (!n_per_dev || !d_ballots || !d_status) return fail(EG_ERR_BAD_ARG, "bad argument");
+  for (int d = 0; d < n_dev; ++d)
+    if (n_per_dev[d] && (!d_ballots[d] || !d_status[d])) return fail(EG_ERR_BAD_ARG, "null device pointer for a non-empty slab");
+  const size_t tally_bytes = (size_t)per_device[0]->eng->plan.tally_slots.size() * 32;
+  std::vector<int> rcs(n_dev, EG_OK);
+  std::vector<std::string> errs(n_dev);
+  TallyRollback<Params> rb{per_device, n_dev, tally_bytes, {}};
+  TRY(rb.save());
+  multi_run(n_dev, rcs, errs, [&](int d) {
+    hipStream_t s = streams ? (hipStream_t)streams[d] : nullptr;
+    TRY(verify_dev(per_device[d], n_per_dev[d], d_ballots[d], d_status[d], (void*)s));
+    HIPCHK(hipStreamSynchronize(s));
+    return (int)EG_OK;
+  });
+  TRY(multi_fail(per_device, n_dev, rcs, errs, rb));
+  if (tally_out && tally_bytes) {
+    // the batch's own tally = (running tally after) - (running tally before), slab by slab, merged: all on 64 n_options bytes per device
+    std::vector<std::vector<uint8_t>> tallies(n_dev, std::vector<uint8_t>(tally_bytes));
     std::vector<uint8_t> ok(tally_bytes / 32);
-    for (int d = 1; d < n_dev; ++d) {
-      TRY(eg_point_add_batch(per_device[0]->eng->ctx, tally_bytes / 32, tally_out, tallies[d].data(), 0, tally_out, ok.data()));
-      for (uint8_t o : ok) if (!o) return fail(EG_ERR_HIP, "a slab's tally does not decode");
+    int rc = EG_OK;
+    for (int d = 0; d < n_dev && !rc; ++d) {
+      { std::lock_guard<std::recursive_mutex> g(per_device[d]->eng->ctx->mu);
+        rc = hipSetDevice(per_device[d]->eng->ctx->device) == hipSuccess ? engine_tally_encode(per_device[d]->eng, tallies[d].data()) : fail(EG_ERR_HIP, "hipSetDevice"); }
+      if (!rc) rc = eg_point_add_batch(per_device[d]->eng->ctx, tally_bytes / 32, tallies[d].data(), rb.saved[d].data(), 1, tallies[d].data(), ok.data());
+      if (!rc) for (uint8_t o : ok) if (!o) rc = fail(EG_ERR_HIP, "the tally of slab " + std::to_string(d) + " does not decode");
     }
+    if (!rc) rc = multi_merge(per_device, n_dev, tallies, tally_bytes, tally_out);
+    if (rc) { const std::string why = g_err; (void)rb.restore(); return fail(rc, why); }
   }
   return EG_OK;
 }
 // sum of the RUNNING tallies of the params objects (each keeps the tally of the slabs it verified)
 template <class Params, class EncodeFn>
 static int tally_encode_multi(Params* const* per_device, int n_dev, uint8_t* out, EncodeFn encode) {
-  if (!per_device || n_dev < 1 || n_dev > 64 || !out) return fail(EG_ERR_BAD_ARG, "bad argument");
-  for (int d = 0; d < n_dev; ++d) if (!per_device[d]) return fail(EG_ERR_BAD_ARG, "null params object");
+  TRY(multi_check(per_device, n_dev));
+  if (!out) return fail(EG_ERR_BAD_ARG, "bad argument");
   const size_t tally_bytes = (size_t)per_device[0]->eng->plan.tally_slots.size() * 32;
-  std::vector<uint8_t> t(tally_bytes), ok(tally_bytes / 32 + 1);
-  TRY(encode(per_device[0], out));
-  for (int d = 1; d < n_dev; ++d) {
-    if ((size_t)per_device[d]->eng->plan.tally_slots.size() * 32 != tally_bytes) return fail(EG_ERR_BAD_ARG, "params objects of different elections");
-    TRY(encode(per_device[d], t.data()));
-    TRY(eg_point_add_batch(per_device[0]->eng->ctx, tally_bytes / 32, out, t.data(), 0, out, ok.data()));
-  }
-  return EG_OK;
+  std::vector<std::vector<uint8_t>> tallies(n_dev, std::vector<uint8_t>(tally_bytes));
+  for (int d = 0; d < n_dev; ++d) TRY(encode(per_device[d], tallies[d].data()));
+  return multi_merge(per_device, n_dev, tallies, tally_bytes, out);
 }
 }  // extern "C++"
 int eg_verify_choice_batch_multi(eg_choice_params* const* per_device, int n_dev, size_t n, const uint8_t* ballots, uint32_t* status,
@@ -1496,6 +1639,14 @@ int eg_verify_choice_batch_multi(eg_choice_params* const* per_device, int n_dev,
 int eg_verify_qv_batch_multi(eg_qv_params* const* per_device, int n_dev, size_t n, const uint8_t* ballots, uint32_t* status,
                              uint8_t* tally_out) {
   return verify_batch_multi(per_device, n_dev, n, ballots, status, tally_out, eg_verify_qv_batch);
+}
+int eg_verify_choice_batch_multi_device(eg_choice_params* const* per_device, int n_dev, const size_t* n_per_dev, const void* const* d_ballots,
+                                        void* const* d_status, void* const* streams, uint8_t* tally_out) {
+  return verify_batch_multi_device(per_device, n_dev, n_per_dev, d_ballots, d_status, streams, tally_out, eg_verify_choice_batch_device);
+}
+int eg_verify_qv_batch_multi_device(eg_qv_params* const* per_device, int n_dev, const size_t* n_per_dev, const void* const* d_ballots,
+                                    void* const* d_status, void* const* streams, uint8_t* tally_out) {
+  return verify_batch_multi_device(per_device, n_dev, n_per_dev, d_ballots, d_status, streams, tally_out, eg_verify_qv_batch_device);
 }
 int eg_choice_tally_encode_multi(eg_choice_params* const* per_device, int n_dev, uint8_t* out) {
   return tally_encode_multi(per_device, n_dev, out, eg_choice_tally_encode);
@@ -1715,8 +1866,7 @@ static int verify_json_common(Engine* e, const char* json, size_t json_len, int 
   // drained GPU, 0.85 of the HBM-resident rate).  Consecutive submissions go through two control streams, so that the chunks of
   // submission k+1 queue behind those of submission k on the work sets' streams without waiting for k's join; the sets' shares of the
   // tally are merged once at the end.  Ballots of another shape (EG_PACK_RESHAPE) are collected and resolved after the last window.
-  const size_t env_ring = getenv("EG_JSON_RING_KB") ? (size_t)atol(getenv("EG_JSON_RING_KB")) << 10 : 0;        // test knobs
-  const size_t env_window = getenv("EG_JSON_WINDOW_KB") ? (size_t)atol(getenv("EG_JSON_WINDOW_KB")) << 10 : 0;
+  const size_t env_ring = e->knobs.json_ring_kb << 10, env_window = e->knobs.json_window_kb << 10;        // test knobs (read at params creation)
   const size_t ring_max = env_ring ? env_ring : (size_t)1 << 30;
   const size_t ring_bytes = std::max(std::min(json_len / 4 * 3 + stride, ring_max), 64 * stride);
   const size_t cap = ring_bytes / stride;                          // ballots in the ring
@@ -1809,8 +1959,8 @@ static int verify_json_common(Engine* e, const char* json, size_t json_len, int 
   // the kernels run well exactly when the GPU is the slower side, and stay small (and early) when the parser is.
   struct Group { size_t n_regions, first, off, m; hipEvent_t uploaded, done; };
   std::deque<Group> groups;
-  const size_t growth = getenv("EG_JSON_GROWTH") ? (size_t)atol(getenv("EG_JSON_GROWTH")) : 150;   // per cent (measurement knob; A/B block 6)
-  const bool trace = getenv("EG_JSON_TRACE") != nullptr;             // developer aid: the timeline of the submissions on stderr
+  const size_t growth = e->knobs.json_growth;   // per cent (measurement knob; A/B block 6)
+  const bool trace = e->knobs.json_trace;       // developer aid: the timeline of the submissions on stderr
   const auto t_start = std::chrono::steady_clock::now();
   auto ms_now = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
   size_t n_submitted = 0;

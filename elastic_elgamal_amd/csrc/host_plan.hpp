@@ -890,9 +890,25 @@ inline std::string check_flat_plan(const Plan& P, const FlatPlan& F) {
     } else if (finish_stage >= 0 || last_acc_stage >= 0) return "accumulators in an ungrouped plan";
   }
   size_t counted = 0, live = 0;      // live = table slots that hold a table while the stage's equations run
-  for (auto& sd : F.stages) {
+  // whose tables those are: ALL (ungrouped plan), the tables of ring group `resident` (>= 0), or the SUMS' tables (after sum_finish).  A
+  // table-backed term must name a table that is resident when its equation runs AND the slot that its base's table was built into: a
+  // term over a base of another group would pass the range check and silently read a different ring's table.
+  enum { RES_ALL = -1, RES_SUMS = -2, RES_NONE = -3 };
+  int resident = P.grouped() ? RES_NONE : RES_ALL;
+  for (size_t si = 0; si < F.stages.size(); ++si) {
+    const StageDev& sd = F.stages[si];
     if (sd.build_count) live = (size_t)sd.build_count + (sd.sums_direct ? F.sums.size() : 0);
     if (sd.sum_finish) live = F.sums.size();
+    if (P.grouped()) {
+      if (sd.build_count) {
+        int g_here = -1;
+        for (size_t g = 0; g < P.group_stage.size(); ++g)
+          if (P.group_stage[g] == (int)si && P.group_size((int)g)) { if (g_here >= 0) return "two groups build their tables in one stage"; g_here = (int)g; }
+        if (g_here < 0 || P.group_size(g_here) != (size_t)sd.build_count) return "a stage builds tables that are no group's";
+        resident = g_here;
+      }
+      if (sd.sum_finish) resident = RES_SUMS;
+    }
     for (int f = 0; f < N_FAM; ++f) {
       if (sd.fam_first[f] < 0 || (size_t)sd.fam_first[f] + sd.fam_count[f] > F.jobs.size()) return "family range out of range";
       counted += sd.fam_count[f];
@@ -907,6 +923,18 @@ inline std::string check_flat_plan(const Plan& P, const FlatPlan& F) {
           const VarTerm& v = P.vterms[j.term_first + t];
           if (!scalar_ok(v.s) || v.s.kind == SRC_NONE) return "term scalar out of range";
           if (v.base == 0xffff ? (int)v.slot >= P.n_pt_slots : (v.base >= n_tab || v.base >= live)) return "term base out of range";
+          if (v.base != 0xffff) {
+            auto it = P.base_index_of.find(v.slot);
+            if (it != P.base_index_of.end()) {            // an ordinary base: its own slot, in its own group's residency
+              const uint16_t i = it->second;
+              if (P.base_local[i] != v.base) return "term names another base's table slot";
+              if (P.grouped() && resident != (int)P.base_group[i]) return "term over a base whose group's tables are not resident at this stage";
+            } else {                                        // a sum of bases: the sums' tables
+              const size_t first_sum = P.grouped() ? 0 : P.base_slots.size();
+              if (v.base < first_sum || v.base - first_sum >= F.sums.size()) return "sum term names a table slot that is no sum's";
+              if (P.grouped() && resident != RES_SUMS) return "sum term before the sums' tables are finished";
+            }
+          }
         }
       }
     }

@@ -36,6 +36,32 @@
  * forms first wait for the whole device, so they may follow `_device` calls directly).  `_device` / `_async` functions only
  * enqueue work on the hipStream_t they are given - NULL is HIP's null stream, as everywhere - and share the context's
  * workspaces, so a caller that uses several streams with one context must order them itself (events).
+ *
+ * RUN-TIME KNOBS.  Every environment variable the library looks at, complete (csrc/eg_hip.hip: struct Knobs, read_knobs - the only
+ * place the environment is read).  They are read at TWO moments only - eg_init (context-wide knobs; the context keeps its copy) and the
+ * creation of a params object (eg_*_params_create; the engine keeps its copy) - never per call: changing the environment afterwards
+ * does nothing to live objects.  None of them changes a verdict or a tally (tests force each and compare with the oracle); the shipped
+ * library has NO failure-injection switch (tests build their own copy with fault points: tests/faultlib).
+ *
+ *   name                  read at        default            effect
+ *   EG_ALLOW_ANY_ARCH     eg_init        unset              accept a device that is not gfx950 (development only; kernels are built for gfx950)
+ *   EG_COMB_BIG_BITS      eg_init        24                 window width of the WIDE fixed-base comb tables (11.8 GB per base); 0 = never build them
+ *   EG_COMB_BIG_MIN       eg_init        524288             items an engine must have verified before the wide tables are built for it
+ *   EG_MSM_BLOCKS_PER_CU  eg_init        32                 grid of the table / equation / multi-scalar kernels per CU (sets the 2.4 GB per-lane workspace)
+ *   EG_MSM_LANES          eg_init        131072             lanes a multi-scalar call should cover before terms share doubling chains (1 = always chunks of 8)
+ *   EG_MSM_BUCKET_MIN     eg_init        1048576            terms per product from which the bucket (Pippenger) method replaces Straus; eg_msm_scratch_bytes follows it
+ *   EG_TEETH              params create  by plan (5 or 6)   comb shape of the per-ballot tables: 5 x 51 (2 KiB) or 6 x 43 (4 KiB)
+ *   EG_STREAMS            params create  2                  work sets (each with its own stream) the chunks of a call alternate between: 1 or 2
+ *   EG_CHUNK              params create  by plan / memory   ballots per chunk and work set (default 2^19, or 2^18 where two sets would pass 40 GB)
+ *   EG_RING_GROUP         params create  by plan            ring-group walk of choice ballots: rings whose tables are resident at a time; 0 = all
+ *                                                           (default: all below 256 options); a memory knob, 0.6-4 % slower
+ *   EG_JSON_RING_KB       params create  1048576            pinned staging ring of eg_verify_*_json, KiB
+ *   EG_JSON_WINDOW_KB     params create  98304              JSON text per parser window, KiB
+ *   EG_JSON_GROWTH        params create  150                a second JSON submission is enqueued once it is this many per cent of the first
+ *   EG_JSON_TRACE         params create  unset              timeline of the JSON submissions on stderr
+ *
+ * The Python mirror adds two of its own (elastic_elgamal_amd/__init__.py, read at import): EG_LIB = path of another build of this
+ * library (A/B measurements, the fault-point build of the tests), EG_NO_TORCH_PRELOAD = do not import torch before loading the library.
  */
 #ifndef EG_HIP_H
 #define EG_HIP_H
@@ -132,9 +158,9 @@ int eg_vartime_multi_mul_batch(eg_ctx*, size_t n, size_t terms, const uint8_t* s
  * chunks' partial sums are added up with wavefront shuffles; from 2^20 terms per problem on, the bucket method (Pippenger, dalek's choice
  * above 190 terms; csrc/pippenger.cuh) takes over, one problem after the other: 13 ms instead of 21 for 2^22 terms.  A call that is cut
  * into several chunks per problem (more than 8 terms, or few problems of many terms) or that uses the bucket method needs d_scratch of
- * eg_msm_scratch_bytes(n, terms) bytes (0 when it needs none; ~250 bytes per term for the bucket method: 1 GB at 2^22 terms).  A caller
+ * eg_msm_scratch_bytes(ctx, n, terms) bytes (0 when it needs none; ~250 bytes per term for the bucket method: 1 GB at 2^22 terms).  A caller
  * that keeps its operands in HBM pays no copy and no synchronisation. */
-size_t eg_msm_scratch_bytes(size_t n, size_t terms);
+size_t eg_msm_scratch_bytes(eg_ctx*, size_t n, size_t terms);   /* by the context: its switch to the bucket method is fixed at eg_init */
 int eg_vartime_multi_mul_batch_device(eg_ctx*, size_t n, size_t terms, const void* d_scalars, const void* d_points, const void* d_r,
                                       void* d_scratch, void* d_out, void* d_ok, void* stream);
 
@@ -216,18 +242,38 @@ int eg_qv_tally_encode_device(eg_qv_params*, void* d_out, void* stream);
 
 /* ---- batch tier on several GPUs of ONE process (SURVEY.md 8b `device_mask`; the reference's host is one single-threaded process,
  * examples/voting.rs:179-213) -----------------------------------------------------------------------------------------------------
- * per_device[d], d < n_dev: params objects of the SAME election, each created on its own context (eg_init(d, ..): one per GPU; two
- * contexts on one GPU work too).  The batch is cut into contiguous slabs - slab d = ballots [n d / n_dev, n (d + 1) / n_dev) - and one
- * host thread per params object inside the library runs eg_verify_*_batch on its slab (its own device, streams, uploads; pin the
- * ballots with hipHostRegister / hipHostMalloc for full upload speed).  status: n words, in ballot order.  Every params object
- * adds its slab to its OWN running tally; tally_out (may be NULL) receives the tally of this call's whole batch, the slabs' tallies
- * merged with the element addition of the primitive tier - the in-process counterpart of the RCCL all-gather of the one-process-per-GPU
- * path (examples/tally_exchange.cpp).  eg_*_tally_encode_multi = the sum of the running tallies.  An error in any slab fails the call
- * (eg_last_error names the slab); verdicts of other slabs may have been written. */
+ * per_device[d], d < n_dev: params objects of the SAME election (same key, options, kind), each created on its own context
+ * (eg_init(d, ..): one per GPU; two contexts on one GPU work too).
+ *
+ * eg_verify_*_batch_multi (HOST buffers): the batch is cut into contiguous slabs - slab d = ballots [n d / n_dev, n (d + 1) / n_dev) -
+ * and one host thread per params object inside the library runs eg_verify_*_batch on its slab (its own device, streams, uploads; pin
+ * the ballots with hipHostRegister / hipHostMalloc for full upload speed).  status: n words, in ballot order.
+ *
+ * eg_verify_*_batch_multi_device (DEVICE buffers): slab d is ALREADY RESIDENT on GPU d - a host that generated or received its ballots
+ * per GPU pays no copy.  n_per_dev[d] ballots at d_ballots[d], verdicts to d_status[d] (n_per_dev[d] words), both device pointers on
+ * per_device[d]'s device; streams[d] a hipStream_t of that device (streams == NULL: the null streams).  One host thread per slab
+ * enqueues eg_verify_*_batch_device on its stream and waits for that stream: the call returns with every verdict written.
+ *
+ * Tallies.  Every params object ADDS the accepted ballots of its slab to its OWN running tally; tally_out (may be NULL, n_options*64
+ * bytes) receives the tally of this call's whole batch alone, the slabs' tallies merged with the element addition of the primitive
+ * tier - the in-process counterpart of the RCCL all-gather of the one-process-per-GPU path (examples/tally_exchange.cpp).
+ * eg_*_tally_encode_multi = the sum of the running tallies (every encoding is checked: a running tally that does not decode, or params
+ * objects of different elections, fail the call).
+ *
+ * AFTER A FAILURE.  An error in any slab fails the whole call; eg_last_error names the slab.  Verdicts of other slabs may have been
+ * written, but NO running tally has advanced: every multi verify call snapshots the running tallies before it starts (64 n_options
+ * bytes per device) and puts them back when any slab, or the final merge, fails - the caller may simply retry the batch, or go on with
+ * the next one, without resetting anything.  Only if putting them back fails as well (the device is gone) does the error text say
+ * "could not be restored"; then reset every params object (eg_*_tally_reset) and re-import the last checkpoint (eg_*_tally_add).
+ * Nothing thrown inside a slab's thread crosses the ABI: it becomes that slab's error. */
 int eg_verify_choice_batch_multi(eg_choice_params* const* per_device, int n_dev, size_t n, const uint8_t* ballots, uint32_t* status,
                                  uint8_t* tally_out);
 int eg_verify_qv_batch_multi(eg_qv_params* const* per_device, int n_dev, size_t n, const uint8_t* ballots, uint32_t* status,
                              uint8_t* tally_out);
+int eg_verify_choice_batch_multi_device(eg_choice_params* const* per_device, int n_dev, const size_t* n_per_dev, const void* const* d_ballots,
+                                        void* const* d_status, void* const* streams, uint8_t* tally_out);
+int eg_verify_qv_batch_multi_device(eg_qv_params* const* per_device, int n_dev, const size_t* n_per_dev, const void* const* d_ballots,
+                                    void* const* d_status, void* const* streams, uint8_t* tally_out);
 int eg_choice_tally_encode_multi(eg_choice_params* const* per_device, int n_dev, uint8_t* out /* n_options*64 */);
 int eg_qv_tally_encode_multi(eg_qv_params* const* per_device, int n_dev, uint8_t* out /* n_options*64 */);
 

@@ -240,6 +240,37 @@ inline BatchVerdict<QuadraticVotingError> verify_batch_multi(const std::vector<c
   return v;
 }
 
+// The same with every slab already resident on its GPU (eg_verify_*_batch_multi_device): slab d = counts[d] packed ballots at the device
+// pointer d_ballots[d] on the device of per_device[d], verdicts (uint32 words) to d_status[d], streams[d] a hipStream_t of that device
+// (empty vector: the null streams).  Returns the tally of this batch; every params object's running tally advances by its slab.  A
+// failure in any slab throws and leaves every running tally as it was (eg_hip.h: "AFTER A FAILURE").
+inline std::vector<Ciphertext> verify_batch_multi_device(const std::vector<const ChoiceParams*>& per_device, const std::vector<size_t>& counts,
+                                                         const std::vector<const void*>& d_ballots, const std::vector<void*>& d_status,
+                                                         const std::vector<void*>& streams = {}) {
+  const size_t k = per_device.size();
+  if (!k || counts.size() != k || d_ballots.size() != k || d_status.size() != k || (!streams.empty() && streams.size() != k))
+    throw Error(EG_ERR_BAD_ARG, "one count, ballot pointer, status pointer (and stream) per params object");
+  std::vector<eg_choice_params*> raw;
+  for (auto* p : per_device) raw.push_back(p->raw());
+  Bytes tally(64 * per_device[0]->options_count());
+  check(eg_verify_choice_batch_multi_device(raw.data(), (int)k, counts.data(), d_ballots.data(), d_status.data(),
+                                            streams.empty() ? nullptr : streams.data(), tally.data()));
+  return unpack_totals(tally);
+}
+inline std::vector<Ciphertext> verify_batch_multi_device(const std::vector<const QuadraticVotingParams*>& per_device, const std::vector<size_t>& counts,
+                                                         const std::vector<const void*>& d_ballots, const std::vector<void*>& d_status,
+                                                         const std::vector<void*>& streams = {}) {
+  const size_t k = per_device.size();
+  if (!k || counts.size() != k || d_ballots.size() != k || d_status.size() != k || (!streams.empty() && streams.size() != k))
+    throw Error(EG_ERR_BAD_ARG, "one count, ballot pointer, status pointer (and stream) per params object");
+  std::vector<eg_qv_params*> raw;
+  for (auto* p : per_device) raw.push_back(p->raw());
+  Bytes tally(64 * per_device[0]->options_count());
+  check(eg_verify_qv_batch_multi_device(raw.data(), (int)k, counts.data(), d_ballots.data(), d_status.data(),
+                                        streams.empty() ? nullptr : streams.data(), tally.data()));
+  return unpack_totals(tally);
+}
+
 // Wire ingest (src/serde.rs:19-80,179-355): ballots as JSON text in the reference's serde layout -> packed ballots, on the host.
 // status[k]: EG_ST_OK (packed[k] valid), EG_ST_MALFORMED (does not deserialise) or EG_PACK_RESHAPE (wrong number of choices /
 // responses / partial ciphertexts for this election: OptionsLenMismatch / LenMismatch territory).

@@ -34,6 +34,33 @@ int pc_plan(int kind, int n, unsigned long long v) {
     default: return -2;
   }
 }
+// A grouped choice plan with ONE table-backed term bent on purpose, so that the safety net of the ring-group walk can be seen to
+// catch it: mutation 0 = untouched (must pass), 1 = a term's point slot replaced by the base of ANOTHER group that sits in
+// the same table slot (passes every range check, would read a different ring's table), 2 = a term's table slot replaced by another slot
+// of its own group.  Returns 0 if check_flat_plan accepts the plan, 1 if it refuses it, -2 if the plan offers no such term.
+int pc_plan_mutated(int n, int single, int ring_group, int mutation, char* why_out, int cap) {
+  uint8_t pk[32]; memset(pk, 7, 32);
+  Plan P = build_choice_plan(n, single != 0, ring_group);
+  if (P.pk_off >= 0) memcpy(P.blob.data() + P.pk_off, pk, 32);
+  if (!P.grouped()) return -2;
+  bool done = mutation == 0;
+  for (auto& v : P.vterms) {
+    if (done) break;
+    if (v.base == 0xffff) continue;
+    auto it = P.base_index_of.find(v.slot);
+    if (it == P.base_index_of.end()) continue;
+    const uint16_t i = it->second;
+    for (size_t k = 0; k < P.base_slots.size() && !done; ++k) {
+      if (mutation == 1 && P.base_group[k] != P.base_group[i] && P.base_local[k] == P.base_local[i]) { v.slot = P.base_slots[k]; done = true; }
+      if (mutation == 2 && P.base_group[k] == P.base_group[i] && P.base_local[k] != P.base_local[i]) { v.base = P.base_local[k]; done = true; }
+    }
+  }
+  if (!done) return -2;
+  const FlatPlan F = flatten_plan(P);
+  const std::string why = check_flat_plan(P, F);
+  if (why_out && cap > 0) { strncpy(why_out, why.c_str(), cap - 1); why_out[cap - 1] = 0; }
+  return why.empty() ? 0 : 1;
+}
 int pc_range(unsigned long long ub, char* buf, int cap) {
   const std::string s = optimal_range(ub).to_string();
   if ((int)s.size() + 1 > cap) return -1;

@@ -41,6 +41,30 @@ def test_no_oracle_in_product():
     assert "liboracle" not in out
 
 
+def test_no_test_hooks_and_one_documented_list_of_knobs(lib_path):
+    """VERDICT r4 task 5: no failure-injection switch in the shipped product (sources, Python, binary); the environment is read in ONE
+    function of the library (read_knobs) and the table "RUN-TIME KNOBS" of include/eg_hip.h lists exactly the names it reads."""
+    pkg = ROOT / "elastic_elgamal_amd"
+    for f in pkg.rglob("*"):
+        if f.is_file() and f.suffix in {".py", ".hip", ".cuh", ".hpp", ".h", ".cpp"}:
+            assert "EG_TEST" not in f.read_text(), f
+    assert b"EG_TEST" not in (pkg / "libeg_hip.so").read_bytes()
+    src = (pkg / "csrc" / "eg_hip.hip").read_text()
+    a, b = src.index("static Knobs read_knobs()"), src.index("// Fault points:")
+    assert "getenv" not in src[:a] + src[b:], "the environment is read outside read_knobs"
+    for f in (pkg / "csrc").iterdir():
+        if f.name != "eg_hip.hip" and f.suffix in {".hip", ".cuh", ".hpp", ".h"}:
+            assert "getenv" not in f.read_text(), f
+    read = set(re.findall(r'"(EG_[A-Z_]+)"', src[a:b]))
+    header = (ROOT / "include" / "eg_hip.h").read_text()
+    table = header[header.index("RUN-TIME KNOBS"):header.index("#ifndef EG_HIP_H")]
+    listed = set(re.findall(r"^ \*   (EG_[A-Z_]+) ", table, re.M))
+    assert read == listed and len(read) == 14, (read ^ listed)
+    py_env = set(re.findall(r'environ(?:\.get)?[\[(]"(EG_[A-Z_]+)"', "".join(f.read_text() for f in pkg.glob("*.py"))))
+    py_env |= set(re.findall(r'"(EG_[A-Z_]+)" in os\.environ', "".join(f.read_text() for f in pkg.glob("*.py"))))
+    assert py_env == {"EG_LIB", "EG_NO_TORCH_PRELOAD"} and all(k in table for k in py_env), py_env
+
+
 def test_ballot_sizes_and_missing_gpu_is_loud(lib_path):
     import elastic_elgamal_amd as eg
 

@@ -60,6 +60,26 @@ def test_bench_started_bare_refuses_more_gpus_than_the_node_has():
     assert not [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
 
 
+def test_bench_in_process_devices_rehearsed():
+    """`bench.py --in-process-devices 3`: the step of the ranked path through ONE process - three contexts (all on device 0 here), one
+    resident slab and one stream each, eg_verify_*_batch_multi_device, the running tallies merged by eg_*_tally_encode_multi; the merged
+    tally is also the running tally of one engine that verified every slab (VERDICT r4 task 6c; examples/voting.rs:179-213 is one
+    process).  Weak (3 x 30 000, 1 % tampered) and strong (100 001 ballots cut in three)."""
+    for extra, total, tampered in ((["--ballots", "30000", "--tampered-percent", "1"], 90000, 900),
+                                   (["--total-ballots", "100001", "--workload", "qv"], 100001, 0)):
+        r = _run_bare(["--in-process-devices", "3", "--rehearse-one-gpu", "--steps", "2", "--warmup", "1", *extra],
+                      {"EG_CHUNK": "32768", "EG_COMB_BIG_BITS": "0"})
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+        assert len(lines) == 1, lines
+        line = json.loads(lines[0])
+        cfg = line["config"]
+        assert line["n_gpus"] == 3 and cfg["parallelism"] == "in-process3-on-one-gpu" and cfg["devices"] == [0, 0, 0]
+        assert cfg["total_ballots"] == total and cfg["tampered"] == tampered and cfg["accepted"] == total - tampered
+        assert cfg["tally_exchange_ok"] is True and cfg["tally_checked_against_one_engine"] is True
+        assert line["scaling"] == ("weak" if total == 90000 else "strong") and line["value"] > 1e4 and line["steps"] == 2
+
+
 def test_bench_four_ranks_ten_million_ballots_rehearsed():
     """BASELINE configs[4] - 10 M single-choice ballots, sharded, 1 % tampered, ONE tally exchange - with four ranks time-sharing the
     GPU (gloo for the exchange), per-rank memory bounded (chunks of 65 536 ballots, narrow comb tables): shards of 2.5 M each,

@@ -65,6 +65,26 @@ def test_every_plan_shape_builds_flattens_and_checks(lib):
     assert "plans" in out
 
 
+def test_index_check_catches_terms_over_another_groups_tables(lib):
+    """in a grouped plan (ring-group walk) a table-backed term names a table SLOT; a term bent onto the base of another
+    group that sits in the same slot passes every range check and would silently read a different ring's table.  check_flat_plan now
+    derives which group's tables are resident at each stage and refuses it (and a term that names another slot of its own group)."""
+    out = _run(lib, """
+        why = C.create_string_buffer(200)
+        seen = set()
+        for n, single, rg in ((5, 1, 2), (5, 1, 1), (16, 0, 4), (9, 1, 4), (40, 0, 8), (6, 1, 3)):
+            assert L.pc_plan_mutated(n, single, rg, 0, why, 200) == 0, (n, single, rg, why.value)
+            for mutation in (1, 2):
+                r = L.pc_plan_mutated(n, single, rg, mutation, why, 200)
+                if rg == 1 and mutation == 2:
+                    assert r in (1, -2)          # one ring per group: R and B are its only two slots
+                assert r == 1 or (r == -2 and rg == 1), (n, single, rg, mutation, r, why.value)
+                if r == 1: seen.add(why.value.decode())
+        print(sorted(seen))
+    """)
+    assert "not resident" in out and "another base's table slot" in out, out
+
+
 def test_wire_packer_survives_fuzzed_json(lib):
     out = _run(lib, """
         from elastic_elgamal_amd import serde, ingest

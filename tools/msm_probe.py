@@ -22,8 +22,12 @@ out = torch.empty(32, dtype=torch.uint8, device="cuda")
 import os
 sizes = [(n, "default") for n in (1 << 12, 1 << 14, 1 << 16, 1 << 17, 1 << 18, 1 << 19, 1 << 20, 1 << 21, 1 << 22)]
 sizes = [(n, mode) for n, _ in sizes for mode in (("straus", "buckets") if n >= 1 << 14 else ("straus",))]
+ctxs = {}
+for mode in ("straus", "buckets"):        # the switch is read once, by eg_init: one context per forced path
+    os.environ["EG_MSM_BUCKET_MIN"] = str(1 << 30) if mode == "straus" else "4096"
+    ctxs[mode] = eg.Ristretto(eg.Context(0))
 for n, mode in sizes:
-    os.environ["EG_MSM_BUCKET_MIN"] = str(1 << 30) if mode == "straus" else "4096"       # force one path or the other
+    grp = ctxs[mode]
     scratch = torch.empty(max(grp.msm_scratch_bytes(1, n), 16), dtype=torch.uint8, device="cuda")
     for _ in range(2):
         grp.vartime_multi_mul_device(1, n, sc.data_ptr(), pts.data_ptr(), out.data_ptr(), 0, scratch.data_ptr()); torch.cuda.synchronize()
