@@ -165,6 +165,12 @@ def _load() -> C.CDLL:
         "eg_qv_ballot_size_for": (sz, [C.c_int, C.c_uint64]),
         "eg_verify_choice_json": (C.c_int, [vp, vp, sz, C.c_int, sz, vp, C.POINTER(sz), vp]),
         "eg_verify_qv_json": (C.c_int, [vp, vp, sz, C.c_int, sz, vp, C.POINTER(sz), vp]),
+        "eg_verify_choice_json_begin": (C.c_int, [vp, C.c_int, C.POINTER(vp)]),
+        "eg_verify_qv_json_begin": (C.c_int, [vp, C.c_int, C.POINTER(vp)]),
+        "eg_verify_json_feed": (C.c_int, [vp, vp, sz, C.POINTER(sz)]),
+        "eg_verify_json_take": (C.c_int, [vp, vp, sz, C.POINTER(sz)]),
+        "eg_verify_json_end": (C.c_int, [vp, vp, sz, C.POINTER(sz), C.POINTER(sz), vp]),
+        "eg_verify_json_abort": (None, [vp]),
         "eg_range_decomposition": (C.c_int, [C.c_uint64, cp, sz]),
         "eg_plan_describe": (C.c_int, [C.c_int, C.c_int, C.c_uint64, cp, sz]),
         "eg_profile_enable": (C.c_int, [vp, C.c_int]),
@@ -498,8 +504,81 @@ def tally_encode_multi(per_device) -> bytes:
     return out.raw
 
 
+class JsonStream:
+    """``eg_verify_*_json_begin / eg_verify_json_feed / _take / _end / _abort``: the JSON text of a batch of ballots in pieces of any size
+    (a ballot may straddle pieces); verdicts and tally are those of ``verify_json`` on the concatenated text.  Between begin and
+    end / abort the params object belongs to the stream."""
+
+    def __init__(self, params, threads: int = 0):
+        self._h = C.c_void_p()
+        self.params = params
+        self.objects = 0
+        fn = getattr(_load(), f"eg_verify_{params._prefix}_json_begin")
+        _check(fn(params._h, threads or (os.cpu_count() or 1), C.byref(self._h)))
+
+    def feed(self, piece) -> int:
+        """The next piece of the text (bytes / bytearray / memoryview / str); returns the number of complete objects seen so far."""
+        if isinstance(piece, str):
+            piece = piece.encode()
+        piece = bytes(piece)
+        n = C.c_size_t(0)
+        _check(_load().eg_verify_json_feed(self._h, C.cast(C.c_char_p(piece), C.c_void_p), len(piece), C.byref(n)))
+        self.objects = n.value
+        return n.value
+
+    def feed_ptr(self, ptr: int, length: int) -> int:
+        n = C.c_size_t(0)
+        _check(_load().eg_verify_json_feed(self._h, C.c_void_p(ptr), length, C.byref(n)))
+        self.objects = n.value
+        return n.value
+
+    def take(self, cap: int = 1 << 20):
+        """Verdicts that are final so far (in order, from where the last take stopped); never blocks."""
+        st = (C.c_uint32 * max(cap, 1))()
+        n = C.c_size_t(0)
+        _check(_load().eg_verify_json_take(self._h, st, cap, C.byref(n)))
+        return list(st[: n.value])
+
+    def end(self, with_tally: bool = True, cap: int | None = None):
+        """Flushes the stream: (verdicts not yet taken, tally of the stream's ballots or None).  The stream is gone afterwards."""
+        cap = self.objects + 1 if cap is None else cap
+        st = (C.c_uint32 * max(cap, 1))()
+        n, total = C.c_size_t(0), C.c_size_t(0)
+        tally = C.create_string_buffer(64 * self.params.n_options) if with_tally else None
+        h, self._h = self._h, C.c_void_p()
+        rc = _load().eg_verify_json_end(h, st, cap, C.byref(n), C.byref(total), tally)
+        if rc and b"are left" in _load().eg_last_error():
+            self._h = h                    # the stream is still open: room for the verdicts was missing
+        _check(rc)
+        self.objects = total.value
+        return list(st[: n.value]), (tally.raw if with_tally else None)
+
+    def end_into(self, status, with_tally: bool = False):
+        """As end(), verdicts into a caller-owned ctypes uint32 array (bench.py: no Python list of a million words)."""
+        n, total = C.c_size_t(0), C.c_size_t(0)
+        tally = C.create_string_buffer(64 * self.params.n_options) if with_tally else None
+        h, self._h = self._h, C.c_void_p()
+        _check(_load().eg_verify_json_end(h, status, len(status), C.byref(n), C.byref(total), tally))
+        self.objects = total.value
+        return n.value, (tally.raw if with_tally else None)
+
+    def abort(self):
+        if self._h:
+            _load().eg_verify_json_abort(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.abort()
+        except Exception:
+            pass
+
+
 class _BatchParams:
     _prefix = ""
+
+    def json_stream(self, threads: int = 0) -> JsonStream:
+        return JsonStream(self, threads)
 
     def _fn(self, name):
         return getattr(_load(), f"eg_{self._prefix}_{name}")

@@ -254,6 +254,7 @@ struct Engine {
   u32* json_status_ring = nullptr;     // pinned verdicts of the ballots in the ring
   size_t json_ring_ballots = 0;
   hipStream_t json_ctl[2] = {nullptr, nullptr};   // control streams of consecutive windows (fork / join of a window's chunks)
+  struct eg_json_stream* stream_open = nullptr;   // the JSON stream (eg_verify_json_begin ... _end) that owns this engine's work sets, ring and tally just now
   // staging for the host-pointer API
   hipStream_t copy_stream = nullptr;
   unsigned char* d_wire = nullptr;
@@ -801,6 +802,12 @@ static int engine_verify_host(Engine* e, size_t n, const uint8_t* ballots, uint3
 struct eg_choice_params { Engine* eng; int n_options; int single; };
 struct eg_qv_params { Engine* eng; int n_options; uint64_t credits; eghost::QvShape shape; };
 struct eg_proof_params { Engine* eng; int kind; size_t item_size; };
+// between eg_verify_*_json_begin and eg_verify_json_end / _abort the params object belongs to the stream: its work sets, staging ring and
+// running tally are in use, so every other verify / tally call on it is refused
+static int refuse_if_streaming(const Engine* e) {
+  return e->stream_open ? fail(EG_ERR_BAD_ARG, "a JSON stream is open on this params object (eg_verify_json_end or _abort it first)") : EG_OK;
+}
+void eg_verify_json_abort(struct eg_json_stream* S);
 
 // The context is reference counted: the caller holds one reference (dropped by eg_destroy) and every params object
 // created on it holds another, so params may be destroyed after the context they were created on.
@@ -824,6 +831,8 @@ static void params_destroy(Params* p) {
   eg_ctx* c = p->eng->ctx;
   {
     std::lock_guard<std::recursive_mutex> lk(c->mu);
+    (void)hipSetDevice(c->device);
+    if (p->eng->stream_open) eg_verify_json_abort(p->eng->stream_open);      // a stream left open dies with its params object
     engine_free(p->eng);
     delete p;
   }
@@ -1378,10 +1387,12 @@ int eg_choice_params_create(eg_ctx* c, const uint8_t pk[32], int n_options, int 
 void eg_choice_params_destroy(eg_choice_params* p) { params_destroy(p); }
 int eg_verify_choice_batch(eg_choice_params* p, size_t n, const uint8_t* ballots, uint32_t* status, uint8_t* tally_out) { EG_LOCK_P(p);
   if (!p || (n && (!ballots || !status))) return fail(EG_ERR_BAD_ARG, "bad argument");
+  TRY(refuse_if_streaming(p->eng));
   return engine_verify_host(p->eng, n, ballots, status, tally_out);
 }
 int eg_verify_choice_batch_device(eg_choice_params* p, size_t n, const void* d_ballots, void* d_status, void* stream) { EG_LOCK_P(p);
   if (!p || (n && (!d_ballots || !d_status))) return fail(EG_ERR_BAD_ARG, "bad argument");
+  TRY(refuse_if_streaming(p->eng));
   HIPCHK(hipSetDevice(p->eng->ctx->device));
   return engine_verify_device(p->eng, n, d_ballots, d_status, (hipStream_t)stream);
 }
@@ -1399,10 +1410,12 @@ static int tally_encode_device(Engine* e, void* d_out, hipStream_t s) {
 }
 int eg_choice_tally_encode_device(eg_choice_params* p, void* d_out, void* stream) { EG_LOCK_P(p);
   if (!p || !d_out) return fail(EG_ERR_BAD_ARG, "bad argument");
+  TRY(refuse_if_streaming(p->eng));
   return tally_encode_device(p->eng, d_out, (hipStream_t)stream);
 }
 int eg_qv_tally_encode_device(eg_qv_params* p, void* d_out, void* stream) { EG_LOCK_P(p);
   if (!p || !d_out) return fail(EG_ERR_BAD_ARG, "bad argument");
+  TRY(refuse_if_streaming(p->eng));
   return tally_encode_device(p->eng, d_out, (hipStream_t)stream);
 }
 int eg_points_sum_device(eg_ctx* c, int n_ranks, int n_points, const void* d_in, void* d_out, void* d_bad, void* stream) { EG_LOCK(c);
@@ -1424,18 +1437,21 @@ static int prepare_wide(Engine* e) {
 }
 int eg_choice_prepare_wide_tables(eg_choice_params* p) { EG_LOCK_P(p); return p ? prepare_wide(p->eng) : fail(EG_ERR_BAD_ARG, "null"); }
 int eg_qv_prepare_wide_tables(eg_qv_params* p) { EG_LOCK_P(p); return p ? prepare_wide(p->eng) : fail(EG_ERR_BAD_ARG, "null"); }
-int eg_choice_tally_reset(eg_choice_params* p) { EG_LOCK_P(p); return p ? tally_reset(p->eng, p->eng->ctx->stream, true) : fail(EG_ERR_BAD_ARG, "null"); }
-int eg_choice_tally_reset_async(eg_choice_params* p, void* stream) { EG_LOCK_P(p); return p ? tally_reset(p->eng, (hipStream_t)stream, false) : fail(EG_ERR_BAD_ARG, "null"); }
+int eg_choice_tally_reset(eg_choice_params* p) { EG_LOCK_P(p); if (!p) return fail(EG_ERR_BAD_ARG, "null"); TRY(refuse_if_streaming(p->eng)); return tally_reset(p->eng, p->eng->ctx->stream, true); }
+int eg_choice_tally_reset_async(eg_choice_params* p, void* stream) { EG_LOCK_P(p); if (!p) return fail(EG_ERR_BAD_ARG, "null"); TRY(refuse_if_streaming(p->eng)); return tally_reset(p->eng, (hipStream_t)stream, false); }
 int eg_choice_tally_add(eg_choice_params* p, const uint8_t* in) { EG_LOCK_P(p);
   if (!p || !in) return fail(EG_ERR_BAD_ARG, "bad argument");
+  TRY(refuse_if_streaming(p->eng));
   return engine_tally_add(p->eng, in);
 }
 int eg_qv_tally_add(eg_qv_params* p, const uint8_t* in) { EG_LOCK_P(p);
   if (!p || !in) return fail(EG_ERR_BAD_ARG, "bad argument");
+  TRY(refuse_if_streaming(p->eng));
   return engine_tally_add(p->eng, in);
 }
 int eg_choice_tally_encode(eg_choice_params* p, uint8_t* out) { EG_LOCK_P(p);
   if (!p || !out) return fail(EG_ERR_BAD_ARG, "bad argument");
+  TRY(refuse_if_streaming(p->eng));
   return engine_tally_encode(p->eng, out);
 }
 
@@ -1452,17 +1468,20 @@ void eg_qv_params_destroy(eg_qv_params* p) { params_destroy(p); }
 size_t eg_qv_ballot_size(const eg_qv_params* p) { return p ? p->shape.ballot_size : 0; }
 int eg_verify_qv_batch(eg_qv_params* p, size_t n, const uint8_t* ballots, uint32_t* status, uint8_t* tally_out) { EG_LOCK_P(p);
   if (!p || (n && (!ballots || !status))) return fail(EG_ERR_BAD_ARG, "bad argument");
+  TRY(refuse_if_streaming(p->eng));
   return engine_verify_host(p->eng, n, ballots, status, tally_out);
 }
 int eg_verify_qv_batch_device(eg_qv_params* p, size_t n, const void* d_ballots, void* d_status, void* stream) { EG_LOCK_P(p);
   if (!p || (n && (!d_ballots || !d_status))) return fail(EG_ERR_BAD_ARG, "bad argument");
+  TRY(refuse_if_streaming(p->eng));
   HIPCHK(hipSetDevice(p->eng->ctx->device));
   return engine_verify_device(p->eng, n, d_ballots, d_status, (hipStream_t)stream);
 }
-int eg_qv_tally_reset(eg_qv_params* p) { EG_LOCK_P(p); return p ? tally_reset(p->eng, p->eng->ctx->stream, true) : fail(EG_ERR_BAD_ARG, "null"); }
-int eg_qv_tally_reset_async(eg_qv_params* p, void* stream) { EG_LOCK_P(p); return p ? tally_reset(p->eng, (hipStream_t)stream, false) : fail(EG_ERR_BAD_ARG, "null"); }
+int eg_qv_tally_reset(eg_qv_params* p) { EG_LOCK_P(p); if (!p) return fail(EG_ERR_BAD_ARG, "null"); TRY(refuse_if_streaming(p->eng)); return tally_reset(p->eng, p->eng->ctx->stream, true); }
+int eg_qv_tally_reset_async(eg_qv_params* p, void* stream) { EG_LOCK_P(p); if (!p) return fail(EG_ERR_BAD_ARG, "null"); TRY(refuse_if_streaming(p->eng)); return tally_reset(p->eng, (hipStream_t)stream, false); }
 int eg_qv_tally_encode(eg_qv_params* p, uint8_t* out) { EG_LOCK_P(p);
   if (!p || !out) return fail(EG_ERR_BAD_ARG, "bad argument");
+  TRY(refuse_if_streaming(p->eng));
   return engine_tally_encode(p->eng, out);
 }
 
@@ -1842,6 +1861,7 @@ static int verify_json_common(Engine* e, const char* json, size_t json_len, int 
                               size_t* n_objects, uint8_t* tally_out, const PackPieceFn& pack_piece, const ReshapeFn& reshape) {
   if ((json_len && !json) || (max_objects && !status)) return fail(EG_ERR_BAD_ARG, "bad argument");
   if (n_objects) *n_objects = 0;
+  TRY(refuse_if_streaming(e));
   HIPCHK(hipSetDevice(e->ctx->device));
   const size_t stride = e->plan.stride;
   const int ns = (int)e->plan.tally_slots.size();
@@ -2103,6 +2123,328 @@ int eg_verify_qv_json(eg_qv_params* p, const char* json, size_t json_len, int th
                               return egwire::resolve_qv_objects(text, odd, n_options, vote, credit, sh.ballot_size, make_check_items(e->ctx),
                                                                 make_verify_packed(e), out);
                             });
+}
+// ---- the JSON text in PIECES: eg_verify_{choice,qv}_json_begin / eg_verify_json_feed / _take / _end / _abort --------------------------------
+// (examples/voting.rs:195-198 emits ballots one at a time; src/serde.rs:19-80 is the layout.)  The caller's thread does everything, piece by
+// piece: eg_verify_json_feed cuts the piece (egwire::StreamSplitter: values may straddle pieces), packs its complete ballots on the
+// stream's pool of host threads into the pinned ring, and then PUMPS the GPU side without ever waiting for it - retire the submissions
+// that have landed, enqueue what has piled up (upload, verification on the two work sets, download of the verdicts).  The first submission
+// waits until 2^17 ballots are packed (the small first submissions of the one-shot entry cost it 5-8 %: the kernels run well from ~10^5
+// ballots on), later ones go when they are 1.5 x the one in flight, at most two in flight; feed only blocks when the ring is full.
+// Nothing of the caller's text is referenced after feed returns (the tail of a piece that is not a whole value yet is copied: at most one
+// ballot's text).  Between begin and end the params object belongs to the stream (other verify / tally calls on it are refused).
+struct eg_json_stream {
+  Engine* e = nullptr;
+  int threads = 1, n_ctl = 1, ns = 0;
+  PackPieceFn pack_piece;
+  ReshapeFn reshape;
+  std::unique_ptr<egwire::WorkerPool> pool;
+  std::unique_ptr<egwire::StreamSplitter> split;
+  size_t stride = 0, cap = 0, first_min = 0, growth = 150;
+  struct Region { size_t first, off, m; bool submitted; };
+  std::deque<Region> regions;          // in text order; the front is the oldest one not yet retired
+  struct Group { size_t n_regions, first, off, m; hipEvent_t uploaded, done; };
+  std::deque<Group> groups;            // submissions in flight, oldest first
+  std::vector<uint32_t> verdicts;      // by object: its pack verdict until (if it packed) the GPU's verdict lands
+  std::vector<uint32_t> pack_tmp;
+  std::vector<std::string> odd_text;   // objects of another shape than the election's: resolved at the end (the object path needs the GPU to itself)
+  std::vector<size_t> odd_at;
+  size_t landed = 0, taken = 0, n_submitted = 0;
+  bool set_aside = false, flushed = false, trace = false;
+  int failed = EG_OK;
+  std::string err;
+};
+static int stream_fail(eg_json_stream* S, int code, const std::string& msg) {
+  if (!S->failed) { S->failed = code; S->err = msg; }
+  return fail(S->failed, S->err);
+}
+static void stream_retire_oldest(eg_json_stream* S) {     // the oldest submission has landed: its verdicts, its part of the ring
+  Engine* e = S->e;
+  const eg_json_stream::Group g = S->groups.front();
+  S->groups.pop_front();
+  for (size_t k = 0; k < g.n_regions; ++k) {
+    const eg_json_stream::Region r = S->regions.front();
+    S->regions.pop_front();
+    for (size_t i = 0; i < r.m; ++i)
+      if (S->verdicts[r.first + i] == EG_ST_OK) S->verdicts[r.first + i] = e->json_status_ring[r.off + i];
+  }
+  S->landed = g.first + g.m;
+  (void)hipEventDestroy(g.uploaded); (void)hipEventDestroy(g.done);
+  if (S->trace) fprintf(stderr, "[json stream] landed    %zu ballots from %zu\n", g.m, g.first);
+}
+// enqueue what has piled up, if it is time (or `force`: the ring is full, or the text has ended); never waits for the GPU
+static int stream_pump(eg_json_stream* S, bool force) {
+  Engine* e = S->e;
+  for (;;) {
+    while (!S->groups.empty() && hipEventQuery(S->groups.front().done) == hipSuccess) stream_retire_oldest(S);
+    (void)hipGetLastError();                           // a submission still running reads as hipErrorNotReady: not an error to keep
+    if (S->groups.size() >= 2) return EG_OK;
+    eg_json_stream::Group g{0, 0, 0, 0, nullptr, nullptr};
+    for (auto& r : S->regions) {                       // the run of packed windows behind the submitted ones, contiguous in the ring
+      if (r.submitted) continue;
+      if (g.n_regions && r.off != g.off + g.m) break;
+      if (!g.n_regions) { g.first = r.first; g.off = r.off; }
+      ++g.n_regions; g.m += r.m;
+    }
+    if (!g.n_regions) return EG_OK;
+    bool go = force;
+    if (!go && S->groups.empty()) go = S->n_submitted ? true : g.m >= S->first_min;       // an idle GPU takes whatever there is - except the very first time
+    if (!go && S->groups.size() == 1) go = g.m * 100 >= S->groups.back().m * S->growth && g.m >= std::min(S->first_min, S->cap / 8);
+    if (!go) return EG_OK;
+    hipStream_t ctl = e->json_ctl[S->n_submitted % (size_t)S->n_ctl];
+    const char* what = "window upload: ";
+    hipError_t he = hipEventCreateWithFlags(&g.uploaded, hipEventDisableTiming);
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&g.done, hipEventDisableTiming | hipEventBlockingSync);
+    if (he == hipSuccess) he = hipMemcpyAsync(e->d_wire + g.off * S->stride, e->json_ring + g.off * S->stride, g.m * S->stride, hipMemcpyHostToDevice, e->copy_stream);
+    if (he == hipSuccess) he = hipEventRecord(g.uploaded, e->copy_stream);
+    if (he == hipSuccess) he = hipStreamWaitEvent(ctl, g.uploaded, 0);
+    int rc = EG_OK;
+    if (he == hipSuccess) {
+      rc = engine_verify_device(e, g.m, e->d_wire + g.off * S->stride, e->d_status + g.off, ctl, VD_FORCE_SETS | VD_KEEP_SET_TALLY);
+      what = "verdict download: ";
+      if (rc == EG_OK) he = hipMemcpyAsync(e->json_status_ring + g.off, e->d_status + g.off, g.m * sizeof(u32), hipMemcpyDeviceToHost, ctl);
+      if (rc == EG_OK && he == hipSuccess) he = hipEventRecord(g.done, ctl);
+    }
+    if (he != hipSuccess) rc = fail(EG_ERR_HIP, std::string(what) + hipGetErrorString(he));
+    if (rc) {
+      if (g.uploaded) (void)hipEventDestroy(g.uploaded);
+      if (g.done) (void)hipEventDestroy(g.done);
+      return stream_fail(S, rc, g_err);
+    }
+    size_t k = 0;
+    for (auto& r : S->regions) { if (r.submitted) continue; if (k++ == g.n_regions) break; r.submitted = true; }
+    S->groups.push_back(g);
+    ++S->n_submitted;
+    if (S->trace) fprintf(stderr, "[json stream] submitted %zu windows, %zu ballots from %zu (%zu in flight)\n", g.n_regions, g.m, g.first, S->groups.size());
+  }
+}
+// room for m packed ballots in the ring (behind the newest region, or from the start again once the oldest regions there have been
+// retired); waits for the GPU only when there is none
+static int stream_place(eg_json_stream* S, size_t m, size_t* off) {
+  for (;;) {
+    if (S->regions.empty()) { *off = 0; return EG_OK; }
+    const size_t head = S->regions.back().off + S->regions.back().m, tail = S->regions.front().off;
+    if (head > tail) {                            // the occupied part does not wrap
+      if (head + m <= S->cap) { *off = head; return EG_OK; }
+      if (m <= tail) { *off = 0; return EG_OK; }
+    } else if (head + m <= tail) { *off = head; return EG_OK; }
+    if (S->groups.empty()) {
+      TRY(stream_pump(S, true));                  // the ring is full of packed ballots nobody has submitted yet
+      if (S->groups.empty()) return stream_fail(S, EG_ERR_NOMEM, "a window of ballots does not fit the staging ring");
+    }
+    const hipError_t he = hipEventSynchronize(S->groups.front().done);
+    if (he != hipSuccess) return stream_fail(S, EG_ERR_HIP, std::string("window: ") + hipGetErrorString(he));
+    stream_retire_oldest(S);
+  }
+}
+// the complete values of one window of the text: pack them into the ring, remember the ones that need the object path, pump the GPU
+static bool stream_emit(eg_json_stream* S, const char* base, const std::vector<std::pair<size_t, size_t>>& spans, size_t first) {
+  Engine* e = S->e;
+  size_t off = 0;
+  if (stream_place(S, spans.size(), &off)) return false;
+  S->pack_tmp.resize(spans.size());
+  S->pack_piece(base, spans, S->threads, e->json_ring + off * S->stride, S->pack_tmp.data(), S->pool.get());
+  if (S->verdicts.size() < first + spans.size()) S->verdicts.resize(first + spans.size());
+  for (size_t i = 0; i < spans.size(); ++i) {
+    S->verdicts[first + i] = S->pack_tmp[i];
+    if (S->pack_tmp[i] == EG_PACK_RESHAPE) { S->odd_text.emplace_back(base + spans[i].first, spans[i].second); S->odd_at.push_back(first + i); }
+  }
+  S->regions.push_back({first, off, spans.size(), false});
+  return stream_pump(S, false) == EG_OK;
+}
+static void stream_release(eg_json_stream* S, bool keep_partial_tally) {      // the engine goes back to its owner; the stream is deleted
+  Engine* e = S->e;
+  (void)hipDeviceSynchronize();                         // nothing may still read the ring or the work sets
+  for (auto& g : S->groups) { if (g.uploaded) (void)hipEventDestroy(g.uploaded); if (g.done) (void)hipEventDestroy(g.done); }
+  S->groups.clear();
+  hipStream_t s = e->ctx->stream;
+  if (S->ns && e->n_sets == 2) {
+    if (keep_partial_tally) hipLaunchKernelGGL(k_tally_add_points, dim3(blocks_of((size_t)S->ns)), dim3(NT), 0, s, e->set[1].tally, S->ns, e->set[0].tally);
+    hipLaunchKernelGGL(k_tally_init, dim3(blocks_of((size_t)S->ns)), dim3(NT), 0, s, e->set[1].tally, S->ns);
+  }
+  if (S->set_aside && S->ns) {
+    // a finished stream: running tally = what it was + the stream's ballots; an aborted or failed one: what it was
+    if (keep_partial_tally) hipLaunchKernelGGL(k_tally_add_points, dim3(blocks_of((size_t)S->ns)), dim3(NT), 0, s, e->tally_saved2, S->ns, e->tally);
+    else (void)hipMemcpyAsync(e->tally, e->tally_saved2, (size_t)S->ns * PT_WORDS * sizeof(u32), hipMemcpyDeviceToDevice, s);
+  }
+  (void)hipStreamSynchronize(s);
+  e->stream_open = nullptr;
+  delete S;
+}
+static int stream_begin(Engine* e, int threads, PackPieceFn pack_piece, ReshapeFn reshape, eg_json_stream** out) {
+  if (!out) return fail(EG_ERR_BAD_ARG, "bad argument");
+  *out = nullptr;
+  if (e->stream_open) return fail(EG_ERR_BAD_ARG, "a JSON stream is already open on this params object");
+  HIPCHK(hipSetDevice(e->ctx->device));
+  std::unique_ptr<eg_json_stream> S(new eg_json_stream());
+  S->e = e; S->threads = std::max(threads, 1); S->pack_piece = std::move(pack_piece); S->reshape = std::move(reshape);
+  S->stride = e->plan.stride; S->ns = (int)e->plan.tally_slots.size();
+  S->growth = e->knobs.json_growth; S->trace = e->knobs.json_trace;
+  hipStream_t s = e->ctx->stream;
+  HIPCHK(hipDeviceSynchronize());
+  const size_t ring_bytes = std::max(e->knobs.json_ring_kb ? e->knobs.json_ring_kb << 10 : (size_t)1 << 30, 64 * S->stride);
+  S->cap = ring_bytes / S->stride;
+  S->first_min = std::min<size_t>((size_t)1 << 17, S->cap / 4);
+  if (S->cap * S->stride > e->json_ring_bytes || S->cap > e->json_ring_ballots) {
+    if (e->json_ring) (void)hipHostFree(e->json_ring);
+    if (e->json_status_ring) (void)hipHostFree(e->json_status_ring);
+    e->json_ring = nullptr; e->json_status_ring = nullptr; e->json_ring_bytes = 0; e->json_ring_ballots = 0;
+    if (hipHostMalloc((void**)&e->json_ring, S->cap * S->stride, hipHostMallocPortable) != hipSuccess ||
+        hipHostMalloc((void**)&e->json_status_ring, S->cap * sizeof(u32), hipHostMallocPortable) != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(EG_ERR_NOMEM, "pinned staging allocation failed");
+    }
+    e->json_ring_bytes = S->cap * S->stride; e->json_ring_ballots = S->cap;
+  } else S->cap = std::min(S->cap, e->json_ring_ballots);
+  TRY(engine_stage_reserve(e, S->cap));
+  if (!e->copy_stream) HIPCHK(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+  S->n_ctl = e->n_sets == 2 ? 2 : 1;
+  for (int k = 0; k < S->n_ctl; ++k)
+    if (!e->json_ctl[k]) HIPCHK(hipStreamCreateWithFlags(&e->json_ctl[k], hipStreamNonBlocking));
+  {
+    const size_t per_set = (S->cap + e->n_sets - 1) / e->n_sets + NT;
+    const int rr = engine_reserve(e, (u32)std::min<size_t>(per_set, e->max_cap));
+    if (rr != EG_OK && rr != EG_ERR_NOMEM) return rr;
+  }
+  if (S->ns) {        // the stream's own tally is reported at the end; the running tally keeps accumulating (eg_hip.h)
+    HIPCHK(hipMemcpyAsync(e->tally_saved2, e->tally, (size_t)S->ns * PT_WORDS * sizeof(u32), hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_tally_init, dim3(blocks_of((size_t)S->ns)), dim3(NT), 0, s, e->tally, S->ns);
+    S->set_aside = true;
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  S->pool.reset(new egwire::WorkerPool(S->threads));
+  eg_json_stream* raw = S.get();
+  const size_t window = e->knobs.json_window_kb ? e->knobs.json_window_kb << 10 : (size_t)32 << 20;
+  S->split.reset(new egwire::StreamSplitter(S->threads, S->pool.get(),
+                                            [raw](const char* base, const std::vector<std::pair<size_t, size_t>>& spans, size_t first) {
+                                              return stream_emit(raw, base, spans, first);
+                                            },
+                                            window, std::max<size_t>(1, S->cap / 8)));
+  e->stream_open = raw;
+  *out = S.release();
+  return EG_OK;
+}
+int eg_verify_json_feed(eg_json_stream* S, const char* text, size_t len, size_t* n_objects) {
+  if (!S) return fail(EG_ERR_BAD_ARG, "bad argument");
+  EG_LOCK(S->e->ctx);
+  if (len && !text) return fail(EG_ERR_BAD_ARG, "bad argument");
+  if (S->failed) return fail(S->failed, S->err);
+  if (S->flushed) return fail(EG_ERR_BAD_ARG, "the stream has been ended");
+  if (!S->split->feed(text, len)) {
+    if (!S->failed) stream_fail(S, EG_ERR_BAD_ARG, S->split->error().empty() ? std::string("the piece could not be packed") : S->split->error());
+    return fail(S->failed, S->err);
+  }
+  TRY(stream_pump(S, false));
+  if (n_objects) *n_objects = S->split->count();
+  return EG_OK;
+}
+// verdicts that are final so far, in order, from where the last take stopped: every ballot before the first one that is still on the GPU
+// or waits for the object path (a ballot of another shape than the election's gets its verdict at the end)
+static size_t stream_final_upto(const eg_json_stream* S) {
+  size_t upto = S->flushed ? S->verdicts.size() : S->landed;
+  if (!S->flushed && !S->odd_at.empty()) upto = std::min(upto, S->odd_at.front());
+  return upto;
+}
+int eg_verify_json_take(eg_json_stream* S, uint32_t* status, size_t cap, size_t* n_taken) {
+  if (!S || !n_taken || (cap && !status)) return fail(EG_ERR_BAD_ARG, "bad argument");
+  EG_LOCK(S->e->ctx);
+  *n_taken = 0;
+  if (S->failed) return fail(S->failed, S->err);
+  if (!S->flushed) TRY(stream_pump(S, false));
+  const size_t upto = stream_final_upto(S);
+  const size_t n = std::min(cap, upto > S->taken ? upto - S->taken : 0);
+  if (n) memcpy(status, S->verdicts.data() + S->taken, n * sizeof(uint32_t));
+  S->taken += n;
+  *n_taken = n;
+  return EG_OK;
+}
+int eg_verify_json_end(eg_json_stream* S, uint32_t* status, size_t cap, size_t* n_taken, size_t* n_objects, uint8_t* tally_out) {
+  if (!S || (cap && !status)) return fail(EG_ERR_BAD_ARG, "bad argument");
+  eg_ctx* ctx = S->e->ctx;
+  EG_LOCK(ctx);
+  if (n_taken) *n_taken = 0;
+  Engine* e = S->e;
+  if (!S->flushed && !S->failed) {
+    if (!S->split->finish()) stream_fail(S, EG_ERR_BAD_ARG, S->split->error());
+    while (!S->failed && (!S->regions.empty() || !S->groups.empty())) {
+      if (stream_pump(S, true)) break;
+      if (S->groups.empty()) continue;
+      const hipError_t he = hipEventSynchronize(S->groups.front().done);
+      if (he != hipSuccess) { stream_fail(S, EG_ERR_HIP, std::string("window: ") + hipGetErrorString(he)); break; }
+      stream_retire_oldest(S);
+    }
+    if (!S->failed) {
+      (void)hipDeviceSynchronize();
+      hipStream_t s = ctx->stream;
+      if (S->ns && e->n_sets == 2) {                           // the sets' shares of the tally, once
+        hipLaunchKernelGGL(k_tally_add_points, dim3(blocks_of((size_t)S->ns)), dim3(NT), 0, s, e->set[1].tally, S->ns, e->set[0].tally);
+        hipLaunchKernelGGL(k_tally_init, dim3(blocks_of((size_t)S->ns)), dim3(NT), 0, s, e->set[1].tally, S->ns);
+        if (hipStreamSynchronize(s) != hipSuccess) stream_fail(S, EG_ERR_HIP, "tally merge failed");
+      }
+    }
+    if (!S->failed && !S->odd_at.empty()) {   // OptionsLenMismatch / LenMismatch territory: the object path, in the reference's order of checks
+      std::string all;
+      std::vector<std::pair<size_t, size_t>> spans;
+      for (auto& t : S->odd_text) { spans.push_back({all.size(), t.size()}); all += t; all += '\n'; }
+      std::vector<uint32_t> v;
+      e->stream_open = nullptr;               // the object path verifies substitute ballots through the ordinary host entry
+      const bool ok = S->reshape(all.data(), spans, v);
+      e->stream_open = S;
+      if (!ok) stream_fail(S, EG_ERR_HIP, g_err.empty() ? std::string("object path: a GPU call failed") : g_err);
+      else for (size_t i = 0; i < S->odd_at.size(); ++i) S->verdicts[S->odd_at[i]] = v[i];
+    }
+    S->flushed = true;
+  }
+  if (S->failed) {
+    const int rc = S->failed;
+    const std::string why = S->err;
+    stream_release(S, false);
+    return fail(rc, why);
+  }
+  const size_t left = S->verdicts.size() - S->taken;
+  if (left > cap) return fail(EG_ERR_BAD_ARG, "status holds " + std::to_string(cap) + " verdicts, " + std::to_string(left) + " are left: call again with room for them (or eg_verify_json_abort)");
+  if (left) memcpy(status, S->verdicts.data() + S->taken, left * sizeof(uint32_t));
+  if (n_taken) *n_taken = left;
+  if (n_objects) *n_objects = S->verdicts.size();
+  int rc = EG_OK;
+  if (tally_out && S->ns) rc = engine_tally_encode(e, tally_out);       // the stream's own tally (the running tally gets it added below)
+  const std::string why = g_err;
+  stream_release(S, true);
+  return rc ? fail(rc, why) : EG_OK;
+}
+void eg_verify_json_abort(eg_json_stream* S) {
+  if (!S) return;
+  eg_ctx* ctx = S->e->ctx;
+  EG_LOCK(ctx);
+  stream_release(S, false);
+}
+int eg_verify_choice_json_begin(eg_choice_params* p, int threads, eg_json_stream** out) { EG_LOCK_P(p);
+  if (!p) return fail(EG_ERR_BAD_ARG, "bad argument");
+  const int n_options = p->n_options, single = p->single;
+  const size_t stride = p->eng->plan.stride;
+  Engine* e = p->eng;
+  return stream_begin(e, threads,
+                      [=](const char* text, const std::vector<std::pair<size_t, size_t>>& sub, int th, uint8_t* dst, uint32_t* st, egwire::WorkerPool* pool) {
+                        egwire::pack_parallel(text, sub, stride, th, dst, st, [&](egwire::Cursor& c, uint8_t* d) { return egwire::pack_choice(c, n_options, single != 0, d); }, pool);
+                      },
+                      [=](const char* text, const std::vector<std::pair<size_t, size_t>>& odd, std::vector<uint32_t>& res) {
+                        return egwire::resolve_choice_objects(text, odd, n_options, single != 0, stride, make_check_items(e->ctx), make_verify_packed(e), res);
+                      }, out);
+}
+int eg_verify_qv_json_begin(eg_qv_params* p, int threads, eg_json_stream** out) { EG_LOCK_P(p);
+  if (!p) return fail(EG_ERR_BAD_ARG, "bad argument");
+  const int n_options = p->n_options;
+  const eghost::QvShape sh = p->shape;
+  const egwire::RangeShape vote{sh.vote_range.rings.size(), (size_t)sh.vote_range.rings_size()};
+  const egwire::RangeShape credit{sh.credit_range.rings.size(), (size_t)sh.credit_range.rings_size()};
+  Engine* e = p->eng;
+  return stream_begin(e, threads,
+                      [=](const char* text, const std::vector<std::pair<size_t, size_t>>& sub, int th, uint8_t* dst, uint32_t* st, egwire::WorkerPool* pool) {
+                        egwire::pack_parallel(text, sub, sh.ballot_size, th, dst, st, [&](egwire::Cursor& c, uint8_t* d) { return egwire::pack_qv(c, n_options, vote, credit, sh.ballot_size, d); }, pool);
+                      },
+                      [=](const char* text, const std::vector<std::pair<size_t, size_t>>& odd, std::vector<uint32_t>& res) {
+                        return egwire::resolve_qv_objects(text, odd, n_options, vote, credit, sh.ballot_size, make_check_items(e->ctx), make_verify_packed(e), res);
+                      }, out);
 }
 size_t eg_qv_ballot_size_for(int n_options, uint64_t credits) {
   if (n_options < 1 || n_options > 256 || credits < 1 || credits > 100000) return 0;

@@ -697,9 +697,12 @@ struct SplitCursor {
 // reached (then the tail has been checked as well).  A window that holds no complete value is grown; at most `max_values` values are
 // emitted per call (the caller's staging is finite, and a window of `{}` junk holds millions).  false = not a sequence of JSON objects.  Work inside a window: every chunk counts unescaped quotes (-> string state of the next chunks), then records its
 // bracket events outside strings; a short sequential walk over the events (about 1 % of the bytes) finds the values.
+// `partial` (the streaming entry points, StreamSplitter below): s[0, len) is a PIECE of a longer text.  Reaching its end inside a value,
+// or between values, is then not an error: the call returns with done = true and cur.pos at the end of the last complete value, and
+// s[cur.pos, len) - separators and / or the beginning of a value - is the caller's to carry over in front of the next piece.
 inline bool split_next(const char* s, size_t len, size_t window, int threads, SplitCursor& cur,
                        std::vector<std::pair<size_t, size_t>>& spans, bool& done, size_t max_values = (size_t)-1,
-                       WorkerPool* pool = nullptr) {
+                       WorkerPool* pool = nullptr, bool partial = false) {
   auto is_ws = [](char ch) { return ch == ' ' || ch == '\n' || ch == '\t' || ch == '\r'; };
   done = false;
   if (!cur.started) {
@@ -823,6 +826,7 @@ inline bool split_next(const char* s, size_t len, size_t window, int threads, Sp
       return true;
     }
     if (b == len) {                               // end of text without a closing bracket
+      if (partial) { cur.count += emitted; cur.pos = prev_end; done = true; return true; }     // the rest belongs to the next piece
       if (depth != 0 || cur.array) return false;  // truncated value, or an array that never closes
       if (!separators_ok(prev_end, len, false)) return false;
       cur.count += emitted; cur.pos = len; done = true;
@@ -842,6 +846,114 @@ inline bool split_objects_parallel(const char* s, size_t len, int threads, std::
   bool done = false;
   return split_next(s, len, len, threads, cur, spans, done) && done;
 }
+
+// ---- the text in PIECES (eg_verify_json_begin / _feed / _end; examples/voting.rs:195-198 prints ballots one at a time) ----------------
+// Pieces of any size; a value, a string, an escape sequence may straddle any number of piece boundaries.  Every piece is cut by the window
+// splitter above in its `partial` mode; what follows the last complete value of a piece (separators, the beginning of a value) is
+// carried over - only that, never the piece - and the lexical state at the end of the carry (bracket depth, inside a string, after a
+// backslash) is kept, so that the end of the straddling value is found in the next piece by a walk over that value alone.  The buffers
+// handed to the window splitter always begin right after a complete value (or at the start of the text), which is what its separator
+// rules (one comma between the values of an array, none in a sequence, none before the closing bracket) need in order to hold across
+// pieces exactly as they hold inside one text.  emit(base, spans, index of the first value): the values of one window; base is valid only
+// during the call.
+struct LexState { long depth = 0; bool in_str = false, esc = false; };
+inline void lex_advance(const char* s, size_t n, LexState& st) {
+  for (size_t i = 0; i < n; ++i) {
+    const char ch = s[i];
+    if (st.in_str) { if (st.esc) st.esc = false; else if (ch == '\\') st.esc = true; else if (ch == '"') st.in_str = false; continue; }
+    if (ch == '"') st.in_str = true;
+    else if (ch == '{' || ch == '[') ++st.depth;
+    else if (ch == '}' || ch == ']') --st.depth;
+  }
+}
+class StreamSplitter {
+ public:
+  typedef std::function<bool(const char*, const std::vector<std::pair<size_t, size_t>>&, size_t)> Emit;
+  StreamSplitter(int threads, WorkerPool* pool, Emit emit, size_t window = (size_t)96 << 20, size_t max_values = (size_t)-1,
+                 size_t max_carry = (size_t)256 << 20)
+      : threads_(threads < 1 ? 1 : threads), pool_(pool), emit_(std::move(emit)), window_(window ? window : 1), max_values_(max_values ? max_values : 1),
+        max_carry_(max_carry) {}
+  bool feed(const char* s, size_t n) {
+    if (failed_) return false;
+    if (cur_.closed) {
+      for (size_t i = 0; i < n; ++i) if (!is_ws(s[i])) return fail("text after the closing bracket of the array");
+      return true;
+    }
+    if (!cur_.started && carry_.empty()) {         // the opening bracket, if any, must be seen by the window splitter: skip leading white space
+      while (n && is_ws(*s)) { ++s; --n; }
+      if (!n) return true;
+    }
+    if (!carry_.empty()) {
+      // where does the value that straddles the boundary end (or, between values: where does the next value end, or the array close)?
+      size_t h = 0;
+      bool value_end = false, closer = false;
+      for (; h < n; ++h) {
+        const char ch = s[h];
+        if (st_.in_str) { if (st_.esc) st_.esc = false; else if (ch == '\\') st_.esc = true; else if (ch == '"') st_.in_str = false; continue; }
+        if (ch == '"') st_.in_str = true;
+        else if (ch == '{' || ch == '[') ++st_.depth;
+        else if (ch == '}' || ch == ']') {
+          if (st_.depth == 0) { closer = true; ++h; break; }        // the array's closing bracket: taken along, the window splitter checks it
+          if (--st_.depth == 0) { value_end = true; ++h; break; }
+        }
+      }
+      if (carry_.size() + h > max_carry_) return fail("a value larger than the carry-over limit");
+      carry_.append(s, h);
+      if (!value_end && !closer) return true;        // the whole piece is inside the value: wait for more
+      std::string x;
+      x.swap(carry_);
+      st_ = LexState();
+      if (!run(x.data(), x.size())) return false;     // ends at a value's end or at the closing bracket: nothing is left over
+      s += h; n -= h;
+      if (cur_.closed) return feed(s, n);
+    }
+    return run(s, n);
+  }
+  // end of the text: nothing may be left but white space, and an array must have been closed
+  bool finish() {
+    if (failed_) return false;
+    if (cur_.array && !cur_.closed) return fail("the array never closes");
+    for (char ch : carry_) if (!is_ws(ch)) return fail(st_.depth || st_.in_str ? "the text ends inside a value" : "a separator at the end of the text");
+    carry_.clear();
+    return true;
+  }
+  size_t count() const { return cur_.count; }
+  bool failed() const { return failed_; }
+  const std::string& error() const { return err_; }
+  size_t carried() const { return carry_.size(); }
+
+ private:
+  static bool is_ws(char ch) { return ch == ' ' || ch == '\n' || ch == '\t' || ch == '\r'; }
+  bool fail(const char* why) { failed_ = true; if (err_.empty()) err_ = why; return false; }
+  bool run(const char* s, size_t n) {
+    cur_.pos = 0;
+    for (;;) {
+      spans_.clear();
+      bool done = false;
+      const size_t first = cur_.count;
+      if (!split_next(s, n, window_, threads_, cur_, spans_, done, max_values_, pool_, true))
+        return fail("the text is neither a JSON array of objects nor a sequence of JSON objects");
+      if (!spans_.empty() && !emit_(s, spans_, first)) return fail("");
+      if (done) break;
+    }
+    if (cur_.pos < n) {
+      if (carry_.size() + (n - cur_.pos) > max_carry_) return fail("a value larger than the carry-over limit");
+      carry_.append(s + cur_.pos, n - cur_.pos);
+      lex_advance(s + cur_.pos, n - cur_.pos, st_);
+    }
+    return true;
+  }
+  int threads_;
+  WorkerPool* pool_;
+  Emit emit_;
+  size_t window_, max_values_, max_carry_;
+  SplitCursor cur_;
+  std::string carry_;
+  LexState st_;
+  std::vector<std::pair<size_t, size_t>> spans_;
+  bool failed_ = false;
+  std::string err_;
+};
 
 template <class PackOne>
 inline void pack_parallel(const char* json, const std::vector<std::pair<size_t, size_t>>& spans, size_t stride, int threads,

@@ -354,6 +354,33 @@ int eg_choice_pack_json(int n_options, int single, const char* json, size_t json
 int eg_qv_pack_json(int n_options, uint64_t credits, const char* json, size_t json_len, int threads, size_t max_objects,
                     uint8_t* packed, uint32_t* status, size_t* n_objects);
 size_t eg_qv_ballot_size_for(int n_options, uint64_t credits);   /* eg_qv_ballot_size without a params object (host only) */
+
+/* ---- the JSON text in PIECES (examples/voting.rs:195-198 prints ballots one at a time; src/serde.rs:19-80 is the layout) ----------------
+ * eg_verify_{choice,qv}_json_begin opens a stream on a params object; eg_verify_json_feed takes the next piece of the text - ANY size, a
+ * ballot (a string, an escape sequence) may straddle any number of pieces; the text as a whole is what eg_verify_*_json accepts: one JSON
+ * array of objects, or objects back to back / one per line; eg_verify_json_end closes it.  Verdicts and tally are exactly those of the
+ * one-shot entry on the concatenated text.
+ *   feed   cuts the piece, packs its complete ballots on the stream's `threads` host threads into a pinned ring, and enqueues GPU work
+ *          without waiting for it (the first submission once 2^17 ballots are packed, at most two in flight; feed blocks only while the
+ *          ring is full).  Nothing of `text` is referenced after it returns.  *n_objects (may be NULL): complete objects seen so far.
+ *   take   (optional, never blocks) hands out, in order, the verdicts that are final so far: those of every ballot before the first one
+ *          that is still on the GPU or whose shape is not the election's (such a ballot gets its OptionsLenMismatch / LenMismatch
+ *          verdict from the object path, which runs at the end).
+ *   end    waits for the GPU, resolves the ballots of another shape, writes the verdicts not yet taken (status: room for `cap`; if more
+ *          are left the call fails with EG_ERR_BAD_ARG and the stream stays open: call again with room, or abort), *n_objects = objects
+ *          in the whole text, tally_out (may be NULL) = the tally of the STREAM's ballots; the params object's running tally has them
+ *          added.  Destroys the stream - also when it reports an error of the text (not a sequence of objects, truncated) or of the GPU.
+ *   abort  destroys the stream; the running tally is what it was before begin.  A failed feed leaves the stream dead: end returns the
+ *          same error and cleans up, with the running tally as it was.
+ * Between begin and end / abort the params object belongs to the stream: every other verify / tally call on it fails with EG_ERR_BAD_ARG.
+ * One stream per params object; several params objects (contexts, GPUs) may stream at the same time from different threads. */
+typedef struct eg_json_stream eg_json_stream;
+int eg_verify_choice_json_begin(eg_choice_params*, int threads, eg_json_stream** out);
+int eg_verify_qv_json_begin(eg_qv_params*, int threads, eg_json_stream** out);
+int eg_verify_json_feed(eg_json_stream*, const char* text, size_t len, size_t* n_objects);
+int eg_verify_json_take(eg_json_stream*, uint32_t* status, size_t cap, size_t* n_taken);
+int eg_verify_json_end(eg_json_stream*, uint32_t* status, size_t cap, size_t* n_taken, size_t* n_objects, uint8_t* tally_out);
+void eg_verify_json_abort(eg_json_stream*);
 /* JSON text -> verdicts and tally in one call (what a service that receives the output of examples/voting.rs:195-198 needs).  A pool of
  * `threads` host threads cuts the text into windows and packs them into a pinned ring (<= 1 GiB) while the calling thread uploads the
  * finished windows and enqueues their verification, two submissions in flight; memory: the ring, as much device staging, the chunk

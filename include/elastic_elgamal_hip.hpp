@@ -309,6 +309,45 @@ inline PackedJson pack_qv_json(size_t options, uint64_t credits, const std::stri
   return r;
 }
 
+// The JSON text of a batch of ballots in PIECES (eg_verify_*_json_begin / eg_verify_json_feed / _take / _end): what a host does with
+// ballots that arrive one at a time or in network-sized chunks (examples/voting.rs:195-198).  Pieces of any size, a ballot may straddle
+// them.  RAII: a stream that is not finished is aborted (the params object's running tally is then what it was before).
+class JsonStream {
+ public:
+  JsonStream(const ChoiceParams& p, int threads = 1) : options_(p.options_count()) { check(eg_verify_choice_json_begin(p.raw(), threads, &s_)); }
+  JsonStream(const QuadraticVotingParams& p, int threads = 1) : options_(p.options_count()) { check(eg_verify_qv_json_begin(p.raw(), threads, &s_)); }
+  JsonStream(const JsonStream&) = delete;
+  JsonStream& operator=(const JsonStream&) = delete;
+  ~JsonStream() { if (s_) eg_verify_json_abort(s_); }
+  // the next piece; returns the number of complete objects seen so far
+  size_t feed(const char* text, size_t len) { size_t n = 0; check(eg_verify_json_feed(s_, text, len, &n)); objects_ = n; return n; }
+  size_t feed(const std::string& piece) { return feed(piece.data(), piece.size()); }
+  // status words that are final so far, in order (never blocks)
+  std::vector<uint32_t> take(size_t cap = 1 << 20) {
+    std::vector<uint32_t> st(cap);
+    size_t n = 0;
+    check(eg_verify_json_take(s_, st.data(), cap, &n));
+    st.resize(n);
+    return st;
+  }
+  // flushes: the status words not yet taken; totals = the tally of the stream's ballots (the running tally of the params has them added)
+  std::vector<uint32_t> finish(std::vector<Ciphertext>* totals = nullptr) {
+    std::vector<uint32_t> st(objects_ + 1);
+    Bytes tally(64 * options_);
+    size_t n = 0, total = 0;
+    eg_json_stream* s = s_;
+    s_ = nullptr;                  // eg_verify_json_end destroys the stream on success and on every error but "no room"
+    const int rc = eg_verify_json_end(s, st.data(), st.size(), &n, &total, tally.data());
+    if (rc != EG_OK) throw Error(rc, eg_last_error());
+    st.resize(n);
+    if (totals) *totals = unpack_totals(tally);
+    return st;
+  }
+ private:
+  eg_json_stream* s_ = nullptr;
+  size_t options_, objects_ = 0;
+};
+
 // Ristretto: the Group backend (ristretto.rs), one problem per call shown here; *_batch in eg_hip.h for many.
 // The reference's typed Elements cannot be invalid; here elements are byte strings, so the operations that take
 // elements throw Error(EG_ERR_BAD_ARG) when an operand is not a valid ristretto255 encoding instead of silently

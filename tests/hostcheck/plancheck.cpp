@@ -61,6 +61,39 @@ int pc_plan_mutated(int n, int single, int ring_group, int mutation, char* why_o
   if (why_out && cap > 0) { strncpy(why_out, why.c_str(), cap - 1); why_out[cap - 1] = 0; }
   return why.empty() ? 0 : 1;
 }
+// The streaming splitter (egwire::StreamSplitter: eg_verify_json_begin / _feed / _end) against the one-shot splitter: the text is fed in
+// pieces cut at the given offsets; the values it emits, in order, must be byte for byte the values split_objects finds in the whole text,
+// and it must refuse a text (at any piece, or at finish) exactly when split_objects refuses it.  Returns the number of values, -1 if both
+// refuse, -7 on any disagreement.  window / max_values small: many windows per piece.
+int pc_stream_split(const char* json, size_t len, const size_t* cuts, size_t n_cuts, int threads, size_t window, size_t max_values) {
+  std::vector<std::pair<size_t, size_t>> want;
+  const bool want_ok = egwire::split_objects(json, len, want);
+  std::vector<std::string> got;
+  bool index_ok = true;
+  egwire::WorkerPool pool(threads);
+  egwire::StreamSplitter sp(threads, &pool, [&](const char* base, const std::vector<std::pair<size_t, size_t>>& spans, size_t first) {
+    if (first != got.size()) index_ok = false;
+    for (auto& sp : spans) got.emplace_back(base + sp.first, sp.second);
+    return true;
+  }, window, max_values);
+  bool ok = true;
+  size_t at = 0;
+  for (size_t k = 0; k <= n_cuts && ok; ++k) {
+    const size_t to = k < n_cuts ? cuts[k] : len;
+    if (to < at || to > len) return -9;
+    // every piece in a buffer of its own, of its exact size: a read past a piece's end is the sanitizer's to catch
+    std::vector<char> piece(json + at, json + to);
+    ok = sp.feed(piece.data(), piece.size());
+    at = to;
+  }
+  if (ok) ok = sp.finish();
+  if (ok != want_ok) return -7;
+  if (!ok) return -1;
+  if (!index_ok || got.size() != want.size() || sp.count() != want.size()) return -7;
+  for (size_t i = 0; i < want.size(); ++i)
+    if (got[i].size() != want[i].second || memcmp(got[i].data(), json + want[i].first, want[i].second)) return -7;
+  return (int)want.size();
+}
 int pc_range(unsigned long long ub, char* buf, int cap) {
   const std::string s = optimal_range(ub).to_string();
   if ((int)s.size() + 1 > cap) return -1;

@@ -127,6 +127,56 @@ def test_wire_packer_survives_fuzzed_json(lib):
     assert "fuzzed 3000" in out
 
 
+def test_streaming_splitter_agrees_with_the_one_shot_splitter(lib):
+    """eg_verify_json_begin / _feed / _end below the C ABI (csrc/wire_json.hpp: StreamSplitter), under ASan + UBSan: texts (arrays, sequences,
+    one object per line; escaped quotes, brackets and backslashes inside strings, nested junk; truncated, unbalanced and garbage
+    variants) fed in pieces cut at random offsets, at EVERY offset of a short text, one byte at a time and as one piece: the values
+    emitted are byte for byte those of split_objects on the whole text, and a text is refused exactly when split_objects refuses it."""
+    out = _run(lib, r"""
+        L.pc_stream_split.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_size_t, C.c_int, C.c_size_t, C.c_size_t]
+        rnd = random.Random(5)
+        def obj(i):
+            tricky = ['a"b', 'x\\\\', 'br{ack}[et]s', '\\\\"', 'u\\u0041', '', ']}', '\\\\\\"{']
+            return json.dumps({"k": i, "s": tricky[i % len(tricky)], "n": {"a": [1, {"b": "}"}], "c": "["}, "pad": "x" * rnd.randrange(0, 40)})
+        objs = [obj(i) for i in range(40)]
+        texts = ["[" + ", ".join(objs) + "]", " [\n" + ",\n".join(objs) + "\n]  \n", "\n".join(objs), "".join(objs), " ".join(objs) + "\n",
+                 "[]", "", "  ", "[ ]", "[" + objs[0] + "]", objs[0]]
+        bad = ["[" + ", ".join(objs[:5]) + ",]", "[" + ", ".join(objs[:5]), ", ".join(objs[:5]), "[" + " ".join(objs[:5]) + "]", objs[0][:-1],
+               "[" + objs[0] + "] x", "[" + objs[0] + "]]", "x" + objs[0], "[[" + objs[0] + "]]", objs[0] + "}", "[" + objs[0] + ",," + objs[1] + "]",
+               objs[0] + "\\" + objs[1], '{"a": "unterminated', "[1, 2]", "]"]
+        total = refused = 0
+        def run(t, cuts, threads=3, window=64, maxv=5):
+            b = t.encode()
+            arr = (C.c_size_t * max(len(cuts), 1))(*cuts)
+            return L.pc_stream_split(b, len(b), arr, len(cuts), threads, window, maxv)
+        for t in texts + bad:
+            n = len(t.encode())
+            want = run(t, [])
+            assert want != -7 and want != -9, t[:60]
+            assert (want >= 0) == (t in texts), (t[:60], want)
+            plans = [[], list(range(1, n)), sorted(rnd.sample(range(n + 1), min(n + 1, 7)))] + [sorted(rnd.randrange(n + 1) for _ in range(rnd.randrange(1, 30))) for _ in range(25)]
+            if n <= 400:
+                plans += [[k] for k in range(n + 1)] + [[k, k] for k in range(0, n + 1, 3)]
+            for cuts in plans:
+                for threads, window, maxv in ((3, 64, 5), (1, 1 << 20, 1 << 20), (4, 7, 1)):
+                    got = run(t, cuts, threads, window, maxv)
+                    assert got == want, (t[:60], cuts[:10], threads, window, maxv, got, want)
+                    total += 1; refused += got < 0
+        # ballots of the reference's own shape, many pieces
+        snaps = json.loads(open(@@SNAP@@).read())
+        c = json.dumps(snaps["encrypted-choice"]); q = json.dumps(snaps["qv-ballot"])
+        big = "[" + ",".join([c, q] * 300) + "]"
+        n = len(big)
+        for k in range(12):
+            cuts = sorted(rnd.randrange(n + 1) for _ in range(rnd.choice((1, 10, 200, 3000))))
+            assert run(big, cuts, 4, 5000, 50) == 600
+            total += 1
+        print("stream split cases", total, "refused", refused)
+    """.replace("@@SNAP@@", repr(str(ROOT / "tests" / "golden" / "snapshots_serde.json"))))
+    assert "stream split cases" in out and "refused 0" not in out
+    assert int(out.split("stream split cases")[1].split()[0]) > 5000, out
+
+
 def test_worker_pool_under_thread_sanitizer(tmp_path):
     """The parser's worker pool (egwire::WorkerPool: split passes and packing of every window of eg_verify_*_json) in a
     -fsanitize=thread build: 3000 objects cut and packed on 8 threads, windows of 5 kB, five times over; any data race fails the run."""
