@@ -71,6 +71,7 @@ struct Knobs {
   size_t msm_bucket_min = (size_t)1 << 20;  // EG_MSM_BUCKET_MIN
   size_t json_ring_kb = 0, json_window_kb = 0;   // EG_JSON_RING_KB, EG_JSON_WINDOW_KB   0 = 1 GiB ring, 96 MiB windows
   size_t json_growth = 150;         // EG_JSON_GROWTH      per cent
+  size_t json_first_min = 0;        // EG_JSON_FIRST_MIN   0 = the stream's default (stream_begin)
   bool json_trace = false;          // EG_JSON_TRACE
   bool allow_any_arch = false;      // EG_ALLOW_ANY_ARCH
 };
@@ -89,6 +90,7 @@ static Knobs read_knobs() {
   k.json_ring_kb = (size_t)std::max<long long>(0, num("EG_JSON_RING_KB", 0));
   k.json_window_kb = (size_t)std::max<long long>(0, num("EG_JSON_WINDOW_KB", 0));
   k.json_growth = (size_t)std::max<long long>(0, num("EG_JSON_GROWTH", 150));
+  k.json_first_min = (size_t)std::max<long long>(0, num("EG_JSON_FIRST_MIN", 0));
   k.json_trace = getenv("EG_JSON_TRACE") != nullptr;
   k.allow_any_arch = getenv("EG_ALLOW_ANY_ARCH") != nullptr;
   return k;
@@ -2284,7 +2286,7 @@ static int stream_begin(Engine* e, int threads, PackPieceFn pack_piece, ReshapeF
   HIPCHK(hipDeviceSynchronize());
   const size_t ring_bytes = std::max(e->knobs.json_ring_kb ? e->knobs.json_ring_kb << 10 : (size_t)1 << 30, 64 * S->stride);
   S->cap = ring_bytes / S->stride;
-  S->first_min = std::min<size_t>((size_t)1 << 17, S->cap / 4);
+  S->first_min = std::min<size_t>(e->knobs.json_first_min ? e->knobs.json_first_min : (size_t)1 << 17, S->cap / 4);
   if (S->cap * S->stride > e->json_ring_bytes || S->cap > e->json_ring_ballots) {
     if (e->json_ring) (void)hipHostFree(e->json_ring);
     if (e->json_status_ring) (void)hipHostFree(e->json_status_ring);

@@ -59,7 +59,7 @@ def test_no_test_hooks_and_one_documented_list_of_knobs(lib_path):
     header = (ROOT / "include" / "eg_hip.h").read_text()
     table = header[header.index("RUN-TIME KNOBS"):header.index("#ifndef EG_HIP_H")]
     listed = set(re.findall(r"^ \*   (EG_[A-Z_]+) ", table, re.M))
-    assert read == listed and len(read) == 14, (read ^ listed)
+    assert read == listed and len(read) == 15, (read ^ listed)
     py_env = set(re.findall(r'environ(?:\.get)?[\[(]"(EG_[A-Z_]+)"', "".join(f.read_text() for f in pkg.glob("*.py"))))
     py_env |= set(re.findall(r'"(EG_[A-Z_]+)" in os\.environ', "".join(f.read_text() for f in pkg.glob("*.py"))))
     assert py_env == {"EG_LIB", "EG_NO_TORCH_PRELOAD"} and all(k in table for k in py_env), py_env
