@@ -541,14 +541,19 @@ class JsonStream:
 
     def end(self, with_tally: bool = True, cap: int | None = None):
         """Flushes the stream: (verdicts not yet taken, tally of the stream's ballots or None).  The stream is gone afterwards."""
-        cap = self.objects + 1 if cap is None else cap
-        st = (C.c_uint32 * max(cap, 1))()
-        n, total = C.c_size_t(0), C.c_size_t(0)
+        import re
+
+        cap = self.objects + 1024 if cap is None else cap
         tally = C.create_string_buffer(64 * self.params.n_options) if with_tally else None
         h, self._h = self._h, C.c_void_p()
-        rc = _load().eg_verify_json_end(h, st, cap, C.byref(n), C.byref(total), tally)
-        if rc and b"are left" in _load().eg_last_error():
-            self._h = h                    # the stream is still open: room for the verdicts was missing
+        while True:
+            st = (C.c_uint32 * max(cap, 1))()
+            n, total = C.c_size_t(0), C.c_size_t(0)
+            rc = _load().eg_verify_json_end(h, st, cap, C.byref(n), C.byref(total), tally)
+            m = re.search(rb"(\d+) are left", _load().eg_last_error()) if rc else None
+            if not m:
+                break
+            cap = int(m.group(1))              # the stream is still open (and flushed): the count it cut was ahead of what feed() had reported
         _check(rc)
         self.objects = total.value
         return list(st[: n.value]), (tally.raw if with_tally else None)

@@ -831,10 +831,11 @@ template <class Params>
 static void params_destroy(Params* p) {
   if (!p) return;
   eg_ctx* c = p->eng->ctx;
+  if (p->eng->stream_open) eg_verify_json_abort(p->eng->stream_open);      // a stream left open dies with its params object (its worker thread
+                                                                             // takes the context's lock: joined before we take it)
   {
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     (void)hipSetDevice(c->device);
-    if (p->eng->stream_open) eg_verify_json_abort(p->eng->stream_open);      // a stream left open dies with its params object
     engine_free(p->eng);
     delete p;
   }
@@ -2153,12 +2154,28 @@ struct eg_json_stream {
   std::vector<size_t> odd_at;
   size_t landed = 0, taken = 0, n_submitted = 0;
   bool set_aside = false, flushed = false, trace = false;
-  int failed = EG_OK;
+  std::atomic<int> failed{EG_OK};      // set once (stream_fail), after err has been written
   std::string err;
+  // Front end: the caller's pieces reach the worker thread through a short queue.  Pieces below `direct_min` are copied into blocks of
+  // `block_bytes` (the caller's thread pays one memcpy and returns; cutting, packing and GPU submission happen on the worker thread, in
+  // parallel with the caller producing the next piece); larger pieces are handed over in place and feed waits until the worker is through
+  // with them.  Everything above (regions, groups, verdicts, splitter) is touched by the worker thread only, under the context's lock,
+  // until the worker has been joined (end / abort) - take() takes that lock too.
+  struct Item { std::vector<char> own; const char* ptr = nullptr; size_t len = 0; uint64_t id = 0; bool finish = false; };
+  std::thread worker;
+  std::mutex qmu;
+  std::condition_variable q_push, q_pop;
+  std::deque<Item> queue;
+  std::vector<std::vector<char>> spare;    // emptied blocks
+  std::vector<char> acc;                   // the block being filled by feed
+  uint64_t next_id = 1, consumed_id = 0;
+  bool stop = false, worker_joined = false;
+  std::atomic<size_t> objects{0};          // complete objects cut so far (by the worker)
+  size_t block_bytes = (size_t)16 << 20, direct_min = (size_t)8 << 20;
 };
 static int stream_fail(eg_json_stream* S, int code, const std::string& msg) {
-  if (!S->failed) { S->failed = code; S->err = msg; }
-  return fail(S->failed, S->err);
+  if (!S->failed.load(std::memory_order_acquire)) { S->err = msg; S->failed.store(code, std::memory_order_release); }
+  return fail(S->failed.load(), S->err);
 }
 static void stream_retire_oldest(eg_json_stream* S) {     // the oldest submission has landed: its verdicts, its part of the ring
   Engine* e = S->e;
@@ -2273,6 +2290,7 @@ static void stream_release(eg_json_stream* S, bool keep_partial_tally) {      //
   e->stream_open = nullptr;
   delete S;
 }
+static void stream_worker(eg_json_stream* S);
 static int stream_begin(Engine* e, int threads, PackPieceFn pack_piece, ReshapeFn reshape, eg_json_stream** out) {
   if (!out) return fail(EG_ERR_BAD_ARG, "bad argument");
   *out = nullptr;
@@ -2323,21 +2341,97 @@ static int stream_begin(Engine* e, int threads, PackPieceFn pack_piece, ReshapeF
                                             },
                                             window, std::max<size_t>(1, S->cap / 8)));
   e->stream_open = raw;
+  S->worker = std::thread(stream_worker, raw);
   *out = S.release();
   return EG_OK;
 }
-int eg_verify_json_feed(eg_json_stream* S, const char* text, size_t len, size_t* n_objects) {
-  if (!S) return fail(EG_ERR_BAD_ARG, "bad argument");
-  EG_LOCK(S->e->ctx);
-  if (len && !text) return fail(EG_ERR_BAD_ARG, "bad argument");
-  if (S->failed) return fail(S->failed, S->err);
-  if (S->flushed) return fail(EG_ERR_BAD_ARG, "the stream has been ended");
-  if (!S->split->feed(text, len)) {
-    if (!S->failed) stream_fail(S, EG_ERR_BAD_ARG, S->split->error().empty() ? std::string("the piece could not be packed") : S->split->error());
-    return fail(S->failed, S->err);
+// the worker thread of a stream: pieces in order through the splitter (-> stream_emit -> ring, GPU), each under the context's lock
+static void stream_worker(eg_json_stream* S) {
+  eg_ctx* ctx = S->e->ctx;
+  for (;;) {
+    eg_json_stream::Item it;
+    {
+      std::unique_lock<std::mutex> lk(S->qmu);
+      S->q_push.wait(lk, [&]() { return S->stop || !S->queue.empty(); });
+      if (S->stop) return;
+      it = std::move(S->queue.front());
+      S->queue.pop_front();
+    }
+    if (!it.finish && !S->failed.load(std::memory_order_acquire)) {
+      std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+      (void)hipSetDevice(ctx->device);
+      const char* text = it.ptr ? it.ptr : it.own.data();
+      if (!S->split->feed(text, it.len)) {
+        if (!S->failed.load()) stream_fail(S, EG_ERR_BAD_ARG, S->split->error().empty() ? std::string("the piece could not be packed") : S->split->error());
+      } else (void)stream_pump(S, false);
+      S->objects.store(S->split->count(), std::memory_order_release);
+    }
+    {
+      std::lock_guard<std::mutex> lk(S->qmu);
+      S->consumed_id = it.id;
+      if (!it.own.empty() || it.own.capacity()) { it.own.clear(); S->spare.push_back(std::move(it.own)); }
+    }
+    S->q_pop.notify_all();
+    if (it.finish) return;
   }
-  TRY(stream_pump(S, false));
-  if (n_objects) *n_objects = S->split->count();
+}
+// hands an item to the worker (at most four blocks wait in the queue); wait = until the worker is through with it
+static void stream_enqueue(eg_json_stream* S, std::unique_lock<std::mutex>& lk, eg_json_stream::Item&& it, bool wait) {
+  S->q_pop.wait(lk, [&]() { return S->queue.size() < 4; });
+  const uint64_t id = it.id = S->next_id++;
+  S->queue.push_back(std::move(it));
+  S->q_push.notify_one();
+  if (wait) S->q_pop.wait(lk, [&]() { return S->consumed_id >= id; });
+}
+static void stream_flush_acc(eg_json_stream* S, std::unique_lock<std::mutex>& lk) {
+  if (S->acc.empty()) return;
+  eg_json_stream::Item it;
+  it.len = S->acc.size();
+  it.own = std::move(S->acc);
+  S->acc = std::vector<char>();
+  if (!S->spare.empty()) { S->acc = std::move(S->spare.back()); S->spare.pop_back(); }
+  stream_enqueue(S, lk, std::move(it), false);
+}
+static void stream_join_worker(eg_json_stream* S, bool finish) {      // never called with the context's lock held: the worker takes it per piece
+  if (S->worker_joined) return;
+  {
+    std::unique_lock<std::mutex> lk(S->qmu);
+    if (finish) {
+      stream_flush_acc(S, lk);
+      eg_json_stream::Item fin;
+      fin.finish = true;
+      stream_enqueue(S, lk, std::move(fin), false);
+    } else {
+      S->stop = true;
+      S->q_push.notify_all();
+    }
+  }
+  if (S->worker.joinable()) S->worker.join();
+  S->worker_joined = true;
+}
+int eg_verify_json_feed(eg_json_stream* S, const char* text, size_t len, size_t* n_objects) {
+  if (!S || (len && !text)) return fail(EG_ERR_BAD_ARG, "bad argument");
+  {
+    std::unique_lock<std::mutex> lk(S->qmu);
+    if (S->failed.load(std::memory_order_acquire)) return fail(S->failed.load(), S->err);
+    if (S->flushed || S->worker_joined) return fail(EG_ERR_BAD_ARG, "the stream has been ended");
+    if (len >= S->direct_min) {                    // a large piece: in place, and feed returns when the worker is through with it
+      stream_flush_acc(S, lk);
+      eg_json_stream::Item it;
+      it.ptr = text; it.len = len;
+      stream_enqueue(S, lk, std::move(it), true);
+    } else {
+      while (len) {                                // small pieces: copied into the block that is being filled
+        if (S->acc.capacity() < S->block_bytes) S->acc.reserve(S->block_bytes);
+        const size_t take = std::min(len, S->block_bytes - S->acc.size());
+        S->acc.insert(S->acc.end(), text, text + take);
+        text += take; len -= take;
+        if (S->acc.size() >= S->block_bytes) stream_flush_acc(S, lk);
+      }
+    }
+    if (S->failed.load(std::memory_order_acquire)) return fail(S->failed.load(), S->err);
+  }
+  if (n_objects) *n_objects = S->objects.load(std::memory_order_acquire);
   return EG_OK;
 }
 // verdicts that are final so far, in order, from where the last take stopped: every ballot before the first one that is still on the GPU
@@ -2349,10 +2443,14 @@ static size_t stream_final_upto(const eg_json_stream* S) {
 }
 int eg_verify_json_take(eg_json_stream* S, uint32_t* status, size_t cap, size_t* n_taken) {
   if (!S || !n_taken || (cap && !status)) return fail(EG_ERR_BAD_ARG, "bad argument");
-  EG_LOCK(S->e->ctx);
   *n_taken = 0;
-  if (S->failed) return fail(S->failed, S->err);
-  if (!S->flushed) TRY(stream_pump(S, false));
+  if (S->failed.load(std::memory_order_acquire)) return fail(S->failed.load(), S->err);
+  {   // pieces copied so far go to the worker now: a slow source gets its verdicts without waiting for a block to fill up
+    std::unique_lock<std::mutex> lk(S->qmu);
+    if (!S->flushed && !S->worker_joined) stream_flush_acc(S, lk);
+  }
+  EG_LOCK(S->e->ctx);                               // the worker holds it while it cuts and packs a piece
+  if (!S->flushed) TRY(stream_pump(S, S->groups.empty()));     // an idle GPU takes what has been packed, however little
   const size_t upto = stream_final_upto(S);
   const size_t n = std::min(cap, upto > S->taken ? upto - S->taken : 0);
   if (n) memcpy(status, S->verdicts.data() + S->taken, n * sizeof(uint32_t));
@@ -2363,19 +2461,20 @@ int eg_verify_json_take(eg_json_stream* S, uint32_t* status, size_t cap, size_t*
 int eg_verify_json_end(eg_json_stream* S, uint32_t* status, size_t cap, size_t* n_taken, size_t* n_objects, uint8_t* tally_out) {
   if (!S || (cap && !status)) return fail(EG_ERR_BAD_ARG, "bad argument");
   eg_ctx* ctx = S->e->ctx;
+  stream_join_worker(S, true);                      // every piece cut and packed; from here on this thread owns the stream
   EG_LOCK(ctx);
   if (n_taken) *n_taken = 0;
   Engine* e = S->e;
-  if (!S->flushed && !S->failed) {
+  if (!S->flushed && !S->failed.load()) {
     if (!S->split->finish()) stream_fail(S, EG_ERR_BAD_ARG, S->split->error());
-    while (!S->failed && (!S->regions.empty() || !S->groups.empty())) {
+    while (!S->failed.load() && (!S->regions.empty() || !S->groups.empty())) {
       if (stream_pump(S, true)) break;
       if (S->groups.empty()) continue;
       const hipError_t he = hipEventSynchronize(S->groups.front().done);
       if (he != hipSuccess) { stream_fail(S, EG_ERR_HIP, std::string("window: ") + hipGetErrorString(he)); break; }
       stream_retire_oldest(S);
     }
-    if (!S->failed) {
+    if (!S->failed.load()) {
       (void)hipDeviceSynchronize();
       hipStream_t s = ctx->stream;
       if (S->ns && e->n_sets == 2) {                           // the sets' shares of the tally, once
@@ -2384,7 +2483,7 @@ int eg_verify_json_end(eg_json_stream* S, uint32_t* status, size_t cap, size_t* 
         if (hipStreamSynchronize(s) != hipSuccess) stream_fail(S, EG_ERR_HIP, "tally merge failed");
       }
     }
-    if (!S->failed && !S->odd_at.empty()) {   // OptionsLenMismatch / LenMismatch territory: the object path, in the reference's order of checks
+    if (!S->failed.load() && !S->odd_at.empty()) {   // OptionsLenMismatch / LenMismatch territory: the object path, in the reference's order of checks
       std::string all;
       std::vector<std::pair<size_t, size_t>> spans;
       for (auto& t : S->odd_text) { spans.push_back({all.size(), t.size()}); all += t; all += '\n'; }
@@ -2397,8 +2496,8 @@ int eg_verify_json_end(eg_json_stream* S, uint32_t* status, size_t cap, size_t* 
     }
     S->flushed = true;
   }
-  if (S->failed) {
-    const int rc = S->failed;
+  if (S->failed.load()) {
+    const int rc = S->failed.load();
     const std::string why = S->err;
     stream_release(S, false);
     return fail(rc, why);
@@ -2417,6 +2516,7 @@ int eg_verify_json_end(eg_json_stream* S, uint32_t* status, size_t cap, size_t* 
 void eg_verify_json_abort(eg_json_stream* S) {
   if (!S) return;
   eg_ctx* ctx = S->e->ctx;
+  stream_join_worker(S, false);
   EG_LOCK(ctx);
   stream_release(S, false);
 }

@@ -1326,15 +1326,16 @@ def test_json_stream_equals_the_one_shot_entry(eg, ctx, oracle, pk, kind, monkey
                 else:
                     sizes = plan
                 for k, size in enumerate(sizes):
-                    seen = st.feed(data[at : at + size])
+                    seen = st.feed(data[at : at + size])             # objects the stream's worker has cut so far (it may lag behind the feeds)
                     at += size
+                    assert seen <= len(batch)
                     if k % 5 == 0:
-                        part = st.take(1000)
-                        got += part
-                        assert len(got) <= seen
-                assert at == len(data) and seen == len(batch)
+                        got += st.take(1000)
+                        assert len(got) <= len(batch)
+                assert at == len(data)
                 rest, tally = st.end()
                 got += rest
+                assert st.objects == len(batch)
                 assert got == want, (plan if plan != "bytes" else "bytes", ring_kb, [(i, a, b) for i, (a, b) in enumerate(zip(got, want)) if a != b][:5])
                 assert tally == want_tally == p.tally_encode()                    # the running tally has the stream's ballots
                 # a second stream on the same object: aborted half way, the running tally stays; then one that fails in the text
@@ -1400,10 +1401,9 @@ def test_json_stream_one_million_ballots_in_one_megabyte_pieces(eg, ctx, pk):
     base = C.cast(C.c_char_p(text), C.c_void_p).value
     for at in range(0, len(text), 1 << 20):
         st.feed_ptr(base + at, min(1 << 20, len(text) - at))
-    assert st.objects == m
     got = (C.c_uint32 * m)()
     taken, tally = st.end_into(got, with_tally=True)
-    assert taken == m
+    assert taken == m and st.objects == m
     g, w = np.frombuffer(got, dtype=np.uint32), np.frombuffer(want, dtype=np.uint32)
     assert np.array_equal(g, w) and int((g == 0).sum()) == m - m // 1000
     assert tally == want_tally == p.tally_encode()
