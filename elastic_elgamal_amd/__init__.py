@@ -568,9 +568,9 @@ class JsonStream:
         return n.value, (tally.raw if with_tally else None)
 
     def abort(self):
-        if self._h:
-            _load().eg_verify_json_abort(self._h)
-            self._h = C.c_void_p()
+        if getattr(self, "_h", None):
+            h, self._h = self._h, C.c_void_p()
+            _load().eg_verify_json_abort(h)
 
     def __del__(self):
         try:
@@ -583,7 +583,18 @@ class _BatchParams:
     _prefix = ""
 
     def json_stream(self, threads: int = 0) -> JsonStream:
-        return JsonStream(self, threads)
+        import weakref
+
+        st = JsonStream(self, threads)
+        if not hasattr(self, "_streams"):
+            self._streams = weakref.WeakSet()
+        self._streams.add(st)
+        return st
+
+    def _forget_streams(self):
+        """The library aborts a stream that is still open when its params object is destroyed: the Python handles must not outlive it."""
+        for st in list(getattr(self, "_streams", ())):
+            st._h = C.c_void_p()
 
     def _fn(self, name):
         return getattr(_load(), f"eg_{self._prefix}_{name}")
@@ -713,6 +724,7 @@ class ChoiceParams(_BatchParams):
     def close(self):
         if getattr(self, "_h", None):
             _load().eg_choice_params_destroy(self._h)
+            self._forget_streams()
             self._h = None
 
     def __del__(self):
@@ -808,6 +820,7 @@ class QuadraticVotingParams(_BatchParams):
     def close(self):
         if getattr(self, "_h", None):
             _load().eg_qv_params_destroy(self._h)
+            self._forget_streams()
             self._h = None
 
     def __del__(self):

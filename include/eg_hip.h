@@ -361,10 +361,15 @@ size_t eg_qv_ballot_size_for(int n_options, uint64_t credits);   /* eg_qv_ballot
  * ballot (a string, an escape sequence) may straddle any number of pieces; the text as a whole is what eg_verify_*_json accepts: one JSON
  * array of objects, or objects back to back / one per line; eg_verify_json_end closes it.  Verdicts and tally are exactly those of the
  * one-shot entry on the concatenated text.
- *   feed   cuts the piece, packs its complete ballots on the stream's `threads` host threads into a pinned ring, and enqueues GPU work
- *          without waiting for it (the first submission once 2^17 ballots are packed, at most two in flight; feed blocks only while the
- *          ring is full).  Nothing of `text` is referenced after it returns.  *n_objects (may be NULL): complete objects seen so far.
- *   take   (optional, never blocks) hands out, in order, the verdicts that are final so far: those of every ballot before the first one
+ *   feed   hands the piece to the stream's worker thread, which cuts it, packs its complete ballots on `threads` host threads into a
+ *          pinned ring, and enqueues GPU work without waiting for it (the first submission once EG_JSON_FIRST_MIN ballots are packed, at
+ *          most two in flight).  A piece below 8 MB is copied (one memcpy on the caller's thread; feed returns at once unless four 16 MB
+ *          blocks are already waiting); a larger piece is read in place and feed returns when the worker is through with it.  Either
+ *          way nothing of `text` is referenced after feed returns.  *n_objects (may be NULL): complete objects the worker has cut so
+ *          far - it may lag behind the pieces fed.  An error of the text (not a sequence of objects) or of the GPU found in a copied
+ *          piece is reported by a LATER feed or take, and at the latest by end.
+ *   take   (optional; waits at most for the worker to finish the piece it is cutting, never for the GPU) sends what has been copied so
+ *          far to the worker, lets an idle GPU start on whatever is packed, and hands out, in order, the verdicts that are final so far: those of every ballot before the first one
  *          that is still on the GPU or whose shape is not the election's (such a ballot gets its OptionsLenMismatch / LenMismatch
  *          verdict from the object path, which runs at the end).
  *   end    waits for the GPU, resolves the ballots of another shape, writes the verdicts not yet taken (status: room for `cap`; if more
