@@ -51,6 +51,19 @@ class EgError(RuntimeError):
     pass
 
 
+def effective_cores() -> int:
+    """Hardware threads this process may actually use (affinity mask and cgroup CPU quota): the default size of the parser's thread pool.
+    os.cpu_count() is the machine's - 256 on a box that grants 16 - and oversubscribing the pool 16-fold costs an order of magnitude."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
 def library_path() -> Path:
     return _LIB
 
@@ -200,7 +213,7 @@ def pack_json(text, n_options: int, single: bool | None = None, credits: int | N
     lib = _load()
     data = text.encode() if isinstance(text, str) else bytes(text)
     if not threads:
-        threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        threads = effective_cores()
     size = lib.eg_qv_ballot_size_for(n_options, credits) if credits is not None else lib.eg_choice_ballot_size(n_options, int(bool(single)))
     if not size:
         raise EgError("bad election parameters")
@@ -235,7 +248,7 @@ class JsonPacker:
     def __init__(self, n_options: int, max_objects: int, single: bool | None = None, credits: int | None = None, threads: int = 0):
         lib = _load()
         self.n_options, self.single, self.credits, self.max_objects = n_options, single, credits, max_objects
-        self.threads = threads or (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+        self.threads = threads or effective_cores()
         self.ballot_size = (lib.eg_qv_ballot_size_for(n_options, credits) if credits is not None
                             else lib.eg_choice_ballot_size(n_options, int(bool(single))))
         if not self.ballot_size:
@@ -514,7 +527,7 @@ class JsonStream:
         self.params = params
         self.objects = 0
         fn = getattr(_load(), f"eg_verify_{params._prefix}_json_begin")
-        _check(fn(params._h, threads or (os.cpu_count() or 1), C.byref(self._h)))
+        _check(fn(params._h, threads or effective_cores(), C.byref(self._h)))
 
     def feed(self, piece) -> int:
         """The next piece of the text (bytes / bytearray / memoryview / str); returns the number of complete objects seen so far."""
@@ -545,7 +558,7 @@ class JsonStream:
 
         cap = self.objects + 1024 if cap is None else cap
         tally = C.create_string_buffer(64 * self.params.n_options) if with_tally else None
-        h, self._h = self._h, C.c_void_p()
+        h, self._h = self._h, None
         while True:
             st = (C.c_uint32 * max(cap, 1))()
             n, total = C.c_size_t(0), C.c_size_t(0)
@@ -562,14 +575,15 @@ class JsonStream:
         """As end(), verdicts into a caller-owned ctypes uint32 array (bench.py: no Python list of a million words)."""
         n, total = C.c_size_t(0), C.c_size_t(0)
         tally = C.create_string_buffer(64 * self.params.n_options) if with_tally else None
-        h, self._h = self._h, C.c_void_p()
+        h, self._h = self._h, None
         _check(_load().eg_verify_json_end(h, status, len(status), C.byref(n), C.byref(total), tally))
         self.objects = total.value
         return n.value, (tally.raw if with_tally else None)
 
     def abort(self):
-        if getattr(self, "_h", None):
-            h, self._h = self._h, C.c_void_p()
+        h, self._h = getattr(self, "_h", None), None
+        # a params object that has been destroyed took its open stream with it (eg_*_params_destroy aborts it): the handle is stale then
+        if h and getattr(self.params, "_h", None):
             _load().eg_verify_json_abort(h)
 
     def __del__(self):
@@ -594,7 +608,7 @@ class _BatchParams:
     def _forget_streams(self):
         """The library aborts a stream that is still open when its params object is destroyed: the Python handles must not outlive it."""
         for st in list(getattr(self, "_streams", ())):
-            st._h = C.c_void_p()
+            st._h = None
 
     def _fn(self, name):
         return getattr(_load(), f"eg_{self._prefix}_{name}")
@@ -621,7 +635,7 @@ class _BatchParams:
         verify()'s order) from the library's object path."""
         data = text.encode() if isinstance(text, str) else bytes(text)
         if not threads:
-            threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            threads = effective_cores()
         if not max_objects:
             max_objects = data.count(b"{") + 1
         st = (C.c_uint32 * max(max_objects, 1))()
