@@ -1860,237 +1860,36 @@ static egwire::VerifyPackedFn make_verify_packed(Engine* e) {
     return engine_verify_host(e, n, packed.data(), status.data(), nullptr) == EG_OK;
   };
 }
+struct eg_json_stream;
+static int stream_begin(Engine* e, int threads, PackPieceFn pack_piece, ReshapeFn reshape, size_t size_hint, eg_json_stream** out);
+// The one-shot entry = the streaming entry fed with the whole text (in place, 64 MB at a time) - one pipeline for both (round 5; rounds 3-4
+// had a second one here, a producer thread and a consumer loop over the same ring).
 static int verify_json_common(Engine* e, const char* json, size_t json_len, int threads, size_t max_objects, uint32_t* status,
                               size_t* n_objects, uint8_t* tally_out, const PackPieceFn& pack_piece, const ReshapeFn& reshape) {
   if ((json_len && !json) || (max_objects && !status)) return fail(EG_ERR_BAD_ARG, "bad argument");
   if (n_objects) *n_objects = 0;
-  TRY(refuse_if_streaming(e));
-  HIPCHK(hipSetDevice(e->ctx->device));
-  const size_t stride = e->plan.stride;
-  const int ns = (int)e->plan.tally_slots.size();
-  hipStream_t s = e->ctx->stream;
-  HIPCHK(hipDeviceSynchronize());
-  bool set_aside = false;
-  ScopeExit restore{[&]() {     // running tally = saved + this call, on every exit path
-    if (!set_aside) return;
-    hipLaunchKernelGGL(k_tally_add_points, dim3(blocks_of((size_t)ns)), dim3(NT), 0, s, e->tally_saved2, ns, e->tally);
-    (void)hipStreamSynchronize(s);
-  }};
-  if (tally_out && ns) {        // tally_out = the tally of THIS call; the running tally keeps accumulating (eg_hip.h)
-    HIPCHK(hipMemcpyAsync(e->tally_saved2, e->tally, (size_t)ns * PT_WORDS * sizeof(u32), hipMemcpyDeviceToDevice, s));
-    hipLaunchKernelGGL(k_tally_init, dim3(blocks_of((size_t)ns)), dim3(NT), 0, s, e->tally, ns);
-    set_aside = true;
-    HIPCHK(hipStreamSynchronize(s));
+  eg_json_stream* S = nullptr;
+  {   // the context's lock only while the stream is opened: its worker thread takes the lock piece by piece, and so does end
+    EG_LOCK(e->ctx);
+    if (e->stream_open) return fail(EG_ERR_BAD_ARG, "a JSON call is already running on this params object (one at a time: the work sets, the staging ring and the tally are its)");
+    TRY(stream_begin(e, threads, pack_piece, reshape, json_len, &S));
   }
-  // Pipeline (round 3, second form).  A producer thread cuts the text window by window and packs each window on `threads` workers into a
-  // pinned RING of packed ballots; this thread uploads the finished windows, enqueues their verification and the download of their
-  // verdicts, and only then looks at what has completed - so the GPU holds the next submission's work while it finishes the current one
-  // (the first form verified window k with a blocking host call while window k+1 was parsed: every window paid an exposed upload and a
-  // drained GPU, 0.85 of the HBM-resident rate).  Consecutive submissions go through two control streams, so that the chunks of
-  // submission k+1 queue behind those of submission k on the work sets' streams without waiting for k's join; the sets' shares of the
-  // tally are merged once at the end.  Ballots of another shape (EG_PACK_RESHAPE) are collected and resolved after the last window.
-  const size_t env_ring = e->knobs.json_ring_kb << 10, env_window = e->knobs.json_window_kb << 10;        // test knobs (read at params creation)
-  const size_t ring_max = env_ring ? env_ring : (size_t)1 << 30;
-  const size_t ring_bytes = std::max(std::min(json_len / 4 * 3 + stride, ring_max), 64 * stride);
-  const size_t cap = ring_bytes / stride;                          // ballots in the ring
-  const size_t max_values = std::max<size_t>(1, cap / 4);          // per window: at least four windows fit
-  const size_t window_bytes = env_window ? env_window : (size_t)96 << 20, first_window = std::max<size_t>(window_bytes / 4, 1);
-  if (cap * stride > e->json_ring_bytes || cap > e->json_ring_ballots) {
-    if (e->json_ring) (void)hipHostFree(e->json_ring);
-    if (e->json_status_ring) (void)hipHostFree(e->json_status_ring);
-    e->json_ring = nullptr; e->json_status_ring = nullptr; e->json_ring_bytes = 0; e->json_ring_ballots = 0;
-    if (hipHostMalloc((void**)&e->json_ring, cap * stride, hipHostMallocPortable) != hipSuccess ||
-        hipHostMalloc((void**)&e->json_status_ring, cap * sizeof(u32), hipHostMallocPortable) != hipSuccess) {
-      (void)hipGetLastError();
-      return fail(EG_ERR_NOMEM, "pinned staging allocation failed");
-    }
-    e->json_ring_bytes = cap * stride; e->json_ring_ballots = cap;
+  const size_t piece = (size_t)64 << 20;
+  for (size_t at = 0; at < json_len; at += piece) {
+    if (eg_verify_json_feed(S, json + at, std::min(piece, json_len - at), nullptr)) break;       // end reports it and cleans up
   }
-  TRY(engine_stage_reserve(e, cap));
-  if (!e->copy_stream) HIPCHK(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
-  const int n_ctl = e->n_sets == 2 ? 2 : 1;            // one work set: its buffers serve one window at a time
-  for (int k = 0; k < n_ctl; ++k)
-    if (!e->json_ctl[k]) HIPCHK(hipStreamCreateWithFlags(&e->json_ctl[k], hipStreamNonBlocking));
-  {   // no regrowth of the chunk workspace while submissions are in flight (engine_reserve waits for the device and frees the old buffers):
-      // a submission holds whatever has piled up, at most the ring
-    const size_t per_set = (cap + e->n_sets - 1) / e->n_sets + NT;
-    const int rr = engine_reserve(e, (u32)std::min<size_t>(per_set, e->max_cap));
-    if (rr != EG_OK && rr != EG_ERR_NOMEM) return rr;         // out of memory: engine_verify_device falls back to smaller chunks
+  size_t taken = 0, total = 0;
+  const int rc = eg_verify_json_end(S, status, max_objects, &taken, &total, tally_out);
+  if (rc && g_err.find("are left") != std::string::npos) {       // the stream is still open: the caller's buffer is too small
+    eg_verify_json_abort(S);
+    return fail(EG_ERR_BAD_ARG, "more objects in the text than max_objects");
   }
-  if (e->items_seen + json_len / (2 * stride) >= e->ctx->big_min) TRY(ensure_big_tables(e, s));   // the text is worth the wide comb tables
-  HIPCHK(hipStreamSynchronize(s));
-
-  struct Region {
-    size_t first = 0, off = 0, m = 0;                 // index of its first ballot in the text, offset in the ring, ballots
-    std::vector<std::pair<size_t, size_t>> spans;
-    std::vector<uint32_t> pack_status;
-    bool ready = false, submitted = false;
-  };
-  std::list<Region> regions;                           // in text order; the front is the oldest one not yet retired
-  std::mutex mu;
-  std::condition_variable cv_ready, cv_space;
-  egwire::SplitCursor cur;
-  bool producer_done = false, abort_all = false, split_ok = true, too_many = false;
-  const int device = e->ctx->device;
-  std::thread producer([&]() {
-    (void)hipSetDevice(device);                  // HIP's current device is per thread
-    egwire::WorkerPool pool(std::max(threads, 1));      // the parser's threads, for the length of the call
-    bool done = false;
-    size_t window = first_window;
-    while (!done) {
-      Region r;
-      r.first = cur.count;
-      const bool ok = egwire::split_next(json, json_len, window, threads, cur, r.spans, done, max_values, &pool);
-      window = window_bytes;
-      Region* slot = nullptr;
-      {
-        std::unique_lock<std::mutex> lk(mu);
-        if (!ok) { split_ok = false; break; }
-        if (cur.count > max_objects) { too_many = true; break; }
-        r.m = r.spans.size();
-        if (r.m == 0) continue;
-        // room in the ring: behind the newest region, or from the start again once the oldest regions there have been retired
-        for (;;) {
-          if (abort_all) break;
-          if (regions.empty()) { r.off = 0; break; }
-          const size_t head = regions.back().off + regions.back().m, tail = regions.front().off;
-          if (head > tail) {                            // the occupied part does not wrap
-            if (head + r.m <= cap) { r.off = head; break; }
-            if (r.m <= tail) { r.off = 0; break; }
-          } else if (head + r.m <= tail) { r.off = head; break; }
-          cv_space.wait(lk);
-        }
-        if (abort_all) break;
-        regions.push_back(std::move(r));
-        slot = &regions.back();
-      }
-      slot->pack_status.resize(slot->m);
-      pack_piece(json, slot->spans, threads, e->json_ring + slot->off * stride, slot->pack_status.data(), &pool);
-      std::lock_guard<std::mutex> lk(mu);
-      slot->ready = true;
-      cv_ready.notify_all();
-    }
-    std::lock_guard<std::mutex> lk(mu);
-    producer_done = true;
-    cv_ready.notify_all();
-  });
-  int rc = EG_OK;
-  std::vector<std::pair<size_t, size_t>> odd;
-  std::vector<size_t> odd_at;
-  // A submission = the run of finished windows that has piled up (contiguous in the ring): one upload, one verification, one download.
-  // At most two are in flight: while the GPU works through them the parser's windows accumulate, so submissions grow to the size at which
-  // the kernels run well exactly when the GPU is the slower side, and stay small (and early) when the parser is.
-  struct Group { size_t n_regions, first, off, m; hipEvent_t uploaded, done; };
-  std::deque<Group> groups;
-  const size_t growth = e->knobs.json_growth;   // per cent (measurement knob; A/B block 6)
-  const bool trace = e->knobs.json_trace;       // developer aid: the timeline of the submissions on stderr
-  const auto t_start = std::chrono::steady_clock::now();
-  auto ms_now = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
-  size_t n_submitted = 0;
-  auto retire_oldest = [&]() {         // the oldest submission has landed: verdicts to the caller, its part of the ring back to the producer
-    const Group g = groups.front();
-    groups.pop_front();
-    if (trace) fprintf(stderr, "[json] %8.2f ms  landed    %zu ballots from %zu\n", ms_now(), g.m, g.first);
-    std::memcpy(status + g.first, e->json_status_ring + g.off, g.m * sizeof(u32));
-    for (size_t k = 0; k < g.n_regions; ++k) {
-      Region* r;
-      { std::lock_guard<std::mutex> lk(mu); r = &regions.front(); }
-      for (size_t i = 0; i < r->m; ++i) {
-        if (r->pack_status[i] != EG_ST_OK) status[r->first + i] = r->pack_status[i];
-        if (r->pack_status[i] == EG_PACK_RESHAPE) { odd.push_back(r->spans[i]); odd_at.push_back(r->first + i); }
-      }
-      std::lock_guard<std::mutex> lk(mu);
-      regions.pop_front();
-    }
-    (void)hipEventDestroy(g.uploaded); (void)hipEventDestroy(g.done);
-    std::lock_guard<std::mutex> lk(mu);
-    cv_space.notify_all();
-  };
-  for (;;) {
-    while (!groups.empty() && hipEventQuery(groups.front().done) == hipSuccess) retire_oldest();
-    (void)hipGetLastError();                           // a submission still running reads as hipErrorNotReady: not an error to keep
-    Group g{0, 0, 0, 0, nullptr, nullptr};
-    bool finished = false, wait_gpu = false, again = false;
-    {
-      std::unique_lock<std::mutex> lk(mu);
-      if (split_ok && !too_many) {
-        for (Region& r : regions) {                    // the run of finished windows behind the submitted ones
-          if (r.submitted) continue;
-          if (!r.ready || (g.n_regions && r.off != g.off + g.m)) break;
-          if (!g.n_regions) { g.first = r.first; g.off = r.off; }
-          ++g.n_regions; g.m += r.m;
-        }
-        // nothing in flight: whatever is ready goes now.  One in flight: a second one joins it once it is 1.5x as large (the upload
-        // and the first kernels of the second overlap the tail of the first, and sizes can only grow) or the text has ended.
-        const bool submit = g.n_regions && (groups.empty() || (groups.size() < 2 && (g.m * 100 >= groups.back().m * growth || producer_done)));
-        if (submit) {
-          size_t k = 0;
-          for (Region& r : regions) { if (r.submitted) continue; if (k++ == g.n_regions) break; r.submitted = true; }
-        } else {
-          const bool pending = g.n_regions != 0;
-          g.n_regions = 0;
-          if (groups.empty()) {
-            if (producer_done && regions.empty()) finished = true;
-            else { cv_ready.wait(lk); again = true; }
-          } else if (groups.size() >= 2 || (producer_done && !pending)) wait_gpu = true;
-          else { cv_ready.wait_for(lk, std::chrono::microseconds(200)); again = true; }     // a window may finish, or the submission land
-        }
-      }
-    }
-    if (again) continue;
-    if (!split_ok) { rc = fail(EG_ERR_BAD_ARG, "the text is neither a JSON array of objects nor a sequence of JSON objects"); break; }
-    if (too_many) { rc = fail(EG_ERR_BAD_ARG, "more objects in the text than max_objects"); break; }
-    if (finished) break;
-    if (g.n_regions) {
-      hipStream_t ctl = e->json_ctl[n_submitted % (size_t)n_ctl];
-      const char* what = "window upload: ";
-      hipError_t he = hipEventCreateWithFlags(&g.uploaded, hipEventDisableTiming);
-      if (he == hipSuccess) he = hipEventCreateWithFlags(&g.done, hipEventDisableTiming | hipEventBlockingSync);   // the waiting thread must not take a core from the parser
-      if (he == hipSuccess) he = hipMemcpyAsync(e->d_wire + g.off * stride, e->json_ring + g.off * stride, g.m * stride, hipMemcpyHostToDevice,
-                                                e->copy_stream);
-      if (he == hipSuccess) he = hipEventRecord(g.uploaded, e->copy_stream);
-      if (he == hipSuccess) he = hipStreamWaitEvent(ctl, g.uploaded, 0);
-      if (he == hipSuccess) {
-        rc = engine_verify_device(e, g.m, e->d_wire + g.off * stride, e->d_status + g.off, ctl, VD_FORCE_SETS | VD_KEEP_SET_TALLY);
-        what = "verdict download: ";
-        if (rc == EG_OK) he = hipMemcpyAsync(e->json_status_ring + g.off, e->d_status + g.off, g.m * sizeof(u32), hipMemcpyDeviceToHost, ctl);
-        if (rc == EG_OK && he == hipSuccess) he = hipEventRecord(g.done, ctl);
-      }
-      if (he != hipSuccess) rc = fail(EG_ERR_HIP, std::string(what) + hipGetErrorString(he));
-      if (rc) {
-        if (g.uploaded) (void)hipEventDestroy(g.uploaded);
-        if (g.done) (void)hipEventDestroy(g.done);
-        break;
-      }
-      groups.push_back(g);
-      ++n_submitted;
-      if (trace) fprintf(stderr, "[json] %8.2f ms  submitted %zu windows, %zu ballots from %zu (%zu in flight)\n", ms_now(), g.n_regions, g.m, g.first, groups.size());
-    } else if (wait_gpu) {                               // two in flight, or nothing left to add: wait for the oldest submission
-      const hipError_t he = hipEventSynchronize(groups.front().done);
-      if (he != hipSuccess) { rc = fail(EG_ERR_HIP, std::string("window: ") + hipGetErrorString(he)); break; }
-      retire_oldest();
-    }
-  }
-  { std::lock_guard<std::mutex> lk(mu); abort_all = true; cv_space.notify_all(); }
-  producer.join();
-  (void)hipDeviceSynchronize();                         // also on the error paths: nothing may still read the ring or the work sets
-  for (Group& g : groups) { if (g.uploaded) (void)hipEventDestroy(g.uploaded); if (g.done) (void)hipEventDestroy(g.done); }
-  if (ns && e->n_sets == 2) {                           // the sets' shares of the tally, once
-    hipLaunchKernelGGL(k_tally_add_points, dim3(blocks_of((size_t)ns)), dim3(NT), 0, s, e->set[1].tally, ns, e->set[0].tally);
-    hipLaunchKernelGGL(k_tally_init, dim3(blocks_of((size_t)ns)), dim3(NT), 0, s, e->set[1].tally, ns);
-    HIPCHK(hipStreamSynchronize(s));
-  }
-  if (rc == EG_OK && !odd.empty()) {   // OptionsLenMismatch / LenMismatch territory: the object path, in the reference's order of checks
-    std::vector<uint32_t> verdicts;
-    if (!reshape(json, odd, verdicts)) rc = g_err.empty() ? fail(EG_ERR_HIP, "object path: a GPU call failed") : EG_ERR_HIP;
-    else for (size_t i = 0; i < odd.size(); ++i) status[odd_at[i]] = verdicts[i];
-  }
-  if (n_objects) *n_objects = cur.count;
-  if (tally_out && ns && rc == EG_OK) rc = engine_tally_encode(e, tally_out);      // (the guard merges the running tally back afterwards)
-  return rc;
+  if (rc) return rc;
+  if (n_objects) *n_objects = total;
+  return EG_OK;
 }
 int eg_verify_choice_json(eg_choice_params* p, const char* json, size_t json_len, int threads, size_t max_objects, uint32_t* status,
-                          size_t* n_objects, uint8_t* tally_out) { EG_LOCK_P(p);
+                          size_t* n_objects, uint8_t* tally_out) { 
   if (!p) return fail(EG_ERR_BAD_ARG, "bad argument");
   const int n_options = p->n_options, single = p->single;
   const size_t stride = p->eng->plan.stride;
@@ -2108,7 +1907,7 @@ int eg_verify_choice_json(eg_choice_params* p, const char* json, size_t json_len
                             });
 }
 int eg_verify_qv_json(eg_qv_params* p, const char* json, size_t json_len, int threads, size_t max_objects, uint32_t* status,
-                      size_t* n_objects, uint8_t* tally_out) { EG_LOCK_P(p);
+                      size_t* n_objects, uint8_t* tally_out) { 
   if (!p) return fail(EG_ERR_BAD_ARG, "bad argument");
   const int n_options = p->n_options;
   const eghost::QvShape sh = p->shape;
@@ -2128,14 +1927,15 @@ int eg_verify_qv_json(eg_qv_params* p, const char* json, size_t json_len, int th
                             });
 }
 // ---- the JSON text in PIECES: eg_verify_{choice,qv}_json_begin / eg_verify_json_feed / _take / _end / _abort --------------------------------
-// (examples/voting.rs:195-198 emits ballots one at a time; src/serde.rs:19-80 is the layout.)  The caller's thread does everything, piece by
-// piece: eg_verify_json_feed cuts the piece (egwire::StreamSplitter: values may straddle pieces), packs its complete ballots on the
-// stream's pool of host threads into the pinned ring, and then PUMPS the GPU side without ever waiting for it - retire the submissions
-// that have landed, enqueue what has piled up (upload, verification on the two work sets, download of the verdicts).  The first submission
-// waits until 2^17 ballots are packed (the small first submissions of the one-shot entry cost it 5-8 %: the kernels run well from ~10^5
-// ballots on), later ones go when they are 1.5 x the one in flight, at most two in flight; feed only blocks when the ring is full.
-// Nothing of the caller's text is referenced after feed returns (the tail of a piece that is not a whole value yet is copied: at most one
-// ballot's text).  Between begin and end the params object belongs to the stream (other verify / tally calls on it are refused).
+// (examples/voting.rs:195-198 emits ballots one at a time; src/serde.rs:19-80 is the layout.)  ONE worker thread per stream takes the
+// pieces in order (stream_worker): it cuts a piece (egwire::StreamSplitter: values may straddle pieces), packs its complete ballots on
+// the stream's pool of host threads into the pinned ring (stream_emit), and then PUMPS the GPU side without ever waiting for it
+// (stream_pump) - retire the submissions that have landed, enqueue what has piled up (upload, verification on the two work sets, download
+// of the verdicts).  The first submission goes once 2^14 ballots are packed (EG_JSON_FIRST_MIN; measured, profiles/r05_json_stream_probe.txt:
+// 2^13 ... 2^14 ballots 0.91 of the HBM-resident rate, 2^15 0.90, 2^17 0.86 - waiting longer idles the GPU for longer than the small first
+// launches cost), later ones when they are 1.5 x the one in flight, at most two in flight; the worker only waits for the GPU when the ring
+// is full.  The one-shot entries (eg_verify_*_json) are this pipeline fed with the whole text in place.  Between begin and end the params
+// object belongs to the stream (other verify / tally calls on it are refused).
 struct eg_json_stream {
   Engine* e = nullptr;
   int threads = 1, n_ctl = 1, ns = 0;
@@ -2291,7 +2091,8 @@ static void stream_release(eg_json_stream* S, bool keep_partial_tally) {      //
   delete S;
 }
 static void stream_worker(eg_json_stream* S);
-static int stream_begin(Engine* e, int threads, PackPieceFn pack_piece, ReshapeFn reshape, eg_json_stream** out) {
+// size_hint: bytes of text to come if the caller knows (the one-shot entry does: a short text gets a short ring), else 0
+static int stream_begin(Engine* e, int threads, PackPieceFn pack_piece, ReshapeFn reshape, size_t size_hint, eg_json_stream** out) {
   if (!out) return fail(EG_ERR_BAD_ARG, "bad argument");
   *out = nullptr;
   if (e->stream_open) return fail(EG_ERR_BAD_ARG, "a JSON stream is already open on this params object");
@@ -2302,9 +2103,10 @@ static int stream_begin(Engine* e, int threads, PackPieceFn pack_piece, ReshapeF
   S->growth = e->knobs.json_growth; S->trace = e->knobs.json_trace;
   hipStream_t s = e->ctx->stream;
   HIPCHK(hipDeviceSynchronize());
-  const size_t ring_bytes = std::max(e->knobs.json_ring_kb ? e->knobs.json_ring_kb << 10 : (size_t)1 << 30, 64 * S->stride);
+  const size_t ring_max = e->knobs.json_ring_kb ? e->knobs.json_ring_kb << 10 : (size_t)1 << 30;
+  const size_t ring_bytes = std::max(size_hint ? std::min(size_hint / 4 * 3 + S->stride, ring_max) : ring_max, 64 * S->stride);
   S->cap = ring_bytes / S->stride;
-  S->first_min = std::min<size_t>(e->knobs.json_first_min ? e->knobs.json_first_min : (size_t)1 << 17, S->cap / 4);
+  S->first_min = std::min<size_t>(e->knobs.json_first_min ? e->knobs.json_first_min : (size_t)1 << 14, S->cap / 4);
   if (S->cap * S->stride > e->json_ring_bytes || S->cap > e->json_ring_ballots) {
     if (e->json_ring) (void)hipHostFree(e->json_ring);
     if (e->json_status_ring) (void)hipHostFree(e->json_status_ring);
@@ -2531,7 +2333,7 @@ int eg_verify_choice_json_begin(eg_choice_params* p, int threads, eg_json_stream
                       },
                       [=](const char* text, const std::vector<std::pair<size_t, size_t>>& odd, std::vector<uint32_t>& res) {
                         return egwire::resolve_choice_objects(text, odd, n_options, single != 0, stride, make_check_items(e->ctx), make_verify_packed(e), res);
-                      }, out);
+                      }, 0, out);
 }
 int eg_verify_qv_json_begin(eg_qv_params* p, int threads, eg_json_stream** out) { EG_LOCK_P(p);
   if (!p) return fail(EG_ERR_BAD_ARG, "bad argument");
@@ -2546,7 +2348,7 @@ int eg_verify_qv_json_begin(eg_qv_params* p, int threads, eg_json_stream** out) 
                       },
                       [=](const char* text, const std::vector<std::pair<size_t, size_t>>& odd, std::vector<uint32_t>& res) {
                         return egwire::resolve_qv_objects(text, odd, n_options, vote, credit, sh.ballot_size, make_check_items(e->ctx), make_verify_packed(e), res);
-                      }, out);
+                      }, 0, out);
 }
 size_t eg_qv_ballot_size_for(int n_options, uint64_t credits) {
   if (n_options < 1 || n_options > 256 || credits < 1 || credits > 100000) return 0;

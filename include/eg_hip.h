@@ -58,7 +58,7 @@
  *   EG_JSON_RING_KB       params create  1048576            pinned staging ring of eg_verify_*_json, KiB
  *   EG_JSON_WINDOW_KB     params create  98304              JSON text per parser window, KiB
  *   EG_JSON_GROWTH        params create  150                a second JSON submission is enqueued once it is this many per cent of the first
- *   EG_JSON_FIRST_MIN     params create  131072             packed ballots a JSON STREAM (eg_verify_json_feed) waits for before its first GPU submission
+ *   EG_JSON_FIRST_MIN     params create  16384              packed ballots the JSON entry points wait for before their first GPU submission
  *   EG_JSON_TRACE         params create  unset              timeline of the JSON submissions on stderr
  *
  * The Python mirror adds two of its own (elastic_elgamal_amd/__init__.py, read at import): EG_LIB = path of another build of this
