@@ -1972,6 +1972,8 @@ struct eg_json_stream {
   bool stop = false, worker_joined = false;
   std::atomic<size_t> objects{0};          // complete objects cut so far (by the worker)
   size_t block_bytes = (size_t)16 << 20, direct_min = (size_t)8 << 20;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();      // EG_JSON_TRACE: the timeline on stderr, ms since begin
+  double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
 };
 static int stream_fail(eg_json_stream* S, int code, const std::string& msg) {
   if (!S->failed.load(std::memory_order_acquire)) { S->err = msg; S->failed.store(code, std::memory_order_release); }
@@ -1989,7 +1991,7 @@ static void stream_retire_oldest(eg_json_stream* S) {     // the oldest submissi
   }
   S->landed = g.first + g.m;
   (void)hipEventDestroy(g.uploaded); (void)hipEventDestroy(g.done);
-  if (S->trace) fprintf(stderr, "[json stream] landed    %zu ballots from %zu\n", g.m, g.first);
+  if (S->trace) fprintf(stderr, "[json stream] %8.2f ms  landed    %zu ballots from %zu\n", S->ms(), g.m, g.first);
 }
 // enqueue what has piled up, if it is time (or `force`: the ring is full, or the text has ended); never waits for the GPU
 static int stream_pump(eg_json_stream* S, bool force) {
@@ -2034,7 +2036,7 @@ static int stream_pump(eg_json_stream* S, bool force) {
     for (auto& r : S->regions) { if (r.submitted) continue; if (k++ == g.n_regions) break; r.submitted = true; }
     S->groups.push_back(g);
     ++S->n_submitted;
-    if (S->trace) fprintf(stderr, "[json stream] submitted %zu windows, %zu ballots from %zu (%zu in flight)\n", g.n_regions, g.m, g.first, S->groups.size());
+    if (S->trace) fprintf(stderr, "[json stream] %8.2f ms  submitted %zu windows, %zu ballots from %zu (%zu in flight)\n", S->ms(), g.n_regions, g.m, g.first, S->groups.size());
   }
 }
 // room for m packed ballots in the ring (behind the newest region, or from the start again once the oldest regions there have been
@@ -2143,6 +2145,7 @@ static int stream_begin(Engine* e, int threads, PackPieceFn pack_piece, ReshapeF
                                             },
                                             window, std::max<size_t>(1, S->cap / 8)));
   e->stream_open = raw;
+  if (S->trace) fprintf(stderr, "[json stream] %8.2f ms  begun (ring of %zu ballots, first submission from %zu)\n", S->ms(), S->cap, S->first_min);
   S->worker = std::thread(stream_worker, raw);
   *out = S.release();
   return EG_OK;
@@ -2265,6 +2268,7 @@ int eg_verify_json_end(eg_json_stream* S, uint32_t* status, size_t cap, size_t* 
   eg_ctx* ctx = S->e->ctx;
   stream_join_worker(S, true);                      // every piece cut and packed; from here on this thread owns the stream
   EG_LOCK(ctx);
+  if (S->trace) fprintf(stderr, "[json stream] %8.2f ms  every piece packed (%zu objects), %zu submissions in flight\n", S->ms(), S->split->count(), S->groups.size());
   if (n_taken) *n_taken = 0;
   Engine* e = S->e;
   if (!S->flushed && !S->failed.load()) {
@@ -2310,9 +2314,13 @@ int eg_verify_json_end(eg_json_stream* S, uint32_t* status, size_t cap, size_t* 
   if (n_taken) *n_taken = left;
   if (n_objects) *n_objects = S->verdicts.size();
   int rc = EG_OK;
+  if (S->trace) fprintf(stderr, "[json stream] %8.2f ms  verdicts copied\n", S->ms());
   if (tally_out && S->ns) rc = engine_tally_encode(e, tally_out);       // the stream's own tally (the running tally gets it added below)
   const std::string why = g_err;
+  const bool trace = S->trace;
+  const auto t0 = S->t0;
   stream_release(S, true);
+  if (trace) fprintf(stderr, "[json stream] %8.2f ms  released\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   return rc ? fail(rc, why) : EG_OK;
 }
 void eg_verify_json_abort(eg_json_stream* S) {
