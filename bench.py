@@ -898,10 +898,10 @@ def main():
             for _ in range(3):
                 sstatus = (ctypes.c_uint32 * jn)()
                 t0 = time.perf_counter()
-                st = params.json_stream(threads=cores)
+                js = params.json_stream(threads=cores)
                 for at in range(0, len(jtext), piece):
-                    st.feed_ptr(jbase + at, min(piece, len(jtext) - at))
-                taken, _ = st.end_into(sstatus)
+                    js.feed_ptr(jbase + at, min(piece, len(jtext) - at))
+                taken, _ = js.end_into(sstatus)
                 dt = time.perf_counter() - t0
                 best_s = dt if best_s is None else min(best_s, dt)
                 ok = ok and taken == jn and np.array_equal(np.frombuffer(sstatus, dtype=np.uint32), jarr)
