@@ -131,6 +131,9 @@ def _load() -> C.CDLL:
         "eg_dlog_table_destroy": (None, [vp]),
         "eg_dlog_table_get": (C.c_int, [vp, sz, cp, C.POINTER(C.c_uint64), cp]),
         "eg_vartime_multi_mul_batch_device": (C.c_int, [vp, sz, sz, vp, vp, vp, vp, vp, vp, vp]),
+        "eg_prepared_point_size": (sz, []),
+        "eg_points_prepare_device": (C.c_int, [vp, sz, vp, vp, vp, vp]),
+        "eg_vartime_multi_mul_prepared_batch_device": (C.c_int, [vp, sz, sz, vp, vp, vp, vp, vp, vp]),
         "eg_choice_params_create": (C.c_int, [vp, cp, C.c_int, C.c_int, C.POINTER(vp)]),
         "eg_choice_params_destroy": (None, [vp]),
         "eg_choice_ballot_size": (sz, [C.c_int, C.c_int]),
@@ -460,10 +463,23 @@ class Ristretto:
     def msm_scratch_bytes(self, n: int, terms: int) -> int:
         return int(_load().eg_msm_scratch_bytes(self.ctx._h, n, terms))
 
+    def prepare_points_device(self, n: int, d_encodings: int, d_prepared: int, d_ok: int = 0, stream: int = 0):
+        """Decodes n elements once into prepared points (prepared_point_size() bytes each) for repeated products over them."""
+        _check(_load().eg_points_prepare_device(self.ctx._h, n, d_encodings, d_prepared, d_ok, stream))
+
+    def vartime_multi_mul_prepared_device(self, n: int, terms: int, d_scalars: int, d_prepared: int, d_out: int, d_r: int = 0, d_scratch: int = 0,
+                                          stream: int = 0):
+        """vartime_multi_mul over prepared points (no decoding per term)."""
+        _check(_load().eg_vartime_multi_mul_prepared_batch_device(self.ctx._h, n, terms, d_scalars, d_prepared, d_r, d_scratch, d_out, stream))
+
     def vartime_multi_mul_device(self, n: int, terms: int, d_scalars: int, d_points: int, d_out: int, d_r: int = 0, d_scratch: int = 0,
                                  d_ok: int = 0, stream: int = 0):
         """The multi-scalar multiplication on device buffers, asynchronous on `stream` (eg_vartime_multi_mul_batch_device)."""
         _check(_load().eg_vartime_multi_mul_batch_device(self.ctx._h, n, terms, d_scalars, d_points, d_r, d_scratch, d_out, d_ok, stream))
+
+
+def prepared_point_size() -> int:
+    return int(_load().eg_prepared_point_size())
 
 
 def verify_batch_multi(per_device, ballots: bytes, with_tally: bool = True):

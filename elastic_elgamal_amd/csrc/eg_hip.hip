@@ -884,7 +884,9 @@ int eg_init(int device, eg_ctx** out) {
                              EG_MULTI_GROUP * 9 * NT * (int)sizeof(u32)));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_eq_table<true, 6>), hipFuncAttributeMaxDynamicSharedMemorySize,
                              EG_MULTI_GROUP * 9 * NT * (int)sizeof(u32)));
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_prim_msm), hipFuncAttributeMaxDynamicSharedMemorySize,
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_prim_msm<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             MSM_CHUNK * 8 * NT * (int)sizeof(u32)));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_prim_msm<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                              MSM_CHUNK * 8 * NT * (int)sizeof(u32)));
   if (per_cu < 1) per_cu = 1;
   c->resident_blocks = per_cu * c->cus;
@@ -1181,7 +1183,7 @@ static PipLayout pip_layout(size_t terms) {
   return L;
 }
 static int pip_launch(eg_ctx* c, size_t terms, const u32* d_scalars, const u32* d_points, const u32* d_r, void* d_scratch, u32* d_out,
-                      unsigned char* d_ok, hipStream_t s) {
+                      unsigned char* d_ok, hipStream_t s, bool prepared = false) {
   const PipLayout L = pip_layout(terms);
   if (L.levels > PIP_MAX_LEVELS) return fail(EG_ERR_BAD_ARG, "too many terms for the bucket method");
   char* base = static_cast<char*>(d_scratch);
@@ -1194,7 +1196,8 @@ static int pip_launch(eg_ctx* c, size_t terms, const u32* d_scalars, const u32* 
   uint4* psum[2] = {reinterpret_cast<uint4*>(base + L.psum[0]), reinterpret_cast<uint4*>(base + L.psum[1])};
   HIPCHK(hipMemsetAsync(P.counts, 0, (size_t)nb * sizeof(u32), s));
   HIPCHK(hipMemsetAsync(P.all_ok, 0x01, sizeof(u32), s));
-  hipLaunchKernelGGL(k_pip_prepare, dim3((unsigned)((terms + NT - 1) / NT)), dim3(NT), 0, s, terms, L.c, d_scalars, d_points, P);
+  if (prepared) hipLaunchKernelGGL(k_pip_prepare<true>, dim3((unsigned)((terms + NT - 1) / NT)), dim3(NT), 0, s, terms, L.c, d_scalars, d_points, P);
+  else hipLaunchKernelGGL(k_pip_prepare<false>, dim3((unsigned)((terms + NT - 1) / NT)), dim3(NT), 0, s, terms, L.c, d_scalars, d_points, P);
   {
     PipScan S;
     S.offsets = P.offsets; S.cursors = P.cursors; S.totals = totals; S.tile_sums = at(L.tiles);
@@ -1234,11 +1237,12 @@ static size_t msm_scratch_for(const eg_ctx* ctx, size_t n, size_t terms) {
 // out[i] = enc( sum_t [k_it]P_it + [r_i]G ) on device pointers (kernels.cuh: k_prim_msm, k_prim_msm_fold, k_prim_msm_reduce; very large
 // products: pippenger.cuh, one problem after the other); asynchronous on s
 static int prim_msm_launch(eg_ctx* c, size_t n, size_t terms, const u32* d_scalars, const u32* d_points, const u32* d_r, void* d_scratch,
-                           u32* d_out, unsigned char* d_ok, hipStream_t s) {
+                           u32* d_out, unsigned char* d_ok, hipStream_t s, bool prepared = false) {
+  const size_t pw = prepared ? PREP_WORDS : 8;          // words per point: a prepared point (96 bytes) or an encoding (32)
   if (msm_uses_buckets(c, terms)) {
     for (size_t i = 0; i < n; ++i)
-      TRY(pip_launch(c, terms, d_scalars + i * terms * 8, d_points + i * terms * 8, d_r ? d_r + i * 8 : nullptr, d_scratch, d_out + i * 8,
-                     d_ok ? d_ok + i : nullptr, s));
+      TRY(pip_launch(c, terms, d_scalars + i * terms * 8, d_points + i * terms * pw, d_r ? d_r + i * 8 : nullptr, d_scratch, d_out + i * 8,
+                     d_ok ? d_ok + i : nullptr, s, prepared));
     return EG_OK;
   }
   int chunk, n_chunks;
@@ -1246,8 +1250,10 @@ static int prim_msm_launch(eg_ctx* c, size_t n, size_t terms, const u32* d_scala
   const MsmScratch m = msm_scratch_at(d_scratch, n, (size_t)n_chunks);
   // every lane owns `chunk` tables in the per-lane workspace: the grid shrinks accordingly (the workspace is msm_blocks x one table)
   const int grid = grid_for(n * (size_t)n_chunks, std::max(1, c->msm_blocks / chunk));
-  hipLaunchKernelGGL(k_prim_msm, dim3(grid), dim3(NT), (size_t)chunk * 8 * NT * sizeof(u32), s, n, (int)terms, chunk, n_chunks, d_scalars,
-                     d_points, d_r, c->tabG, c->ws, m.part[0], m.ok[0], d_out, d_ok);
+  if (prepared) hipLaunchKernelGGL(k_prim_msm<true>, dim3(grid), dim3(NT), (size_t)chunk * 8 * NT * sizeof(u32), s, n, (int)terms, chunk, n_chunks,
+                                   d_scalars, d_points, d_r, c->tabG, c->ws, m.part[0], m.ok[0], d_out, d_ok);
+  else hipLaunchKernelGGL(k_prim_msm<false>, dim3(grid), dim3(NT), (size_t)chunk * 8 * NT * sizeof(u32), s, n, (int)terms, chunk, n_chunks, d_scalars,
+                          d_points, d_r, c->tabG, c->ws, m.part[0], m.ok[0], d_out, d_ok);
   if (n_chunks > 1) msm_fold_reduce(c, n, n_chunks, m, d_r, d_out, d_ok, s);
   HIPCHK(hipGetLastError());
   return EG_OK;
@@ -1297,6 +1303,29 @@ int eg_vartime_multi_mul_batch_device(eg_ctx* c, size_t n, size_t terms, const v
   HIPCHK(hipSetDevice(c->device));
   return prim_msm_launch(c, n, terms, (const u32*)d_scalars, (const u32*)d_points, (const u32*)d_r, need ? d_scratch : nullptr, (u32*)d_out,
                          (unsigned char*)d_ok, (hipStream_t)stream);
+}
+
+// Prepared points: decode a point set ONCE, multiply over it many times (ristretto.rs:139-145: vartime_multi_mul takes Elements, which in
+// the reference ARE decoded points - its callers never pay a decoding per product; eg_vartime_multi_mul_batch_device, which takes
+// encodings, does).
+size_t eg_prepared_point_size(void) { return PREP_WORDS * sizeof(u32); }
+int eg_points_prepare_device(eg_ctx* c, size_t n, const void* d_encodings, void* d_prepared, void* d_ok, void* stream) { EG_LOCK(c);
+  if (!c || (n && (!d_encodings || !d_prepared))) return fail(EG_ERR_BAD_ARG, "bad argument");
+  if (n == 0) return EG_OK;
+  hipLaunchKernelGGL(k_prim_points_prepare, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, n, (const u32*)d_encodings,
+                     (u32*)d_prepared, (unsigned char*)d_ok);
+  HIPCHK(hipGetLastError());
+  return EG_OK;
+}
+int eg_vartime_multi_mul_prepared_batch_device(eg_ctx* c, size_t n, size_t terms, const void* d_scalars, const void* d_prepared, const void* d_r,
+                                               void* d_scratch, void* d_out, void* stream) { EG_LOCK(c);
+  if (!c || (n && !d_out) || (n && terms && (!d_scalars || !d_prepared)) || (n && !terms && !d_r)) return fail(EG_ERR_BAD_ARG, "bad argument");
+  if (terms > ((size_t)1 << 24)) return fail(EG_ERR_BAD_ARG, "at most 2^24 terms per problem");
+  const size_t need = msm_scratch_for(c, n, terms);
+  if (n && need && !d_scratch) return fail(EG_ERR_BAD_ARG, "this call is cut into several chunks per problem (or uses the bucket method) and needs d_scratch (eg_msm_scratch_bytes)");
+  if (n == 0) return EG_OK;
+  return prim_msm_launch(c, n, terms, (const u32*)d_scalars, (const u32*)d_prepared, (const u32*)d_r, need ? d_scratch : nullptr, (u32*)d_out,
+                         nullptr, (hipStream_t)stream, true);
 }
 
 // ---- tally stage (examples/voting.rs:122-177) --------------------------------------------------------------------------

@@ -897,6 +897,33 @@ __device__ __forceinline__ void msm_finish(ge& acc, size_t i, const u32* r, cons
   u32 o[8]; ristretto_encode(o, acc);
   st8(out + i * 8, o);
 }
+// A PREPARED point: a ristretto255 element decoded once (k_prim_points_prepare), kept in device memory as affine (x, y, t = xy), 3 x 256
+// bits packed = 96 bytes, Z = 1 implied.  Products over one point set (eg_vartime_multi_mul_prepared_batch_device) then skip the 285
+// field operations of a decoding per term - a third of the bucket method's time (profiles/r04_msm_by_size.txt).  An encoding that does
+// not decode is prepared as the identity (0, 1, 0) and flagged by the prepare call.
+constexpr int PREP_WORDS = 24;
+EG_D void prepared_load(ge& p, const u32* src) {
+  u32 w[PREP_WORDS];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) { const uint4 v = reinterpret_cast<const uint4*>(src)[q]; w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w; }
+  fe_unpack8(p.X, w); fe_unpack8(p.Y, w + 8); fe_unpack8(p.T, w + 16); fe_1(p.Z);
+}
+__global__ void __launch_bounds__(NT, 2) k_prim_points_prepare(size_t n, const u32* in, u32* out, unsigned char* ok) {
+  const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+  if (i >= n) return;
+  u32 pw[8];
+  ld8(pw, in + i * 8);
+  ge p;
+  const bool good = ristretto_decode(p, pw);          // p = the identity when the encoding does not decode
+  fe_carry(p.X); fe_carry(p.Y); fe_carry(p.T);
+  u32 w[PREP_WORDS];
+  fe_pack8(w, p.X); fe_pack8(w + 8, p.Y); fe_pack8(w + 16, p.T);
+  uint4* dst = reinterpret_cast<uint4*>(out + i * PREP_WORDS);
+#pragma unroll
+  for (int q = 0; q < 6; ++q) dst[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+  if (ok) ok[i] = good ? 1 : 0;
+}
+template <bool PREPARED>
 __global__ void __launch_bounds__(NT, 2) k_prim_msm(size_t n, int terms, int chunk, int n_chunks, const u32* scalars, const u32* points,
                                                     const u32* r, const uint4* tabG, uint4* ws, u32* partial, unsigned char* ok_partial,
                                                     u32* out, unsigned char* ok) {
@@ -909,11 +936,15 @@ __global__ void __launch_bounds__(NT, 2) k_prim_msm(size_t n, int terms, int chu
     bool okk = true;
 #pragma unroll 1
     for (int t = 0; t < m; ++t) {
-      u32 pw[8], s[8], dg[8];
-      ld8(pw, points + (i * terms + t0 + t) * 8);
+      u32 s[8], dg[8];
       ld8(s, scalars + (i * terms + t0 + t) * 8);
       ge p;
-      okk = okk & ristretto_decode(p, pw);
+      if constexpr (PREPARED) prepared_load(p, points + (i * terms + t0 + t) * (size_t)PREP_WORDS);
+      else {
+        u32 pw[8];
+        ld8(pw, points + (i * terms + t0 + t) * 8);
+        okk = okk & ristretto_decode(p, pw);
+      }
       sc_recode_radix16(dg, s);
 #pragma unroll
       for (int w = 0; w < 8; ++w) msm_dig[(t * 8 + w) * NT + threadIdx.x] = dg[w];

@@ -74,16 +74,21 @@ __device__ __forceinline__ u32 pip_wave_atomic_inc(u32* ctr, size_t key, bool ac
   return old;
 }
 
+template <bool PREPARED>      // PREPARED: points are prepared points (kernels.cuh: 96 bytes, already decoded)
 __global__ void __launch_bounds__(NT, 2) k_pip_prepare(size_t terms, int c, const u32* scalars, const u32* points, PipBufs P) {
   const size_t t0 = (size_t)blockIdx.x * NT + threadIdx.x;
   const bool live = t0 < terms;                               // dead lanes stay for the wave-level atomics
   const size_t t = live ? t0 : terms - 1;
   const int W = pip_windows(c), B = 1 << (c - 1);
-  u32 pw[8], s[8];
-  ld8(pw, points + t * 8);
+  u32 s[8];
   ld8(s, scalars + t * 8);
   ge p;
-  if (!ristretto_decode(p, pw) && live) atomicAnd(P.all_ok, 0u);     // p is then the identity: the term contributes nothing
+  if constexpr (PREPARED) prepared_load(p, points + t * (size_t)PREP_WORDS);
+  else {
+    u32 pw[8];
+    ld8(pw, points + t * 8);
+    if (!ristretto_decode(p, pw) && live) atomicAnd(P.all_ok, 0u);     // p is then the identity: the term contributes nothing
+  }
   if (live) {
     const fe d2 = EG_FE_2D;
     fe ypx, ymx, xy2d;

@@ -165,6 +165,18 @@ size_t eg_msm_scratch_bytes(eg_ctx*, size_t n, size_t terms);   /* by the contex
 int eg_vartime_multi_mul_batch_device(eg_ctx*, size_t n, size_t terms, const void* d_scalars, const void* d_points, const void* d_r,
                                       void* d_scratch, void* d_out, void* d_ok, void* stream);
 
+/* Prepared points.  In the reference an Element IS a decoded point, so Group::vartime_multi_mul (ristretto.rs:139-145) never pays a
+ * decoding per product; the entry above, which takes 32-byte encodings, does - 285 field operations per term, a third of the bucket
+ * method's time.  A caller that multiplies over one point set repeatedly decodes it once: eg_points_prepare_device writes
+ * eg_prepared_point_size() (= 96) bytes per point - affine (x, y, xy), an opaque layout that is valid for this library build only, never
+ * a wire format - and d_ok[i] = 1 if encoding i decodes (an encoding that does not is prepared as the IDENTITY: it contributes nothing to a
+ * product, and the prepare call is the only place that says so; d_ok may be NULL).  eg_vartime_multi_mul_prepared_batch_device is
+ * eg_vartime_multi_mul_batch_device over such points (terms per problem x n problems, 96 bytes each, same scratch, same paths). */
+size_t eg_prepared_point_size(void);
+int eg_points_prepare_device(eg_ctx*, size_t n, const void* d_encodings, void* d_prepared, void* d_ok, void* stream);
+int eg_vartime_multi_mul_prepared_batch_device(eg_ctx*, size_t n, size_t terms, const void* d_scalars, const void* d_prepared, const void* d_r,
+                                               void* d_scratch, void* d_out, void* stream);
+
 /* ---- tally stage (examples/voting.rs:122-177) -------------------------------------------------------------------------------
  * Params::combine_shares (src/sharing/mod.rs:302-325, lagrange_coefficients :139-170): combines the FIRST `threshold` of the n given
  * decryption shares (zero-based participant indexes, dh elements of 32 bytes; verify them first: eg_share_params_create) into the

@@ -120,6 +120,24 @@ def test_scalar_multiplication(grp, oracle):
     assert ok == b"\0"
 
 
+def _check_prepared_points(eg, ctx, grp, m, terms, ds, dp, dr, want_out):
+    """eg_points_prepare_device + eg_vartime_multi_mul_prepared_batch_device (ristretto.rs:139-145 takes decoded Elements): the same
+    operands, decoded once into prepared points, give the same encodings as the entry that decodes per term."""
+    import torch
+
+    n_pts = m * terms
+    assert eg.prepared_point_size() == 96
+    prep = torch.zeros(n_pts * 96, dtype=torch.uint8, device="cuda")
+    pok = torch.zeros(n_pts, dtype=torch.uint8, device="cuda")
+    grp.prepare_points_device(n_pts, dp.data_ptr(), prep.data_ptr(), d_ok=pok.data_ptr())
+    do = torch.zeros(32 * m, dtype=torch.uint8, device="cuda")
+    scratch = torch.zeros(max(grp.msm_scratch_bytes(m, terms), 16), dtype=torch.uint8, device="cuda")
+    grp.vartime_multi_mul_prepared_device(m, terms, ds.data_ptr(), prep.data_ptr(), do.data_ptr(), d_r=dr.data_ptr(), d_scratch=scratch.data_ptr())
+    ctx.synchronize()
+    assert int(pok.min()) == 1
+    assert bytes(do.cpu().numpy()) == want_out, (m, terms)
+
+
 def test_multi_scalar_mul_any_size(eg, ctx, grp, oracle):
     """Group::vartime_multi_mul for every size class of the kernel (ristretto.rs:139-145; dalek: Straus / Pippenger): one chunk (<= 8
     terms on one doubling chain), several chunks reduced with wave shuffles (9, 16, 255, 256 terms) and one 65 536-term product;
@@ -163,6 +181,7 @@ def test_multi_scalar_mul_any_size(eg, ctx, grp, oracle):
             want = oracle.point_add(got[32 * i : 32 * i + 32], oracle.point_mul_generator(r[32 * i : 32 * i + 32]))
             assert out[32 * i : 32 * i + 32] == want, (terms, i)
         assert dok.cpu().tolist() == [1] * m
+        _check_prepared_points(eg, ctx, grp, m, terms, ds, dp, dr, out)
         if terms in (9, 256):          # one undecodable point in the last chunk of problem 1
             bad = bytearray(pb)
             bad[(1 * terms + terms - 1) * 32 : (1 * terms + terms) * 32] = b"\xff" * 32
@@ -1961,6 +1980,7 @@ def test_bucket_method_multi_scalar_mul(eg, ctx, grp, oracle, monkeypatch):
         for i in range(m):
             assert out[32 * i : 32 * i + 32] == oracle.point_add(got[32 * i : 32 * i + 32], oracle.point_mul_generator(r[32 * i : 32 * i + 32])), (terms, mode, i)
         assert dok.cpu().tolist() == [1] * m
+        _check_prepared_points(eg, ctx, grp, m, terms, ds, dp, dr, out)
         with pytest.raises(eg.EgError):          # the bucket path cannot run without its scratch
             grp.vartime_multi_mul_device(m, terms, ds.data_ptr(), dp.data_ptr(), do.data_ptr())
         if mode == "random" and m == 2:          # an undecodable point in problem 1: flagged, and it contributes the identity
@@ -1970,6 +1990,16 @@ def test_bucket_method_multi_scalar_mul(eg, ctx, grp, oracle, monkeypatch):
             assert list(ok2) == [1, 0] and out2[:32] == got[:32]
             rest_s = b"".join(scal[1][:77] + scal[1][78:]); rest_p = b"".join(pp[1][:77] + pp[1][78:])
             assert out2[32:] == oracle.point_multi_mul(rest_s, rest_p)
+            # prepared: the prepare call flags it and prepares the identity, so the product is the one without that term
+            dbad = torch.frombuffer(bytearray(bad), dtype=torch.uint8).cuda()
+            prep = torch.zeros(m * terms * 96, dtype=torch.uint8, device="cuda")
+            pok = torch.zeros(m * terms, dtype=torch.uint8, device="cuda")
+            grp.prepare_points_device(m * terms, dbad.data_ptr(), prep.data_ptr(), d_ok=pok.data_ptr())
+            grp.vartime_multi_mul_prepared_device(m, terms, ds.data_ptr(), prep.data_ptr(), do.data_ptr(), d_scratch=scratch.data_ptr())
+            ctx.synchronize()
+            flags = pok.cpu().tolist()
+            assert flags.count(0) == 1 and flags[terms + 77] == 0
+            assert bytes(do.cpu().numpy()) == out2
     # a size of the order of the default switch (2^20 terms): both paths must give the same encoding on the same operands
     terms = (1 << 17) + 12345
     g = torch.Generator(device="cpu").manual_seed(5)

@@ -19,6 +19,7 @@ grp_pts = grp.mul_generator(bytes(sc[:4096].cpu().numpy().tobytes()))
 base = torch.frombuffer(bytearray(grp_pts), dtype=torch.uint8).cuda()
 pts = base.repeat(big // 4096)
 out = torch.empty(32, dtype=torch.uint8, device="cuda")
+prep = torch.empty(big * 96, dtype=torch.uint8, device="cuda")
 import os
 sizes = [(n, "default") for n in (1 << 12, 1 << 14, 1 << 16, 1 << 17, 1 << 18, 1 << 19, 1 << 20, 1 << 21, 1 << 22)]
 sizes = [(n, mode) for n, _ in sizes for mode in (("straus", "buckets") if n >= 1 << 14 else ("straus",))]
@@ -36,4 +37,18 @@ for n, mode in sizes:
         grp.vartime_multi_mul_device(1, n, sc.data_ptr(), pts.data_ptr(), out.data_ptr(), 0, scratch.data_ptr())
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 5
-    print(f"{n:8d} terms  {mode:8s}: {dt * 1e3:8.3f} ms  ({n / dt / 1e6:7.1f} M terms/s)   result {bytes(out.cpu().numpy()).hex()[:16]}", flush=True)
+    first = bytes(out.cpu().numpy())
+    # the same product over PREPARED points (decoded once: eg_points_prepare_device)
+    t0 = time.perf_counter()
+    grp.prepare_points_device(n, pts.data_ptr(), prep.data_ptr()); torch.cuda.synchronize()
+    t_prep = time.perf_counter() - t0
+    for _ in range(2):
+        grp.vartime_multi_mul_prepared_device(1, n, sc.data_ptr(), prep.data_ptr(), out.data_ptr(), 0, scratch.data_ptr()); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        grp.vartime_multi_mul_prepared_device(1, n, sc.data_ptr(), prep.data_ptr(), out.data_ptr(), 0, scratch.data_ptr())
+    torch.cuda.synchronize()
+    dp = (time.perf_counter() - t0) / 5
+    same = bytes(out.cpu().numpy()) == first
+    print(f"{n:8d} terms  {mode:8s}: {dt * 1e3:8.3f} ms  ({n / dt / 1e6:7.1f} M terms/s)   prepared points: {dp * 1e3:8.3f} ms ({n / dp / 1e6:7.1f} M terms/s; "
+          f"prepare once {t_prep * 1e3:.3f} ms; same result: {same})   result {first.hex()[:16]}", flush=True)
