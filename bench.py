@@ -891,7 +891,7 @@ def main():
                                  "note": "eg_verify_*_json: JSON text in host memory -> status words; parse, upload and verify pipelined"}
         # the same text through the STREAMING entry (eg_verify_json_begin / _feed / _end): pieces of 64 MB and of 1 MB, no producer thread -
         # the calling thread cuts and packs a piece on the pool and pumps the GPU without waiting for it
-        stream = {}
+        piece_rates = {}
         jbase = ctypes.cast(ctypes.c_char_p(jtext), ctypes.c_void_p).value
         for label, piece in (("64MB", 64 << 20), ("1MB", 1 << 20)):
             best_s, ok = None, True
@@ -905,8 +905,8 @@ def main():
                 dt = time.perf_counter() - t0
                 best_s = dt if best_s is None else min(best_s, dt)
                 ok = ok and taken == jn and np.array_equal(np.frombuffer(sstatus, dtype=np.uint32), jarr)
-            stream[label] = {"value": jn / best_s, "ms": best_s * 1e3, "vs_value": jn / best_s / value, "verdicts_match_one_shot": bool(ok)}
-        out["json_stream"] = {"unit": "ballots/s", "objects": jn, "threads": cores, "pieces": stream,
+            piece_rates[label] = {"value": jn / best_s, "ms": best_s * 1e3, "vs_value": jn / best_s / value, "verdicts_match_one_shot": bool(ok)}
+        out["json_stream"] = {"unit": "ballots/s", "objects": jn, "threads": cores, "pieces": piece_rates,
                               "note": "eg_verify_json_begin / _feed / _end on the same text as json_inclusive, fed in pieces of the given size"}
         del jtext
         out["wire_ingest"] = {"value": n_obj / best, "unit": "ballots/s", "threads": cores, "json_bytes": len(text), "objects": n_obj,
