@@ -78,7 +78,11 @@ struct Knobs {
 static Knobs read_knobs() {
   Knobs k;
   auto num = [](const char* name, long long dflt) { const char* v = getenv(name); return v && *v ? strtoll(v, nullptr, 10) : dflt; };
-  { const long long t = num("EG_TEETH", 0); if (t == 5 || t == 6) k.teeth = (int)t; }
+  { const long long t = num("EG_TEETH", 0); if (t == 5 || t == 6) k.teeth = (int)t;
+#ifdef EG_TEETH7
+    if (t == 7) k.teeth = 7;
+#endif
+  }
   if (getenv("EG_STREAMS")) k.streams = num("EG_STREAMS", 2) >= 2 ? 2 : 1;
   k.chunk = (size_t)std::max<long long>(0, num("EG_CHUNK", 0));
   if (getenv("EG_RING_GROUP")) k.ring_group = (int)std::max<long long>(0, num("EG_RING_GROUP", 0));
@@ -540,7 +544,11 @@ static int ensure_big_tables(Engine* e, hipStream_t s) {
 }
 
 // the kernels that touch the per-ballot comb tables exist once per comb shape (template parameter T, ge25519.cuh: Teeth<T>)
+#ifdef EG_TEETH7      // measurement builds only (tools/build_variant.sh teeth7 -DEG_TEETH7): the 7 x 37 comb (64 entries, 8 KiB per table) as a third shape
+#define EG_WITH_TEETH(teeth, ...) do { if ((teeth) == 5) { constexpr int T = 5; __VA_ARGS__; } else if ((teeth) == 7) { constexpr int T = 7; __VA_ARGS__; } else { constexpr int T = 6; __VA_ARGS__; } } while (0)
+#else
 #define EG_WITH_TEETH(teeth, ...) do { if ((teeth) == 5) { constexpr int T = 5; __VA_ARGS__; } else { constexpr int T = 6; __VA_ARGS__; } } while (0)
+#endif
 
 // verify n ballots (device pointers), accumulating accepted ciphertexts into the running tally
 // flags (the streaming JSON entry points overlap consecutive calls on different control streams `s`):
@@ -884,6 +892,10 @@ int eg_init(int device, eg_ctx** out) {
                              EG_MULTI_GROUP * 9 * NT * (int)sizeof(u32)));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_eq_table<true, 6>), hipFuncAttributeMaxDynamicSharedMemorySize,
                              EG_MULTI_GROUP * 9 * NT * (int)sizeof(u32)));
+#ifdef EG_TEETH7
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_eq_table<true, 7>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             EG_MULTI_GROUP * 9 * NT * (int)sizeof(u32)));
+#endif
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_prim_msm<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                              MSM_CHUNK * 8 * NT * (int)sizeof(u32)));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_prim_msm<true>), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -80,6 +80,22 @@ extern "C" int hc_point_roundtrip(const uint8_t in[32], uint8_t out[32]) {
   return ok ? 1 : 0;
 }
 
+// the PREPARED form of a point (kernels.cuh: k_prim_points_prepare / prepared_load): decode, carry the three affine coordinates to class 1,
+// pack them to 3 x 256 bits, unpack, Z = 1, encode again - the limb-class preconditions of fe_pack8 / fe_unpack8 are asserted on the way
+extern "C" int hc_prepared_roundtrip(const uint8_t in[32], uint8_t out[32], uint8_t prepared[96]) {
+  u32 w[8], o[8]; words_from_bytes(w, in, 8);
+  ge p; const bool ok = ristretto_decode(p, w);
+  fe_carry(p.X); fe_carry(p.Y); fe_carry(p.T);
+  u32 pw[24];
+  fe_pack8(pw, p.X); fe_pack8(pw + 8, p.Y); fe_pack8(pw + 16, p.T);
+  bytes_from_words(prepared, pw, 24);
+  ge q;
+  fe_unpack8(q.X, pw); fe_unpack8(q.Y, pw + 8); fe_unpack8(q.T, pw + 16); fe_1(q.Z);
+  ristretto_encode(o, q);
+  bytes_from_words(out, o, 8);
+  return ok ? 1 : 0;
+}
+
 // out = enc([k]P + [r]G)   (Group::vartime_double_mul_generator)
 extern "C" int hc_double_mul_generator(const uint8_t k[32], const uint8_t p_enc[32], const uint8_t r[32], uint8_t out[32]) {
   if (!g_base_table.ready) { ge g; ge_generator(g); build_fixed(g_base_table, g); }

@@ -127,6 +127,15 @@ def test_ristretto_codec_and_group(hc, oracle):
         assert bool(ok) == (want is not None)
         if want is not None:
             assert out.raw == want
+    # prepared points (eg_points_prepare_device): the packed affine form round-trips, an undecodable encoding is prepared as the identity
+    import ctypes as C
+    for p in pts:
+        out, prep = _b(), C.create_string_buffer(96)
+        assert hc.hc_prepared_roundtrip(p, out, prep) == 1 and out.raw == p
+    for e in bad[:40]:
+        out, prep = _b(), C.create_string_buffer(96)
+        if not hc.hc_prepared_roundtrip(e, out, prep):
+            assert out.raw == b"\x00" * 32 and prep.raw == b"\x00" * 32 + b"\x01" + b"\x00" * 63
     for a, b in zip(pts[:20], pts[20:40]):
         out = _b()
         assert hc.hc_point_add(a, b, 0, out) == 1 and out.raw == oracle.point_add(a, b)

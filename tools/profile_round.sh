@@ -45,4 +45,12 @@ for w in single multi qv; do
   EG_STREAMS=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_serial_$w -o stats --output-format csv -- \
     python3 bench.py --steps 3 --warmup 1 --workload $w --no-cpu-baseline --no-host-inclusive --no-wire-ingest --no-isolated --no-extra-configs > gpurun_out/prof_serial_$w.log 2>&1 || exit 1
 done
+# round 5: the probes behind DESIGN's paragraphs on memory-side watts, the JSON stream, the multi-scalar multiplication by size, and the
+# in-process multi-GPU leg rehearsed with two contexts on this one GPU (its value means nothing: two engines time-share the chip)
+timeout -k 10 120 python3 tools/hbm_power_probe.py > gpurun_out/hbm_power_probe.txt 2>&1 || exit 1
+timeout -k 10 300 python3 tools/json_stream_probe.py > gpurun_out/json_stream_probe.txt 2>&1 || exit 1
+timeout -k 10 200 python3 tools/json_trace_probe.py > gpurun_out/json_trace.txt 2>&1 || exit 1
+timeout -k 10 300 python3 tools/msm_probe.py > gpurun_out/msm_by_size.txt 2>&1 || exit 1
+timeout -k 10 300 python3 bench.py --in-process-devices 2 --rehearse-one-gpu --steps 3 --warmup 1 --ballots 500000 > gpurun_out/bench_in_process2.json 2> gpurun_out/bench_in_process2.err || exit 1
+timeout -k 10 300 python3 bench.py --gpus 2 --rehearse-one-gpu --steps 3 --warmup 1 --ballots 500000 --no-isolated > gpurun_out/bench_bare2.json 2> gpurun_out/bench_bare2.err || exit 1
 echo "profile round done"

@@ -42,12 +42,24 @@ def kname(name):
 # ---- bench lines ---------------------------------------------------------------------------------------------------
 for src, dst in () if TRAFFIC_ONLY else (("bench_single.json", "bench_line.json"), ("bench_multi.json", "bench_line_multi16.json"), ("bench_qv.json", "bench_line_qv.json"),
                  ("bench_10M.json", "bench_line_10M.json"), ("bench_tampered1pct.json", "bench_line_tampered1pct.json"),
-                 ("bench_msm.json", "bench_line_msm.json")):
+                 ("bench_msm.json", "bench_line_msm.json"), ("bench_in_process2.json", "bench_line_in_process2_one_gpu.json"),
+                 ("bench_bare2.json", "bench_line_bare_gpus2_one_gpu.json")):
     f = OUT / src
     if f.exists() and f.read_text().strip():
         line = f.read_text().strip().splitlines()[-1]
         json.loads(line)
         (PROF / f"{tag}_{dst}").write_text(line + "\n")
+
+# ---- round 5 probes: copied as they are (the command that made each is its first line) ----------------------------------------
+for src, dst, head in () if TRAFFIC_ONLY else (
+        ("hbm_power_probe.txt", "hbm_power_probe.txt", "# python3 tools/hbm_power_probe.py   (MI355X; package power from hwmon while device-to-device copies stream)"),
+        ("json_stream_probe.txt", "json_stream_probe.txt", "# python3 tools/json_stream_probe.py   (MI355X, 16 host threads; 1 M single-choice ballots as 1.39 GB of JSON)"),
+        ("json_trace.txt", "json_stream_trace.txt", "# EG_JSON_TRACE=1 python3 tools/json_trace_probe.py   (MI355X; timeline of eg_verify_choice_json on 1 M ballots, three calls)"),
+        ("msm_by_size.txt", "msm_by_size.txt", "# python3 tools/msm_probe.py   (MI355X; one vartime_multi_mul, operands in HBM, Straus and bucket paths forced; encodings vs prepared points)")):
+    f = OUT / src
+    if f.exists() and f.read_text().strip():
+        body = "\n".join(l for l in f.read_text().splitlines() if "amdgpu.ids" not in l)
+        (PROF / f"{tag}_{dst}").write_text(head + "\n" + body + "\n")
 
 # ---- kernel stats --------------------------------------------------------------------------------------------------
 for w in () if TRAFFIC_ONLY else WORKLOADS:

@@ -38,10 +38,10 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == c:
                 v = float(r["Counter_Value"]); tot[c] += v; per[r["Kernel_Name"].split("(")[0][:60]][c] += v
-b = (2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024 / 1e6
+b = (2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024 / 1e9
 print(f"  memory side, one step of 1 M ballots: FETCH_SIZE x2 = {2*tot['FETCH_SIZE']*1024/1e9:.1f} GB, WRITE_SIZE = {tot['WRITE_SIZE']*1024/1e9:.1f} GB -> {b:.1f} KB per ballot")
 for k, v in sorted(per.items(), key=lambda kv: -(2 * kv[1]['FETCH_SIZE'] + kv[1]['WRITE_SIZE']))[:4]:
-    print(f"    {k}: {(2*v['FETCH_SIZE']+v['WRITE_SIZE'])*1024/1e6:.1f} KB per ballot (fetch x2 {2*v['FETCH_SIZE']*1024/1e6:.1f}, write {v['WRITE_SIZE']*1024/1e6:.1f})")
+    print(f"    {k}: {(2*v['FETCH_SIZE']+v['WRITE_SIZE'])*1024/1e9:.1f} KB per ballot (fetch x2 {2*v['FETCH_SIZE']*1024/1e9:.1f}, write {v['WRITE_SIZE']*1024/1e9:.1f})")
 PY
 done
 cat "$out"
