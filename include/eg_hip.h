@@ -380,7 +380,8 @@ size_t eg_qv_ballot_size_for(int n_options, uint64_t credits);   /* eg_qv_ballot
  *          way nothing of `text` is referenced after feed returns.  *n_objects (may be NULL): complete objects the worker has cut so
  *          far - it may lag behind the pieces fed.  An error of the text (not a sequence of objects) or of the GPU found in a copied
  *          piece is reported by a LATER feed or take, and at the latest by end.
- *   take   (optional; waits at most for the worker to finish the piece it is cutting, never for the GPU) sends what has been copied so
+ *   take   (optional; waits at most for the worker to finish the window of the piece it is cutting - which, while the staging ring is
+ *          full, includes the worker's own wait for the oldest submission - never for the GPU to drain) sends what has been copied so
  *          far to the worker, lets an idle GPU start on whatever is packed, and hands out, in order, the verdicts that are final so far: those of every ballot before the first one
  *          that is still on the GPU or whose shape is not the election's (such a ballot gets its OptionsLenMismatch / LenMismatch
  *          verdict from the object path, which runs at the end).
