@@ -570,8 +570,6 @@ class JsonStream:
 
     def end(self, with_tally: bool = True, cap: int | None = None):
         """Flushes the stream: (verdicts not yet taken, tally of the stream's ballots or None).  The stream is gone afterwards."""
-        import re
-
         cap = self.objects + 1024 if cap is None else cap
         tally = C.create_string_buffer(64 * self.params.n_options) if with_tally else None
         h, self._h = self._h, None
@@ -579,10 +577,9 @@ class JsonStream:
             st = (C.c_uint32 * max(cap, 1))()
             n, total = C.c_size_t(0), C.c_size_t(0)
             rc = _load().eg_verify_json_end(h, st, cap, C.byref(n), C.byref(total), tally)
-            m = re.search(rb"(\d+) are left", _load().eg_last_error()) if rc else None
-            if not m:
+            if not (rc and n.value > cap):
                 break
-            cap = int(m.group(1))              # the stream is still open (and flushed): the count it cut was ahead of what feed() had reported
+            cap = n.value                      # the stream is still open (and flushed): it had cut more objects than feed() had reported yet
         _check(rc)
         self.objects = total.value
         return list(st[: n.value]), (tally.raw if with_tally else None)
@@ -592,7 +589,10 @@ class JsonStream:
         n, total = C.c_size_t(0), C.c_size_t(0)
         tally = C.create_string_buffer(64 * self.params.n_options) if with_tally else None
         h, self._h = self._h, None
-        _check(_load().eg_verify_json_end(h, status, len(status), C.byref(n), C.byref(total), tally))
+        rc = _load().eg_verify_json_end(h, status, len(status), C.byref(n), C.byref(total), tally)
+        if rc and n.value > len(status):
+            self._h = h                        # no room for the n.value verdicts that are left: the stream is still open
+        _check(rc)
         self.objects = total.value
         return n.value, (tally.raw if with_tally else None)
 

@@ -2350,7 +2350,10 @@ int eg_verify_json_end(eg_json_stream* S, uint32_t* status, size_t cap, size_t* 
     return fail(rc, why);
   }
   const size_t left = S->verdicts.size() - S->taken;
-  if (left > cap) return fail(EG_ERR_BAD_ARG, "status holds " + std::to_string(cap) + " verdicts, " + std::to_string(left) + " are left: call again with room for them (or eg_verify_json_abort)");
+  if (left > cap) {            // the stream stays open (and flushed): *n_taken says how much room the caller must come back with
+    if (n_taken) *n_taken = left;
+    return fail(EG_ERR_BAD_ARG, "status holds " + std::to_string(cap) + " verdicts, " + std::to_string(left) + " are left: call again with room for them (or eg_verify_json_abort)");
+  }
   if (left) memcpy(status, S->verdicts.data() + S->taken, left * sizeof(uint32_t));
   if (n_taken) *n_taken = left;
   if (n_objects) *n_objects = S->verdicts.size();

@@ -5,7 +5,9 @@
 // compare with the EXPECTED totals the voters' choices add up to.  Threshold sharing of the key (examples/voting.rs:105-120) is out
 // of scope; a single key pair stands in for the shared key (tests/test_gpu_parity.py::test_threshold_tally_end_to_end
 // runs the 7-of-10 tally stage).  With --devices N the batch goes through the in-process multi-GPU entry
-// (eg_verify_*_batch_multi) over N contexts on the visible GPUs (all on GPU 0 when fewer are visible).
+// (eg_verify_*_batch_multi) over N contexts on the visible GPUs (all on GPU 0 when fewer are visible).  With --json the ballots travel
+// the way examples/voting.rs:195-198 prints them - serde_json text, ONE BALLOT AT A TIME - into the streaming entry
+// (JsonStream = eg_verify_choice_json_begin / eg_verify_json_feed / _end), which cuts, packs and verifies them as they arrive.
 //
 //   g++ -std=c++17 -Iinclude examples/voting.cpp -Lelastic_elgamal_amd -leg_hip -Wl,-rpath,$PWD/elastic_elgamal_amd -o voting
 #include <cstdio>
@@ -45,12 +47,37 @@ static bool tally(const Context& ctx, const Ristretto& group, const Scalar& sk, 
   return ok;
 }
 
+// serde's human-readable form of an EncryptedChoice (src/serde.rs:19-80: every element and scalar as unpadded base64url; field names of
+// choice.rs:276-280, ring.rs:282-287, log_equality.rs:96-101), from the packed ballot
+static std::string b64url(const uint8_t* p, size_t n) {
+  static const char* A = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789-_";
+  std::string out;
+  for (size_t i = 0; i < n; i += 3) {
+    const uint32_t v = (uint32_t)p[i] << 16 | (i + 1 < n ? (uint32_t)p[i + 1] << 8 : 0u) | (i + 2 < n ? (uint32_t)p[i + 2] : 0u);
+    out += A[v >> 18]; out += A[(v >> 12) & 63];
+    if (i + 1 < n) out += A[(v >> 6) & 63];
+    if (i + 2 < n) out += A[v & 63];
+  }
+  return out;
+}
+static std::string choice_to_json(const uint8_t* b, size_t options) {
+  auto item = [&](size_t k) { return "\"" + b64url(b + 32 * k, 32) + "\""; };
+  std::string s = "{\"choices\":[";
+  for (size_t k = 0; k < options; ++k)
+    s += std::string(k ? "," : "") + "{\"random_element\":" + item(2 * k) + ",\"blinded_element\":" + item(2 * k + 1) + "}";
+  s += "],\"range_proof\":{\"common_challenge\":" + item(2 * options) + ",\"ring_responses\":[";
+  for (size_t k = 0; k < 2 * options; ++k) s += std::string(k ? "," : "") + item(2 * options + 1 + k);
+  s += "]},\"sum_proof\":{\"challenge\":" + item(4 * options + 1) + ",\"response\":" + item(4 * options + 2) + "}}";
+  return s;
+}
+
 int main(int argc, char** argv) {
-  bool qv = false;
+  bool qv = false, json = false;
   int devices = 1;
   std::vector<std::string> pos;
   for (int i = 1; i < argc; ++i) {
     if (!strcmp(argv[i], "--qv")) qv = true;
+    else if (!strcmp(argv[i], "--json")) json = true;
     else if (!strcmp(argv[i], "--devices") && i + 1 < argc) devices = atoi(argv[++i]);
     else pos.push_back(argv[i]);
   }
@@ -88,7 +115,18 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < votes; ++i) if (i != forged) expected[choices[i]] += 1;
     std::vector<const ChoiceParams*> per;
     for (auto& p : params) per.push_back(p.get());
-    auto verdict = devices > 1 ? verify_batch_multi(per, ballots) : params[0]->verify_batch(ballots);   // encrypted.verify(&params)
+    BatchVerdict<ChoiceVerificationError> verdict;
+    if (json) {
+      // println!("{}", serde_json::to_string_pretty(&encrypted)) per voter (examples/voting.rs:195-198): every ballot is fed as it is made
+      JsonStream stream(*params[0], 4);
+      const size_t bs = params[0]->ballot_size();
+      for (size_t i = 0; i < votes; ++i) stream.feed(choice_to_json(ballots.data() + i * bs, options) + "\n");
+      std::vector<Ciphertext> totals;
+      for (uint32_t st : stream.finish(&totals)) verdict.results.push_back(choice_error_from_status(st));
+      verdict.totals = totals;
+      printf("(%zu ballots went through the JSON stream one at a time)\n", stream.objects());
+    } else
+      verdict = devices > 1 ? verify_batch_multi(per, ballots) : params[0]->verify_batch(ballots);   // encrypted.verify(&params)
     printf("%zu of %zu ballots verified\n", verdict.accepted(), votes);
     for (size_t i = 0; i < verdict.results.size(); ++i)
       if (verdict.results[i]) printf("  voter #%zu rejected: %s\n", i + 1, verdict.results[i]->to_string().c_str());

@@ -386,7 +386,8 @@ size_t eg_qv_ballot_size_for(int n_options, uint64_t credits);   /* eg_qv_ballot
  *          that is still on the GPU or whose shape is not the election's (such a ballot gets its OptionsLenMismatch / LenMismatch
  *          verdict from the object path, which runs at the end).
  *   end    waits for the GPU, resolves the ballots of another shape, writes the verdicts not yet taken (status: room for `cap`; if more
- *          are left the call fails with EG_ERR_BAD_ARG and the stream stays open: call again with room, or abort), *n_objects = objects
+ *          are left the call fails with EG_ERR_BAD_ARG, *n_taken = the number that is left, and the stream stays open: call again with
+ *          that much room, or abort), *n_objects = objects
  *          in the whole text, tally_out (may be NULL) = the tally of the STREAM's ballots; the params object's running tally has them
  *          added.  Destroys the stream - also when it reports an error of the text (not a sequence of objects, truncated) or of the GPU.
  *   abort  destroys the stream; the running tally is what it was before begin.  A failed feed leaves the stream dead: end returns the

@@ -332,17 +332,24 @@ class JsonStream {
   }
   // flushes: the status words not yet taken; totals = the tally of the stream's ballots (the running tally of the params has them added)
   std::vector<uint32_t> finish(std::vector<Ciphertext>* totals = nullptr) {
-    std::vector<uint32_t> st(objects_ + 1);
+    std::vector<uint32_t> st(objects_ + 1024);
     Bytes tally(64 * options_);
     size_t n = 0, total = 0;
-    eg_json_stream* s = s_;
-    s_ = nullptr;                  // eg_verify_json_end destroys the stream on success and on every error but "no room"
-    const int rc = eg_verify_json_end(s, st.data(), st.size(), &n, &total, tally.data());
-    if (rc != EG_OK) throw Error(rc, eg_last_error());
+    for (;;) {
+      const int rc = eg_verify_json_end(s_, st.data(), st.size(), &n, &total, tally.data());
+      if (rc == EG_OK) break;
+      if (rc == EG_ERR_BAD_ARG && n > st.size()) { st.resize(n); continue; }     // more verdicts than feed() had reported yet: the stream is still open
+      const std::string why = eg_last_error();
+      s_ = nullptr;                // every other error: the library has destroyed the stream
+      throw Error(rc, why);
+    }
+    s_ = nullptr;
     st.resize(n);
+    objects_ = total;
     if (totals) *totals = unpack_totals(tally);
     return st;
   }
+  size_t objects() const { return objects_; }
  private:
   eg_json_stream* s_ = nullptr;
   size_t options_, objects_ = 0;

@@ -583,6 +583,12 @@ def test_cpp_voting_example(tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     assert "149 of 150 quadratic-voting ballots verified" in out.stdout and "voter #4 rejected" in out.stdout
     assert "OK: the decrypted totals equal the expected ones" in out.stdout
+    # the ballots as serde_json text, one ballot at a time, through the C++ mirror of the streaming entry (examples/voting.rs:195-198)
+    out = subprocess.run([str(exe), "--json", "700", "5", "9"], capture_output=True, text=True, timeout=180)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "(700 ballots went through the JSON stream one at a time)" in out.stdout
+    assert "699 of 700 ballots verified" in out.stdout and "voter #4 rejected" in out.stdout
+    assert "OK: the decrypted totals equal the expected ones" in out.stdout
     # the same elections through the in-process multi-GPU entry (two contexts; both on GPU 0 when the box has one GPU)
     for args in (["--devices", "2", "300", "5", "3"], ["--qv", "--devices", "2", "120", "3", "10", "5"]):
         out = subprocess.run([str(exe)] + args, capture_output=True, text=True, timeout=240)
