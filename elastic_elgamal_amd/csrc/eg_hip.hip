@@ -261,6 +261,7 @@ struct Engine {
   size_t json_ring_ballots = 0;
   hipStream_t json_ctl[2] = {nullptr, nullptr};   // control streams of consecutive windows (fork / join of a window's chunks)
   struct eg_json_stream* stream_open = nullptr;   // the JSON stream (eg_verify_json_begin ... _end) that owns this engine's work sets, ring and tally just now
+  std::mutex json_call_mu;                        // one-shot JSON calls on one params object run one after the other (they do not hold the context's lock)
   // staging for the host-pointer API
   hipStream_t copy_stream = nullptr;
   unsigned char* d_wire = nullptr;
@@ -818,6 +819,21 @@ static int refuse_if_streaming(const Engine* e) {
   return e->stream_open ? fail(EG_ERR_BAD_ARG, "a JSON stream is open on this params object (eg_verify_json_end or _abort it first)") : EG_OK;
 }
 void eg_verify_json_abort(struct eg_json_stream* S);
+static bool stream_is_one_shot(const struct eg_json_stream* S);
+// A one-shot JSON call (eg_verify_*_json) does not hold the context's lock for its length - its worker thread takes it piece by piece - but
+// it is still ONE call on the params object as far as other threads are concerned: their calls on that object wait for it, as they would
+// for any other entry point (the call holds the engine's json_call_mu from start to end; the waiter drops the context's lock, queues on
+// that mutex, takes the lock again and looks again).  An explicitly opened stream is the caller's own doing: calls are refused.
+// (lk_ is the unique_lock of EG_LOCK / EG_LOCK_P in the calling entry point.)
+#define EG_WAIT_JSON(e)                                                                          \
+  do {                                                                                           \
+    while ((e)->stream_open && stream_is_one_shot((e)->stream_open)) {                           \
+      lk_.unlock();                                                                              \
+      { std::lock_guard<std::mutex> wait_((e)->json_call_mu); }                                  \
+      lk_.lock();                                                                                \
+    }                                                                                            \
+    TRY(refuse_if_streaming(e));                                                                 \
+  } while (0)
 
 // The context is reference counted: the caller holds one reference (dropped by eg_destroy) and every params object
 // created on it holds another, so params may be destroyed after the context they were created on.
@@ -1431,12 +1447,12 @@ int eg_choice_params_create(eg_ctx* c, const uint8_t pk[32], int n_options, int 
 void eg_choice_params_destroy(eg_choice_params* p) { params_destroy(p); }
 int eg_verify_choice_batch(eg_choice_params* p, size_t n, const uint8_t* ballots, uint32_t* status, uint8_t* tally_out) { EG_LOCK_P(p);
   if (!p || (n && (!ballots || !status))) return fail(EG_ERR_BAD_ARG, "bad argument");
-  TRY(refuse_if_streaming(p->eng));
+  EG_WAIT_JSON(p->eng);
   return engine_verify_host(p->eng, n, ballots, status, tally_out);
 }
 int eg_verify_choice_batch_device(eg_choice_params* p, size_t n, const void* d_ballots, void* d_status, void* stream) { EG_LOCK_P(p);
   if (!p || (n && (!d_ballots || !d_status))) return fail(EG_ERR_BAD_ARG, "bad argument");
-  TRY(refuse_if_streaming(p->eng));
+  EG_WAIT_JSON(p->eng);
   HIPCHK(hipSetDevice(p->eng->ctx->device));
   return engine_verify_device(p->eng, n, d_ballots, d_status, (hipStream_t)stream);
 }
@@ -1454,12 +1470,12 @@ static int tally_encode_device(Engine* e, void* d_out, hipStream_t s) {
 }
 int eg_choice_tally_encode_device(eg_choice_params* p, void* d_out, void* stream) { EG_LOCK_P(p);
   if (!p || !d_out) return fail(EG_ERR_BAD_ARG, "bad argument");
-  TRY(refuse_if_streaming(p->eng));
+  EG_WAIT_JSON(p->eng);
   return tally_encode_device(p->eng, d_out, (hipStream_t)stream);
 }
 int eg_qv_tally_encode_device(eg_qv_params* p, void* d_out, void* stream) { EG_LOCK_P(p);
   if (!p || !d_out) return fail(EG_ERR_BAD_ARG, "bad argument");
-  TRY(refuse_if_streaming(p->eng));
+  EG_WAIT_JSON(p->eng);
   return tally_encode_device(p->eng, d_out, (hipStream_t)stream);
 }
 int eg_points_sum_device(eg_ctx* c, int n_ranks, int n_points, const void* d_in, void* d_out, void* d_bad, void* stream) { EG_LOCK(c);
@@ -1481,21 +1497,21 @@ static int prepare_wide(Engine* e) {
 }
 int eg_choice_prepare_wide_tables(eg_choice_params* p) { EG_LOCK_P(p); return p ? prepare_wide(p->eng) : fail(EG_ERR_BAD_ARG, "null"); }
 int eg_qv_prepare_wide_tables(eg_qv_params* p) { EG_LOCK_P(p); return p ? prepare_wide(p->eng) : fail(EG_ERR_BAD_ARG, "null"); }
-int eg_choice_tally_reset(eg_choice_params* p) { EG_LOCK_P(p); if (!p) return fail(EG_ERR_BAD_ARG, "null"); TRY(refuse_if_streaming(p->eng)); return tally_reset(p->eng, p->eng->ctx->stream, true); }
-int eg_choice_tally_reset_async(eg_choice_params* p, void* stream) { EG_LOCK_P(p); if (!p) return fail(EG_ERR_BAD_ARG, "null"); TRY(refuse_if_streaming(p->eng)); return tally_reset(p->eng, (hipStream_t)stream, false); }
+int eg_choice_tally_reset(eg_choice_params* p) { EG_LOCK_P(p); if (!p) return fail(EG_ERR_BAD_ARG, "null"); EG_WAIT_JSON(p->eng); return tally_reset(p->eng, p->eng->ctx->stream, true); }
+int eg_choice_tally_reset_async(eg_choice_params* p, void* stream) { EG_LOCK_P(p); if (!p) return fail(EG_ERR_BAD_ARG, "null"); EG_WAIT_JSON(p->eng); return tally_reset(p->eng, (hipStream_t)stream, false); }
 int eg_choice_tally_add(eg_choice_params* p, const uint8_t* in) { EG_LOCK_P(p);
   if (!p || !in) return fail(EG_ERR_BAD_ARG, "bad argument");
-  TRY(refuse_if_streaming(p->eng));
+  EG_WAIT_JSON(p->eng);
   return engine_tally_add(p->eng, in);
 }
 int eg_qv_tally_add(eg_qv_params* p, const uint8_t* in) { EG_LOCK_P(p);
   if (!p || !in) return fail(EG_ERR_BAD_ARG, "bad argument");
-  TRY(refuse_if_streaming(p->eng));
+  EG_WAIT_JSON(p->eng);
   return engine_tally_add(p->eng, in);
 }
 int eg_choice_tally_encode(eg_choice_params* p, uint8_t* out) { EG_LOCK_P(p);
   if (!p || !out) return fail(EG_ERR_BAD_ARG, "bad argument");
-  TRY(refuse_if_streaming(p->eng));
+  EG_WAIT_JSON(p->eng);
   return engine_tally_encode(p->eng, out);
 }
 
@@ -1512,20 +1528,20 @@ void eg_qv_params_destroy(eg_qv_params* p) { params_destroy(p); }
 size_t eg_qv_ballot_size(const eg_qv_params* p) { return p ? p->shape.ballot_size : 0; }
 int eg_verify_qv_batch(eg_qv_params* p, size_t n, const uint8_t* ballots, uint32_t* status, uint8_t* tally_out) { EG_LOCK_P(p);
   if (!p || (n && (!ballots || !status))) return fail(EG_ERR_BAD_ARG, "bad argument");
-  TRY(refuse_if_streaming(p->eng));
+  EG_WAIT_JSON(p->eng);
   return engine_verify_host(p->eng, n, ballots, status, tally_out);
 }
 int eg_verify_qv_batch_device(eg_qv_params* p, size_t n, const void* d_ballots, void* d_status, void* stream) { EG_LOCK_P(p);
   if (!p || (n && (!d_ballots || !d_status))) return fail(EG_ERR_BAD_ARG, "bad argument");
-  TRY(refuse_if_streaming(p->eng));
+  EG_WAIT_JSON(p->eng);
   HIPCHK(hipSetDevice(p->eng->ctx->device));
   return engine_verify_device(p->eng, n, d_ballots, d_status, (hipStream_t)stream);
 }
-int eg_qv_tally_reset(eg_qv_params* p) { EG_LOCK_P(p); if (!p) return fail(EG_ERR_BAD_ARG, "null"); TRY(refuse_if_streaming(p->eng)); return tally_reset(p->eng, p->eng->ctx->stream, true); }
-int eg_qv_tally_reset_async(eg_qv_params* p, void* stream) { EG_LOCK_P(p); if (!p) return fail(EG_ERR_BAD_ARG, "null"); TRY(refuse_if_streaming(p->eng)); return tally_reset(p->eng, (hipStream_t)stream, false); }
+int eg_qv_tally_reset(eg_qv_params* p) { EG_LOCK_P(p); if (!p) return fail(EG_ERR_BAD_ARG, "null"); EG_WAIT_JSON(p->eng); return tally_reset(p->eng, p->eng->ctx->stream, true); }
+int eg_qv_tally_reset_async(eg_qv_params* p, void* stream) { EG_LOCK_P(p); if (!p) return fail(EG_ERR_BAD_ARG, "null"); EG_WAIT_JSON(p->eng); return tally_reset(p->eng, (hipStream_t)stream, false); }
 int eg_qv_tally_encode(eg_qv_params* p, uint8_t* out) { EG_LOCK_P(p);
   if (!p || !out) return fail(EG_ERR_BAD_ARG, "bad argument");
-  TRY(refuse_if_streaming(p->eng));
+  EG_WAIT_JSON(p->eng);
   return engine_tally_encode(p->eng, out);
 }
 
@@ -1903,6 +1919,7 @@ static egwire::VerifyPackedFn make_verify_packed(Engine* e) {
 }
 struct eg_json_stream;
 static int stream_begin(Engine* e, int threads, PackPieceFn pack_piece, ReshapeFn reshape, size_t size_hint, eg_json_stream** out);
+static void stream_mark_one_shot(eg_json_stream* S);
 // The one-shot entry = the streaming entry fed with the whole text (in place, 64 MB at a time) - one pipeline for both (round 5; rounds 3-4
 // had a second one here, a producer thread and a consumer loop over the same ring).
 static int verify_json_common(Engine* e, const char* json, size_t json_len, int threads, size_t max_objects, uint32_t* status,
@@ -1910,10 +1927,12 @@ static int verify_json_common(Engine* e, const char* json, size_t json_len, int 
   if ((json_len && !json) || (max_objects && !status)) return fail(EG_ERR_BAD_ARG, "bad argument");
   if (n_objects) *n_objects = 0;
   eg_json_stream* S = nullptr;
+  std::lock_guard<std::mutex> one_at_a_time(e->json_call_mu);       // concurrent one-shot calls on one params object are serialised, as every entry point is
   {   // the context's lock only while the stream is opened: its worker thread takes the lock piece by piece, and so does end
     EG_LOCK(e->ctx);
-    if (e->stream_open) return fail(EG_ERR_BAD_ARG, "a JSON call is already running on this params object (one at a time: the work sets, the staging ring and the tally are its)");
+    if (e->stream_open) return fail(EG_ERR_BAD_ARG, "a JSON stream is open on this params object (eg_verify_json_end or _abort it first)");
     TRY(stream_begin(e, threads, pack_piece, reshape, json_len, &S));
+    stream_mark_one_shot(S);
   }
   const size_t piece = (size_t)64 << 20;
   for (size_t at = 0; at < json_len; at += piece) {
@@ -1995,6 +2014,7 @@ struct eg_json_stream {
   std::vector<size_t> odd_at;
   size_t landed = 0, taken = 0, n_submitted = 0;
   bool set_aside = false, flushed = false, trace = false;
+  bool one_shot = false;               // opened by eg_verify_*_json for the length of that call: other calls on the params object wait for it
   std::atomic<int> failed{EG_OK};      // set once (stream_fail), after err has been written
   std::string err;
   // Front end: the caller's pieces reach the worker thread through a short queue.  Pieces below `direct_min` are copied into blocks of
@@ -2016,6 +2036,8 @@ struct eg_json_stream {
   std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();      // EG_JSON_TRACE: the timeline on stderr, ms since begin
   double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
 };
+static void stream_mark_one_shot(eg_json_stream* S) { S->one_shot = true; }
+static bool stream_is_one_shot(const eg_json_stream* S) { return S->one_shot; }
 static int stream_fail(eg_json_stream* S, int code, const std::string& msg) {
   if (!S->failed.load(std::memory_order_acquire)) { S->err = msg; S->failed.store(code, std::memory_order_release); }
   return fail(S->failed.load(), S->err);
@@ -2376,6 +2398,11 @@ void eg_verify_json_abort(eg_json_stream* S) {
 }
 int eg_verify_choice_json_begin(eg_choice_params* p, int threads, eg_json_stream** out) { EG_LOCK_P(p);
   if (!p) return fail(EG_ERR_BAD_ARG, "bad argument");
+  while (p->eng->stream_open && stream_is_one_shot(p->eng->stream_open)) {      // a one-shot JSON call of another thread: wait for it (EG_WAIT_JSON)
+    lk_.unlock();
+    { std::lock_guard<std::mutex> wait_(p->eng->json_call_mu); }
+    lk_.lock();
+  }
   const int n_options = p->n_options, single = p->single;
   const size_t stride = p->eng->plan.stride;
   Engine* e = p->eng;
@@ -2389,6 +2416,11 @@ int eg_verify_choice_json_begin(eg_choice_params* p, int threads, eg_json_stream
 }
 int eg_verify_qv_json_begin(eg_qv_params* p, int threads, eg_json_stream** out) { EG_LOCK_P(p);
   if (!p) return fail(EG_ERR_BAD_ARG, "bad argument");
+  while (p->eng->stream_open && stream_is_one_shot(p->eng->stream_open)) {      // a one-shot JSON call of another thread: wait for it (EG_WAIT_JSON)
+    lk_.unlock();
+    { std::lock_guard<std::mutex> wait_(p->eng->json_call_mu); }
+    lk_.lock();
+  }
   const int n_options = p->n_options;
   const eghost::QvShape sh = p->shape;
   const egwire::RangeShape vote{sh.vote_range.rings.size(), (size_t)sh.vote_range.rings_size()};

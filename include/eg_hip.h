@@ -393,7 +393,9 @@ size_t eg_qv_ballot_size_for(int n_options, uint64_t credits);   /* eg_qv_ballot
  *   abort  destroys the stream; the running tally is what it was before begin.  A failed feed leaves the stream dead: end returns the
  *          same error and cleans up, with the running tally as it was.
  * Between begin and end / abort the params object belongs to the stream: every other verify / tally call on it fails with EG_ERR_BAD_ARG.
- * One stream per params object; several params objects (contexts, GPUs) may stream at the same time from different threads. */
+ * One stream per params object; several params objects (contexts, GPUs) may stream at the same time from different threads.
+ * (The one-shot entries eg_verify_*_json run on the same pipeline, but a one-shot call is ONE call like any other: while it runs, calls of
+ * other threads on the same params object - verify, tally, another one-shot, a begin - WAIT for it, they are not refused.) */
 typedef struct eg_json_stream eg_json_stream;
 int eg_verify_choice_json_begin(eg_choice_params*, int threads, eg_json_stream** out);
 int eg_verify_qv_json_begin(eg_qv_params*, int threads, eg_json_stream** out);

@@ -926,6 +926,35 @@ def test_concurrent_host_calls_are_serialised(eg, ctx, oracle, pk):
     for t in threads:
         t.join()
     assert not errors, errors
+    # a one-shot JSON call does not hold the context's lock for its length (its worker thread takes it piece by piece), yet it is ONE call on
+    # the params object for other threads: their verify / tally / JSON calls on the same object wait for it instead of being refused
+    import json
+    from elastic_elgamal_amd import serde
+    sz = op.ballot_size
+    text = json.dumps([serde.unpack_encrypted_choice(ballots[i * sz : (i + 1) * sz], 4, True) for i in range(40)] * 50)
+
+    def worker2(kind):
+        try:
+            for _ in range(5):
+                if kind == 0:
+                    assert p.verify_json(text)[0] == want * 50
+                elif kind == 1:
+                    assert p.verify_batch(ballots)[0] == want
+                elif kind == 2:
+                    assert len(p.tally_encode()) == 64 * 4
+                else:
+                    st = p.json_stream(threads=2)
+                    st.feed(text)
+                    assert st.end()[0] == want * 50
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker2, args=(k,)) for k in (0, 1, 2, 0, 1)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
 
 
 def test_large_election_chunks_follow_device_memory(eg, ctx, oracle, pk):
