@@ -300,14 +300,29 @@ __global__ void __launch_bounds__(NT, 2) k_pip_window(int c, PipBufs P, const ui
     }
     ge_add_full(t1, tot, run); tot = t1;
   }
-  // tot = sum (j - b0 + 1) S_j; the weights are j + 1: add [b0] run (b0 < 2^14, a multiple of PIP_SEG)
+  // tot = sum (j - b0 + 1) S_j; the weights are j + 1: add [b0] run (b0 < 2^14, a multiple of PIP_SEG).  tot is not needed while
+  // [b0] run is made: it waits in LDS (word-interleaved, 36 KB per block), which keeps the double-and-add below 256 registers
+  // without scratch (round 4: 256 VGPR + 20 B)
+  __shared__ u32 tot_park[PT_WORDS][NT];
+  {
+    u32 w[PT_WORDS];
+    ge_to_words(w, tot);
+#pragma unroll
+    for (int k = 0; k < PT_WORDS; ++k) tot_park[k][threadIdx.x] = w[k];
+  }
   ge m; ge_identity(m);
 #pragma unroll 1
   for (int bit = 13; bit >= 0; --bit) {
     ge d; ge_dbl_full(d, m); m = d;
     if ((b0 >> bit) & 1) { ge t1; ge_add_full(t1, m, run); m = t1; }
   }
-  { ge t1; ge_add_full(t1, tot, m); tot = t1; }
+  {
+    u32 w[PT_WORDS];
+#pragma unroll
+    for (int k = 0; k < PT_WORDS; ++k) w[k] = tot_park[k][threadIdx.x];
+    words_to_ge(tot, w);
+    ge t1; ge_add_full(t1, tot, m); tot = t1;
+  }
   wave_reduce_points(tot);                        // the 64 segments of a wavefront belong to one window (segs is a multiple of 64)
   if ((threadIdx.x & 63) == 0) {
     if (c * w > 0) {                              // times 2^(c w): doublings without T until the last one
