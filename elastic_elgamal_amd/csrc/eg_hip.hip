@@ -255,6 +255,8 @@ struct Engine {
   u32* tally = nullptr;        // [2n][PT_WORDS] running tally (extended points) = set[0].tally
   u32* tally_saved = nullptr;  // [2n][PT_WORDS] the running tally set aside while a host call computes its per-batch tally
   u32* tally_saved2 = nullptr; // the same for the JSON entry points, which call the host form piece by piece
+  u32* tally_saved3 = nullptr; // the running tally as a multi-GPU call found it (TallyRollback: put back if any slab fails)
+  u32* d_tally_enc = nullptr;  // [2n][8] device staging of engine_tally_encode (no allocation per call)
   uint8_t* json_ring = nullptr;        // pinned staging of the JSON entry points: a ring of packed ballots that the parser threads fill
   size_t json_ring_bytes = 0;          // window by window while earlier windows are uploaded and verified
   u32* json_status_ring = nullptr;     // pinned verdicts of the ballots in the ring
@@ -296,7 +298,7 @@ static void engine_free(Engine* e) {
   if (!e) return;
   void* ptrs[] = {e->d_pt_items, e->d_sc_items, e->d_dclasses, e->d_dterms, e->d_jobs, e->d_vterms, e->d_insts, e->d_ops,
                   e->d_rules, e->d_tally_slots, e->d_base_slots, e->d_sum_bases, e->d_sum_members, e->d_acc_sums, e->d_acc_members, e->d_defer_slots, e->d_blob, e->d_cpts, e->d_prefixes, e->d_key_words,
-                  e->tally_saved, e->tally_saved2, e->d_wire, e->d_status, e->gen_ws, e->d_gen_desc};
+                  e->tally_saved, e->tally_saved2, e->tally_saved3, e->d_tally_enc, e->d_wire, e->d_status, e->gen_ws, e->d_gen_desc};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& w : e->set) {
     void* sp[] = {w.pts, w.cmp, w.chal, w.states, w.flags, w.bad_item, w.btab, w.dpt, w.sacc, w.encw, w.partial, w.tally};
@@ -511,6 +513,8 @@ static int engine_create(eg_ctx* ctx, eghost::Plan&& plan, const uint8_t pk[32],
   e->tally = e->set[0].tally;
   HIPCHK(hipMalloc((void**)&e->tally_saved, tally_bytes));
   HIPCHK(hipMalloc((void**)&e->tally_saved2, tally_bytes));
+  HIPCHK(hipMalloc((void**)&e->tally_saved3, tally_bytes));
+  HIPCHK(hipMalloc((void**)&e->d_tally_enc, std::max<size_t>(P.tally_slots.size(), 1) * 32));
   HIPCHK(hipMalloc((void**)&e->d_prefixes, (size_t)std::max(P.n_prefixes, 1) * 52 * sizeof(u32)));
 
   // hoisted transcript prefixes: run the prefix programs once (a single lane each)
@@ -693,18 +697,18 @@ static int engine_verify_device(Engine* e, size_t n, const void* d_ballots, void
   return EG_OK;
 }
 
-static int engine_tally_encode(Engine* e, uint8_t* out) {
+// encodes a tally held in device memory (the running tally, or a snapshot of it) into host bytes
+static int engine_tally_encode_from(Engine* e, const u32* d_tally, uint8_t* out) {
   hipStream_t s = e->ctx->stream;
   HIPCHK(hipDeviceSynchronize());   // batches enqueued on caller streams by the _device entry points must have landed
   const int ns = (int)e->plan.tally_slots.size();
-  u32* d_out = nullptr;
-  HIPCHK(hipMalloc((void**)&d_out, (size_t)ns * 32));
-  hipLaunchKernelGGL(k_tally_encode, dim3(blocks_of((size_t)ns)), dim3(NT), 0, s, e->tally, ns, d_out);
-  HIPCHK(hipMemcpyAsync(out, d_out, (size_t)ns * 32, hipMemcpyDeviceToHost, s));
+  if (!ns) return EG_OK;
+  hipLaunchKernelGGL(k_tally_encode, dim3(blocks_of((size_t)ns)), dim3(NT), 0, s, d_tally, ns, e->d_tally_enc);
+  HIPCHK(hipMemcpyAsync(out, e->d_tally_enc, (size_t)ns * 32, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
-  (void)hipFree(d_out);
   return EG_OK;
 }
+static int engine_tally_encode(Engine* e, uint8_t* out) { return engine_tally_encode_from(e, e->tally, out); }
 
 // running tally += the points encoded in `in` (n_slots x 32 bytes): checkpoint / resume and merging of earlier batches
 static int engine_tally_add(Engine* e, const uint8_t* in) {
@@ -1595,23 +1599,39 @@ static void multi_run(int n_dev, std::vector<int>& rcs, std::vector<std::string>
 template <class Params>
 struct TallyRollback {
   Params* const* per_device; int n_dev; size_t bytes;
-  std::vector<std::vector<uint8_t>> saved;
+  // the running tallies before the call stay ON their devices (Engine::tally_saved3: a device-to-device copy of 2n points, no allocation,
+  // no encoding); encoded_before() encodes one of them when the caller asked for the tally of this call alone
   int save() {
-    saved.assign(n_dev, std::vector<uint8_t>(bytes));
     if (!bytes) return EG_OK;
-    for (int d = 0; d < n_dev; ++d) { std::lock_guard<std::recursive_mutex> g(per_device[d]->eng->ctx->mu); HIPCHK(hipSetDevice(per_device[d]->eng->ctx->device)); TRY(engine_tally_encode(per_device[d]->eng, saved[d].data())); }
+    for (int d = 0; d < n_dev; ++d) {
+      Engine* e = per_device[d]->eng;
+      std::lock_guard<std::recursive_mutex> g(e->ctx->mu);
+      HIPCHK(hipSetDevice(e->ctx->device));
+      HIPCHK(hipDeviceSynchronize());          // earlier _device calls on caller streams must have landed in the tally that is set aside
+      HIPCHK(hipMemcpyAsync(e->tally_saved3, e->tally, e->plan.tally_slots.size() * PT_WORDS * sizeof(u32), hipMemcpyDeviceToDevice, e->ctx->stream));
+      HIPCHK(hipStreamSynchronize(e->ctx->stream));
+    }
     return EG_OK;
+  }
+  int encoded_before(int d, uint8_t* out) {
+    Engine* e = per_device[d]->eng;
+    std::lock_guard<std::recursive_mutex> g(e->ctx->mu);
+    HIPCHK(hipSetDevice(e->ctx->device));
+    return engine_tally_encode_from(e, e->tally_saved3, out);
   }
   int restore() {
     if (!bytes) return EG_OK;
     int first = EG_OK;
     for (int d = 0; d < n_dev; ++d) {
-      std::lock_guard<std::recursive_mutex> g(per_device[d]->eng->ctx->mu);
       Engine* e = per_device[d]->eng;
-      int rc = hipSetDevice(e->ctx->device) == hipSuccess ? EG_OK : EG_ERR_HIP;
-      if (!rc) rc = tally_reset(e, e->ctx->stream, true);
-      if (!rc) rc = engine_tally_add(e, saved[d].data());
-      if (rc && !first) first = rc;
+      std::lock_guard<std::recursive_mutex> g(e->ctx->mu);
+      hipError_t he = hipSetDevice(e->ctx->device);
+      if (he == hipSuccess) he = hipDeviceSynchronize();
+      if (he == hipSuccess) he = hipMemcpyAsync(e->tally, e->tally_saved3, e->plan.tally_slots.size() * PT_WORDS * sizeof(u32), hipMemcpyDeviceToDevice, e->ctx->stream);
+      if (he == hipSuccess && e->n_sets == 2)        // a share of the failed call that set 1 still holds must not reach the tally later
+        hipLaunchKernelGGL(k_tally_init, dim3(blocks_of(e->plan.tally_slots.size())), dim3(NT), 0, e->ctx->stream, e->set[1].tally, (int)e->plan.tally_slots.size());
+      if (he == hipSuccess) he = hipStreamSynchronize(e->ctx->stream);
+      if (he != hipSuccess && !first) first = EG_ERR_HIP;
     }
     return first;
   }
@@ -1648,7 +1668,7 @@ static int verify_batch_multi(Params* const* per_device, int n_dev, size_t n, co
   std::vector<std::vector<uint8_t>> tallies(n_dev, std::vector<uint8_t>(tally_bytes));
   std::vector<int> rcs(n_dev, EG_OK);
   std::vector<std::string> errs(n_dev);
-  TallyRollback<Params> rb{per_device, n_dev, tally_bytes, {}};
+  TallyRollback<Params> rb{per_device, n_dev, tally_bytes};
   TRY(rb.save());
   multi_run(n_dev, rcs, errs, [&](int d) {
     const size_t b = n * (size_t)d / (size_t)n_dev, e = n * (size_t)(d + 1) / (size_t)n_dev;
@@ -1675,7 +1695,7 @@ static int verify_batch_multi_device(Params* const* per_device, int n_dev, const
   const size_t tally_bytes = (size_t)per_device[0]->eng->plan.tally_slots.size() * 32;
   std::vector<int> rcs(n_dev, EG_OK);
   std::vector<std::string> errs(n_dev);
-  TallyRollback<Params> rb{per_device, n_dev, tally_bytes, {}};
+  TallyRollback<Params> rb{per_device, n_dev, tally_bytes};
   TRY(rb.save());
   multi_run(n_dev, rcs, errs, [&](int d) {
     hipStream_t s = streams ? (hipStream_t)streams[d] : nullptr;
@@ -1687,12 +1707,13 @@ static int verify_batch_multi_device(Params* const* per_device, int n_dev, const
   if (tally_out && tally_bytes) {
     // the batch's own tally = (running tally after) - (running tally before), slab by slab, merged: all on 64 n_options bytes per device
     std::vector<std::vector<uint8_t>> tallies(n_dev, std::vector<uint8_t>(tally_bytes));
-    std::vector<uint8_t> ok(tally_bytes / 32);
+    std::vector<uint8_t> ok(tally_bytes / 32), before(tally_bytes);
     int rc = EG_OK;
     for (int d = 0; d < n_dev && !rc; ++d) {
       { std::lock_guard<std::recursive_mutex> g(per_device[d]->eng->ctx->mu);
         rc = hipSetDevice(per_device[d]->eng->ctx->device) == hipSuccess ? engine_tally_encode(per_device[d]->eng, tallies[d].data()) : fail(EG_ERR_HIP, "hipSetDevice"); }
-      if (!rc) rc = eg_point_add_batch(per_device[d]->eng->ctx, tally_bytes / 32, tallies[d].data(), rb.saved[d].data(), 1, tallies[d].data(), ok.data());
+      if (!rc) rc = rb.encoded_before(d, before.data());
+      if (!rc) rc = eg_point_add_batch(per_device[d]->eng->ctx, tally_bytes / 32, tallies[d].data(), before.data(), 1, tallies[d].data(), ok.data());
       if (!rc) for (uint8_t o : ok) if (!o) rc = fail(EG_ERR_HIP, "the tally of slab " + std::to_string(d) + " does not decode");
     }
     if (!rc) rc = multi_merge(per_device, n_dev, tallies, tally_bytes, tally_out);

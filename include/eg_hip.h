@@ -274,8 +274,8 @@ int eg_qv_tally_encode_device(eg_qv_params*, void* d_out, void* stream);
  * objects of different elections, fail the call).
  *
  * AFTER A FAILURE.  An error in any slab fails the whole call; eg_last_error names the slab.  Verdicts of other slabs may have been
- * written, but NO running tally has advanced: every multi verify call snapshots the running tallies before it starts (64 n_options
- * bytes per device) and puts them back when any slab, or the final merge, fails - the caller may simply retry the batch, or go on with
+ * written, but NO running tally has advanced: every multi verify call sets the running tallies aside before it starts (a
+ * device-to-device copy of 2 n_options points on each GPU) and puts them back when any slab, or the final merge, fails - the caller may simply retry the batch, or go on with
  * the next one, without resetting anything.  Only if putting them back fails as well (the device is gone) does the error text say
  * "could not be restored"; then reset every params object (eg_*_tally_reset) and re-import the last checkpoint (eg_*_tally_add).
  * Nothing thrown inside a slab's thread crosses the ABI: it becomes that slab's error. */
