@@ -65,6 +65,15 @@ def test_no_test_hooks_and_one_documented_list_of_knobs(lib_path):
     assert py_env == {"EG_LIB", "EG_NO_TORCH_PRELOAD"} and all(k in table for k in py_env), py_env
 
 
+def test_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: include/eg_hip.h must be valid C99 on its own (a cgo / JNI / ctypes binding includes it from C)."""
+    src = tmp_path / "c_check.c"
+    src.write_text('#include "eg_hip.h"\nint main(void) { return eg_prepared_point_size() == 96 ? 0 : 1; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", f"-I{ROOT / 'include'}", "-fsyntax-only", str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 def test_ballot_sizes_and_missing_gpu_is_loud(lib_path):
     import elastic_elgamal_amd as eg
 
