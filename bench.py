@@ -180,7 +180,18 @@ def parse():
                          "--rehearse-one-gpu the N contexts all sit on device 0.  A second scaling measurement beside the ranked path")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even for one rank: exercises the N > 1 code path on a 1-GPU box")
-    return ap.parse_args()
+    ap.add_argument("--spawn", action="store_true",
+                    help="started bare, launch the rank(s) as a child torch.distributed.run even for --gpus 1: the whole bare-launch path "
+                         "(count the GPUs without touching HIP, child launcher, rendezvous, RCCL init with --force-dist) on a 1-GPU box")
+    ap.add_argument("--from-host", action="store_true",
+                    help="with --in-process-devices: the whole batch sits in ONE pinned host buffer and goes through eg_verify_*_batch_multi "
+                         "(uploads inside the library, one host thread per GPU) - what a single-process host with its ballots in host memory "
+                         "gets, PCIe included; the line says so (config.input = host) and is never the headline")
+    ap.add_argument("--selfbench-seconds", type=float, default=2.0,
+                    help="length of the field-multiplication calibration run before the timed region (valu_roofline.box); 0 = skip")
+    args = ap.parse_args()
+    args.box_fmul_g = None           # set by the calibration run (valu_roofline.box); the extra configs quote their fractions against it
+    return args
 
 
 def cpu_model() -> str:
@@ -305,6 +316,26 @@ def bench_msm(args, ctx, eg, torch, dev, world):
     print(json.dumps(line))
 
 
+def oracle_sample_check(args, torch, p, b, st, m, bad, n_random=5000, n_bad=1000):
+    """Verdicts of a sample of the batch - up to n_bad of the tampered ballots and n_random drawn at random - through the CPU oracle, all
+    hardware threads; returns (sample size, tampered ones in it, verdicts identical).  After the timed steps; the checker, never the product."""
+    from oracle import oracle as o
+
+    pk = bytes.fromhex(PUBLIC_KEY_HEX)
+    op = o.QvParams(pk, p.n_options, args.credits) if p.kind_name == "qv" else o.ChoiceParams(pk, p.n_options, p.kind_name == "single")
+    g = torch.Generator(device="cpu").manual_seed(args.seed + 1)
+    idx = torch.randperm(m, generator=g)[: min(n_random, m)]
+    n_in = 0
+    if bad is not None and len(bad):
+        idx = torch.cat([bad[:n_bad].cpu(), idx])
+        n_in = min(n_bad, len(bad))
+    idx_d = idx.to(b.device)
+    sample = bytes(b.view(m, p.ballot_size)[idx_d].cpu().numpy())
+    want = op.verify_batch(sample, threads=effective_cores())
+    got = st[idx_d].cpu().tolist()
+    return len(idx), n_in, want == [x & 0xFFFFFFFF for x in got]
+
+
 def extra_configs(args, ctx, eg, torch, dev, pk, stream, steps: int = 10):
     """Short runs of the BASELINE configs that are not the headline - configs[3] multi-choice 3-of-16, configs[2] quadratic voting
     5 options / 20 credits, configs[4]'s 10 M single-choice batch on this one GPU, configs[1] with 1 % tampered ballots -
@@ -325,6 +356,7 @@ def extra_configs(args, ctx, eg, torch, dev, pk, stream, steps: int = 10):
             tl = torch.empty(64 * p.n_options, dtype=torch.uint8, device=dev)
             p.encrypt_batch_device(args.seed, 0, m, b.data_ptr(), stream=stream, **gen_kw)
             n_t = int(m * tampered / 100.0)
+            bad = None
             if n_t:
                 g = torch.Generator(device="cpu").manual_seed(args.seed)
                 bad = torch.randperm(m, generator=g)[:n_t].to(dev)
@@ -350,6 +382,11 @@ def extra_configs(args, ctx, eg, torch, dev, pk, stream, steps: int = 10):
                 desc = eg.plan_describe(p.kind_name, p.n_options, args.credits if p.kind_name == "qv" else 0)
                 fm, fs = plan_field_ops(desc, wide_combs=ctx.comb_table_bits()[1] != 0)
                 res[name]["fmul_equiv_frac_sustained"] = m * k / dt * (fm + SQ_WEIGHT * fs) / 1e9 / FMUL_SUSTAINED_G
+                if args.box_fmul_g:
+                    res[name]["fmul_equiv_frac_sustained_box"] = m * k / dt * (fm + SQ_WEIGHT * fs) / 1e9 / args.box_fmul_g
+            if not args.no_cpu_baseline:      # >= 5000 ballots of every leg through the oracle (the tampered leg: 1000 tampered ones among them)
+                cs, cb, same = oracle_sample_check(args, torch, p, b, st, m, bad)
+                res[name].update({"cpu_sample": cs, "cpu_sample_tampered": cb, "cpu_sample_verdicts_match": bool(same)})
             del b, st, tl
             p.close()
             torch.cuda.empty_cache()
@@ -365,10 +402,123 @@ def extra_configs(args, ctx, eg, torch, dev, pk, stream, steps: int = 10):
     return res
 
 
+def host_inclusive_leg(torch, params, ballots, status, B, resident_value, before_each=None, iters=3):
+    """PCIe-inclusive rate (first H2D byte to last status byte D2H): the rank's own batch from a pinned host buffer through the
+    host-pointer entry point (pipelined uploads, eg_verify_*_batch).  Reported beside `value`, never as it.  before_each: a barrier, so that
+    with several ranks every iteration starts on all of them at the same time (they share one host's memory and PCIe root)."""
+    host = torch.empty(ballots.shape, dtype=torch.uint8, pin_memory=True)
+    host.copy_(ballots)
+    host_status = torch.empty(B, dtype=torch.int32, pin_memory=True)
+    torch.cuda.synchronize()
+    times = []
+    for it in range(iters + 1):                      # the first call sizes the staging buffers
+        if before_each:
+            before_each()
+        t0 = time.perf_counter()
+        params.verify_batch_host_ptr(B, host.data_ptr(), host_status.data_ptr())
+        times.append(time.perf_counter() - t0)
+    hs = sum(times[1:]) / iters
+    return {"value": B / hs, "unit": "ballots/s", "ms": hs * 1e3, "iterations": iters, "pinned": True,
+            "bytes_h2d": B * params.ballot_size, "bytes_d2h": 4 * B,
+            "verdicts_match_device_path": bool(torch.equal(host_status, status.cpu())),
+            "vs_value": B / hs / resident_value}
+
+
+def ballots_as_json(args, eg, torch, params, ballots, B, n_opt, reps_for):
+    """The first min(B, 1000) ballots of the batch as JSON objects in serde's layout (src/serde.rs:19-80), and a text builder: text(reps) =
+    one JSON array holding those objects `reps` times."""
+    from elastic_elgamal_amd import ingest as eging, serde as egserde
+
+    distinct = min(B, 1000)
+    raw = bytes(ballots[: distinct * params.ballot_size].cpu().numpy())
+    if args.workload == "qv":
+        objs = [eging.unpack_qv_ballot(raw[i * params.ballot_size : (i + 1) * params.ballot_size], n_opt, args.credits) for i in range(distinct)]
+    else:
+        objs = [egserde.unpack_encrypted_choice(raw[i * params.ballot_size : (i + 1) * params.ballot_size], n_opt, args.workload == "single")
+                for i in range(distinct)]
+    one = [json.dumps(o) for o in objs]
+    return distinct, raw, one, (lambda reps: ("[" + ",".join(one * reps) + "]").encode())
+
+
+def json_inclusive_leg(args, eg, torch, params, ballots, status, B, n_opt, resident_value, threads, before_each=None, text=None, distinct=None):
+    """The whole wire path inside the library (eg_verify_*_json): JSON text in host memory -> status words, on as many objects as the
+    step has ballots (the first 1000 ballots repeated); host threads pack piece k+1 while the GPU verifies piece k."""
+    import ctypes
+    import numpy as np
+
+    if text is None:
+        distinct, _, _, build = ballots_as_json(args, eg, torch, params, ballots, B, n_opt, None)
+        text = build(max(1, B // distinct))
+    jreps = max(1, B // distinct)
+    jn = distinct * jreps
+    jstatus = (ctypes.c_uint32 * jn)()
+    json_s, jgot = None, 0
+    for _ in range(3):
+        if before_each:
+            before_each()
+        t0 = time.perf_counter()
+        jgot = params.verify_json_into(text, jstatus, threads)
+        dt = time.perf_counter() - t0
+        json_s = dt if json_s is None else min(json_s, dt)
+    jarr = np.frombuffer(jstatus, dtype=np.uint32)
+    first_status = status[:distinct].cpu().numpy().astype(np.uint32)
+    return {"value": jn / json_s, "unit": "ballots/s", "objects": jn, "json_bytes": len(text), "ms": json_s * 1e3,
+            "threads": threads, "vs_value": jn / json_s / resident_value,
+            "verdicts_match_device_path": bool(jgot == jn and np.array_equal(jarr.reshape(jreps, distinct), np.tile(first_status, (jreps, 1)))),
+            "note": "eg_verify_*_json: JSON text in host memory -> status words; parse, upload and verify pipelined"}, jarr
+
+
 def die(code: int, msg: str):
     """Loud, early end of this rank: message on stderr, non-zero exit (torch.distributed.run then ends the other ranks)."""
     print(f"bench.py rank {os.environ.get('RANK', '0')}: FATAL: {msg}", file=sys.stderr, flush=True)
     raise SystemExit(code)
+
+
+def count_gpus_without_hip(topology: str = "/sys/class/kfd/kfd/topology/nodes", env=None):
+    """GPUs a HIP process started from this environment would see, counted WITHOUT touching HIP: the KFD topology nodes with
+    simd_count > 0 (CPU nodes have 0), then ROCR_VISIBLE_DEVICES (indices into those, or GPU-<uuid> names) and HIP_VISIBLE_DEVICES /
+    CUDA_VISIBLE_DEVICES (indices into what ROCr left visible) applied the way the runtimes apply them: entries in order, the list ends at
+    the first one that is not a visible device.  None when the topology is not readable (no KFD in this container)."""
+    env = os.environ if env is None else env
+    gpus = []
+    try:
+        nodes = sorted(os.listdir(topology), key=lambda x: int(x) if x.isdigit() else 1 << 30)
+    except OSError:
+        return None
+    for node in nodes:
+        try:
+            props = dict(line.split(None, 1) for line in open(os.path.join(topology, node, "properties")).read().splitlines() if " " in line)
+        except OSError:
+            continue                      # a node this user may not read (another tenant's partition): not ours
+        if int(props.get("simd_count", "0")) > 0:
+            gpus.append(props.get("unique_id", "").strip())
+    n = len(gpus)
+    rocr = env.get("ROCR_VISIBLE_DEVICES")
+    if rocr is not None:
+        seen = 0
+        for tok in rocr.split(","):
+            tok = tok.strip()
+            if tok.upper().startswith("GPU-"):
+                ok = any(u and int(u) == int(tok[4:], 16) for u in gpus if u.isdigit())
+            else:
+                ok = tok.isdigit() and int(tok) < n
+            if not ok:
+                break
+            seen += 1
+        n = seen
+    for name in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = env.get(name)
+        if v is None:
+            continue
+        seen = 0
+        for tok in v.split(","):
+            tok = tok.strip()
+            if not (tok.isdigit() and int(tok) < n):
+                break
+            seen += 1
+        n = seen
+        break                             # HIP reads HIP_VISIBLE_DEVICES first and CUDA_VISIBLE_DEVICES only in its absence
+    return n
 
 
 def launch_ranks(args) -> int:
@@ -380,13 +530,17 @@ def launch_ranks(args) -> int:
     import socket
     import subprocess
 
+    # NOTHING before the spawn initialises HIP: this process imports neither torch nor the library, and the GPUs are counted from the
+    # KFD topology in sysfs (round 5 asked torch.cuda.device_count(), which on this ROCm build goes through amdsmi and falls back to
+    # hipGetDeviceCount - a runtime initialisation in the parent - when amdsmi fails).
     if not args.rehearse_one_gpu:
-        import torch                      # device_count() does not initialise the runtime
-        have = torch.cuda.device_count()
-        if have < args.gpus:
+        have = count_gpus_without_hip()
+        if have is not None and have < args.gpus:
             print(f"bench.py: FATAL: --gpus {args.gpus} but this node shows {have} GPU(s) (use --rehearse-one-gpu to time-share device 0 "
                   "over gloo)", file=sys.stderr, flush=True)
             return 2
+        if have is None:
+            print("bench.py: the KFD topology is not readable here: cannot count the GPUs before launching (the ranks will say)", file=sys.stderr, flush=True)
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -453,11 +607,27 @@ def bench_in_process(args):
     gen_s = time.time() - t0
     ptr_b, ptr_s, ptr_q = [x.data_ptr() for x in ballots], [x.data_ptr() for x in status], [x.cuda_stream for x in streams]
     merged = [None]
+    host = host_status = None
+    if args.from_host:
+        # the WHOLE batch in ONE pinned host buffer, slab after slab in ballot order (what examples/voting.rs:179-213 holds after reading its
+        # ballots): eg_verify_*_batch_multi cuts it into the same contiguous slabs and uploads each to its GPU inside the library
+        sz = params[0].ballot_size
+        host = torch.empty(max(total, 1) * sz, dtype=torch.uint8, pin_memory=True)
+        host_status = torch.empty(max(total, 1), dtype=torch.int32, pin_memory=True)
+        at = 0
+        for b, c in zip(ballots, counts):
+            host[at * sz : (at + c) * sz].copy_(b[: c * sz])
+            at += c
+        for dev_i in set(devs):
+            torch.cuda.synchronize(dev_i)
 
     def step():
         for p in params:
             p.tally_reset()
-        eg.verify_batch_multi_device(params, counts, ptr_b, ptr_s, ptr_q)
+        if args.from_host:
+            eg.verify_batch_multi_host_ptr(params, total, host.data_ptr(), host_status.data_ptr())
+        else:
+            eg.verify_batch_multi_device(params, counts, ptr_b, ptr_s, ptr_q)
         merged[0] = eg.tally_encode_multi(params)
 
     for _ in range(args.warmup):
@@ -471,7 +641,10 @@ def bench_in_process(args):
         torch.cuda.synchronize(dev_i)
     elapsed = time.perf_counter() - t0
     clock = sampler.stop()
-    accepted = sum(int((st[:c] == 0).sum().item()) for st, c in zip(status, counts))
+    if args.from_host:
+        accepted = int((host_status[:total] == 0).sum().item())
+    else:
+        accepted = sum(int((st[:c] == 0).sum().item()) for st, c in zip(status, counts))
     n_tampered = sum(int(c * args.tampered_percent / 100.0) for c in counts)
     # the merged tally is the sum of the per-GPU running tallies, each of which is the tally of its own slab: re-merge them with the
     # primitive tier one by one, and (one GPU's worth of work, untimed) let ONE engine verify every slab and compare its running tally
@@ -500,9 +673,18 @@ def bench_in_process(args):
                    "ballots_per_gpu": counts[0], "total_ballots": total, "options": n_opt, "ballot_bytes": params[0].ballot_size,
                    "seed": args.seed, "accepted": accepted, "tampered": n_tampered, "tally_exchange_ok": bool(tally_ok),
                    "tally_checked_against_one_engine": check_one_engine, "generator_s": round(gen_s, 3),
-                   "parallelism": f"in-process{N}" + ("-on-one-gpu" if args.rehearse_one_gpu else ""), "devices": devs},
+                   "parallelism": f"in-process{N}" + ("-on-one-gpu" if args.rehearse_one_gpu else ""), "devices": devs,
+                   "input": "host" if args.from_host else "hbm"},
         "clock": clock,
     }
+    if args.from_host:
+        out["config"]["workload"] = (f"{total} {args.workload} {n_opt}-option ballots in ONE pinned host buffer per step; eg_verify_*_batch_multi cuts it "
+                                     f"into {N} contiguous slabs, uploads and verifies each on its GPU (one host thread per GPU inside the library), "
+                                     "merges the tallies: PCIe-INCLUSIVE, not the headline metric")
+        out["host_inclusive"] = {"value": out["value"], "unit": "ballots/s", "bytes_h2d": total * params[0].ballot_size, "bytes_d2h": 4 * total,
+                                 "pinned": True, "h2d_gb_per_s": total * params[0].ballot_size * args.steps / elapsed / 1e9,
+                                 "note": "`value` of this line IS the PCIe-inclusive rate (first H2D byte to last status byte D2H, every step)"}
+    #JSON_MULTI_LEG#
     print(json.dumps(out), flush=True)
     if not tally_ok:
         raise SystemExit(5)
@@ -512,8 +694,8 @@ def main():
     args = parse()
     if args.in_process_devices:
         return bench_in_process(args)
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        raise SystemExit(launch_ranks(args))
+    if (args.gpus > 1 or args.spawn) and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))           # nothing above this line has imported torch or loaded the library: HIP is untouched
     import torch
     import torch.distributed as dist
 
@@ -598,13 +780,21 @@ def main():
     final_tally = torch.empty(64 * n_opt, dtype=torch.uint8, device=dev)
     bad_terms = torch.zeros(1, dtype=torch.int32, device=dev)   # gathered encodings that failed to decode (must stay 0)
 
-    def step():
+    # HIP events around the ONE exchange of a step (tally encode -> all-gather -> k_points_sum), on the stream all of it is enqueued on:
+    # a scaling point that comes out sub-linear can then be told apart (verification, exchange, or a slow rank: `per_rank`, `exchange`)
+    ex_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(max(args.steps, 1))]
+
+    def step(k=None):
         params.tally_reset(stream)
         params.verify_batch_device(B, ballots.data_ptr(), status.data_ptr(), stream)
+        if k is not None:
+            ex_ev[k][0].record()
         params.tally_encode_device(local_tally.data_ptr(), stream)
         gathered = egd.gather_tallies(local_tally)            # the ONE collective (RCCL all-gather, 64*n bytes/rank)
         ctx.points_sum_device(gathered.shape[0], 2 * n_opt, gathered.data_ptr(), final_tally.data_ptr(), stream,
                               d_bad=bad_terms.data_ptr())
+        if k is not None:
+            ex_ev[k][1].record()
 
     def barrier():
         torch.cuda.synchronize()
@@ -646,19 +836,39 @@ def main():
         barrier()
         import ctypes
         ctypes.CDLL(None).fflush(None)
+    # ---- the VALU roof of THIS box (every rank, at the same time: the GPUs of a node share its power budget and cooling), after the
+    # warm-up and outside the timed region: the shipped fe_mul in a bare chain for --selfbench-seconds (eg_selfbench_fmul)
+    dev_index = dev.index if dev.index is not None else 0
+    box = None
+    if args.selfbench_seconds > 0:
+        barrier()
+        bs = ClockSampler(torch, dev_index)
+        bs.start()
+        try:
+            box_g, box_mhz = ctx.selfbench_fmul(args.selfbench_seconds)
+            bc = bs.stop()
+            box = {"fmul_sustained_g": box_g, "sclk_mhz": box_mhz, "power_w": bc["power_w"] if bc else None,
+                   "sclk_mhz_hwmon": bc["sclk_mhz"] if bc else None, "seconds": args.selfbench_seconds, "waves_per_simd": 3,
+                   "source": "eg_selfbench_fmul: the shipped fe_mul in a bare dependent chain, launched back to back; rate and clock "
+                             "(s_memtime / s_memrealtime) over the second half of the run, on the GPU and in the process that runs the bench"}
+        except eg.EgError as e:             # a calibration must never cost the line
+            bs.stop()
+            box = {"error": repr(e)}
     ctx.profile_enable(True)
     ctx.profile_read()
     ctx.profile_read_tables()
-    sampler = ClockSampler(torch, dev.index if dev.index is not None else 0) if rank == 0 else None
+    sampler = ClockSampler(torch, dev_index)       # every rank samples its own GPU (`per_rank`); rank 0's is the line's `clock`
     barrier()
-    if sampler:
-        sampler.start()
+    sampler.start()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for k in range(args.steps):
+        step(k)
+    torch.cuda.synchronize()
+    own_elapsed = time.perf_counter() - t0            # this rank's own steps, before it waits for the others
     barrier()
     elapsed = time.perf_counter() - t0
-    clock = sampler.stop() if sampler else None
+    clock = sampler.stop()
+    exchange_ms = sum(a.elapsed_time(b) for a, b in ex_ev[: args.steps]) / max(args.steps, 1)
     msm_ms, msm_launches, all_ms = ctx.profile_read()
     tables_ms, tables_launches = ctx.profile_read_tables()
     # one more, untimed step with the chunks run one after the other on one work set: in the timed steps a launch shares the chip with the
@@ -678,6 +888,25 @@ def main():
     accepted_all = egd.sum_over_ranks(accepted, dev)
     value = total * args.steps / elapsed
     ms_per_step = elapsed / args.steps * 1e3
+
+    # ---- legs that EVERY rank runs at the same time when there are several (the scaling risk is host-side staging - N x 736 MB
+    # through one host's memory and PCIe root - not the 320-byte collective): the PCIe-inclusive rate of each rank's own slab from a pinned
+    # host buffer, and the JSON text of it through the native parser with the host's cores divided among the ranks
+    multi = world > 1
+    hi_all = js_all = None
+    if multi and not args.no_host_inclusive:
+        hi_all = host_inclusive_leg(torch, params, ballots, status, B, value / world, before_each=barrier)
+    if multi and not args.no_wire_ingest:
+        js_all, _ = json_inclusive_leg(args, eg, torch, params, ballots, status, B, n_opt, value / world,
+                                       threads=max(1, effective_cores() // world), before_each=barrier)
+    if multi or use_dist:
+        rows = egd.gather_rows([rank, dev_index, own_elapsed / args.steps * 1e3, clock["sclk_mhz"] if clock else 0.0,
+                                clock["power_w"] if clock else 0.0, accepted, exchange_ms * 1e3,
+                                (box or {}).get("fmul_sustained_g") or 0.0, (box or {}).get("sclk_mhz") or 0.0,
+                                hi_all["value"] if hi_all else 0.0, 1.0 if hi_all and hi_all["verdicts_match_device_path"] else 0.0,
+                                js_all["value"] if js_all else 0.0, 1.0 if js_all and js_all["verdicts_match_device_path"] else 0.0], dev)
+    else:
+        rows = None
 
     if rank != 0:
         if use_dist:
@@ -821,102 +1050,113 @@ def main():
     if clock:
         out["clock"] = clock
 
+    # ---- per-rank figures and the exchange of a step on its own (N > 1, or one rank with --force-dist) -----------------------------------
+    if rows is not None:
+        keys = ("rank", "device", "ms_per_step", "sclk_mhz", "power_w", "accepted", "exchange_us_per_step", "fmul_box_g", "fmul_box_sclk_mhz",
+                "host_inclusive_value", "host_inclusive_ok", "json_inclusive_value", "json_inclusive_ok")
+        out["per_rank"] = [{k: (int(v) if k in ("rank", "device", "accepted") else (bool(v) if k.endswith("_ok") else v))
+                            for k, v in zip(keys, r)} for r in rows]
+        out["exchange"] = {"us_per_step": max(r[6] for r in rows), "us_per_step_rank0": exchange_ms * 1e3,
+                           "bytes_per_rank": 64 * n_opt, "bytes_gathered_per_rank": 64 * n_opt * world,
+                           "share_of_step": max(r[6] for r in rows) / 1e3 / ms_per_step,
+                           "note": "HIP events on the step's stream around eg_*_tally_encode_device -> all-gather of the 64 n-byte tallies "
+                                   "(RCCL; gloo through host memory in a one-GPU rehearsal) -> eg_points_sum_device; max over ranks: it "
+                                   "includes the wait for the slowest rank to reach the collective"}
+        out["slowest_rank"] = max(out["per_rank"], key=lambda r: r["ms_per_step"])["rank"]
+    if box:
+        out["valu_roofline"]["box"] = box
+        if box.get("fmul_sustained_g"):
+            vr = out["valu_roofline"]
+            vr["fmul_equiv_frac_sustained_box"] = value / world * (vr["fe_mul_per_ballot"] + SQ_WEIGHT * vr["fe_sq_per_ballot"]) / 1e9 / box["fmul_sustained_g"]
+
     # ---- PCIe-inclusive rate (first H2D byte to last status byte D2H): the same batch from a pinned host buffer
     # through the host-pointer entry point (pipelined uploads, eg_verify_*_batch).  Reported beside `value`, never as it.
-    if not args.no_host_inclusive and world == 1:
-        host = torch.empty(ballots.shape, dtype=torch.uint8, pin_memory=True)
-        host.copy_(ballots)
-        host_status = torch.empty(B, dtype=torch.int32, pin_memory=True)
-        torch.cuda.synchronize()
-        iters, times = 3, []
-        for it in range(iters + 1):                      # the first call sizes the staging buffers
-            t0 = time.perf_counter()
-            params.verify_batch_host_ptr(B, host.data_ptr(), host_status.data_ptr())
-            times.append(time.perf_counter() - t0)
-        hs = sum(times[1:]) / iters
-        out["host_inclusive"] = {"value": B / hs, "unit": "ballots/s", "ms": hs * 1e3, "iterations": iters, "pinned": True,
-                                 "bytes_h2d": B * params.ballot_size, "bytes_d2h": 4 * B,
-                                 "verdicts_match_device_path": bool(torch.equal(host_status, status.cpu())),
-                                 "vs_value": B / hs / value}
+    if hi_all is not None:             # several ranks: every rank ran it on its own slab, all at the same time
+        out["host_inclusive"] = dict(hi_all)
+        vals = [r[9] for r in rows]
+        out["host_inclusive"]["all_ranks"] = {"sum_value": sum(vals), "min_value": min(vals), "max_value": max(vals), "ranks": world,
+                                              "verdicts_match_device_path": all(r[10] == 1.0 for r in rows), "vs_value": sum(vals) / value,
+                                              "note": "every rank verifies its own slab from its own pinned host buffer through eg_verify_*_batch, "
+                                                      "all ranks at the same time (a barrier before each iteration): the sum is the "
+                                                      "PCIe-inclusive rate of the node through ONE host"}
+    elif not args.no_host_inclusive and world == 1:
+        out["host_inclusive"] = host_inclusive_leg(torch, params, ballots, status, B, value)
+    if js_all is not None:
+        out["json_inclusive"] = dict(js_all)
+        vals = [r[11] for r in rows]
+        out["json_inclusive"]["all_ranks"] = {"sum_value": sum(vals), "min_value": min(vals), "max_value": max(vals), "ranks": world,
+                                              "threads_per_rank": js_all["threads"], "verdicts_match_device_path": all(r[12] == 1.0 for r in rows),
+                                              "vs_value": sum(vals) / value,
+                                              "note": "every rank parses and verifies the JSON text of its own slab (eg_verify_*_json) at the same "
+                                                      "time, the host's cores divided among the ranks"}
 
     # ---- wire ingest: the same ballots as JSON text in serde's layout through the native packer -------------
     if not args.no_wire_ingest and world == 1:
-        from elastic_elgamal_amd import ingest as eging, serde as egserde
+        from elastic_elgamal_amd import serde as egserde
+        import ctypes
+        import numpy as np
 
-        distinct = min(B, 1000)
-        raw = bytes(ballots[: distinct * params.ballot_size].cpu().numpy())
-        if args.workload == "qv":
-            objs = [eging.unpack_qv_ballot(raw[i * params.ballot_size : (i + 1) * params.ballot_size], n_opt, args.credits) for i in range(distinct)]
-        else:
-            objs = [egserde.unpack_encrypted_choice(raw[i * params.ballot_size : (i + 1) * params.ballot_size], n_opt, args.workload == "single")
-                    for i in range(distinct)]
-        one = [json.dumps(o) for o in objs]
+        distinct, raw, one, build = ballots_as_json(args, eg, torch, params, ballots, B, n_opt, None)
         reps = max(1, min(100, B // distinct))
-        text = ("[" + ",".join(one * reps) + "]").encode()
+        text = build(reps)
         n_obj = distinct * reps
         cores = effective_cores()
         kw = {"credits": args.credits} if args.workload == "qv" else {"single": args.workload == "single"}
-        native = eg.JsonPacker(n_opt, n_obj, threads=cores, **kw)       # caller-owned output buffers, reused: the C call is what is timed
-        best = None
-        for _ in range(4):
-            t0 = time.perf_counter()
-            got = native.pack(text)
-            dt = time.perf_counter() - t0
-            best = dt if best is None else min(best, dt)
+        by_threads = {}
+        best, got, native = None, 0, None
+        for th in sorted({t for t in (4, 8, 16, 32, 64) if t < cores} | {cores}):      # the packer by thread count, up to what the box grants
+            native = eg.JsonPacker(n_opt, n_obj, threads=th, **kw)   # caller-owned output buffers, reused: the C call is what is timed
+            b_th = None
+            for _ in range(4 if th == cores else 2):
+                t0 = time.perf_counter()
+                got = native.pack(text)
+                dt = time.perf_counter() - t0
+                b_th = dt if b_th is None else min(b_th, dt)
+            by_threads[str(th)] = n_obj / b_th
+            best = b_th                      # the last one is `cores`
         packed = native.packed.raw[: distinct * params.ballot_size]
         st = list(native.status[:got])
         t0 = time.perf_counter()
         packer = egserde.pack_qv_ballot if args.workload == "qv" else egserde.pack_encrypted_choice
         ref = b"".join(packer(o) for o in json.loads(text[: 1 + sum(len(x) + 1 for x in one) - 1].decode() + "]"))
         py_s = time.perf_counter() - t0
-        # the whole wire path inside the library: JSON text -> verdicts (host threads pack piece k+1 while the GPU verifies piece k),
-        # on as many objects as the step has ballots (the 1000 distinct ballots repeated)
-        import ctypes
         jreps = max(1, B // distinct)
-        jtext = text if jreps == reps else ("[" + ",".join(one * jreps) + "]").encode()
+        jtext = text if jreps == reps else build(jreps)
         jn = distinct * jreps
-        jstatus = (ctypes.c_uint32 * jn)()
-        json_s = None
-        for _ in range(3):
-            t0 = time.perf_counter()
-            jgot = params.verify_json_into(jtext, jstatus, cores)
-            dt = time.perf_counter() - t0
-            json_s = dt if json_s is None else min(json_s, dt)
-        import numpy as np
-        jarr = np.frombuffer(jstatus, dtype=np.uint32)
-        first_status = status[:distinct].cpu().numpy().astype(np.uint32)
-        out["json_inclusive"] = {"value": jn / json_s, "unit": "ballots/s", "objects": jn, "json_bytes": len(jtext), "ms": json_s * 1e3,
-                                 "threads": cores, "vs_value": jn / json_s / value,
-                                 "verdicts_match_device_path": bool(jgot == jn and np.array_equal(jarr.reshape(jreps, distinct), np.tile(first_status, (jreps, 1)))),
-                                 "note": "eg_verify_*_json: JSON text in host memory -> status words; parse, upload and verify pipelined"}
-        # the same text through the STREAMING entry (eg_verify_json_begin / _feed / _end): pieces of 64 MB and of 1 MB, no producer thread -
-        # the calling thread cuts and packs a piece on the pool and pumps the GPU without waiting for it
+        out["json_inclusive"], jarr = json_inclusive_leg(args, eg, torch, params, ballots, status, B, n_opt, value, threads=cores, text=jtext,
+                                                         distinct=distinct)
+        # the same text through the STREAMING entry (eg_verify_json_begin / _feed / _end): pieces of 64 MB (read in place), of 1 MB copied
+        # by feed on the caller's thread, and of 1 MB handed over without a copy (eg_verify_json_feed_owned)
         piece_rates = {}
         jbase = ctypes.cast(ctypes.c_char_p(jtext), ctypes.c_void_p).value
-        for label, piece in (("64MB", 64 << 20), ("1MB", 1 << 20)):
+        for label, piece, owned in (("64MB", 64 << 20, False), ("1MB", 1 << 20, False), ("1MB_owned", 1 << 20, True)):
             best_s, ok = None, True
             for _ in range(3):
                 sstatus = (ctypes.c_uint32 * jn)()
                 t0 = time.perf_counter()
                 js = params.json_stream(threads=cores)
                 for at in range(0, len(jtext), piece):
-                    js.feed_ptr(jbase + at, min(piece, len(jtext) - at))
+                    (js.feed_owned_ptr if owned else js.feed_ptr)(jbase + at, min(piece, len(jtext) - at))
                 taken, _ = js.end_into(sstatus)
                 dt = time.perf_counter() - t0
                 best_s = dt if best_s is None else min(best_s, dt)
                 ok = ok and taken == jn and np.array_equal(np.frombuffer(sstatus, dtype=np.uint32), jarr)
             piece_rates[label] = {"value": jn / best_s, "ms": best_s * 1e3, "vs_value": jn / best_s / value, "verdicts_match_one_shot": bool(ok)}
         out["json_stream"] = {"unit": "ballots/s", "objects": jn, "threads": cores, "pieces": piece_rates,
-                              "note": "eg_verify_json_begin / _feed / _end on the same text as json_inclusive, fed in pieces of the given size"}
+                              "note": "eg_verify_json_begin / _feed / _end on the same text as json_inclusive, fed in pieces of the given size; "
+                                      "1MB_owned: eg_verify_json_feed_owned (the library reads the caller's block in place and calls its "
+                                      "release function when the worker is through with it: no copy on the caller's thread)"}
         del jtext
         out["wire_ingest"] = {"value": n_obj / best, "unit": "ballots/s", "threads": cores, "json_bytes": len(text), "objects": n_obj,
                               "json_mb_per_s": len(text) / best / 1e6, "all_packed": st.count(0) == n_obj,
                               "equals_device_ballots": got == n_obj and packed == raw == ref,
+                              "by_threads": by_threads,
                               "python_mirror_value": distinct / py_s,
-                              "note": "JSON text (serde layout, base64url) -> packed bytes on the host, before the PCIe-inclusive path above"}
+                              "note": "JSON text (serde layout, base64url) -> packed bytes on the host, before the PCIe-inclusive path above; "
+                                      "by_threads: the same call with fewer parser threads (up to the hardware threads this process may use)"}
 
     # ---- CPU baseline: the oracle ("port": CPU restatement, not curve25519-dalek) on a bounded sample --------------
-    if not args.no_cpu_baseline and world == 1:
+    if not args.no_cpu_baseline:          # at every N, on rank 0 (the other ranks have nothing left to do: the host's cores are rank 0's)
         from oracle import oracle as o
 
         cores = effective_cores()
@@ -954,6 +1194,7 @@ def main():
         del ballots, status
         params.close()                         # frees the chunk workspace and the key's comb tables before the next election's are made
         torch.cuda.empty_cache()
+        args.box_fmul_g = (box or {}).get("fmul_sustained_g")
         out["extra"] = {"configs": extra_configs(args, ctx, eg, torch, dev, pk, stream),
                         "note": "10 timed steps each (3 for the 10 M batch; 1 warm-up), same process and GPU, after the headline measurement; value "
                                 "in ballots/s (msm: vartime_double_mul_generator operations/s); NOT part of `value`"}

@@ -84,6 +84,15 @@ def build(verbose: bool = False) -> Path:
 
 
 _lib = None
+_RELEASE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t)      # eg_json_release_fn
+_released_blocks = [0]
+
+
+def _count_release(user, text, length):        # the release function of feed_owned_ptr: the Python caller keeps its buffer alive itself
+    _released_blocks[0] += 1
+
+
+_COUNT_RELEASE = _RELEASE_FN(_count_release)
 
 
 def _load() -> C.CDLL:
@@ -123,7 +132,9 @@ def _load() -> C.CDLL:
         "eg_mul_generator_batch": (C.c_int, [vp, sz, cp, cp]),
         "eg_vartime_double_mul_generator_batch": (C.c_int, [vp, sz, cp, cp, cp, cp, cp]),
         "eg_vartime_multi_mul_batch": (C.c_int, [vp, sz, sz, cp, cp, cp, cp]),
-        "eg_msm_scratch_bytes": (sz, [vp, sz, sz]),
+        "eg_abi_version": (C.c_int, []),
+        "eg_msm_scratch_bytes_ctx": (sz, [vp, sz, sz]),
+        "eg_selfbench_fmul": (C.c_int, [vp, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "eg_choice_prepare_wide_tables": (C.c_int, [vp]),
         "eg_qv_prepare_wide_tables": (C.c_int, [vp]),
         "eg_combine_shares": (C.c_int, [vp, C.c_uint64, C.c_uint64, sz, C.POINTER(C.c_uint64), cp, cp, C.POINTER(C.c_int)]),
@@ -184,6 +195,7 @@ def _load() -> C.CDLL:
         "eg_verify_choice_json_begin": (C.c_int, [vp, C.c_int, C.POINTER(vp)]),
         "eg_verify_qv_json_begin": (C.c_int, [vp, C.c_int, C.POINTER(vp)]),
         "eg_verify_json_feed": (C.c_int, [vp, vp, sz, C.POINTER(sz)]),
+        "eg_verify_json_feed_owned": (C.c_int, [vp, vp, sz, _RELEASE_FN, vp, C.POINTER(sz)]),
         "eg_verify_json_take": (C.c_int, [vp, vp, sz, C.POINTER(sz)]),
         "eg_verify_json_end": (C.c_int, [vp, vp, sz, C.POINTER(sz), C.POINTER(sz), vp]),
         "eg_verify_json_abort": (None, [vp]),
@@ -201,11 +213,14 @@ def _load() -> C.CDLL:
         fn = getattr(lib, name)  # raises AttributeError if the ABI is incomplete
         fn.restype = res
         fn.argtypes = args
+    if "EG_LIB" not in os.environ and lib.eg_abi_version() != ABI_VERSION:
+        raise EgError(f"{_LIB} speaks ABI version {lib.eg_abi_version()}, this binding expects {ABI_VERSION}: rebuild it")
     _lib = lib
     return lib
 
 
 PACK_RESHAPE = 0xFFFFFFFE
+ABI_VERSION = 6          # include/eg_hip.h: EG_ABI_VERSION
 
 
 def pack_json(text, n_options: int, single: bool | None = None, credits: int | None = None, threads: int = 0, max_objects: int = 0):
@@ -365,6 +380,13 @@ class Context:
         return a.value, n.value
 
 
+    def selfbench_fmul(self, seconds: float = 2.0):
+        """(G field multiplications/s, shader clock MHz) of the shipped fe_mul in a bare chain sustained for `seconds` on this box
+        (eg_selfbench_fmul): the VALU roof bench.py quotes its fractions against."""
+        g, f = C.c_double(), C.c_double()
+        _check(_load().eg_selfbench_fmul(self._h, float(seconds), C.byref(g), C.byref(f)))
+        return g.value, f.value
+
     def comb_table_bits(self):
         """(window bits of the comb tables built at start-up, window bits of the wide tables or 0 while they do not exist)."""
         a, b = C.c_int(), C.c_int()
@@ -461,10 +483,12 @@ class Ristretto:
         return out.raw[: 32 * n], ok.raw[:n]
 
     def msm_scratch_bytes(self, n: int, terms: int) -> int:
-        return int(_load().eg_msm_scratch_bytes(self.ctx._h, n, terms))
+        return int(_load().eg_msm_scratch_bytes_ctx(self.ctx._h, n, terms))
 
-    def prepare_points_device(self, n: int, d_encodings: int, d_prepared: int, d_ok: int = 0, stream: int = 0):
-        """Decodes n elements once into prepared points (prepared_point_size() bytes each) for repeated products over them."""
+    def prepare_points_device(self, n: int, d_encodings: int, d_prepared: int, d_ok: int, stream: int = 0):
+        """Decodes n elements once into prepared points (prepared_point_size() bytes each, 16-byte aligned) for repeated products over
+        them.  d_ok (n bytes, device) is mandatory: an encoding that does not decode is prepared as the identity, and this is the only
+        place that says so."""
         _check(_load().eg_points_prepare_device(self.ctx._h, n, d_encodings, d_prepared, d_ok, stream))
 
     def vartime_multi_mul_prepared_device(self, n: int, terms: int, d_scalars: int, d_prepared: int, d_out: int, d_r: int = 0, d_scratch: int = 0,
@@ -500,6 +524,18 @@ def verify_batch_multi(per_device, ballots: bytes, with_tally: bool = True):
     fn = getattr(_load(), f"eg_verify_{p0._prefix}_batch_multi")
     _check(fn(arr, len(per_device), n, buf, st, tally))
     return list(st[:n]), (tally.raw if with_tally else None)
+
+
+def verify_batch_multi_host_ptr(per_device, n: int, ballots_ptr: int, status_ptr: int, with_tally: bool = False):
+    """``eg_verify_*_batch_multi`` on raw host addresses (e.g. ONE pinned torch tensor holding the whole batch): what a single-process
+    host with its ballots in host memory calls; no Python-side copies.  Returns the tally of this batch or None."""
+    per_device = list(per_device)
+    p0 = per_device[0]
+    arr = (C.c_void_p * len(per_device))(*[p._h for p in per_device])
+    tally = C.create_string_buffer(64 * p0.n_options) if with_tally else None
+    fn = getattr(_load(), f"eg_verify_{p0._prefix}_batch_multi")
+    _check(fn(arr, len(per_device), n, ballots_ptr, status_ptr, tally))
+    return tally.raw if with_tally else None
 
 
 def verify_batch_multi_device(per_device, counts, d_ballots, d_status, streams=None, with_tally: bool = False):
@@ -561,8 +597,18 @@ class JsonStream:
         self.objects = n.value
         return n.value
 
+    def feed_owned_ptr(self, ptr: int, length: int) -> int:
+        """``eg_verify_json_feed_owned``: the library reads the block at `ptr` in place - no copy on this thread, no wait for the worker -
+        until the stream has been ended or aborted; the CALLER keeps the memory alive until then (the release callback only counts)."""
+        n = C.c_size_t(0)
+        _check(_load().eg_verify_json_feed_owned(self._h, C.c_void_p(ptr), length, _COUNT_RELEASE, None, C.byref(n)))
+        self.objects = n.value
+        return n.value
+
     def take(self, cap: int = 1 << 20):
-        """Verdicts that are final so far (in order, from where the last take stopped); never blocks."""
+        """Verdicts that are final so far (in order, from where the last take stopped).  Never waits for the GPU to drain, but it does take
+        the context's lock: it may wait for the worker to finish the window of the piece it is cutting, which - while the staging ring is
+        full - includes the worker's own wait for the oldest submission (include/eg_hip.h, `take`)."""
         st = (C.c_uint32 * max(cap, 1))()
         n = C.c_size_t(0)
         _check(_load().eg_verify_json_take(self._h, st, cap, C.byref(n)))

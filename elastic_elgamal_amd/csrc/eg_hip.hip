@@ -51,6 +51,7 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
       return fail(EG_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_) + " (" + __FILE__ + ":" + std::to_string(__LINE__) + ")"); \
   } while (0)
 
+#define TRY_(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 // runs at scope exit, on every path (early returns of HIPCHK included)
 struct ScopeExit {
   std::function<void()> fn;
@@ -72,6 +73,7 @@ struct Knobs {
   size_t json_ring_kb = 0, json_window_kb = 0;   // EG_JSON_RING_KB, EG_JSON_WINDOW_KB   0 = 1 GiB ring, 96 MiB windows
   size_t json_growth = 150;         // EG_JSON_GROWTH      per cent
   size_t json_first_min = 0;        // EG_JSON_FIRST_MIN   0 = the stream's default (stream_begin)
+  size_t json_odd_max_mb = 256;     // EG_JSON_ODD_MAX_MB  text of wrong-shape ballots a JSON stream keeps for the object path
   bool json_trace = false;          // EG_JSON_TRACE
   bool allow_any_arch = false;      // EG_ALLOW_ANY_ARCH
 };
@@ -95,6 +97,7 @@ static Knobs read_knobs() {
   k.json_window_kb = (size_t)std::max<long long>(0, num("EG_JSON_WINDOW_KB", 0));
   k.json_growth = (size_t)std::max<long long>(0, num("EG_JSON_GROWTH", 150));
   k.json_first_min = (size_t)std::max<long long>(0, num("EG_JSON_FIRST_MIN", 0));
+  k.json_odd_max_mb = (size_t)std::max<long long>(1, num("EG_JSON_ODD_MAX_MB", 256));
   k.json_trace = getenv("EG_JSON_TRACE") != nullptr;
   k.allow_any_arch = getenv("EG_ALLOW_ANY_ARCH") != nullptr;
   return k;
@@ -126,6 +129,14 @@ struct eg_ctx {
   int resident_blocks = 0;   // blocks of the equation kernel that the chip holds at once (two per CU)
   int msm_blocks = 0;        // grid of the table / equation kernels: EG_GRID_OVERSUBSCRIBE x resident_blocks, each block striding over its share
   uint4* ws = nullptr;       // per-lane workspace of those kernels (msm_blocks * WS_QUADS * NT uint4)
+  // The workspace is shared by EVERY engine of the context and by the primitive tier, in two halves (work set k of an engine uses half k;
+  // a one-set call and k_prim_msm use both).  Calls are serialised on the host by `mu`, but their kernels are not: a JSON stream's
+  // submissions, `_device` calls on caller streams and the work sets' own streams all run asynchronously.  Every user therefore makes its
+  // stream wait for the last user of the halves it is about to write (ws_acquire) and leaves an event behind (ws_release): the GPU side
+  // is ordered without any host synchronisation, whatever stream, engine or thread the previous user was.
+  hipEvent_t ws_done[2] = {nullptr, nullptr};
+  hipStream_t ws_last[2] = {nullptr, nullptr};
+  bool ws_used[2] = {false, false};
   void* prim_scratch = nullptr;   // device scratch of the primitive tier, kept between calls and grown on demand (prim_bufs)
   size_t prim_scratch_bytes = 0;
   bool prof = false;
@@ -135,6 +146,18 @@ struct eg_ctx {
   double msm_ms = 0, all_ms = 0, tables_ms = 0;
   uint64_t msm_launches = 0, tables_launches = 0;
 };
+
+// see eg_ctx::ws_done.  halves: bit k = half k of the workspace.  Called under the context's lock.
+static int ws_acquire(eg_ctx* c, unsigned halves, hipStream_t s) {
+  for (int h = 0; h < 2; ++h)
+    if (((halves >> h) & 1u) && c->ws_used[h] && c->ws_last[h] != s) HIPCHK(hipStreamWaitEvent(s, c->ws_done[h], 0));
+  return EG_OK;
+}
+static int ws_release(eg_ctx* c, unsigned halves, hipStream_t s) {
+  for (int h = 0; h < 2; ++h)
+    if ((halves >> h) & 1u) { HIPCHK(hipEventRecord(c->ws_done[h], s)); c->ws_used[h] = true; c->ws_last[h] = s; }
+  return EG_OK;
+}
 
 static int prof_begin(eg_ctx* c, hipStream_t s, int kind, size_t* idx) {
   if (!c->prof) return EG_OK;
@@ -263,7 +286,17 @@ struct Engine {
   size_t json_ring_ballots = 0;
   hipStream_t json_ctl[2] = {nullptr, nullptr};   // control streams of consecutive windows (fork / join of a window's chunks)
   struct eg_json_stream* stream_open = nullptr;   // the JSON stream (eg_verify_json_begin ... _end) that owns this engine's work sets, ring and tally just now
-  std::mutex json_call_mu;                        // one-shot JSON calls on one params object run one after the other (they do not hold the context's lock)
+  // LONG calls - the ones that do not hold the context's lock from start to end: a one-shot JSON call (its worker thread takes the lock piece
+  // by piece) and a multi-GPU call (one host thread per slab) - hold this mutex for their whole length; every other entry point on the
+  // params object WAITS for them (EG_WAIT_LONG).  `reserved` marks the engine as held by a multi-GPU call (set and cleared under the
+  // context's lock): between the moment such a call sets the running tallies aside and its merge or roll-back, nobody else may verify, tally
+  // or open a stream on the object.
+  std::mutex long_call_mu;
+  bool reserved = false;
+  // the tail of the last asynchronous call that touched the running tally (engine_touch): what a later call on ANOTHER stream has to wait
+  // for instead of draining the whole device (TallyRollback)
+  hipEvent_t last_done = nullptr, saved_ev = nullptr;
+  bool last_used = false;
   // staging for the host-pointer API
   hipStream_t copy_stream = nullptr;
   unsigned char* d_wire = nullptr;
@@ -307,6 +340,8 @@ static void engine_free(Engine* e) {
     if (w.done) (void)hipEventDestroy(w.done);
   }
   if (e->fork) (void)hipEventDestroy(e->fork);
+  if (e->last_done) (void)hipEventDestroy(e->last_done);
+  if (e->saved_ev) (void)hipEventDestroy(e->saved_ev);
   comb_table_free(e->d_tabK); comb_table_free(e->d_tabK_big);
   if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
   if (e->json_ring) (void)hipHostFree(e->json_ring);
@@ -510,6 +545,8 @@ static int engine_create(eg_ctx* ctx, eghost::Plan&& plan, const uint8_t pk[32],
     }
   }
   if (e->n_sets > 1) HIPCHK(hipEventCreateWithFlags(&e->fork, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&e->last_done, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&e->saved_ev, hipEventDisableTiming));
   e->tally = e->set[0].tally;
   HIPCHK(hipMalloc((void**)&e->tally_saved, tally_bytes));
   HIPCHK(hipMalloc((void**)&e->tally_saved2, tally_bytes));
@@ -555,6 +592,12 @@ static int ensure_big_tables(Engine* e, hipStream_t s) {
 #define EG_WITH_TEETH(teeth, ...) do { if ((teeth) == 5) { constexpr int T = 5; __VA_ARGS__; } else { constexpr int T = 6; __VA_ARGS__; } } while (0)
 #endif
 
+// marks the end of an asynchronous call that touched the engine's running tally on stream s (Engine::last_done)
+static int engine_touch(Engine* e, hipStream_t s) {
+  HIPCHK(hipEventRecord(e->last_done, s));
+  e->last_used = true;
+  return EG_OK;
+}
 // verify n ballots (device pointers), accumulating accepted ciphertexts into the running tally
 // flags (the streaming JSON entry points overlap consecutive calls on different control streams `s`):
 //   VD_FORCE_SETS     always run on the work sets' own streams (never on `s` with set 0's buffers), whatever the size of the batch;
@@ -595,6 +638,7 @@ static int engine_verify_device(Engine* e, size_t n, const void* d_ballots, void
     joined = true;
     hipError_t first = hipSuccess;
     for (int k = 0; k < 2; ++k) {
+      if (ws_release(ctx, 1u << k, e->set[k].stream) != EG_OK && first == hipSuccess) first = hipErrorUnknown;   // the next user of this half waits for it
       hipError_t he = hipEventRecord(e->set[k].done, e->set[k].stream);
       if (he == hipSuccess) he = hipStreamWaitEvent(s, e->set[k].done, 0);
       if (he != hipSuccess && first == hipSuccess) first = he;
@@ -610,10 +654,18 @@ static int engine_verify_device(Engine* e, size_t n, const void* d_ballots, void
     if (!forked || joined) return;
     if (join() != hipSuccess) (void)hipDeviceSynchronize();     // the streams could not even be tied together: drain the device instead
   }};
+  bool whole_ws = false;       // a one-set call holds both halves of the context's per-lane workspace on `s` until it returns
+  ScopeExit release_ws{[&]() { if (whole_ws) (void)ws_release(ctx, 3u, s); }};
   if (two) {                 // fork: both work sets start after whatever the caller's stream holds so far
     HIPCHK(hipEventRecord(e->fork, s));
     forked = true;
-    for (int k = 0; k < 2; ++k) HIPCHK(hipStreamWaitEvent(e->set[k].stream, e->fork, 0));
+    for (int k = 0; k < 2; ++k) {
+      HIPCHK(hipStreamWaitEvent(e->set[k].stream, e->fork, 0));
+      TRY_(ws_acquire(ctx, 1u << k, e->set[k].stream));      // ... and after the last user of its half of the workspace, whoever that was
+    }
+  } else if (n) {
+    TRY_(ws_acquire(ctx, 3u, s));
+    whole_ws = true;
   }
   const bool inject_failure = two && EG_FAULT_POINT(after_fork);     // constant false in the shipped library (see EG_FAULT_POINT above)
   const int msm_blocks = ctx->msm_blocks / (two ? 2 : 1);
@@ -693,14 +745,16 @@ static int engine_verify_device(Engine* e, size_t n, const void* d_ballots, void
   }
   if (two) HIPCHK(join());
   if ((rc = prof_end(ctx, s, all_idx))) return rc;
+  if ((rc = engine_touch(e, s))) return rc;
   HIPCHK(hipGetLastError());
   return EG_OK;
 }
 
 // encodes a tally held in device memory (the running tally, or a snapshot of it) into host bytes
-static int engine_tally_encode_from(Engine* e, const u32* d_tally, uint8_t* out) {
+static int engine_tally_encode_from(Engine* e, const u32* d_tally, uint8_t* out, bool drain_device = true) {
   hipStream_t s = e->ctx->stream;
-  HIPCHK(hipDeviceSynchronize());   // batches enqueued on caller streams by the _device entry points must have landed
+  if (drain_device) HIPCHK(hipDeviceSynchronize());   // batches enqueued on caller streams by the _device entry points must have landed
+  else if (e->last_used) HIPCHK(hipStreamWaitEvent(s, e->last_done, 0));      // (a caller that knows its streams have been waited for: only the engine's last call)
   const int ns = (int)e->plan.tally_slots.size();
   if (!ns) return EG_OK;
   hipLaunchKernelGGL(k_tally_encode, dim3(blocks_of((size_t)ns)), dim3(NT), 0, s, d_tally, ns, e->d_tally_enc);
@@ -824,18 +878,23 @@ static int refuse_if_streaming(const Engine* e) {
 }
 void eg_verify_json_abort(struct eg_json_stream* S);
 static bool stream_is_one_shot(const struct eg_json_stream* S);
-// A one-shot JSON call (eg_verify_*_json) does not hold the context's lock for its length - its worker thread takes it piece by piece - but
-// it is still ONE call on the params object as far as other threads are concerned: their calls on that object wait for it, as they would
-// for any other entry point (the call holds the engine's json_call_mu from start to end; the waiter drops the context's lock, queues on
-// that mutex, takes the lock again and looks again).  An explicitly opened stream is the caller's own doing: calls are refused.
+// A LONG call (Engine::long_call_mu) - a one-shot JSON call (eg_verify_*_json: its worker thread takes the context's lock piece by piece) or a
+// multi-GPU call (eg_verify_*_batch_multi*: one host thread per slab) - does not hold the context's lock for its length, but it is still
+// ONE call on the params object as far as other threads are concerned: their calls on that object wait for it, as they would for any other
+// entry point (the long call holds the engine's long_call_mu from start to end; the waiter drops the context's lock, queues on that mutex,
+// takes the lock again and looks again).  An explicitly opened stream is the caller's own doing: calls are refused.
 // (lk_ is the unique_lock of EG_LOCK / EG_LOCK_P in the calling entry point.)
-#define EG_WAIT_JSON(e)                                                                          \
+#define EG_WAIT_LONG_ONLY(e)                                                                     \
   do {                                                                                           \
-    while ((e)->stream_open && stream_is_one_shot((e)->stream_open)) {                           \
+    while (((e)->stream_open && stream_is_one_shot((e)->stream_open)) || (e)->reserved) {        \
       lk_.unlock();                                                                              \
-      { std::lock_guard<std::mutex> wait_((e)->json_call_mu); }                                  \
+      { std::lock_guard<std::mutex> wait_((e)->long_call_mu); }                                  \
       lk_.lock();                                                                                \
     }                                                                                            \
+  } while (0)
+#define EG_WAIT_JSON(e)                                                                          \
+  do {                                                                                           \
+    EG_WAIT_LONG_ONLY(e);                                                                        \
     TRY(refuse_if_streaming(e));                                                                 \
   } while (0)
 
@@ -847,6 +906,7 @@ static void ctx_release(eg_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (auto& sp : c->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
   for (auto& ev : c->event_pool) (void)hipEventDestroy(ev);
+  for (hipEvent_t ev : c->ws_done) if (ev) (void)hipEventDestroy(ev);
   comb_table_free(c->tabG); comb_table_free(c->tabG_big);
   if (c->gen_words) (void)hipFree(c->gen_words);
   if (c->ws) (void)hipFree(c->ws);
@@ -879,6 +939,7 @@ static void params_destroy(Params* p) {
 extern "C" {
 
 const char* eg_last_error(void) { return g_err.c_str(); }
+int eg_abi_version(void) { return EG_ABI_VERSION; }
 
 int eg_init(int device, eg_ctx** out) {
   if (!out) return fail(EG_ERR_BAD_ARG, "out is null");
@@ -929,6 +990,7 @@ int eg_init(int device, eg_ctx** out) {
   per_cu = c->knobs.msm_blocks_per_cu;      // 32
   c->msm_blocks = per_cu * c->cus;
   HIPCHK(hipMalloc((void**)&c->ws, (size_t)c->msm_blocks * WS_QUADS * NT * sizeof(uint4)));
+  for (hipEvent_t& ev : c->ws_done) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(hipGetLastError());
   *out = c.release();
@@ -1282,10 +1344,12 @@ static int prim_msm_launch(eg_ctx* c, size_t n, size_t terms, const u32* d_scala
   const MsmScratch m = msm_scratch_at(d_scratch, n, (size_t)n_chunks);
   // every lane owns `chunk` tables in the per-lane workspace: the grid shrinks accordingly (the workspace is msm_blocks x one table)
   const int grid = grid_for(n * (size_t)n_chunks, std::max(1, c->msm_blocks / chunk));
+  TRY(ws_acquire(c, 3u, s));       // the lanes' tables live in the context's per-lane workspace, which engines with work in flight share
   if (prepared) hipLaunchKernelGGL(k_prim_msm<true>, dim3(grid), dim3(NT), (size_t)chunk * 8 * NT * sizeof(u32), s, n, (int)terms, chunk, n_chunks,
                                    d_scalars, d_points, d_r, c->tabG, c->ws, m.part[0], m.ok[0], d_out, d_ok);
   else hipLaunchKernelGGL(k_prim_msm<false>, dim3(grid), dim3(NT), (size_t)chunk * 8 * NT * sizeof(u32), s, n, (int)terms, chunk, n_chunks, d_scalars,
                           d_points, d_r, c->tabG, c->ws, m.part[0], m.ok[0], d_out, d_ok);
+  TRY(ws_release(c, 3u, s));
   if (n_chunks > 1) msm_fold_reduce(c, n, n_chunks, m, d_r, d_out, d_ok, s);
   HIPCHK(hipGetLastError());
   return EG_OK;
@@ -1323,14 +1387,14 @@ int eg_vartime_multi_mul_batch(eg_ctx* c, size_t n, size_t terms, const uint8_t*
   return prim_msm(c, n, terms, scalars, points, nullptr, out, ok);
 }
 // the same on DEVICE buffers, asynchronous on `stream` (a caller that keeps its operands in HBM pays no copies and no synchronisation;
-// what bench.py --workload msm times).  d_scratch must hold eg_msm_scratch_bytes(ctx, n, terms) bytes (0 for <= 8 terms).
-size_t eg_msm_scratch_bytes(eg_ctx* c, size_t n, size_t terms) { return c ? msm_scratch_for(c, n, terms) : 0; }
+// what bench.py --workload msm times).  d_scratch must hold eg_msm_scratch_bytes_ctx(ctx, n, terms) bytes (0 for <= 8 terms).
+size_t eg_msm_scratch_bytes_ctx(eg_ctx* c, size_t n, size_t terms) { return c ? msm_scratch_for(c, n, terms) : 0; }
 int eg_vartime_multi_mul_batch_device(eg_ctx* c, size_t n, size_t terms, const void* d_scalars, const void* d_points, const void* d_r,
                                       void* d_scratch, void* d_out, void* d_ok, void* stream) { EG_LOCK(c);
   if (!c || (n && !d_out) || (n && terms && (!d_scalars || !d_points)) || (n && !terms && !d_r)) return fail(EG_ERR_BAD_ARG, "bad argument");
   if (terms > ((size_t)1 << 24)) return fail(EG_ERR_BAD_ARG, "at most 2^24 terms per problem");
   const size_t need = msm_scratch_for(c, n, terms);
-  if (n && need && !d_scratch) return fail(EG_ERR_BAD_ARG, "this call is cut into several chunks per problem (or uses the bucket method) and needs d_scratch (eg_msm_scratch_bytes)");
+  if (n && need && !d_scratch) return fail(EG_ERR_BAD_ARG, "this call is cut into several chunks per problem (or uses the bucket method) and needs d_scratch (eg_msm_scratch_bytes_ctx)");
   if (n == 0) return EG_OK;
   HIPCHK(hipSetDevice(c->device));
   return prim_msm_launch(c, n, terms, (const u32*)d_scalars, (const u32*)d_points, (const u32*)d_r, need ? d_scratch : nullptr, (u32*)d_out,
@@ -1343,6 +1407,8 @@ int eg_vartime_multi_mul_batch_device(eg_ctx* c, size_t n, size_t terms, const v
 size_t eg_prepared_point_size(void) { return PREP_WORDS * sizeof(u32); }
 int eg_points_prepare_device(eg_ctx* c, size_t n, const void* d_encodings, void* d_prepared, void* d_ok, void* stream) { EG_LOCK(c);
   if (!c || (n && (!d_encodings || !d_prepared))) return fail(EG_ERR_BAD_ARG, "bad argument");
+  if (n && !d_ok) return fail(EG_ERR_BAD_ARG, "d_ok is mandatory: an encoding that does not decode is prepared as the identity, and this is the only place that says so");
+  if (reinterpret_cast<uintptr_t>(d_prepared) & 15u) return fail(EG_ERR_BAD_ARG, "d_prepared must be 16-byte aligned");
   if (n == 0) return EG_OK;
   hipLaunchKernelGGL(k_prim_points_prepare, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, n, (const u32*)d_encodings,
                      (u32*)d_prepared, (unsigned char*)d_ok);
@@ -1353,11 +1419,60 @@ int eg_vartime_multi_mul_prepared_batch_device(eg_ctx* c, size_t n, size_t terms
                                                void* d_scratch, void* d_out, void* stream) { EG_LOCK(c);
   if (!c || (n && !d_out) || (n && terms && (!d_scalars || !d_prepared)) || (n && !terms && !d_r)) return fail(EG_ERR_BAD_ARG, "bad argument");
   if (terms > ((size_t)1 << 24)) return fail(EG_ERR_BAD_ARG, "at most 2^24 terms per problem");
+  if (reinterpret_cast<uintptr_t>(d_prepared) & 15u) return fail(EG_ERR_BAD_ARG, "d_prepared must be 16-byte aligned");
   const size_t need = msm_scratch_for(c, n, terms);
-  if (n && need && !d_scratch) return fail(EG_ERR_BAD_ARG, "this call is cut into several chunks per problem (or uses the bucket method) and needs d_scratch (eg_msm_scratch_bytes)");
+  if (n && need && !d_scratch) return fail(EG_ERR_BAD_ARG, "this call is cut into several chunks per problem (or uses the bucket method) and needs d_scratch (eg_msm_scratch_bytes_ctx)");
   if (n == 0) return EG_OK;
   return prim_msm_launch(c, n, terms, (const u32*)d_scalars, (const u32*)d_prepared, (const u32*)d_r, need ? d_scratch : nullptr, (u32*)d_out,
                          nullptr, (hipStream_t)stream, true);
+}
+
+// The VALU roof of THIS box: the shipped fe_mul in a bare chain (k_selfbench_fmul), launched back to back for `seconds`; the rate and the
+// shader clock are taken over the second half, when the power management has settled (a burst of tens of milliseconds runs 10 % faster:
+// profiles/r03_ubench_field_sustained.txt).  Boxes of one pool differ by +-3 %, so a fraction of a constant measured elsewhere cannot tell
+// a slow box from a regression.
+int eg_selfbench_fmul(eg_ctx* c, double seconds, double* fmul_g_per_s, double* sclk_mhz) { EG_LOCK(c);
+  if (!c || !fmul_g_per_s || !(seconds > 0) || seconds > 30) return fail(EG_ERR_BAD_ARG, "bad argument (0 < seconds <= 30)");
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  const int waves_per_simd = 3, blocks = c->cus * waves_per_simd, iters = 20000;       // ~30 ms a launch
+  const size_t lds = ((size_t)160 * 1024 / waves_per_simd) / 1024 * 1024;
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_selfbench_fmul), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const size_t lanes = (size_t)blocks * NT, waves = lanes / 64;
+  void *d_out = nullptr, *d_st = nullptr;
+  TRY(prim_bufs(c, {lanes * 16 * sizeof(u32), waves * sizeof(uint2)}, {&d_out, &d_st}));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  HIPCHK(hipEventCreate(&e0));
+  ScopeExit ev{[&]() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }};
+  HIPCHK(hipEventCreate(&e1));
+  const double ops_per_launch = 2.0 * iters * (double)lanes;
+  auto burst = [&](int launches, double* g, double* mhz) -> int {
+    HIPCHK(hipEventRecord(e0, s));
+    for (int l = 0; l < launches; ++l)
+      hipLaunchKernelGGL(k_selfbench_fmul, dim3(blocks), dim3(NT), lds, s, (u32*)d_out, (uint2*)d_st, 12345u + (u32)l, iters);
+    HIPCHK(hipEventRecord(e1, s));
+    HIPCHK(hipEventSynchronize(e1));
+    HIPCHK(hipGetLastError());
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<uint2> st(waves);
+    HIPCHK(hipMemcpy(st.data(), d_st, waves * sizeof(uint2), hipMemcpyDeviceToHost));
+    std::vector<double> f(waves);
+    for (size_t i = 0; i < waves; ++i) f[i] = st[i].y ? (double)st[i].x / ((double)st[i].y * 10.0) * 1e3 : 0.0;     // cycles per 10 ns tick -> MHz
+    std::sort(f.begin(), f.end());
+    *g = ops_per_launch * launches / (ms * 1e6);
+    *mhz = f[waves / 2];
+    return EG_OK;
+  };
+  double g = 0, mhz = 0;
+  TRY(burst(1, &g, &mhz));                                   // sizes the halves (and warms the clock up)
+  const double one_ms = ops_per_launch / (g * 1e6);
+  const int half = std::max(1, (int)(seconds * 500.0 / one_ms));
+  TRY(burst(half, &g, &mhz));
+  TRY(burst(half, &g, &mhz));
+  *fmul_g_per_s = g;
+  if (sclk_mhz) *sclk_mhz = mhz;
+  return EG_OK;
 }
 
 // ---- tally stage (examples/voting.rs:122-177) --------------------------------------------------------------------------
@@ -1464,6 +1579,7 @@ static int tally_reset(Engine* e, hipStream_t s, bool wait) {
   if (wait) HIPCHK(hipDeviceSynchronize());   // host form: order after anything still running on caller streams
   hipLaunchKernelGGL(k_tally_init, dim3(blocks_of(e->plan.tally_slots.size())), dim3(NT), 0, s, e->tally, (int)e->plan.tally_slots.size());
   HIPCHK(hipGetLastError());
+  TRY(engine_touch(e, s));
   if (wait) HIPCHK(hipStreamSynchronize(s));
   return EG_OK;
 }
@@ -1594,30 +1710,75 @@ static void multi_run(int n_dev, std::vector<int>& rcs, std::vector<std::string>
   guarded(0);
   for (auto& t : threads) t.join();
 }
-// The running tallies before a multi call, as encodings on the host (64 n_options bytes each), and the way back to them: a multi call that
-// fails in ANY slab leaves every running tally as it found it (a host that retries the batch must not count slabs twice).
+// A multi call HOLDS its params objects from its first check to its merge or roll-back (Engine::long_call_mu + Engine::reserved): it waits
+// for a one-shot JSON call that is running on any of them, REFUSES when an explicitly opened JSON stream owns one (nothing has been touched
+// at that point: the stream's tally share and its set-aside running tally are as they were), and every call of another thread on a held
+// object waits until the multi call is over (EG_WAIT_LONG_ONLY) - so nothing can interleave between save() and restore() (ADVICE r5, medium:
+// a snapshot taken in the middle of another call, or put back over one, lost or misattributed ballots).  The mutexes are taken in address
+// order, so two multi calls over the same objects in different orders cannot deadlock.
+template <class Params>
+struct MultiHold {
+  std::vector<Engine*> held;
+  int acquire(Params* const* per_device, int n_dev) {
+    std::vector<Engine*> order;
+    for (int d = 0; d < n_dev; ++d) order.push_back(per_device[d]->eng);
+    std::sort(order.begin(), order.end(), std::less<Engine*>());
+    for (Engine* e : order) {
+      e->long_call_mu.lock();
+      std::lock_guard<std::recursive_mutex> g(e->ctx->mu);
+      if (e->stream_open) {            // (a one-shot stream cannot be: its call holds long_call_mu)
+        e->long_call_mu.unlock();
+        release();
+        return fail(EG_ERR_BAD_ARG, "a JSON stream is open on one of the params objects (eg_verify_json_end or _abort it first)");
+      }
+      e->reserved = true;
+      held.push_back(e);
+    }
+    return EG_OK;
+  }
+  void release() {
+    for (auto it = held.rbegin(); it != held.rend(); ++it) {
+      { std::lock_guard<std::recursive_mutex> g((*it)->ctx->mu); (*it)->reserved = false; }
+      (*it)->long_call_mu.unlock();
+    }
+    held.clear();
+  }
+  ~MultiHold() { release(); }
+};
+// The running tallies before a multi call and the way back to them: a multi call that fails in ANY slab leaves every running tally as it
+// found it (a host that retries the batch must not count slabs twice).  The tallies stay ON their devices (Engine::tally_saved3: a
+// device-to-device copy of 2n points, no allocation, no encoding), and nothing here drains a device (round 5 did, twice per GPU and call):
+// save() orders the copy after the engine's last asynchronous call with an event (Engine::last_done) and leaves an event behind
+// (Engine::saved_ev) that the slab's stream waits for; restore() waits for the slab's own stream.  The engines are held (MultiHold), so
+// no other call can touch the tallies in between.
 template <class Params>
 struct TallyRollback {
   Params* const* per_device; int n_dev; size_t bytes;
-  // the running tallies before the call stay ON their devices (Engine::tally_saved3: a device-to-device copy of 2n points, no allocation,
-  // no encoding); encoded_before() encodes one of them when the caller asked for the tally of this call alone
+  std::vector<hipStream_t> slab_stream;      // device form: the stream slab d was enqueued on; host form: empty (the contexts' own streams)
   int save() {
     if (!bytes) return EG_OK;
     for (int d = 0; d < n_dev; ++d) {
       Engine* e = per_device[d]->eng;
       std::lock_guard<std::recursive_mutex> g(e->ctx->mu);
       HIPCHK(hipSetDevice(e->ctx->device));
-      HIPCHK(hipDeviceSynchronize());          // earlier _device calls on caller streams must have landed in the tally that is set aside
-      HIPCHK(hipMemcpyAsync(e->tally_saved3, e->tally, e->plan.tally_slots.size() * PT_WORDS * sizeof(u32), hipMemcpyDeviceToDevice, e->ctx->stream));
-      HIPCHK(hipStreamSynchronize(e->ctx->stream));
+      hipStream_t s = e->ctx->stream;
+      if (e->last_used) HIPCHK(hipStreamWaitEvent(s, e->last_done, 0));      // earlier _device calls on caller streams land in the tally that is set aside
+      HIPCHK(hipMemcpyAsync(e->tally_saved3, e->tally, e->plan.tally_slots.size() * PT_WORDS * sizeof(u32), hipMemcpyDeviceToDevice, s));
+      HIPCHK(hipEventRecord(e->saved_ev, s));
     }
+    return EG_OK;
+  }
+  // the slab's work starts after the copy above (device form; the host form runs on the context's own stream, behind the copy)
+  int order_slab_after_save(int d, hipStream_t s) {
+    if (!bytes) return EG_OK;
+    HIPCHK(hipStreamWaitEvent(s, per_device[d]->eng->saved_ev, 0));
     return EG_OK;
   }
   int encoded_before(int d, uint8_t* out) {
     Engine* e = per_device[d]->eng;
     std::lock_guard<std::recursive_mutex> g(e->ctx->mu);
     HIPCHK(hipSetDevice(e->ctx->device));
-    return engine_tally_encode_from(e, e->tally_saved3, out);
+    return engine_tally_encode_from(e, e->tally_saved3, out, false);
   }
   int restore() {
     if (!bytes) return EG_OK;
@@ -1625,12 +1786,19 @@ struct TallyRollback {
     for (int d = 0; d < n_dev; ++d) {
       Engine* e = per_device[d]->eng;
       std::lock_guard<std::recursive_mutex> g(e->ctx->mu);
+      hipStream_t s = e->ctx->stream;
       hipError_t he = hipSetDevice(e->ctx->device);
-      if (he == hipSuccess) he = hipDeviceSynchronize();
-      if (he == hipSuccess) he = hipMemcpyAsync(e->tally, e->tally_saved3, e->plan.tally_slots.size() * PT_WORDS * sizeof(u32), hipMemcpyDeviceToDevice, e->ctx->stream);
-      if (he == hipSuccess && e->n_sets == 2)        // a share of the failed call that set 1 still holds must not reach the tally later
-        hipLaunchKernelGGL(k_tally_init, dim3(blocks_of(e->plan.tally_slots.size())), dim3(NT), 0, e->ctx->stream, e->set[1].tally, (int)e->plan.tally_slots.size());
-      if (he == hipSuccess) he = hipStreamSynchronize(e->ctx->stream);
+      // whatever the failed slab still has in flight sits on its stream (engine_verify_device joins its work sets back into it on every
+      // way out) or, host form, on the context's own: the copy back goes behind it
+      if (he == hipSuccess && !slab_stream.empty() && slab_stream[d] != s) {
+        he = hipEventRecord(e->last_done, slab_stream[d]);
+        if (he == hipSuccess) he = hipStreamWaitEvent(s, e->last_done, 0);
+      }
+      if (he == hipSuccess) he = hipMemcpyAsync(e->tally, e->tally_saved3, e->plan.tally_slots.size() * PT_WORDS * sizeof(u32), hipMemcpyDeviceToDevice, s);
+      if (he == hipSuccess && e->n_sets == 2)        // a share of the failed call that set 1 still holds must not reach the tally later (this call holds the engine)
+        hipLaunchKernelGGL(k_tally_init, dim3(blocks_of(e->plan.tally_slots.size())), dim3(NT), 0, s, e->set[1].tally, (int)e->plan.tally_slots.size());
+      if (he == hipSuccess) he = hipEventRecord(e->last_done, s);
+      if (he == hipSuccess) { e->last_used = true; he = hipStreamSynchronize(s); }
       if (he != hipSuccess && !first) first = EG_ERR_HIP;
     }
     return first;
@@ -1658,21 +1826,32 @@ static int multi_merge(Params* const* per_device, int n_dev, const std::vector<s
   }
   return EG_OK;
 }
-template <class Params, class VerifyFn>
-static int verify_batch_multi(Params* const* per_device, int n_dev, size_t n, const uint8_t* ballots, uint32_t* status, uint8_t* tally_out,
-                              VerifyFn verify) {
+// the entry points' bodies without their wait for long calls: what a multi call, which HOLDS the objects, runs on its slabs
+template <class Params>
+static int held_verify_host(Params* p, size_t n, const uint8_t* ballots, uint32_t* status, uint8_t* tally_out) { EG_LOCK_P(p);
+  return engine_verify_host(p->eng, n, ballots, status, tally_out);
+}
+template <class Params>
+static int held_verify_device(Params* p, size_t n, const void* d_ballots, void* d_status, hipStream_t s) { EG_LOCK_P(p);
+  HIPCHK(hipSetDevice(p->eng->ctx->device));
+  return engine_verify_device(p->eng, n, d_ballots, d_status, s);
+}
+template <class Params>
+static int verify_batch_multi(Params* const* per_device, int n_dev, size_t n, const uint8_t* ballots, uint32_t* status, uint8_t* tally_out) {
   TRY(multi_check(per_device, n_dev));
   if (n && (!ballots || !status)) return fail(EG_ERR_BAD_ARG, "bad argument");
+  MultiHold<Params> hold;
+  TRY(hold.acquire(per_device, n_dev));
   const size_t stride = per_device[0]->eng->plan.stride;
   const size_t tally_bytes = (size_t)per_device[0]->eng->plan.tally_slots.size() * 32;
   std::vector<std::vector<uint8_t>> tallies(n_dev, std::vector<uint8_t>(tally_bytes));
   std::vector<int> rcs(n_dev, EG_OK);
   std::vector<std::string> errs(n_dev);
-  TallyRollback<Params> rb{per_device, n_dev, tally_bytes};
+  TallyRollback<Params> rb{per_device, n_dev, tally_bytes, {}};
   TRY(rb.save());
   multi_run(n_dev, rcs, errs, [&](int d) {
     const size_t b = n * (size_t)d / (size_t)n_dev, e = n * (size_t)(d + 1) / (size_t)n_dev;
-    return verify(per_device[d], e - b, ballots + b * stride, status + b, tally_out ? tallies[d].data() : nullptr);
+    return held_verify_host(per_device[d], e - b, ballots + b * stride, status + b, tally_out ? tallies[d].data() : nullptr);
   });
   TRY(multi_fail(per_device, n_dev, rcs, errs, rb));
   if (tally_out && tally_bytes) {
@@ -1685,21 +1864,26 @@ static int verify_batch_multi(Params* const* per_device, int n_dev, size_t n, co
 // ballots each, streams[d] (may be NULL = all null streams) a stream of that device.  One host thread per slab enqueues
 // eg_verify_*_batch_device and waits for its stream, so that the call returns with every verdict written and every running tally advanced;
 // no byte of a ballot crosses PCIe or xGMI.
-template <class Params, class VerifyDevFn>
+template <class Params>
 static int verify_batch_multi_device(Params* const* per_device, int n_dev, const size_t* n_per_dev, const void* const* d_ballots,
-                                     void* const* d_status, void* const* streams, uint8_t* tally_out, VerifyDevFn verify_dev) {
+                                     void* const* d_status, void* const* streams, uint8_t* tally_out) {
   TRY(multi_check(per_device, n_dev));
   if (!n_per_dev || !d_ballots || !d_status) return fail(EG_ERR_BAD_ARG, "bad argument");
   for (int d = 0; d < n_dev; ++d)
     if (n_per_dev[d] && (!d_ballots[d] || !d_status[d])) return fail(EG_ERR_BAD_ARG, "null device pointer for a non-empty slab");
+  MultiHold<Params> hold;
+  TRY(hold.acquire(per_device, n_dev));
   const size_t tally_bytes = (size_t)per_device[0]->eng->plan.tally_slots.size() * 32;
   std::vector<int> rcs(n_dev, EG_OK);
   std::vector<std::string> errs(n_dev);
-  TallyRollback<Params> rb{per_device, n_dev, tally_bytes};
+  TallyRollback<Params> rb{per_device, n_dev, tally_bytes, std::vector<hipStream_t>(n_dev, nullptr)};
+  for (int d = 0; d < n_dev; ++d) rb.slab_stream[d] = streams ? (hipStream_t)streams[d] : nullptr;
   TRY(rb.save());
   multi_run(n_dev, rcs, errs, [&](int d) {
-    hipStream_t s = streams ? (hipStream_t)streams[d] : nullptr;
-    TRY(verify_dev(per_device[d], n_per_dev[d], d_ballots[d], d_status[d], (void*)s));
+    hipStream_t s = rb.slab_stream[d];
+    HIPCHK(hipSetDevice(per_device[d]->eng->ctx->device));
+    TRY(rb.order_slab_after_save(d, s));
+    TRY(held_verify_device(per_device[d], n_per_dev[d], d_ballots[d], d_status[d], s));
     HIPCHK(hipStreamSynchronize(s));
     return (int)EG_OK;
   });
@@ -1710,8 +1894,9 @@ static int verify_batch_multi_device(Params* const* per_device, int n_dev, const
     std::vector<uint8_t> ok(tally_bytes / 32), before(tally_bytes);
     int rc = EG_OK;
     for (int d = 0; d < n_dev && !rc; ++d) {
-      { std::lock_guard<std::recursive_mutex> g(per_device[d]->eng->ctx->mu);
-        rc = hipSetDevice(per_device[d]->eng->ctx->device) == hipSuccess ? engine_tally_encode(per_device[d]->eng, tallies[d].data()) : fail(EG_ERR_HIP, "hipSetDevice"); }
+      { std::lock_guard<std::recursive_mutex> g(per_device[d]->eng->ctx->mu);       // (every slab's stream has been waited for above)
+        rc = hipSetDevice(per_device[d]->eng->ctx->device) == hipSuccess ? engine_tally_encode_from(per_device[d]->eng, per_device[d]->eng->tally, tallies[d].data(), false)
+                                                                         : fail(EG_ERR_HIP, "hipSetDevice"); }
       if (!rc) rc = rb.encoded_before(d, before.data());
       if (!rc) rc = eg_point_add_batch(per_device[d]->eng->ctx, tally_bytes / 32, tallies[d].data(), before.data(), 1, tallies[d].data(), ok.data());
       if (!rc) for (uint8_t o : ok) if (!o) rc = fail(EG_ERR_HIP, "the tally of slab " + std::to_string(d) + " does not decode");
@@ -1721,39 +1906,42 @@ static int verify_batch_multi_device(Params* const* per_device, int n_dev, const
   }
   return EG_OK;
 }
-// sum of the RUNNING tallies of the params objects (each keeps the tally of the slabs it verified)
-template <class Params, class EncodeFn>
-static int tally_encode_multi(Params* const* per_device, int n_dev, uint8_t* out, EncodeFn encode) {
+// sum of the RUNNING tallies of the params objects (each keeps the tally of the slabs it verified); the objects are held while they are
+// read, so the sum is the tally of whole calls only
+template <class Params>
+static int tally_encode_multi(Params* const* per_device, int n_dev, uint8_t* out) {
   TRY(multi_check(per_device, n_dev));
   if (!out) return fail(EG_ERR_BAD_ARG, "bad argument");
+  MultiHold<Params> hold;
+  TRY(hold.acquire(per_device, n_dev));
   const size_t tally_bytes = (size_t)per_device[0]->eng->plan.tally_slots.size() * 32;
   std::vector<std::vector<uint8_t>> tallies(n_dev, std::vector<uint8_t>(tally_bytes));
-  for (int d = 0; d < n_dev; ++d) TRY(encode(per_device[d], tallies[d].data()));
+  for (int d = 0; d < n_dev; ++d) {
+    Params* p = per_device[d];
+    EG_LOCK_P(p);
+    TRY(engine_tally_encode(p->eng, tallies[d].data()));
+  }
   return multi_merge(per_device, n_dev, tallies, tally_bytes, out);
 }
 }  // extern "C++"
 int eg_verify_choice_batch_multi(eg_choice_params* const* per_device, int n_dev, size_t n, const uint8_t* ballots, uint32_t* status,
                                  uint8_t* tally_out) {
-  return verify_batch_multi(per_device, n_dev, n, ballots, status, tally_out, eg_verify_choice_batch);
+  return verify_batch_multi(per_device, n_dev, n, ballots, status, tally_out);
 }
 int eg_verify_qv_batch_multi(eg_qv_params* const* per_device, int n_dev, size_t n, const uint8_t* ballots, uint32_t* status,
                              uint8_t* tally_out) {
-  return verify_batch_multi(per_device, n_dev, n, ballots, status, tally_out, eg_verify_qv_batch);
+  return verify_batch_multi(per_device, n_dev, n, ballots, status, tally_out);
 }
 int eg_verify_choice_batch_multi_device(eg_choice_params* const* per_device, int n_dev, const size_t* n_per_dev, const void* const* d_ballots,
                                         void* const* d_status, void* const* streams, uint8_t* tally_out) {
-  return verify_batch_multi_device(per_device, n_dev, n_per_dev, d_ballots, d_status, streams, tally_out, eg_verify_choice_batch_device);
+  return verify_batch_multi_device(per_device, n_dev, n_per_dev, d_ballots, d_status, streams, tally_out);
 }
 int eg_verify_qv_batch_multi_device(eg_qv_params* const* per_device, int n_dev, const size_t* n_per_dev, const void* const* d_ballots,
                                     void* const* d_status, void* const* streams, uint8_t* tally_out) {
-  return verify_batch_multi_device(per_device, n_dev, n_per_dev, d_ballots, d_status, streams, tally_out, eg_verify_qv_batch_device);
+  return verify_batch_multi_device(per_device, n_dev, n_per_dev, d_ballots, d_status, streams, tally_out);
 }
-int eg_choice_tally_encode_multi(eg_choice_params* const* per_device, int n_dev, uint8_t* out) {
-  return tally_encode_multi(per_device, n_dev, out, eg_choice_tally_encode);
-}
-int eg_qv_tally_encode_multi(eg_qv_params* const* per_device, int n_dev, uint8_t* out) {
-  return tally_encode_multi(per_device, n_dev, out, eg_qv_tally_encode);
-}
+int eg_choice_tally_encode_multi(eg_choice_params* const* per_device, int n_dev, uint8_t* out) { return tally_encode_multi(per_device, n_dev, out); }
+int eg_qv_tally_encode_multi(eg_qv_params* const* per_device, int n_dev, uint8_t* out) { return tally_encode_multi(per_device, n_dev, out); }
 
 // ---- PublicKey::verify_zero / verify_bool / verify_range in batches ---------------------------------------
 int eg_proof_params_create(eg_ctx* c, const uint8_t pk[32], int kind, uint64_t upper_bound, eg_proof_params** out) { EG_LOCK(c);
@@ -1941,6 +2129,7 @@ static egwire::VerifyPackedFn make_verify_packed(Engine* e) {
 struct eg_json_stream;
 static int stream_begin(Engine* e, int threads, PackPieceFn pack_piece, ReshapeFn reshape, size_t size_hint, eg_json_stream** out);
 static void stream_mark_one_shot(eg_json_stream* S);
+static void stream_set_max_objects(eg_json_stream* S, size_t n);
 // The one-shot entry = the streaming entry fed with the whole text (in place, 64 MB at a time) - one pipeline for both (round 5; rounds 3-4
 // had a second one here, a producer thread and a consumer loop over the same ring).
 static int verify_json_common(Engine* e, const char* json, size_t json_len, int threads, size_t max_objects, uint32_t* status,
@@ -1948,12 +2137,13 @@ static int verify_json_common(Engine* e, const char* json, size_t json_len, int 
   if ((json_len && !json) || (max_objects && !status)) return fail(EG_ERR_BAD_ARG, "bad argument");
   if (n_objects) *n_objects = 0;
   eg_json_stream* S = nullptr;
-  std::lock_guard<std::mutex> one_at_a_time(e->json_call_mu);       // concurrent one-shot calls on one params object are serialised, as every entry point is
+  std::lock_guard<std::mutex> one_at_a_time(e->long_call_mu);       // concurrent one-shot calls on one params object are serialised, as every entry point is
   {   // the context's lock only while the stream is opened: its worker thread takes the lock piece by piece, and so does end
     EG_LOCK(e->ctx);
     if (e->stream_open) return fail(EG_ERR_BAD_ARG, "a JSON stream is open on this params object (eg_verify_json_end or _abort it first)");
     TRY(stream_begin(e, threads, pack_piece, reshape, json_len, &S));
     stream_mark_one_shot(S);
+    stream_set_max_objects(S, max_objects);      // the worker breaks off as soon as the text holds more (nothing further is parsed or verified)
   }
   const size_t piece = (size_t)64 << 20;
   for (size_t at = 0; at < json_len; at += piece) {
@@ -1961,7 +2151,10 @@ static int verify_json_common(Engine* e, const char* json, size_t json_len, int 
   }
   size_t taken = 0, total = 0;
   const int rc = eg_verify_json_end(S, status, max_objects, &taken, &total, tally_out);
-  if (rc && g_err.find("are left") != std::string::npos) {       // the stream is still open: the caller's buffer is too small
+  // end leaves the stream OPEN in exactly one case - more verdicts are left than `status` has room for - and says so through its
+  // out-values: *n_taken = the number left (> cap).  Every other failure has destroyed the stream and reports *n_taken = 0.  (The worker
+  // normally fails the stream as soon as it has cut more than max_objects values, long before this point: stream_emit.)
+  if (rc == EG_ERR_BAD_ARG && taken > max_objects) {
     eg_verify_json_abort(S);
     return fail(EG_ERR_BAD_ARG, "more objects in the text than max_objects");
   }
@@ -2036,6 +2229,8 @@ struct eg_json_stream {
   size_t landed = 0, taken = 0, n_submitted = 0;
   bool set_aside = false, flushed = false, trace = false;
   bool one_shot = false;               // opened by eg_verify_*_json for the length of that call: other calls on the params object wait for it
+  size_t max_objects = (size_t)-1;     // one-shot: the room in the caller's status buffer; a text with more objects fails at once (stream_emit)
+  size_t odd_bytes = 0, odd_max = (size_t)256 << 20;     // text of the ballots of another shape kept for the object path, and its bound (EG_JSON_ODD_MAX_MB)
   std::atomic<int> failed{EG_OK};      // set once (stream_fail), after err has been written
   std::string err;
   // Front end: the caller's pieces reach the worker thread through a short queue.  Pieces below `direct_min` are copied into blocks of
@@ -2043,7 +2238,8 @@ struct eg_json_stream {
   // parallel with the caller producing the next piece); larger pieces are handed over in place and feed waits until the worker is through
   // with them.  Everything above (regions, groups, verdicts, splitter) is touched by the worker thread only, under the context's lock,
   // until the worker has been joined (end / abort) - take() takes that lock too.
-  struct Item { std::vector<char> own; const char* ptr = nullptr; size_t len = 0; uint64_t id = 0; bool finish = false; };
+  struct Item { std::vector<char> own; const char* ptr = nullptr; size_t len = 0; uint64_t id = 0; bool finish = false;
+                eg_json_release_fn release = nullptr; void* user = nullptr; };      // release: a block handed over by eg_verify_json_feed_owned
   std::thread worker;
   std::mutex qmu;
   std::condition_variable q_push, q_pop;
@@ -2051,6 +2247,7 @@ struct eg_json_stream {
   std::vector<std::vector<char>> spare;    // emptied blocks
   std::vector<char> acc;                   // the block being filled by feed
   uint64_t next_id = 1, consumed_id = 0;
+  size_t queued_bytes = 0;                 // text waiting in the queue (copied blocks and handed-over ones): at most ~64 MB, then feed waits
   bool stop = false, worker_joined = false;
   std::atomic<size_t> objects{0};          // complete objects cut so far (by the worker)
   size_t block_bytes = (size_t)16 << 20, direct_min = (size_t)8 << 20;
@@ -2058,6 +2255,7 @@ struct eg_json_stream {
   double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
 };
 static void stream_mark_one_shot(eg_json_stream* S) { S->one_shot = true; }
+static void stream_set_max_objects(eg_json_stream* S, size_t n) { S->max_objects = n; }
 static bool stream_is_one_shot(const eg_json_stream* S) { return S->one_shot; }
 static int stream_fail(eg_json_stream* S, int code, const std::string& msg) {
   if (!S->failed.load(std::memory_order_acquire)) { S->err = msg; S->failed.store(code, std::memory_order_release); }
@@ -2146,13 +2344,27 @@ static int stream_place(eg_json_stream* S, size_t m, size_t* off) {
 static bool stream_emit(eg_json_stream* S, const char* base, const std::vector<std::pair<size_t, size_t>>& spans, size_t first) {
   Engine* e = S->e;
   size_t off = 0;
+  if (first + spans.size() > S->max_objects) {
+    stream_fail(S, EG_ERR_BAD_ARG, "more objects in the text than max_objects");
+    return false;
+  }
   if (stream_place(S, spans.size(), &off)) return false;
   S->pack_tmp.resize(spans.size());
   S->pack_piece(base, spans, S->threads, e->json_ring + off * S->stride, S->pack_tmp.data(), S->pool.get());
   if (S->verdicts.size() < first + spans.size()) S->verdicts.resize(first + spans.size());
   for (size_t i = 0; i < spans.size(); ++i) {
     S->verdicts[first + i] = S->pack_tmp[i];
-    if (S->pack_tmp[i] == EG_PACK_RESHAPE) { S->odd_text.emplace_back(base + spans[i].first, spans[i].second); S->odd_at.push_back(first + i); }
+    if (S->pack_tmp[i] == EG_PACK_RESHAPE) {
+      // a ballot of another shape than the election's keeps its TEXT until the end (the object path needs the GPU to itself): bounded, so
+      // that a text made of such objects cannot make the streaming entry buffer its whole input in host memory
+      S->odd_bytes += spans[i].second;
+      if (S->odd_bytes > S->odd_max) {
+        stream_fail(S, EG_ERR_NOMEM, "the ballots whose shape is not the election's exceed " + std::to_string(S->odd_max >> 20) +
+                                         " MB of text (EG_JSON_ODD_MAX_MB): verify such a text through the object path in smaller pieces");
+        return false;
+      }
+      S->odd_text.emplace_back(base + spans[i].first, spans[i].second); S->odd_at.push_back(first + i);
+    }
   }
   S->regions.push_back({first, off, spans.size(), false});
   return stream_pump(S, false) == EG_OK;
@@ -2187,6 +2399,7 @@ static int stream_begin(Engine* e, int threads, PackPieceFn pack_piece, ReshapeF
   S->e = e; S->threads = std::max(threads, 1); S->pack_piece = std::move(pack_piece); S->reshape = std::move(reshape);
   S->stride = e->plan.stride; S->ns = (int)e->plan.tally_slots.size();
   S->growth = e->knobs.json_growth; S->trace = e->knobs.json_trace;
+  S->odd_max = e->knobs.json_odd_max_mb << 20;
   hipStream_t s = e->ctx->stream;
   HIPCHK(hipDeviceSynchronize());
   const size_t ring_max = e->knobs.json_ring_kb ? e->knobs.json_ring_kb << 10 : (size_t)1 << 30;
@@ -2237,37 +2450,67 @@ static int stream_begin(Engine* e, int threads, PackPieceFn pack_piece, ReshapeF
 // the worker thread of a stream: pieces in order through the splitter (-> stream_emit -> ring, GPU), each under the context's lock
 static void stream_worker(eg_json_stream* S) {
   eg_ctx* ctx = S->e->ctx;
+  std::vector<char> joined;                 // small handed-over blocks that were waiting together, copied into one piece (below)
   for (;;) {
     eg_json_stream::Item it;
+    std::vector<eg_json_stream::Item> more;      // the handed-over blocks behind `it` that are processed with it
     {
       std::unique_lock<std::mutex> lk(S->qmu);
       S->q_push.wait(lk, [&]() { return S->stop || !S->queue.empty(); });
       if (S->stop) return;
       it = std::move(S->queue.front());
       S->queue.pop_front();
+      // Small blocks handed over by eg_verify_json_feed_owned are cheap to take one by one only when they arrive slowly: every piece costs
+      // a hand-over, a window of the splitter, two dispatches on the pool (a ballot straddles almost every boundary) and a look at the
+      // GPU - 1 MB pieces at the rate of the verifier are 1 400 of those in 160 ms.  Blocks that are WAITING TOGETHER are therefore joined
+      // into one piece of up to 16 MB, copied by the pool's threads (not by the caller's, and not one after the other), and given back at once.
+      if (it.release && !it.finish && it.len < S->direct_min) {
+        size_t total = it.len;
+        while (!S->queue.empty() && S->queue.front().release && !S->queue.front().finish && S->queue.front().len < S->direct_min &&
+               total + S->queue.front().len <= S->block_bytes) {
+          total += S->queue.front().len;
+          more.push_back(std::move(S->queue.front()));
+          S->queue.pop_front();
+        }
+      }
+    }
+    const char* text = it.ptr ? it.ptr : it.own.data();
+    size_t len = it.len;
+    if (!more.empty()) {
+      std::vector<const eg_json_stream::Item*> parts{&it};
+      for (auto& m : more) { parts.push_back(&m); len += m.len; }
+      if (joined.size() < len) joined.resize(len);
+      std::vector<size_t> at(parts.size(), 0);
+      for (size_t k = 1; k < parts.size(); ++k) at[k] = at[k - 1] + parts[k - 1]->len;
+      S->pool->run(parts.size(), 1, [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; ++k) memcpy(joined.data() + at[k], parts[k]->ptr, parts[k]->len); });
+      text = joined.data();
+      if (it.release) { it.release(it.user, it.ptr, it.len); it.release = nullptr; }       // copied: the blocks go back before they are parsed
+      for (auto& m : more) m.release(m.user, m.ptr, m.len);
     }
     if (!it.finish && !S->failed.load(std::memory_order_acquire)) {
       std::lock_guard<std::recursive_mutex> lk(ctx->mu);
       (void)hipSetDevice(ctx->device);
-      const char* text = it.ptr ? it.ptr : it.own.data();
-      if (!S->split->feed(text, it.len)) {
+      if (!S->split->feed(text, len)) {
         if (!S->failed.load()) stream_fail(S, EG_ERR_BAD_ARG, S->split->error().empty() ? std::string("the piece could not be packed") : S->split->error());
       } else (void)stream_pump(S, false);
       S->objects.store(S->split->count(), std::memory_order_release);
     }
     {
       std::lock_guard<std::mutex> lk(S->qmu);
-      S->consumed_id = it.id;
+      S->consumed_id = more.empty() ? it.id : more.back().id;
+      S->queued_bytes -= std::min(S->queued_bytes, len);
       if (!it.own.empty() || it.own.capacity()) { it.own.clear(); S->spare.push_back(std::move(it.own)); }
     }
     S->q_pop.notify_all();
+    if (it.release) it.release(it.user, it.ptr, it.len);      // the caller's block goes back: nothing of it is referenced any more
     if (it.finish) return;
   }
 }
 // hands an item to the worker (at most four blocks wait in the queue); wait = until the worker is through with it
 static void stream_enqueue(eg_json_stream* S, std::unique_lock<std::mutex>& lk, eg_json_stream::Item&& it, bool wait) {
-  S->q_pop.wait(lk, [&]() { return S->queue.size() < 4; });
+  S->q_pop.wait(lk, [&]() { return S->queue.empty() || S->queued_bytes < ((size_t)64 << 20); });
   const uint64_t id = it.id = S->next_id++;
+  S->queued_bytes += it.len;
   S->queue.push_back(std::move(it));
   S->q_push.notify_one();
   if (wait) S->q_pop.wait(lk, [&]() { return S->consumed_id >= id; });
@@ -2297,6 +2540,9 @@ static void stream_join_worker(eg_json_stream* S, bool finish) {      // never c
   }
   if (S->worker.joinable()) S->worker.join();
   S->worker_joined = true;
+  for (auto& it : S->queue)                 // an aborted stream: handed-over blocks the worker never got to go back to their owner
+    if (it.release) it.release(it.user, it.ptr, it.len);
+  S->queue.clear();
 }
 int eg_verify_json_feed(eg_json_stream* S, const char* text, size_t len, size_t* n_objects) {
   if (!S || (len && !text)) return fail(EG_ERR_BAD_ARG, "bad argument");
@@ -2319,6 +2565,24 @@ int eg_verify_json_feed(eg_json_stream* S, const char* text, size_t len, size_t*
       }
     }
     if (S->failed.load(std::memory_order_acquire)) return fail(S->failed.load(), S->err);
+  }
+  if (n_objects) *n_objects = S->objects.load(std::memory_order_acquire);
+  return EG_OK;
+}
+// The next piece WITHOUT a copy and without waiting: the library reads the caller's block in place and calls release(user, text, len) -
+// from the stream's worker thread, or from the thread that ends / aborts the stream - when nothing of it is referenced any more.
+// (eg_verify_json_feed copies a small piece on the caller's thread: 1.5 GB of text in 1 MB pieces is 150 ms of memcpy, as long as the GPU
+// needs for the million ballots in it - json_stream.pieces.1MB of the bench line sat at 0.83 of the resident rate for that reason.)
+int eg_verify_json_feed_owned(eg_json_stream* S, const char* text, size_t len, eg_json_release_fn release, void* user, size_t* n_objects) {
+  if (!S || !release || (len && !text)) return fail(EG_ERR_BAD_ARG, "bad argument");
+  {
+    std::unique_lock<std::mutex> lk(S->qmu);
+    if (S->failed.load(std::memory_order_acquire)) return fail(S->failed.load(), S->err);
+    if (S->flushed || S->worker_joined) return fail(EG_ERR_BAD_ARG, "the stream has been ended");
+    stream_flush_acc(S, lk);                        // pieces copied earlier come first
+    eg_json_stream::Item it;
+    it.ptr = text; it.len = len; it.release = release; it.user = user;
+    stream_enqueue(S, lk, std::move(it), false);    // from here on the block is the library's: release will be called, whatever happens
   }
   if (n_objects) *n_objects = S->objects.load(std::memory_order_acquire);
   return EG_OK;
@@ -2419,11 +2683,7 @@ void eg_verify_json_abort(eg_json_stream* S) {
 }
 int eg_verify_choice_json_begin(eg_choice_params* p, int threads, eg_json_stream** out) { EG_LOCK_P(p);
   if (!p) return fail(EG_ERR_BAD_ARG, "bad argument");
-  while (p->eng->stream_open && stream_is_one_shot(p->eng->stream_open)) {      // a one-shot JSON call of another thread: wait for it (EG_WAIT_JSON)
-    lk_.unlock();
-    { std::lock_guard<std::mutex> wait_(p->eng->json_call_mu); }
-    lk_.lock();
-  }
+  EG_WAIT_LONG_ONLY(p->eng);       // a one-shot JSON call or a multi-GPU call of another thread: wait for it
   const int n_options = p->n_options, single = p->single;
   const size_t stride = p->eng->plan.stride;
   Engine* e = p->eng;
@@ -2437,11 +2697,7 @@ int eg_verify_choice_json_begin(eg_choice_params* p, int threads, eg_json_stream
 }
 int eg_verify_qv_json_begin(eg_qv_params* p, int threads, eg_json_stream** out) { EG_LOCK_P(p);
   if (!p) return fail(EG_ERR_BAD_ARG, "bad argument");
-  while (p->eng->stream_open && stream_is_one_shot(p->eng->stream_open)) {      // a one-shot JSON call of another thread: wait for it (EG_WAIT_JSON)
-    lk_.unlock();
-    { std::lock_guard<std::mutex> wait_(p->eng->json_call_mu); }
-    lk_.lock();
-  }
+  EG_WAIT_LONG_ONLY(p->eng);       // a one-shot JSON call or a multi-GPU call of another thread: wait for it
   const int n_options = p->n_options;
   const eghost::QvShape sh = p->shape;
   const egwire::RangeShape vote{sh.vote_range.rings.size(), (size_t)sh.vote_range.rings_size()};

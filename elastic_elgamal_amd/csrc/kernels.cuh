@@ -1054,4 +1054,34 @@ __global__ void __launch_bounds__(NT, 2) k_prim_msm_reduce(size_t n, int n_chunk
   }
 }
 
+// ---- measurement hook (eg_selfbench_fmul; bench.py's valu_roofline.box) -------------------------------------------------------------------
+// The field multiplication of fe25519.cuh - the very function the table and equation kernels inline - in a bare dependent chain on
+// changing 255-bit operands: what tools/ubench/field_bench.hip measures, inside the shipped library so that the bench can calibrate the
+// VALU roof on the box it runs on.  A block asks for a third of a CU's LDS, so exactly three blocks = three waves per SIMD are resident
+// (the occupancy of k_eq_table).  stamps[wave] = (shader clock cycles, 100 MHz real-time ticks) of the chain: the clock the chip held.
+__global__ void __launch_bounds__(NT) k_selfbench_fmul(u32* out, uint2* stamps, u32 seed, int iters) {
+  u32 wa[8], wb[8];
+  u32 x0 = seed ^ (((u32)blockIdx.x * NT + threadIdx.x) * 0x85ebca6bu);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { x0 ^= x0 << 13; x0 ^= x0 >> 17; x0 ^= x0 << 5; wa[i] = x0; }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { x0 ^= x0 << 13; x0 ^= x0 >> 17; x0 ^= x0 << 5; wb[i] = x0; }
+  wa[7] &= 0x3fffffffu; wb[7] &= 0x3fffffffu;
+  fe x, y;
+  fe_from_words(x, wa); fe_from_words(y, wb);
+  const u64 c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#pragma unroll 1
+  for (int it = 0; it < iters; ++it) { fe_mul(x, x, y); fe_mul(y, y, x); }
+  const u64 c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  const size_t g = (size_t)blockIdx.x * NT + threadIdx.x;
+  if ((threadIdx.x & 63) == 0) stamps[g >> 6] = make_uint2((u32)(c1 - c0), (u32)(r1 - r0));
+  u32 o[8];
+  fe_to_words(o, x);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) out[g * 16 + i] = o[i];
+  fe_to_words(o, y);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) out[g * 16 + 8 + i] = o[i];
+}
+
 }  // namespace eg

@@ -58,3 +58,14 @@ def sum_over_ranks(value: int, device) -> int:
     t = torch.tensor([value], dtype=torch.int64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return int(t.item())
+
+
+def gather_rows(row, device) -> list[list[float]]:
+    """One row of numbers per rank -> every rank's rows, rank-major (bench.py's `per_rank` block: step time, clock, power, accepted ...).
+    A measurement helper, called once after the timed loop; not on the data path."""
+    if _single():
+        return [list(map(float, row))]
+    t = torch.tensor(list(map(float, row)), dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
+    parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, t)
+    return [p.cpu().tolist() for p in parts]

@@ -34,8 +34,13 @@
  * it) are serialised by a lock inside the context, and eg_last_error is per thread.  Host-pointer functions return
  * when the results are in the caller's buffers (they run on a stream owned by the context; the tally reset / encode host
  * forms first wait for the whole device, so they may follow `_device` calls directly).  `_device` / `_async` functions only
- * enqueue work on the hipStream_t they are given - NULL is HIP's null stream, as everywhere - and share the context's
- * workspaces, so a caller that uses several streams with one context must order them itself (events).
+ * enqueue work on the hipStream_t they are given - NULL is HIP's null stream, as everywhere.  The context's per-lane workspace, which
+ * every params object of a context and the primitive tier share, is ordered INSIDE the library (each user's stream waits for an event
+ * of the previous user: no host synchronisation), so two params objects of one context may have work in flight at the same time - a JSON
+ * stream on one, `_device` calls or eg_vartime_multi_mul_batch on the other - whatever the streams.  What a caller that uses several
+ * streams with ONE params object must still order itself (events) are that object's own buffers: its chunk workspace and running tally.
+ * LONG calls - eg_verify_*_json and eg_verify_*_batch_multi* - do not hold the context's lock from start to end, but they are one call all
+ * the same: any other call on a params object they are using WAITS until they are over.
  *
  * RUN-TIME KNOBS.  Every environment variable the library looks at, complete (csrc/eg_hip.hip: struct Knobs, read_knobs - the only
  * place the environment is read).  They are read at TWO moments only - eg_init (context-wide knobs; the context keeps its copy) and the
@@ -59,6 +64,8 @@
  *   EG_JSON_WINDOW_KB     params create  98304              JSON text per parser window, KiB
  *   EG_JSON_GROWTH        params create  150                a second JSON submission is enqueued once it is this many per cent of the first
  *   EG_JSON_FIRST_MIN     params create  16384              packed ballots the JSON entry points wait for before their first GPU submission
+ *   EG_JSON_ODD_MAX_MB    params create  256                text of ballots whose shape is not the election's that a JSON stream keeps for the
+ *                                                           object path (they are resolved at the end); a text with more fails with EG_ERR_NOMEM
  *   EG_JSON_TRACE         params create  unset              timeline of the JSON submissions on stderr
  *
  * The Python mirror adds two of its own (elastic_elgamal_amd/__init__.py, read at import): EG_LIB = path of another build of this
@@ -113,6 +120,10 @@ typedef struct eg_choice_params eg_choice_params; /* ChoiceParams<Ristretto, S> 
 typedef struct eg_qv_params eg_qv_params;         /* QuadraticVotingParams<Ristretto> (quadratic_voting.rs:47-76) */
 
 /* ---- context ------------------------------------------------------------------------------------------------ */
+/* Version of this ABI: bumped whenever an exported function changes its prototype or meaning (6 = round 6: eg_msm_scratch_bytes_ctx,
+ * d_ok mandatory in eg_points_prepare_device, the multi-GPU JSON entries).  A binding checks it once after loading the library. */
+#define EG_ABI_VERSION 6
+int eg_abi_version(void);
 int eg_init(int device, eg_ctx** out);   /* no reference analogue: the backend is a ZST */
 void eg_destroy(eg_ctx* ctx);
 const char* eg_last_error(void);         /* text of the last failure on this thread */
@@ -159,9 +170,11 @@ int eg_vartime_multi_mul_batch(eg_ctx*, size_t n, size_t terms, const uint8_t* s
  * chunks' partial sums are added up with wavefront shuffles; from 2^20 terms per problem on, the bucket method (Pippenger, dalek's choice
  * above 190 terms; csrc/pippenger.cuh) takes over, one problem after the other: 13 ms instead of 21 for 2^22 terms.  A call that is cut
  * into several chunks per problem (more than 8 terms, or few problems of many terms) or that uses the bucket method needs d_scratch of
- * eg_msm_scratch_bytes(ctx, n, terms) bytes (0 when it needs none; ~250 bytes per term for the bucket method: 1 GB at 2^22 terms).  A caller
+ * eg_msm_scratch_bytes_ctx(ctx, n, terms) bytes (0 when it needs none; ~250 bytes per term for the bucket method: 1 GB at 2^22 terms).  A caller
  * that keeps its operands in HBM pays no copy and no synchronisation. */
-size_t eg_msm_scratch_bytes(eg_ctx*, size_t n, size_t terms);   /* by the context: its switch to the bucket method is fixed at eg_init */
+/* (named _ctx since ABI version 6: earlier builds exported this function under the name without the suffix, first WITHOUT the context
+ * argument, then with it - a caller built against the old prototype must fail to link, not link and read a garbage size) */
+size_t eg_msm_scratch_bytes_ctx(eg_ctx*, size_t n, size_t terms);   /* by the context: its switch to the bucket method is fixed at eg_init */
 int eg_vartime_multi_mul_batch_device(eg_ctx*, size_t n, size_t terms, const void* d_scalars, const void* d_points, const void* d_r,
                                       void* d_scratch, void* d_out, void* d_ok, void* stream);
 
@@ -169,9 +182,12 @@ int eg_vartime_multi_mul_batch_device(eg_ctx*, size_t n, size_t terms, const voi
  * decoding per product; the entry above, which takes 32-byte encodings, does - 285 field operations per term, a third of the bucket
  * method's time.  A caller that multiplies over one point set repeatedly decodes it once: eg_points_prepare_device writes
  * eg_prepared_point_size() (= 96) bytes per point - affine (x, y, xy), an opaque layout that is valid for this library build only, never
- * a wire format - and d_ok[i] = 1 if encoding i decodes (an encoding that does not is prepared as the IDENTITY: it contributes nothing to a
- * product, and the prepare call is the only place that says so; d_ok may be NULL).  eg_vartime_multi_mul_prepared_batch_device is
- * eg_vartime_multi_mul_batch_device over such points (terms per problem x n problems, 96 bytes each, same scratch, same paths). */
+ * a wire format - and d_ok[i] = 1 if encoding i decodes.  An encoding that does not decode is prepared as the IDENTITY and contributes
+ * nothing to a product; the reference cannot even construct such an Element (deserialize_element returns None), so d_ok is MANDATORY
+ * (EG_ERR_BAD_ARG if NULL): the prepare call is the only place that says which inputs were not elements.  d_prepared must be 16-byte
+ * aligned (hipMalloc'd memory is; EG_ERR_BAD_ARG otherwise - the kernels read it in 128-bit words), also in
+ * eg_vartime_multi_mul_prepared_batch_device, which is eg_vartime_multi_mul_batch_device over such points (terms per problem x n problems,
+ * 96 bytes each, same scratch, same paths) and has no ok output of its own. */
 size_t eg_prepared_point_size(void);
 int eg_points_prepare_device(eg_ctx*, size_t n, const void* d_encodings, void* d_prepared, void* d_ok, void* stream);
 int eg_vartime_multi_mul_prepared_batch_device(eg_ctx*, size_t n, size_t terms, const void* d_scalars, const void* d_prepared, const void* d_r,
@@ -272,6 +288,11 @@ int eg_qv_tally_encode_device(eg_qv_params*, void* d_out, void* stream);
  * tier - the in-process counterpart of the RCCL all-gather of the one-process-per-GPU path (examples/tally_exchange.cpp).
  * eg_*_tally_encode_multi = the sum of the running tallies (every encoding is checked: a running tally that does not decode, or params
  * objects of different elections, fail the call).
+ *
+ * A multi call HOLDS its params objects from its first check to its merge: it waits for a one-shot eg_verify_*_json that is running on
+ * one of them, fails with EG_ERR_BAD_ARG - before it has touched anything - when an explicitly opened JSON stream owns one, and calls of
+ * other threads on a held object wait until it is over.  Nothing in it drains a device: the running tallies are set aside behind an event
+ * of the object's last asynchronous call, and slab d starts behind that copy on streams[d].
  *
  * AFTER A FAILURE.  An error in any slab fails the whole call; eg_last_error names the slab.  Verdicts of other slabs may have been
  * written, but NO running tally has advanced: every multi verify call sets the running tallies aside before it starts (a
@@ -376,7 +397,7 @@ size_t eg_qv_ballot_size_for(int n_options, uint64_t credits);   /* eg_qv_ballot
  *   feed   hands the piece to the stream's worker thread, which cuts it, packs its complete ballots on `threads` host threads into a
  *          pinned ring, and enqueues GPU work without waiting for it (the first submission once EG_JSON_FIRST_MIN ballots are packed, at
  *          most two in flight).  A piece below 8 MB is copied (one memcpy on the caller's thread; feed returns at once unless four 16 MB
- *          blocks are already waiting); a larger piece is read in place and feed returns when the worker is through with it.  Either
+ *          blocks - 64 MB of text - are already waiting); a larger piece is read in place and feed returns when the worker is through with it.  Either
  *          way nothing of `text` is referenced after feed returns.  *n_objects (may be NULL): complete objects the worker has cut so
  *          far - it may lag behind the pieces fed.  An error of the text (not a sequence of objects) or of the GPU found in a copied
  *          piece is reported by a LATER feed or take, and at the latest by end.
@@ -392,7 +413,11 @@ size_t eg_qv_ballot_size_for(int n_options, uint64_t credits);   /* eg_qv_ballot
  *          added.  Destroys the stream - also when it reports an error of the text (not a sequence of objects, truncated) or of the GPU.
  *   abort  destroys the stream; the running tally is what it was before begin.  A failed feed leaves the stream dead: end returns the
  *          same error and cleans up, with the running tally as it was.
- * Between begin and end / abort the params object belongs to the stream: every other verify / tally call on it fails with EG_ERR_BAD_ARG.
+ * Host memory of a stream: the staging ring (EG_JSON_RING_KB), at most four 16 MB blocks of copied text, one status word per object, and the
+ * TEXT of every ballot whose shape is not the election's (kept for the object path at the end): at most EG_JSON_ODD_MAX_MB (256 MB), beyond
+ * which the stream fails with EG_ERR_NOMEM instead of buffering its input.
+ * Between begin and end / abort the params object belongs to the stream: every other verify / tally call on it fails with EG_ERR_BAD_ARG
+ * (the multi-GPU entries included: they refuse before they touch anything).
  * One stream per params object; several params objects (contexts, GPUs) may stream at the same time from different threads.
  * (The one-shot entries eg_verify_*_json run on the same pipeline, but a one-shot call is ONE call like any other: while it runs, calls of
  * other threads on the same params object - verify, tally, another one-shot, a begin - WAIT for it, they are not refused.) */
@@ -400,6 +425,13 @@ typedef struct eg_json_stream eg_json_stream;
 int eg_verify_choice_json_begin(eg_choice_params*, int threads, eg_json_stream** out);
 int eg_verify_qv_json_begin(eg_qv_params*, int threads, eg_json_stream** out);
 int eg_verify_json_feed(eg_json_stream*, const char* text, size_t len, size_t* n_objects);
+/* feed WITHOUT a copy and without waiting for the worker: the block stays the caller's memory but belongs to the library until it calls
+ * release(user, text, len) - exactly once per successful call, from the stream's worker thread (or from the thread that ends / aborts the
+ * stream, for blocks the worker never got to); release must not call back into the stream.  What a producer that receives the text in
+ * its own buffers (a socket, a file mapping) uses: nothing is copied on its thread (eg_verify_json_feed copies a piece below 8 MB).
+ * Returns at once unless ~64 MB of text are already waiting.  If the call FAILS, release is not called: the block is still the caller's. */
+typedef void (*eg_json_release_fn)(void* user, const char* text, size_t len);
+int eg_verify_json_feed_owned(eg_json_stream*, const char* text, size_t len, eg_json_release_fn release, void* user, size_t* n_objects);
 int eg_verify_json_take(eg_json_stream*, uint32_t* status, size_t cap, size_t* n_taken);
 int eg_verify_json_end(eg_json_stream*, uint32_t* status, size_t cap, size_t* n_taken, size_t* n_objects, uint8_t* tally_out);
 void eg_verify_json_abort(eg_json_stream*);
@@ -410,7 +442,8 @@ void eg_verify_json_abort(eg_json_stream*);
  * does not deserialise; for an object that deserialises with another shape than the election's, the reference's verdict from the object
  * path (EG_ST_OPTIONS_LEN, the LenMismatch variants, or whatever verify() says after them: src/app/choice.rs:358-380,
  * src/proofs/mod.rs:73-99).  Tally semantics as eg_verify_*_batch.  *n_objects = objects found; EG_ERR_BAD_ARG if the text is not a
- * sequence of JSON objects or holds more than max_objects (then no verdict of the call is valid). */
+ * sequence of JSON objects or holds more than max_objects (then no verdict of the call is valid; the call breaks off as soon as the parser
+ * has cut one object too many - nothing further is parsed or verified). */
 int eg_verify_choice_json(eg_choice_params*, const char* json, size_t json_len, int threads, size_t max_objects, uint32_t* status,
                           size_t* n_objects, uint8_t* tally_out);
 int eg_verify_qv_json(eg_qv_params*, const char* json, size_t json_len, int threads, size_t max_objects, uint32_t* status,
@@ -432,6 +465,14 @@ int eg_profile_enable(eg_ctx*, int enable);
 int eg_profile_read(eg_ctx*, double* msm_ms_total, uint64_t* msm_launches, double* all_ms_total);
 /* same for the second kernel (k_base_tables), covering the launches folded in by the last eg_profile_read */
 int eg_profile_read_tables(eg_ctx*, double* tables_ms_total, uint64_t* tables_launches);
+
+/* The VALU roof of the box the library runs on: the shipped field multiplication (csrc/fe25519.cuh: fe_mul, the function the table and
+ * equation kernels inline) in a bare dependent chain on changing operands, three waves per SIMD, launched back to back for `seconds`
+ * (0 < seconds <= 30); *fmul_g_per_s = 10^9 multiplications per second chip-wide and *sclk_mhz (may be NULL) = the shader clock the chip
+ * held (s_memtime / s_memrealtime), both over the second half of the run.  bench.py divides its achieved field-multiplication rate by this
+ * figure (`valu_roofline.box`) instead of by a constant measured on another box of the pool.  No reference analogue (the reference's own
+ * helper-multiplication benches: benches/basics.rs:284-319). */
+int eg_selfbench_fmul(eg_ctx*, double seconds, double* fmul_g_per_s, double* sclk_mhz);
 
 /* ---- self-check of the fixed-base comb tables (election setup; no reference analogue: dalek's basepoint table is a compile-time
  * constant) ---------------------------------------------------------------------------------------------------------------------

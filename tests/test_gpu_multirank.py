@@ -60,6 +60,27 @@ def test_bench_started_bare_refuses_more_gpus_than_the_node_has():
     assert not [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
 
 
+def test_bench_spawned_single_rank_goes_through_the_bare_launch_path_over_rccl():
+    """VERDICT r5 task 5: the NON-rehearsed launch path on hardware, every round - `python3 bench.py --gpus 1 --force-dist --spawn`: the
+    parent counts the GPUs from the KFD topology in sysfs (no HIP call before the spawn), starts the rank as a child
+    `python -m torch.distributed.run`, the rank initialises RCCL (backend nccl, world size 1), runs the preflight all-gather and the
+    steps, and prints ONE line with tally_exchange_ok (examples/voting.rs:199-203 is the loop the slabs stand in for).  A second
+    invocation asks for one GPU more than HIP_VISIBLE_DEVICES leaves visible: refused with exit code 2 before any rank starts."""
+    r = _run_bare(["--gpus", "1", "--force-dist", "--spawn", "--steps", "1", "--warmup", "0", "--ballots", "20000", "--selfbench-seconds", "0.5",
+                   "--cpu-seconds", "1", "--no-extra-configs"])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = r.stdout.strip().splitlines()
+    lines = [l for l in out if l.startswith("{")]
+    assert len(lines) == 1 and out[-1] == lines[0], out[-5:]
+    line = json.loads(lines[0])
+    assert "starting the ranks as a child" in r.stderr and "cannot count" not in r.stderr
+    assert line["n_gpus"] == 1 and line["config"]["tally_exchange_ok"] is True and line["config"]["accepted"] == 20000
+    assert len(line["per_rank"]) == 1 and line["per_rank"][0]["accepted"] == 20000 and line["exchange"]["us_per_step"] > 0
+    assert line["cpu_baseline"]["verdicts_match_gpu"] is True
+    r = _run_bare(["--gpus", "2", "--steps", "1", "--warmup", "0", "--ballots", "20000"], {"HIP_VISIBLE_DEVICES": "0"}, timeout=300)
+    assert r.returncode == 2 and "FATAL" in r.stderr and "shows 1 GPU(s)" in r.stderr
+
+
 def test_bench_in_process_devices_rehearsed():
     """`bench.py --in-process-devices 3`: the step of the ranked path through ONE process - three contexts (all on device 0 here), one
     resident slab and one stream each, eg_verify_*_batch_multi_device, the running tallies merged by eg_*_tally_encode_multi; the merged
@@ -78,6 +99,16 @@ def test_bench_in_process_devices_rehearsed():
         assert cfg["total_ballots"] == total and cfg["tampered"] == tampered and cfg["accepted"] == total - tampered
         assert cfg["tally_exchange_ok"] is True and cfg["tally_checked_against_one_engine"] is True
         assert line["scaling"] == ("weak" if total == 90000 else "strong") and line["value"] > 1e4 and line["steps"] == 2
+        assert cfg["input"] == "hbm"
+    # the same through ONE pinned host buffer (--from-host: eg_verify_*_batch_multi; VERDICT r5 task 1): the entry a one-process host
+    # with its ballots in host memory calls had no timing anywhere
+    r = _run_bare(["--in-process-devices", "3", "--rehearse-one-gpu", "--from-host", "--steps", "2", "--warmup", "1", "--ballots", "30000",
+                   "--tampered-percent", "1"], {"EG_CHUNK": "32768", "EG_COMB_BIG_BITS": "0"})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    cfg = line["config"]
+    assert cfg["input"] == "host" and cfg["accepted"] == 90000 - 900 and cfg["tally_exchange_ok"] is True
+    assert line["host_inclusive"]["bytes_h2d"] == 90000 * 736 and line["host_inclusive"]["value"] == line["value"] > 1e4
 
 
 def test_bench_four_ranks_ten_million_ballots_rehearsed():

@@ -693,11 +693,24 @@ def test_full_size_properties(eg, ctx, oracle, pk, workload, n):
     tb = p.tally_encode()
     summed, ok = eg.Ristretto(ctx).element_add(ta, tb)
     assert summed == whole and set(ok) == {1}
-    # oracle on a sample that contains tampered ballots
-    idx = torch.cat([bad[:20], torch.randperm(n, generator=g)[:44].cuda()]).cpu().tolist()
-    sample = b"".join(bytes(view[i].cpu().numpy()) for i in idx)
+    # The oracle at full size (VERDICT r5 task 3): EVERY tampered ballot (n / 100) plus 20 000 drawn at random, through the host form in
+    # one call - verdicts word for word and the tally of the sample.  16 threads: ~12.7 k/s single, 4.8 k/s multi, 3.8 k/s QV.  The 10 M
+    # batch keeps a 64-ballot sample plus all tampered ballots of one 1.25 M slab (the slab of one rank of configs[4]).
+    st.zero_()
+    p.tally_reset()
+    p.verify_batch_device(n, d.data_ptr(), st.data_ptr(), stream)
+    torch.cuda.synchronize()
+    if n <= 1_000_000:
+        idx = torch.cat([bad, torch.randperm(n, generator=g)[:20_000].cuda()])
+    else:
+        slab = bad[(bad >= 1_250_000 * 3) & (bad < 1_250_000 * 4)]
+        idx = torch.cat([slab, torch.randperm(n, generator=g)[:64].cuda()])
+        assert 11_000 < len(slab) < 14_000
+    sample = bytes(view[idx].cpu().numpy())
+    want = op.verify_batch(sample, threads=16)
+    assert [int(v) & 0xFFFFFFFF for v in st[idx].cpu().tolist()] == want          # the verdicts of the FULL-SIZE run, word for word
+    assert want.count(0) >= (20_000 if n <= 1_000_000 else 64) * 0.98 and want[: len(idx) - (20_000 if n <= 1_000_000 else 64)].count(0) == 0
     got, gt = p.verify_batch(sample)
-    want = op.verify_batch(sample)
     assert got == want and gt == op.tally(sample, want)
 
 
@@ -1651,7 +1664,7 @@ def test_bench_two_ranks_rehearsed_on_one_gpu(mode):
     size = ["--ballots", "60000"] if mode == "weak" else ["--total-ballots", "100001"]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(29700 + os.getpid() % 200), str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--rehearse-one-gpu", "--tampered-percent", "1", *size]
+           "--rehearse-one-gpu", "--tampered-percent", "1", "--selfbench-seconds", "0.5", "--cpu-seconds", "2", *size]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(root))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
@@ -1662,7 +1675,19 @@ def test_bench_two_ranks_rehearsed_on_one_gpu(mode):
     assert line["config"]["tally_exchange_ok"] is True
     assert line["config"]["accepted"] == total - line["config"]["tampered"] and line["config"]["tampered"] > 0
     assert line["config"]["parallelism"] == "shard2" and line["value"] > 1e4 and line["roofline"]["isolated"]["frac"] > 0
-    assert "cpu_baseline" not in line or line["cpu_baseline"] is None or line["n_gpus"] == 1
+    # a scaling line that explains itself (VERDICT r5 task 1): every rank's own step time, clock and verdict count, the exchange timed on
+    # its own, the CPU baseline at N > 1, and the PCIe-inclusive and JSON legs on EVERY rank at the same time
+    pr = line["per_rank"]
+    assert [r["rank"] for r in pr] == [0, 1] and all(r["ms_per_step"] > 0 and r["device"] == 0 for r in pr)
+    assert sum(r["accepted"] for r in pr) == line["config"]["accepted"] and line["slowest_rank"] in (0, 1)
+    assert line["exchange"]["us_per_step"] > 0 and line["exchange"]["bytes_per_rank"] == 320
+    assert line["cpu_baseline"]["verdicts_match_gpu"] is True and line["cpu_baseline"]["cores"] >= 1
+    hi = line["host_inclusive"]["all_ranks"]
+    assert hi["ranks"] == 2 and hi["verdicts_match_device_path"] is True and hi["sum_value"] >= hi["max_value"] > 0
+    assert all(r["host_inclusive_ok"] and r["host_inclusive_value"] > 0 for r in pr)
+    js = line["json_inclusive"]["all_ranks"]
+    assert js["ranks"] == 2 and js["verdicts_match_device_path"] is True and js["sum_value"] > 0 and js["threads_per_rank"] >= 1
+    assert 100 < line["valu_roofline"]["box"]["fmul_sustained_g"] < 320 and all(r["fmul_box_g"] > 0 for r in pr)      # (two ranks share the GPU here)
 
 
 def test_two_ranks_real_gpu_tallies(eg, ctx, pk, tmp_path):
@@ -2097,3 +2122,243 @@ def test_ring_group_walk_over_many_chunks(eg, ctx, pk, monkeypatch):
     assert torch.equal(st_a, st_b)
     assert int((st_a == 0).sum()) == n - n // 100
     assert plain.tally_encode() == grouped.tally_encode()
+
+
+# ------------------------------------------------------------------ round 6: the context's shared workspace, held multi calls, the new entries
+def _gpu_ballots_as_json(eg, p, seed, distinct, reps, tamper_every=0, **gen_kw):
+    """distinct GPU-generated ballots (every tamper_every-th tampered) -> (packed bytes of the distinct ones, JSON array text repeating them)."""
+    import json
+
+    import torch
+    from elastic_elgamal_amd import ingest, serde
+
+    sz = p.ballot_size
+    d = torch.empty(distinct * sz, dtype=torch.uint8, device="cuda")
+    p.encrypt_batch_device(seed, 0, distinct, d.data_ptr(), **gen_kw)
+    p.ctx.synchronize()
+    raw = bytearray(d.cpu().numpy().tobytes())
+    if tamper_every:
+        for i in range(0, distinct, tamper_every):
+            raw[i * sz + sz - 32] ^= 1
+    raw = bytes(raw)
+    if p.kind_name == "qv":
+        one = [json.dumps(ingest.unpack_qv_ballot(raw[i * sz : (i + 1) * sz], p.n_options, p.credits)) for i in range(distinct)]
+    else:
+        one = [json.dumps(serde.unpack_encrypted_choice(raw[i * sz : (i + 1) * sz], p.n_options, p.single)) for i in range(distinct)]
+    return raw, ("[" + ",".join(one * reps) + "]").encode()
+
+
+def test_two_params_objects_of_one_context_work_at_the_same_time(eg, ctx, grp, oracle, pk):
+    """the per-lane workspace belongs to the CONTEXT; a JSON stream's submissions are in flight while the context's lock
+    is free, so a second params object of the same context - or the primitive tier - can enqueue kernels that use the same workspace on
+    other streams.  The library orders every user of the workspace behind the previous one with events (ws_acquire / ws_release).
+    (a) two params objects (single-choice and quadratic voting) run eg_verify_*_json on ~10^5 ballots each from two threads while a
+    third thread multiplies through the primitive tier; (b) with a stream open and half fed, the SAME thread calls the primitive tier and
+    verifies on another object.  Everything against the oracle."""
+    import threading
+
+    p1 = eg.ChoiceParams.single_choice(ctx, pk, 5)
+    p2 = eg.QuadraticVotingParams(ctx, pk, 3, 9)
+    o1, o2 = oracle.ChoiceParams(pk, 5, True), oracle.QvParams(pk, 3, 9)
+    raw1, text1 = _gpu_ballots_as_json(eg, p1, 9001, 400, 300, tamper_every=7)
+    raw2, text2 = _gpu_ballots_as_json(eg, p2, 9002, 200, 250, tamper_every=5)
+    want1, want2 = o1.verify_batch(raw1, threads=8), o2.verify_batch(raw2, threads=8)
+    assert 0 < want1.count(0) < 400 and 0 < want2.count(0) < 200
+    rnd = random.Random(6)
+    ks = b"".join(sc(rnd.randrange(L)) for _ in range(3 * 96))
+    pts = b"".join(oracle.point_mul_generator(sc(rnd.randrange(L))) for _ in range(3 * 96))
+    want_msm = b"".join(oracle.point_multi_mul(ks[96 * i : 96 * i + 96], pts[96 * i : 96 * i + 96]) for i in range(96))
+    errors, running = [], [True]
+
+    def json_worker(p, text, want, reps):
+        try:
+            for _ in range(3):
+                got, _ = p.verify_json(text, max_objects=len(want) * reps, threads=4)
+                assert got == want * reps, [(i, a, b) for i, (a, b) in enumerate(zip(got, want * reps)) if a != b][:4]
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    def msm_worker():
+        try:
+            while running[0]:
+                out, ok = grp.vartime_multi_mul(3, ks, pts)
+                assert out == want_msm and set(ok) == {1}
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=json_worker, args=(p1, text1, want1, 300)), threading.Thread(target=json_worker, args=(p2, text2, want2, 250))]
+    third = threading.Thread(target=msm_worker)
+    for t in threads + [third]:
+        t.start()
+    for t in threads:
+        t.join()
+    running[0] = False
+    third.join()
+    assert not errors, errors
+    # (b) one thread: a stream half fed (its submissions in flight), then the primitive tier and another object, then the rest
+    st = p1.json_stream(threads=4)
+    half = len(text1) // 2
+    st.feed(text1[:half])
+    for _ in range(3):
+        out, ok = grp.vartime_multi_mul(3, ks, pts)
+        assert out == want_msm and set(ok) == {1}
+        assert p2.verify_batch(raw2)[0] == want2
+    st.feed(text1[half:])
+    got, _ = st.end()
+    assert got == want1 * 300
+    p1.close(); p2.close()
+
+
+def test_multi_calls_hold_their_params_objects(eg, ctx, grp, oracle, pk):
+    """(a) a multi-GPU call on a params object that an explicitly opened JSON stream owns is refused BEFORE it touches
+    anything - the stream's share of the tally and the running tally it set aside are intact: the stream ends with the verdicts and the
+    tally of the one-shot entry; (b) while a multi call runs, calls of other threads on its objects wait (they used to interleave with
+    the set-aside / roll-back of the running tallies): after three threads have hammered two objects with multi calls, host calls and
+    one-shot JSON calls, every running tally is exactly the sum of the calls made."""
+    import threading
+
+    c2 = eg.Context(0)
+    a, b = eg.ChoiceParams.single_choice(ctx, pk, 5), eg.ChoiceParams.single_choice(c2, pk, 5)
+    op = oracle.ChoiceParams(pk, 5, True)
+    raw, text = _gpu_ballots_as_json(eg, a, 9003, 300, 40, tamper_every=9)
+    sz = a.ballot_size
+    want = op.verify_batch(raw, threads=8)
+    T = op.tally(raw, want)                       # tally of the 300 distinct ballots
+    zero = bytes(64 * 5)
+
+    def times(t, k):                              # k x an encoded tally, through the primitive tier
+        acc = zero
+        for _ in range(k):
+            acc = grp.element_add(acc, t)[0]
+        return acc
+
+    want_json, want_json_tally = b.verify_json(text, max_objects=300 * 40)
+    assert want_json == want * 40 and want_json_tally == times(T, 40)
+    a.tally_reset(); b.tally_reset()
+    # (a) refused while a stream is open on one of the objects, with everything intact
+    st = b.json_stream(threads=4)
+    st.feed(text[: len(text) // 2])
+    with pytest.raises(eg.EgError, match="JSON stream is open"):
+        eg.verify_batch_multi([a, b], raw)
+    with pytest.raises(eg.EgError, match="JSON stream is open"):
+        eg.tally_encode_multi([a, b])
+    st.feed(text[len(text) // 2 :])
+    got, tally = st.end()
+    assert got == want_json and tally == want_json_tally == b.tally_encode() and a.tally_encode() == zero
+    a.tally_reset(); b.tally_reset()
+    # (b) three threads on the same two objects
+    errors = []
+    half = (300 // 2) * sz
+
+    def multi_worker():
+        try:
+            for _ in range(4):
+                stt, t = eg.verify_batch_multi([a, b], raw)
+                assert stt == want and t == T
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    def host_worker():
+        try:
+            for _ in range(6):
+                assert a.verify_batch(raw[:half])[0] == want[:150]
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    def json_worker():
+        try:
+            for _ in range(2):
+                got, t = b.verify_json(text, max_objects=300 * 40, threads=4)
+                assert got == want_json and t == want_json_tally
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=f) for f in (multi_worker, host_worker, json_worker)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    Ta, Tb = op.tally(raw[:half], want[:150]), op.tally(raw[half:], want[150:])           # the slabs of a multi call over two objects
+    want_a = grp.element_add(times(Ta, 4), times(Ta, 6))[0]                                 # 4 multi slabs + 6 host calls on the first half
+    want_b = grp.element_add(times(Tb, 4), times(want_json_tally, 2))[0]                    # 4 multi slabs + 2 JSON texts
+    assert a.tally_encode() == want_a and b.tally_encode() == want_b
+    assert eg.tally_encode_multi([a, b]) == grp.element_add(want_a, want_b)[0]
+    a.close(); b.close(); c2.close()
+
+
+def test_selfbench_abi_version_and_prepared_point_arguments(eg, ctx, grp):
+    """eg_selfbench_fmul (VERDICT r5 task 6): the shipped fe_mul in a bare chain sustains 200-320 G multiplications/s on an MI355X at
+    2.0-2.5 GHz; eg_abi_version is what the header says; eg_points_prepare_device insists on d_ok and on a 16-byte aligned d_prepared
+    (ADVICE r5, low)."""
+    import re
+    from pathlib import Path
+
+    import torch
+
+    g, mhz = ctx.selfbench_fmul(1.0)
+    assert 200 < g < 320 and 1800 < mhz < 2600, (g, mhz)
+    hdr = (Path(__file__).resolve().parent.parent / "include" / "eg_hip.h").read_text()
+    assert eg._load().eg_abi_version() == int(re.search(r"#define EG_ABI_VERSION (\d+)", hdr).group(1)) == eg.ABI_VERSION
+    enc = torch.zeros(32 * 8, dtype=torch.uint8, device="cuda")
+    prep = torch.zeros(eg.prepared_point_size() * 8 + 16, dtype=torch.uint8, device="cuda")
+    ok = torch.zeros(8, dtype=torch.uint8, device="cuda")
+    with pytest.raises(eg.EgError, match="d_ok is mandatory"):
+        grp.prepare_points_device(8, enc.data_ptr(), prep.data_ptr(), 0)
+    with pytest.raises(eg.EgError, match="16-byte aligned"):
+        grp.prepare_points_device(8, enc.data_ptr(), prep.data_ptr() + 4, ok.data_ptr())
+    grp.prepare_points_device(8, enc.data_ptr(), prep.data_ptr(), ok.data_ptr())
+    ctx.synchronize()
+    assert ok.cpu().tolist() == [1] * 8                     # the all-zero encoding is the identity, a valid element
+
+
+def test_json_feed_owned_and_the_bound_on_wrong_shape_text(eg, ctx, oracle, pk, monkeypatch):
+    """eg_verify_json_feed_owned (VERDICT r5 task 4b): blocks handed over without a copy - the release function is called once per block,
+    by end at the latest - give the verdicts and the tally of the one-shot entry; an aborted stream gives every block back too.  A text
+    made of ballots of another shape than the election's stops at EG_JSON_ODD_MAX_MB instead of buffering its input (ADVICE r5, low);
+    a one-shot call whose text holds more objects than max_objects breaks off while parsing."""
+    import ctypes as C
+    import json
+
+    import elastic_elgamal_amd as egmod
+
+    p = eg.ChoiceParams.single_choice(ctx, pk, 5)
+    op = oracle.ChoiceParams(pk, 5, True)
+    raw, text = _gpu_ballots_as_json(eg, p, 9004, 200, 100, tamper_every=11)
+    want = op.verify_batch(raw, threads=8) * 100
+    one_shot, one_tally = p.verify_json(text, max_objects=len(want))
+    assert one_shot == want
+    base = C.cast(C.c_char_p(text), C.c_void_p).value
+    for piece in (1 << 20, 12_345, 1 << 26):
+        before = egmod._released_blocks[0]
+        st = p.json_stream(threads=4)
+        n_blocks = 0
+        for at in range(0, len(text), piece):
+            st.feed_owned_ptr(base + at, min(piece, len(text) - at))
+            n_blocks += 1
+        got, tally = st.end()
+        assert got == want and tally == one_tally
+        assert egmod._released_blocks[0] - before == n_blocks
+    before = egmod._released_blocks[0]
+    st = p.json_stream(threads=2)
+    for at in range(0, len(text), 1 << 16):
+        st.feed_owned_ptr(base + at, min(1 << 16, len(text) - at))
+    st.abort()
+    assert egmod._released_blocks[0] - before == -(-len(text) // (1 << 16))
+    assert p.verify_json(text, max_objects=len(want)) == (one_shot, one_tally)
+    with pytest.raises(eg.EgError, match="max_objects"):
+        p.verify_json(text, max_objects=len(want) // 3)
+    assert p.verify_json(text, max_objects=len(want)) == (one_shot, one_tally)
+    p.close()
+    # ballots of a 4-option election offered to a 5-option one: each deserialises, none has the election's shape
+    monkeypatch.setenv("EG_JSON_ODD_MAX_MB", "1")
+    q = eg.ChoiceParams.single_choice(ctx, pk, 5)
+    monkeypatch.delenv("EG_JSON_ODD_MAX_MB")
+    p4 = eg.ChoiceParams.single_choice(ctx, pk, 4)
+    _, odd = _gpu_ballots_as_json(eg, p4, 9005, 50, 40)            # 2000 objects, ~2.5 MB of text
+    with pytest.raises(eg.EgError, match="EG_JSON_ODD_MAX_MB"):
+        q.verify_json(odd, max_objects=2000)
+    small = json.dumps(json.loads(odd)[:50]).encode()
+    got, _ = q.verify_json(small, max_objects=50)                   # below the bound the object path resolves them: OptionsLenMismatch
+    assert got == [eg.OPTIONS_LEN] * 50
+    p4.close(); q.close()

@@ -40,7 +40,8 @@ for n, mode in sizes:
     first = bytes(out.cpu().numpy())
     # the same product over PREPARED points (decoded once: eg_points_prepare_device)
     t0 = time.perf_counter()
-    grp.prepare_points_device(n, pts.data_ptr(), prep.data_ptr()); torch.cuda.synchronize()
+    pok = torch.empty(n, dtype=torch.uint8, device="cuda")
+    grp.prepare_points_device(n, pts.data_ptr(), prep.data_ptr(), pok.data_ptr()); torch.cuda.synchronize()
     t_prep = time.perf_counter() - t0
     for _ in range(2):
         grp.vartime_multi_mul_prepared_device(1, n, sc.data_ptr(), prep.data_ptr(), out.data_ptr(), 0, scratch.data_ptr()); torch.cuda.synchronize()
