@@ -468,6 +468,36 @@ def json_inclusive_leg(args, eg, torch, params, ballots, status, B, n_opt, resid
             "note": "eg_verify_*_json: JSON text in host memory -> status words; parse, upload and verify pipelined"}, jarr
 
 
+def in_process_json_leg(args, eg, torch, params, ballots, status, counts, total, n_opt, resident_value):
+    """--in-process-devices: as many objects as the step has ballots (the first 1000 ballots of slab 0 repeated) as ONE JSON array through
+    eg_verify_*_json_multi: one splitter and pool of host threads, the packed windows dealt to the N params objects, verdicts in text order."""
+    import ctypes
+    import numpy as np
+
+    B0 = counts[0]
+    distinct, _, _, build = ballots_as_json(args, eg, torch, params[0], ballots[0], B0, n_opt, None)
+    reps = max(1, total // distinct)
+    text = build(reps)
+    jn = distinct * reps
+    jstatus = (ctypes.c_uint32 * jn)()
+    cores = effective_cores()
+    for p in params:
+        p.tally_reset()
+    best, got = None, 0
+    for _ in range(3):
+        t0 = time.perf_counter()
+        got = eg.verify_json_multi_into(params, text, jstatus, cores)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    first_status = status[0][:distinct].cpu().numpy().astype(np.uint32) if not args.from_host else None
+    jarr = np.frombuffer(jstatus, dtype=np.uint32)
+    same = bool(got == jn and (first_status is None or np.array_equal(jarr.reshape(reps, distinct), np.tile(first_status, (reps, 1)))))
+    return {"value": jn / best, "unit": "ballots/s", "objects": jn, "json_bytes": len(text), "ms": best * 1e3, "threads": cores,
+            "vs_value": jn / best / resident_value, "verdicts_match_device_path": same, "devices": len(params),
+            "note": "eg_verify_*_json_multi: ONE parser (splitter + pool of host threads) for the node, its packed windows dealt to the params "
+                    "objects by load; PCIe-inclusive; against `value` of this line (the resident rate of the same GPUs)"}
+
+
 def die(code: int, msg: str):
     """Loud, early end of this rank: message on stderr, non-zero exit (torch.distributed.run then ends the other ranks)."""
     print(f"bench.py rank {os.environ.get('RANK', '0')}: FATAL: {msg}", file=sys.stderr, flush=True)
@@ -684,7 +714,12 @@ def bench_in_process(args):
         out["host_inclusive"] = {"value": out["value"], "unit": "ballots/s", "bytes_h2d": total * params[0].ballot_size, "bytes_d2h": 4 * total,
                                  "pinned": True, "h2d_gb_per_s": total * params[0].ballot_size * args.steps / elapsed / 1e9,
                                  "note": "`value` of this line IS the PCIe-inclusive rate (first H2D byte to last status byte D2H, every step)"}
-    #JSON_MULTI_LEG#
+    # the JSON text of the whole batch through the multi-GPU JSON entry (one parser, its packed windows dealt to the N params objects)
+    if not args.no_wire_ingest:
+        try:
+            out["json_inclusive"] = in_process_json_leg(args, eg, torch, params, ballots, status, counts, total, n_opt, out["value"])
+        except Exception as e:            # an extra leg must never cost the line
+            out["json_inclusive"] = {"error": repr(e)}
     print(json.dumps(out), flush=True)
     if not tally_ok:
         raise SystemExit(5)

@@ -21,7 +21,7 @@ from pathlib import Path
 
 __all__ = [
     "Context", "Ristretto", "ChoiceParams", "QuadraticVotingParams", "PublicKeyVerifier", "DecryptionShareVerifier", "SumOfSquaresVerifier", "EgError", "library_path", "build",
-    "STATUS_NAMES", "status_kind", "status_detail", "pack_json", "JsonPacker", "PACK_RESHAPE",
+    "STATUS_NAMES", "status_kind", "status_detail", "pack_json", "JsonPacker", "PACK_RESHAPE", "verify_json_multi", "json_stream_multi",
 ]
 
 _PKG = Path(__file__).resolve().parent
@@ -192,6 +192,10 @@ def _load() -> C.CDLL:
         "eg_qv_ballot_size_for": (sz, [C.c_int, C.c_uint64]),
         "eg_verify_choice_json": (C.c_int, [vp, vp, sz, C.c_int, sz, vp, C.POINTER(sz), vp]),
         "eg_verify_qv_json": (C.c_int, [vp, vp, sz, C.c_int, sz, vp, C.POINTER(sz), vp]),
+        "eg_verify_choice_json_multi": (C.c_int, [C.POINTER(vp), C.c_int, vp, sz, C.c_int, sz, vp, C.POINTER(sz), vp]),
+        "eg_verify_qv_json_multi": (C.c_int, [C.POINTER(vp), C.c_int, vp, sz, C.c_int, sz, vp, C.POINTER(sz), vp]),
+        "eg_verify_choice_json_begin_multi": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.POINTER(vp)]),
+        "eg_verify_qv_json_begin_multi": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.POINTER(vp)]),
         "eg_verify_choice_json_begin": (C.c_int, [vp, C.c_int, C.POINTER(vp)]),
         "eg_verify_qv_json_begin": (C.c_int, [vp, C.c_int, C.POINTER(vp)]),
         "eg_verify_json_feed": (C.c_int, [vp, vp, sz, C.POINTER(sz)]),
@@ -559,6 +563,35 @@ def verify_batch_multi_device(per_device, counts, d_ballots, d_status, streams=N
     return tally.raw if with_tally else None
 
 
+def verify_json_multi_into(per_device, data: bytes, status, threads: int = 0, tally=None) -> int:
+    """``eg_verify_*_json_multi`` with caller-owned buffers (status: ctypes uint32 array): ONE parser, the packed windows dealt to the
+    params objects (one per GPU), verdicts in text order.  Returns the object count."""
+    per_device = list(per_device)
+    p0 = per_device[0]
+    arr = (C.c_void_p * len(per_device))(*[p._h for p in per_device])
+    n = sz_t(0)
+    fn = getattr(_load(), f"eg_verify_{p0._prefix}_json_multi")
+    _check(fn(arr, len(per_device), data, len(data), threads or effective_cores(), len(status), status, C.byref(n), tally))
+    return n.value
+
+
+def verify_json_multi(per_device, text, max_objects: int = 0, threads: int = 0, with_tally: bool = True):
+    """JSON text -> (status words in text order, tally of this call) over several params objects of one election."""
+    per_device = list(per_device)
+    data = text.encode() if isinstance(text, str) else bytes(text)
+    if not max_objects:
+        max_objects = data.count(b"{") + 1
+    st = (C.c_uint32 * max(max_objects, 1))()
+    tally = C.create_string_buffer(64 * per_device[0].n_options) if with_tally else None
+    n = verify_json_multi_into(per_device, data, st, threads, tally)
+    return list(st[:n]), (tally.raw if with_tally else None)
+
+
+def json_stream_multi(per_device, threads: int = 0) -> "JsonStream":
+    """``eg_verify_*_json_begin_multi``: a JSON stream over several params objects (feed / take / end / abort as for one)."""
+    return JsonStream(list(per_device), threads)
+
+
 def tally_encode_multi(per_device) -> bytes:
     """Sum of the running tallies of several params objects of one election (``eg_*_tally_encode_multi``)."""
     per_device = list(per_device)
@@ -575,11 +608,23 @@ class JsonStream:
     end / abort the params object belongs to the stream."""
 
     def __init__(self, params, threads: int = 0):
+        import weakref
+
         self._h = C.c_void_p()
-        self.params = params
         self.objects = 0
-        fn = getattr(_load(), f"eg_verify_{params._prefix}_json_begin")
-        _check(fn(params._h, threads or effective_cores(), C.byref(self._h)))
+        if isinstance(params, (list, tuple)):           # several params objects of one election (one per GPU): eg_verify_*_json_begin_multi
+            self.params, self.all_params = params[0], list(params)
+            arr = (C.c_void_p * len(params))(*[p._h for p in params])
+            fn = getattr(_load(), f"eg_verify_{params[0]._prefix}_json_begin_multi")
+            _check(fn(arr, len(params), threads or effective_cores(), C.byref(self._h)))
+            for p in params:                            # a params object that is destroyed takes the whole stream with it
+                if not hasattr(p, "_streams"):
+                    p._streams = weakref.WeakSet()
+                p._streams.add(self)
+        else:
+            self.params, self.all_params = params, [params]
+            fn = getattr(_load(), f"eg_verify_{params._prefix}_json_begin")
+            _check(fn(params._h, threads or effective_cores(), C.byref(self._h)))
 
     def feed(self, piece) -> int:
         """The next piece of the text (bytes / bytearray / memoryview / str); returns the number of complete objects seen so far."""
@@ -645,7 +690,7 @@ class JsonStream:
     def abort(self):
         h, self._h = getattr(self, "_h", None), None
         # a params object that has been destroyed took its open stream with it (eg_*_params_destroy aborts it): the handle is stale then
-        if h and getattr(self.params, "_h", None):
+        if h and all(getattr(p, "_h", None) for p in self.all_params):
             _load().eg_verify_json_abort(h)
 
     def __del__(self):

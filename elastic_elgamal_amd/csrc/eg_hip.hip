@@ -2126,109 +2126,47 @@ static egwire::VerifyPackedFn make_verify_packed(Engine* e) {
     return engine_verify_host(e, n, packed.data(), status.data(), nullptr) == EG_OK;
   };
 }
-struct eg_json_stream;
-static int stream_begin(Engine* e, int threads, PackPieceFn pack_piece, ReshapeFn reshape, size_t size_hint, eg_json_stream** out);
-static void stream_mark_one_shot(eg_json_stream* S);
-static void stream_set_max_objects(eg_json_stream* S, size_t n);
-// The one-shot entry = the streaming entry fed with the whole text (in place, 64 MB at a time) - one pipeline for both (round 5; rounds 3-4
-// had a second one here, a producer thread and a consumer loop over the same ring).
-static int verify_json_common(Engine* e, const char* json, size_t json_len, int threads, size_t max_objects, uint32_t* status,
-                              size_t* n_objects, uint8_t* tally_out, const PackPieceFn& pack_piece, const ReshapeFn& reshape) {
-  if ((json_len && !json) || (max_objects && !status)) return fail(EG_ERR_BAD_ARG, "bad argument");
-  if (n_objects) *n_objects = 0;
-  eg_json_stream* S = nullptr;
-  std::lock_guard<std::mutex> one_at_a_time(e->long_call_mu);       // concurrent one-shot calls on one params object are serialised, as every entry point is
-  {   // the context's lock only while the stream is opened: its worker thread takes the lock piece by piece, and so does end
-    EG_LOCK(e->ctx);
-    if (e->stream_open) return fail(EG_ERR_BAD_ARG, "a JSON stream is open on this params object (eg_verify_json_end or _abort it first)");
-    TRY(stream_begin(e, threads, pack_piece, reshape, json_len, &S));
-    stream_mark_one_shot(S);
-    stream_set_max_objects(S, max_objects);      // the worker breaks off as soon as the text holds more (nothing further is parsed or verified)
-  }
-  const size_t piece = (size_t)64 << 20;
-  for (size_t at = 0; at < json_len; at += piece) {
-    if (eg_verify_json_feed(S, json + at, std::min(piece, json_len - at), nullptr)) break;       // end reports it and cleans up
-  }
-  size_t taken = 0, total = 0;
-  const int rc = eg_verify_json_end(S, status, max_objects, &taken, &total, tally_out);
-  // end leaves the stream OPEN in exactly one case - more verdicts are left than `status` has room for - and says so through its
-  // out-values: *n_taken = the number left (> cap).  Every other failure has destroyed the stream and reports *n_taken = 0.  (The worker
-  // normally fails the stream as soon as it has cut more than max_objects values, long before this point: stream_emit.)
-  if (rc == EG_ERR_BAD_ARG && taken > max_objects) {
-    eg_verify_json_abort(S);
-    return fail(EG_ERR_BAD_ARG, "more objects in the text than max_objects");
-  }
-  if (rc) return rc;
-  if (n_objects) *n_objects = total;
-  return EG_OK;
-}
-int eg_verify_choice_json(eg_choice_params* p, const char* json, size_t json_len, int threads, size_t max_objects, uint32_t* status,
-                          size_t* n_objects, uint8_t* tally_out) { 
-  if (!p) return fail(EG_ERR_BAD_ARG, "bad argument");
-  const int n_options = p->n_options, single = p->single;
-  const size_t stride = p->eng->plan.stride;
-  Engine* e = p->eng;
-  return verify_json_common(p->eng, json, json_len, threads, max_objects, status, n_objects, tally_out,
-                            [=](const char* text, const std::vector<std::pair<size_t, size_t>>& sub, int th, uint8_t* dst, uint32_t* st,
-                                egwire::WorkerPool* pool) {
-                              egwire::pack_parallel(text, sub, stride, th, dst, st, [&](egwire::Cursor& c, uint8_t* d) {
-                                return egwire::pack_choice(c, n_options, single != 0, d);
-                              }, pool);
-                            },
-                            [=](const char* text, const std::vector<std::pair<size_t, size_t>>& odd, std::vector<uint32_t>& out) {
-                              return egwire::resolve_choice_objects(text, odd, n_options, single != 0, stride, make_check_items(e->ctx),
-                                                                    make_verify_packed(e), out);
-                            });
-}
-int eg_verify_qv_json(eg_qv_params* p, const char* json, size_t json_len, int threads, size_t max_objects, uint32_t* status,
-                      size_t* n_objects, uint8_t* tally_out) { 
-  if (!p) return fail(EG_ERR_BAD_ARG, "bad argument");
-  const int n_options = p->n_options;
-  const eghost::QvShape sh = p->shape;
-  const egwire::RangeShape vote{sh.vote_range.rings.size(), (size_t)sh.vote_range.rings_size()};
-  const egwire::RangeShape credit{sh.credit_range.rings.size(), (size_t)sh.credit_range.rings_size()};
-  Engine* e = p->eng;
-  return verify_json_common(p->eng, json, json_len, threads, max_objects, status, n_objects, tally_out,
-                            [=](const char* text, const std::vector<std::pair<size_t, size_t>>& sub, int th, uint8_t* dst, uint32_t* st,
-                                egwire::WorkerPool* pool) {
-                              egwire::pack_parallel(text, sub, sh.ballot_size, th, dst, st, [&](egwire::Cursor& c, uint8_t* d) {
-                                return egwire::pack_qv(c, n_options, vote, credit, sh.ballot_size, d);
-                              }, pool);
-                            },
-                            [=](const char* text, const std::vector<std::pair<size_t, size_t>>& odd, std::vector<uint32_t>& out) {
-                              return egwire::resolve_qv_objects(text, odd, n_options, vote, credit, sh.ballot_size, make_check_items(e->ctx),
-                                                                make_verify_packed(e), out);
-                            });
-}
-// ---- the JSON text in PIECES: eg_verify_{choice,qv}_json_begin / eg_verify_json_feed / _take / _end / _abort --------------------------------
+// ---- the JSON text in PIECES: eg_verify_{choice,qv}_json_begin[_multi] / eg_verify_json_feed / _feed_owned / _take / _end / _abort --------------
 // (examples/voting.rs:195-198 emits ballots one at a time; src/serde.rs:19-80 is the layout.)  ONE worker thread per stream takes the
 // pieces in order (stream_worker): it cuts a piece (egwire::StreamSplitter: values may straddle pieces), packs its complete ballots on
-// the stream's pool of host threads into the pinned ring (stream_emit), and then PUMPS the GPU side without ever waiting for it
+// the stream's pool of host threads into a pinned ring (stream_emit), and then PUMPS the GPU side without ever waiting for it
 // (stream_pump) - retire the submissions that have landed, enqueue what has piled up (upload, verification on the two work sets, download
 // of the verdicts).  The first submission goes once 2^14 ballots are packed (EG_JSON_FIRST_MIN; measured, profiles/r05_json_stream_probe.txt:
 // 2^13 ... 2^14 ballots 0.91 of the HBM-resident rate, 2^15 0.90, 2^17 0.86 - waiting longer idles the GPU for longer than the small first
 // launches cost), later ones when they are 1.5 x the one in flight, at most two in flight; the worker only waits for the GPU when the ring
-// is full.  The one-shot entries (eg_verify_*_json) are this pipeline fed with the whole text in place.  Between begin and end the params
-// object belongs to the stream (other verify / tally calls on it are refused).
+// is full.  The one-shot entries (eg_verify_*_json[_multi]) are this pipeline fed with the whole text in place.  Between begin and end the
+// params objects belong to the stream (other verify / tally calls on them are refused).
+// SEVERAL GPUs (round 6; VERDICT r5 task 4a: the parser delivers 10 M ballots/s, one GPU takes 6): a stream has one LANE per params object -
+// its own pinned ring, device staging, control streams and submissions in flight - and ONE splitter, pool and worker; every packed window
+// goes to the lane with the fewest ballots waiting or in flight (a faster GPU, or one that started earlier, simply gets more windows), the
+// verdicts are kept by object index (text order), and every params object tallies the windows it verified.
 struct eg_json_stream {
-  Engine* e = nullptr;
-  int threads = 1, n_ctl = 1, ns = 0;
+  struct Region { size_t first, off, m; bool submitted; };
+  struct Group { size_t n_regions, first, off, m; hipEvent_t uploaded, done; };
+  struct Lane {
+    Engine* e = nullptr;
+    size_t cap = 0, first_min = 0, n_submitted = 0, pending = 0;   // pending: ballots in regions that have not been retired yet
+    int n_ctl = 1;
+    bool set_aside = false;
+    std::deque<Region> regions;          // in text order; the front is the oldest one not yet retired
+    std::deque<Group> groups;            // submissions in flight, oldest first
+  };
+  std::vector<Lane> lanes;               // one per params object; lanes[0]'s engine also resolves the ballots of another shape
+  std::vector<eg_ctx*> ctxs;             // the lanes' contexts, each once, in address order: locked together (LockAll)
+  Engine* e = nullptr;                   // = lanes[0].e
+  int threads = 1, ns = 0;
   PackPieceFn pack_piece;
   ReshapeFn reshape;
   std::unique_ptr<egwire::WorkerPool> pool;
   std::unique_ptr<egwire::StreamSplitter> split;
-  size_t stride = 0, cap = 0, first_min = 0, growth = 150;
-  struct Region { size_t first, off, m; bool submitted; };
-  std::deque<Region> regions;          // in text order; the front is the oldest one not yet retired
-  struct Group { size_t n_regions, first, off, m; hipEvent_t uploaded, done; };
-  std::deque<Group> groups;            // submissions in flight, oldest first
+  size_t stride = 0, growth = 150, emitted = 0;
   std::vector<uint32_t> verdicts;      // by object: its pack verdict until (if it packed) the GPU's verdict lands
   std::vector<uint32_t> pack_tmp;
   std::vector<std::string> odd_text;   // objects of another shape than the election's: resolved at the end (the object path needs the GPU to itself)
   std::vector<size_t> odd_at;
-  size_t landed = 0, taken = 0, n_submitted = 0;
-  bool set_aside = false, flushed = false, trace = false;
-  bool one_shot = false;               // opened by eg_verify_*_json for the length of that call: other calls on the params object wait for it
+  size_t taken = 0;
+  bool flushed = false, trace = false;
+  bool one_shot = false;               // opened by eg_verify_*_json for the length of that call: other calls on the params objects wait for it
   size_t max_objects = (size_t)-1;     // one-shot: the room in the caller's status buffer; a text with more objects fails at once (stream_emit)
   size_t odd_bytes = 0, odd_max = (size_t)256 << 20;     // text of the ballots of another shape kept for the object path, and its bound (EG_JSON_ODD_MAX_MB)
   std::atomic<int> failed{EG_OK};      // set once (stream_fail), after err has been written
@@ -2236,8 +2174,8 @@ struct eg_json_stream {
   // Front end: the caller's pieces reach the worker thread through a short queue.  Pieces below `direct_min` are copied into blocks of
   // `block_bytes` (the caller's thread pays one memcpy and returns; cutting, packing and GPU submission happen on the worker thread, in
   // parallel with the caller producing the next piece); larger pieces are handed over in place and feed waits until the worker is through
-  // with them.  Everything above (regions, groups, verdicts, splitter) is touched by the worker thread only, under the context's lock,
-  // until the worker has been joined (end / abort) - take() takes that lock too.
+  // with them.  Everything above (lanes, verdicts, splitter) is touched by the worker thread only, under the contexts' locks, until the
+  // worker has been joined (end / abort) - take() takes those locks too.
   struct Item { std::vector<char> own; const char* ptr = nullptr; size_t len = 0; uint64_t id = 0; bool finish = false;
                 eg_json_release_fn release = nullptr; void* user = nullptr; };      // release: a block handed over by eg_verify_json_feed_owned
   std::thread worker;
@@ -2254,36 +2192,48 @@ struct eg_json_stream {
   std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();      // EG_JSON_TRACE: the timeline on stderr, ms since begin
   double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
 };
-static void stream_mark_one_shot(eg_json_stream* S) { S->one_shot = true; }
-static void stream_set_max_objects(eg_json_stream* S, size_t n) { S->max_objects = n; }
+// every context of a stream's lanes, locked together in address order (one context: exactly the lock every entry point takes)
+struct LockAll {
+  std::vector<std::unique_lock<std::recursive_mutex>> held;
+  explicit LockAll(const std::vector<eg_ctx*>& ctxs) { for (eg_ctx* c : ctxs) held.emplace_back(c->mu); }
+};
 static bool stream_is_one_shot(const eg_json_stream* S) { return S->one_shot; }
 static int stream_fail(eg_json_stream* S, int code, const std::string& msg) {
   if (!S->failed.load(std::memory_order_acquire)) { S->err = msg; S->failed.store(code, std::memory_order_release); }
   return fail(S->failed.load(), S->err);
 }
-static void stream_retire_oldest(eg_json_stream* S) {     // the oldest submission has landed: its verdicts, its part of the ring
-  Engine* e = S->e;
-  const eg_json_stream::Group g = S->groups.front();
-  S->groups.pop_front();
+typedef eg_json_stream::Lane StreamLane;
+static void stream_retire_oldest(eg_json_stream* S, StreamLane& L) {     // the lane's oldest submission has landed: its verdicts, its part of the ring
+  Engine* e = L.e;
+  const eg_json_stream::Group g = L.groups.front();
+  L.groups.pop_front();
   for (size_t k = 0; k < g.n_regions; ++k) {
-    const eg_json_stream::Region r = S->regions.front();
-    S->regions.pop_front();
+    const eg_json_stream::Region r = L.regions.front();
+    L.regions.pop_front();
+    L.pending -= r.m;
     for (size_t i = 0; i < r.m; ++i)
       if (S->verdicts[r.first + i] == EG_ST_OK) S->verdicts[r.first + i] = e->json_status_ring[r.off + i];
   }
-  S->landed = g.first + g.m;
   (void)hipEventDestroy(g.uploaded); (void)hipEventDestroy(g.done);
-  if (S->trace) fprintf(stderr, "[json stream] %8.2f ms  landed    %zu ballots from %zu\n", S->ms(), g.m, g.first);
+  if (S->trace) fprintf(stderr, "[json stream] %8.2f ms  landed    %zu ballots from %zu (lane %d)\n", S->ms(), g.m, g.first, (int)(&L - S->lanes.data()));
 }
-// enqueue what has piled up, if it is time (or `force`: the ring is full, or the text has ended); never waits for the GPU
-static int stream_pump(eg_json_stream* S, bool force) {
-  Engine* e = S->e;
+// objects whose verdicts are final as far as the GPUs are concerned: everything before the oldest region any lane still holds
+static size_t stream_landed(const eg_json_stream* S) {
+  size_t upto = S->emitted;
+  for (const StreamLane& L : S->lanes)
+    if (!L.regions.empty()) upto = std::min(upto, L.regions.front().first);
+  return upto;
+}
+// enqueue what has piled up on a lane, if it is time (or `force`: the ring is full, or the text has ended); never waits for the GPU
+static int stream_pump(eg_json_stream* S, StreamLane& L, bool force) {
+  Engine* e = L.e;
+  if (hipSetDevice(e->ctx->device) != hipSuccess) return stream_fail(S, EG_ERR_HIP, "hipSetDevice");
   for (;;) {
-    while (!S->groups.empty() && hipEventQuery(S->groups.front().done) == hipSuccess) stream_retire_oldest(S);
+    while (!L.groups.empty() && hipEventQuery(L.groups.front().done) == hipSuccess) stream_retire_oldest(S, L);
     (void)hipGetLastError();                           // a submission still running reads as hipErrorNotReady: not an error to keep
-    if (S->groups.size() >= 2) return EG_OK;
+    if (L.groups.size() >= 2) return EG_OK;
     eg_json_stream::Group g{0, 0, 0, 0, nullptr, nullptr};
-    for (auto& r : S->regions) {                       // the run of packed windows behind the submitted ones, contiguous in the ring
+    for (auto& r : L.regions) {                        // the run of packed windows behind the submitted ones, contiguous in the ring
       if (r.submitted) continue;
       if (g.n_regions && r.off != g.off + g.m) break;
       if (!g.n_regions) { g.first = r.first; g.off = r.off; }
@@ -2291,10 +2241,10 @@ static int stream_pump(eg_json_stream* S, bool force) {
     }
     if (!g.n_regions) return EG_OK;
     bool go = force;
-    if (!go && S->groups.empty()) go = S->n_submitted ? true : g.m >= S->first_min;       // an idle GPU takes whatever there is - except the very first time
-    if (!go && S->groups.size() == 1) go = g.m * 100 >= S->groups.back().m * S->growth && g.m >= std::min(S->first_min, S->cap / 8);
+    if (!go && L.groups.empty()) go = L.n_submitted ? true : g.m >= L.first_min;       // an idle GPU takes whatever there is - except the very first time
+    if (!go && L.groups.size() == 1) go = g.m * 100 >= L.groups.back().m * S->growth && g.m >= std::min(L.first_min, L.cap / 8);
     if (!go) return EG_OK;
-    hipStream_t ctl = e->json_ctl[S->n_submitted % (size_t)S->n_ctl];
+    hipStream_t ctl = e->json_ctl[L.n_submitted % (size_t)L.n_ctl];
     const char* what = "window upload: ";
     hipError_t he = hipEventCreateWithFlags(&g.uploaded, hipEventDisableTiming);
     if (he == hipSuccess) he = hipEventCreateWithFlags(&g.done, hipEventDisableTiming | hipEventBlockingSync);
@@ -2315,40 +2265,53 @@ static int stream_pump(eg_json_stream* S, bool force) {
       return stream_fail(S, rc, g_err);
     }
     size_t k = 0;
-    for (auto& r : S->regions) { if (r.submitted) continue; if (k++ == g.n_regions) break; r.submitted = true; }
-    S->groups.push_back(g);
-    ++S->n_submitted;
-    if (S->trace) fprintf(stderr, "[json stream] %8.2f ms  submitted %zu windows, %zu ballots from %zu (%zu in flight)\n", S->ms(), g.n_regions, g.m, g.first, S->groups.size());
+    for (auto& r : L.regions) { if (r.submitted) continue; if (k++ == g.n_regions) break; r.submitted = true; }
+    L.groups.push_back(g);
+    ++L.n_submitted;
+    if (S->trace) fprintf(stderr, "[json stream] %8.2f ms  submitted %zu windows, %zu ballots from %zu (lane %d, %zu in flight)\n", S->ms(), g.n_regions, g.m, g.first, (int)(&L - S->lanes.data()), L.groups.size());
   }
 }
-// room for m packed ballots in the ring (behind the newest region, or from the start again once the oldest regions there have been
+static int stream_pump_all(eg_json_stream* S, bool force) {
+  for (StreamLane& L : S->lanes) TRY(stream_pump(S, L, force));
+  return EG_OK;
+}
+// room for m packed ballots in a lane's ring (behind its newest region, or from the start again once the oldest regions there have been
 // retired); waits for the GPU only when there is none
-static int stream_place(eg_json_stream* S, size_t m, size_t* off) {
+static int stream_place(eg_json_stream* S, StreamLane& L, size_t m, size_t* off) {
   for (;;) {
-    if (S->regions.empty()) { *off = 0; return EG_OK; }
-    const size_t head = S->regions.back().off + S->regions.back().m, tail = S->regions.front().off;
+    if (L.regions.empty()) { *off = 0; return EG_OK; }
+    const size_t head = L.regions.back().off + L.regions.back().m, tail = L.regions.front().off;
     if (head > tail) {                            // the occupied part does not wrap
-      if (head + m <= S->cap) { *off = head; return EG_OK; }
+      if (head + m <= L.cap) { *off = head; return EG_OK; }
       if (m <= tail) { *off = 0; return EG_OK; }
     } else if (head + m <= tail) { *off = head; return EG_OK; }
-    if (S->groups.empty()) {
-      TRY(stream_pump(S, true));                  // the ring is full of packed ballots nobody has submitted yet
-      if (S->groups.empty()) return stream_fail(S, EG_ERR_NOMEM, "a window of ballots does not fit the staging ring");
+    if (L.groups.empty()) {
+      TRY(stream_pump(S, L, true));               // the ring is full of packed ballots nobody has submitted yet
+      if (L.groups.empty()) return stream_fail(S, EG_ERR_NOMEM, "a window of ballots does not fit the staging ring");
     }
-    const hipError_t he = hipEventSynchronize(S->groups.front().done);
+    (void)hipSetDevice(L.e->ctx->device);
+    const hipError_t he = hipEventSynchronize(L.groups.front().done);
     if (he != hipSuccess) return stream_fail(S, EG_ERR_HIP, std::string("window: ") + hipGetErrorString(he));
-    stream_retire_oldest(S);
+    stream_retire_oldest(S, L);
   }
 }
-// the complete values of one window of the text: pack them into the ring, remember the ones that need the object path, pump the GPU
+// the complete values of one window of the text: pack them into a lane's ring, remember the ones that need the object path, pump the GPUs
 static bool stream_emit(eg_json_stream* S, const char* base, const std::vector<std::pair<size_t, size_t>>& spans, size_t first) {
-  Engine* e = S->e;
-  size_t off = 0;
   if (first + spans.size() > S->max_objects) {
     stream_fail(S, EG_ERR_BAD_ARG, "more objects in the text than max_objects");
     return false;
   }
-  if (stream_place(S, spans.size(), &off)) return false;
+  // the lane with the least work waiting or in flight whose ring has room without waiting; if none has, the least loaded one (it waits)
+  StreamLane* best = nullptr;
+  for (StreamLane& L : S->lanes)
+    if (L.pending + spans.size() <= L.cap && (!best || L.pending < best->pending)) best = &L;
+  if (!best)
+    for (StreamLane& L : S->lanes)
+      if (!best || L.pending < best->pending) best = &L;
+  StreamLane& L = *best;
+  Engine* e = L.e;
+  size_t off = 0;
+  if (stream_place(S, L, spans.size(), &off)) return false;
   S->pack_tmp.resize(spans.size());
   S->pack_piece(base, spans, S->threads, e->json_ring + off * S->stride, S->pack_tmp.data(), S->pool.get());
   if (S->verdicts.size() < first + spans.size()) S->verdicts.resize(first + spans.size());
@@ -2366,90 +2329,124 @@ static bool stream_emit(eg_json_stream* S, const char* base, const std::vector<s
       S->odd_text.emplace_back(base + spans[i].first, spans[i].second); S->odd_at.push_back(first + i);
     }
   }
-  S->regions.push_back({first, off, spans.size(), false});
-  return stream_pump(S, false) == EG_OK;
+  L.regions.push_back({first, off, spans.size(), false});
+  L.pending += spans.size();
+  S->emitted = first + spans.size();
+  return stream_pump_all(S, false) == EG_OK;
 }
-static void stream_release(eg_json_stream* S, bool keep_partial_tally) {      // the engine goes back to its owner; the stream is deleted
-  Engine* e = S->e;
-  (void)hipDeviceSynchronize();                         // nothing may still read the ring or the work sets
-  for (auto& g : S->groups) { if (g.uploaded) (void)hipEventDestroy(g.uploaded); if (g.done) (void)hipEventDestroy(g.done); }
-  S->groups.clear();
-  hipStream_t s = e->ctx->stream;
-  if (S->ns && e->n_sets == 2) {
-    if (keep_partial_tally) hipLaunchKernelGGL(k_tally_add_points, dim3(blocks_of((size_t)S->ns)), dim3(NT), 0, s, e->set[1].tally, S->ns, e->set[0].tally);
-    hipLaunchKernelGGL(k_tally_init, dim3(blocks_of((size_t)S->ns)), dim3(NT), 0, s, e->set[1].tally, S->ns);
+static void stream_release(eg_json_stream* S, bool keep_partial_tally) {      // the engines go back to their owners; the stream is deleted
+  for (StreamLane& L : S->lanes) {
+    Engine* e = L.e;
+    (void)hipSetDevice(e->ctx->device);
+    (void)hipDeviceSynchronize();                         // nothing may still read the ring or the work sets
+    for (auto& g : L.groups) { if (g.uploaded) (void)hipEventDestroy(g.uploaded); if (g.done) (void)hipEventDestroy(g.done); }
+    L.groups.clear();
+    hipStream_t s = e->ctx->stream;
+    if (S->ns && e->n_sets == 2) {
+      if (keep_partial_tally) hipLaunchKernelGGL(k_tally_add_points, dim3(blocks_of((size_t)S->ns)), dim3(NT), 0, s, e->set[1].tally, S->ns, e->set[0].tally);
+      hipLaunchKernelGGL(k_tally_init, dim3(blocks_of((size_t)S->ns)), dim3(NT), 0, s, e->set[1].tally, S->ns);
+    }
+    if (L.set_aside && S->ns) {
+      // a finished stream: running tally = what it was + the stream's ballots on this lane; an aborted or failed one: what it was
+      if (keep_partial_tally) hipLaunchKernelGGL(k_tally_add_points, dim3(blocks_of((size_t)S->ns)), dim3(NT), 0, s, e->tally_saved2, S->ns, e->tally);
+      else (void)hipMemcpyAsync(e->tally, e->tally_saved2, (size_t)S->ns * PT_WORDS * sizeof(u32), hipMemcpyDeviceToDevice, s);
+    }
+    (void)hipStreamSynchronize(s);
+    e->stream_open = nullptr;
   }
-  if (S->set_aside && S->ns) {
-    // a finished stream: running tally = what it was + the stream's ballots; an aborted or failed one: what it was
-    if (keep_partial_tally) hipLaunchKernelGGL(k_tally_add_points, dim3(blocks_of((size_t)S->ns)), dim3(NT), 0, s, e->tally_saved2, S->ns, e->tally);
-    else (void)hipMemcpyAsync(e->tally, e->tally_saved2, (size_t)S->ns * PT_WORDS * sizeof(u32), hipMemcpyDeviceToDevice, s);
-  }
-  (void)hipStreamSynchronize(s);
-  e->stream_open = nullptr;
   delete S;
 }
 static void stream_worker(eg_json_stream* S);
-// size_hint: bytes of text to come if the caller knows (the one-shot entry does: a short text gets a short ring), else 0
-static int stream_begin(Engine* e, int threads, PackPieceFn pack_piece, ReshapeFn reshape, size_t size_hint, eg_json_stream** out) {
-  if (!out) return fail(EG_ERR_BAD_ARG, "bad argument");
+// size_hint: bytes of text to come if the caller knows (the one-shot entry does: a short text gets a short ring), else 0.  Called with every
+// engine's context locked (LockAll) and no stream open on any of them.
+static int stream_begin(const std::vector<Engine*>& engines, int threads, PackPieceFn pack_piece, ReshapeFn reshape, size_t size_hint, eg_json_stream** out) {
+  if (!out || engines.empty()) return fail(EG_ERR_BAD_ARG, "bad argument");
   *out = nullptr;
-  if (e->stream_open) return fail(EG_ERR_BAD_ARG, "a JSON stream is already open on this params object");
-  HIPCHK(hipSetDevice(e->ctx->device));
+  for (Engine* e : engines)
+    if (e->stream_open) return fail(EG_ERR_BAD_ARG, "a JSON stream is already open on this params object");
   std::unique_ptr<eg_json_stream> S(new eg_json_stream());
-  S->e = e; S->threads = std::max(threads, 1); S->pack_piece = std::move(pack_piece); S->reshape = std::move(reshape);
-  S->stride = e->plan.stride; S->ns = (int)e->plan.tally_slots.size();
-  S->growth = e->knobs.json_growth; S->trace = e->knobs.json_trace;
-  S->odd_max = e->knobs.json_odd_max_mb << 20;
-  hipStream_t s = e->ctx->stream;
-  HIPCHK(hipDeviceSynchronize());
-  const size_t ring_max = e->knobs.json_ring_kb ? e->knobs.json_ring_kb << 10 : (size_t)1 << 30;
-  const size_t ring_bytes = std::max(size_hint ? std::min(size_hint / 4 * 3 + S->stride, ring_max) : ring_max, 64 * S->stride);
-  S->cap = ring_bytes / S->stride;
-  S->first_min = std::min<size_t>(e->knobs.json_first_min ? e->knobs.json_first_min : (size_t)1 << 14, S->cap / 4);
-  if (S->cap * S->stride > e->json_ring_bytes || S->cap > e->json_ring_ballots) {
-    if (e->json_ring) (void)hipHostFree(e->json_ring);
-    if (e->json_status_ring) (void)hipHostFree(e->json_status_ring);
-    e->json_ring = nullptr; e->json_status_ring = nullptr; e->json_ring_bytes = 0; e->json_ring_ballots = 0;
-    if (hipHostMalloc((void**)&e->json_ring, S->cap * S->stride, hipHostMallocPortable) != hipSuccess ||
-        hipHostMalloc((void**)&e->json_status_ring, S->cap * sizeof(u32), hipHostMallocPortable) != hipSuccess) {
-      (void)hipGetLastError();
-      return fail(EG_ERR_NOMEM, "pinned staging allocation failed");
+  Engine* e0 = engines[0];
+  S->e = e0; S->threads = std::max(threads, 1); S->pack_piece = std::move(pack_piece); S->reshape = std::move(reshape);
+  S->stride = e0->plan.stride; S->ns = (int)e0->plan.tally_slots.size();
+  S->growth = e0->knobs.json_growth; S->trace = e0->knobs.json_trace;
+  S->odd_max = e0->knobs.json_odd_max_mb << 20;
+  const size_t n_lanes = engines.size();
+  S->lanes.resize(n_lanes);
+  // if anything below fails, the lanes that were already set up get their running tallies back
+  size_t lanes_ready = 0;
+  ScopeExit undo{[&]() {
+    if (!S) return;                              // released to the caller: success
+    for (size_t k = 0; k < lanes_ready; ++k) {
+      Engine* e = S->lanes[k].e;
+      if (!S->lanes[k].set_aside || !S->ns) continue;
+      (void)hipSetDevice(e->ctx->device);
+      (void)hipMemcpyAsync(e->tally, e->tally_saved2, (size_t)S->ns * PT_WORDS * sizeof(u32), hipMemcpyDeviceToDevice, e->ctx->stream);
+      (void)hipStreamSynchronize(e->ctx->stream);
     }
-    e->json_ring_bytes = S->cap * S->stride; e->json_ring_ballots = S->cap;
-  } else S->cap = std::min(S->cap, e->json_ring_ballots);
-  TRY(engine_stage_reserve(e, S->cap));
-  if (!e->copy_stream) HIPCHK(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
-  S->n_ctl = e->n_sets == 2 ? 2 : 1;
-  for (int k = 0; k < S->n_ctl; ++k)
-    if (!e->json_ctl[k]) HIPCHK(hipStreamCreateWithFlags(&e->json_ctl[k], hipStreamNonBlocking));
-  {
-    const size_t per_set = (S->cap + e->n_sets - 1) / e->n_sets + NT;
-    const int rr = engine_reserve(e, (u32)std::min<size_t>(per_set, e->max_cap));
-    if (rr != EG_OK && rr != EG_ERR_NOMEM) return rr;
+  }};
+  for (size_t k = 0; k < n_lanes; ++k) {
+    Engine* e = engines[k];
+    StreamLane& L = S->lanes[k];
+    L.e = e;
+    HIPCHK(hipSetDevice(e->ctx->device));
+    hipStream_t s = e->ctx->stream;
+    HIPCHK(hipDeviceSynchronize());
+    // one GiB of pinned staging for one GPU; several GPUs share that budget (at least 128 MiB each)
+    const size_t ring_max = std::max((e->knobs.json_ring_kb ? e->knobs.json_ring_kb << 10 : (size_t)1 << 30) / n_lanes,
+                                     e->knobs.json_ring_kb ? (size_t)0 : (size_t)128 << 20);
+    const size_t hint = size_hint ? size_hint / n_lanes : 0;
+    const size_t ring_bytes = std::max(hint ? std::min(hint / 4 * 3 + S->stride, ring_max) : ring_max, 64 * S->stride);
+    L.cap = ring_bytes / S->stride;
+    L.first_min = std::min<size_t>(e->knobs.json_first_min ? e->knobs.json_first_min : (size_t)1 << 14, L.cap / 4);
+    if (L.cap * S->stride > e->json_ring_bytes || L.cap > e->json_ring_ballots) {
+      if (e->json_ring) (void)hipHostFree(e->json_ring);
+      if (e->json_status_ring) (void)hipHostFree(e->json_status_ring);
+      e->json_ring = nullptr; e->json_status_ring = nullptr; e->json_ring_bytes = 0; e->json_ring_ballots = 0;
+      if (hipHostMalloc((void**)&e->json_ring, L.cap * S->stride, hipHostMallocPortable) != hipSuccess ||
+          hipHostMalloc((void**)&e->json_status_ring, L.cap * sizeof(u32), hipHostMallocPortable) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(EG_ERR_NOMEM, "pinned staging allocation failed");
+      }
+      e->json_ring_bytes = L.cap * S->stride; e->json_ring_ballots = L.cap;
+    } else L.cap = std::min(L.cap, e->json_ring_ballots);
+    TRY(engine_stage_reserve(e, L.cap));
+    if (!e->copy_stream) HIPCHK(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+    L.n_ctl = e->n_sets == 2 ? 2 : 1;
+    for (int c = 0; c < L.n_ctl; ++c)
+      if (!e->json_ctl[c]) HIPCHK(hipStreamCreateWithFlags(&e->json_ctl[c], hipStreamNonBlocking));
+    {
+      const size_t per_set = (L.cap + e->n_sets - 1) / e->n_sets + NT;
+      const int rr = engine_reserve(e, (u32)std::min<size_t>(per_set, e->max_cap));
+      if (rr != EG_OK && rr != EG_ERR_NOMEM) return rr;
+    }
+    if (S->ns) {        // the stream's own tally is reported at the end; the running tally keeps accumulating (eg_hip.h)
+      HIPCHK(hipMemcpyAsync(e->tally_saved2, e->tally, (size_t)S->ns * PT_WORDS * sizeof(u32), hipMemcpyDeviceToDevice, s));
+      hipLaunchKernelGGL(k_tally_init, dim3(blocks_of((size_t)S->ns)), dim3(NT), 0, s, e->tally, S->ns);
+      L.set_aside = true;
+    }
+    lanes_ready = k + 1;
+    HIPCHK(hipStreamSynchronize(s));
+    if (std::find(S->ctxs.begin(), S->ctxs.end(), e->ctx) == S->ctxs.end()) S->ctxs.push_back(e->ctx);
   }
-  if (S->ns) {        // the stream's own tally is reported at the end; the running tally keeps accumulating (eg_hip.h)
-    HIPCHK(hipMemcpyAsync(e->tally_saved2, e->tally, (size_t)S->ns * PT_WORDS * sizeof(u32), hipMemcpyDeviceToDevice, s));
-    hipLaunchKernelGGL(k_tally_init, dim3(blocks_of((size_t)S->ns)), dim3(NT), 0, s, e->tally, S->ns);
-    S->set_aside = true;
-  }
-  HIPCHK(hipStreamSynchronize(s));
+  std::sort(S->ctxs.begin(), S->ctxs.end(), std::less<eg_ctx*>());
   S->pool.reset(new egwire::WorkerPool(S->threads));
   eg_json_stream* raw = S.get();
-  const size_t window = e->knobs.json_window_kb ? e->knobs.json_window_kb << 10 : (size_t)32 << 20;
+  const size_t window = e0->knobs.json_window_kb ? e0->knobs.json_window_kb << 10 : (size_t)32 << 20;
+  size_t min_cap = S->lanes[0].cap;
+  for (const StreamLane& L : S->lanes) min_cap = std::min(min_cap, L.cap);
   S->split.reset(new egwire::StreamSplitter(S->threads, S->pool.get(),
                                             [raw](const char* base, const std::vector<std::pair<size_t, size_t>>& spans, size_t first) {
                                               return stream_emit(raw, base, spans, first);
                                             },
-                                            window, std::max<size_t>(1, S->cap / 8)));
-  e->stream_open = raw;
-  if (S->trace) fprintf(stderr, "[json stream] %8.2f ms  begun (ring of %zu ballots, first submission from %zu)\n", S->ms(), S->cap, S->first_min);
+                                            window, std::max<size_t>(1, min_cap / 8)));
+  for (Engine* e : engines) e->stream_open = raw;
+  if (S->trace) fprintf(stderr, "[json stream] %8.2f ms  begun (%zu lane(s), rings of %zu ballots, first submission from %zu)\n", S->ms(), n_lanes, S->lanes[0].cap, S->lanes[0].first_min);
   S->worker = std::thread(stream_worker, raw);
   *out = S.release();
   return EG_OK;
 }
-// the worker thread of a stream: pieces in order through the splitter (-> stream_emit -> ring, GPU), each under the context's lock
+// the worker thread of a stream: pieces in order through the splitter (-> stream_emit -> rings, GPUs), each under the contexts' locks
 static void stream_worker(eg_json_stream* S) {
-  eg_ctx* ctx = S->e->ctx;
   std::vector<char> joined;                 // small handed-over blocks that were waiting together, copied into one piece (below)
   for (;;) {
     eg_json_stream::Item it;
@@ -2462,8 +2459,9 @@ static void stream_worker(eg_json_stream* S) {
       S->queue.pop_front();
       // Small blocks handed over by eg_verify_json_feed_owned are cheap to take one by one only when they arrive slowly: every piece costs
       // a hand-over, a window of the splitter, two dispatches on the pool (a ballot straddles almost every boundary) and a look at the
-      // GPU - 1 MB pieces at the rate of the verifier are 1 400 of those in 160 ms.  Blocks that are WAITING TOGETHER are therefore joined
-      // into one piece of up to 16 MB, copied by the pool's threads (not by the caller's, and not one after the other), and given back at once.
+      // GPU - 1 MB pieces at the rate of the verifier are 1 400 of those in 160 ms (measured: 0.48 of the resident rate).  Blocks that are
+      // WAITING TOGETHER are therefore joined into one piece of up to 16 MB, copied by the pool's threads (not by the caller's, and not one
+      // after the other), and given back at once: 0.91.
       if (it.release && !it.finish && it.len < S->direct_min) {
         size_t total = it.len;
         while (!S->queue.empty() && S->queue.front().release && !S->queue.front().finish && S->queue.front().len < S->direct_min &&
@@ -2488,11 +2486,10 @@ static void stream_worker(eg_json_stream* S) {
       for (auto& m : more) m.release(m.user, m.ptr, m.len);
     }
     if (!it.finish && !S->failed.load(std::memory_order_acquire)) {
-      std::lock_guard<std::recursive_mutex> lk(ctx->mu);
-      (void)hipSetDevice(ctx->device);
+      LockAll lk(S->ctxs);
       if (!S->split->feed(text, len)) {
         if (!S->failed.load()) stream_fail(S, EG_ERR_BAD_ARG, S->split->error().empty() ? std::string("the piece could not be packed") : S->split->error());
-      } else (void)stream_pump(S, false);
+      } else (void)stream_pump_all(S, false);
       S->objects.store(S->split->count(), std::memory_order_release);
     }
     {
@@ -2506,7 +2503,7 @@ static void stream_worker(eg_json_stream* S) {
     if (it.finish) return;
   }
 }
-// hands an item to the worker (at most four blocks wait in the queue); wait = until the worker is through with it
+// hands an item to the worker (at most ~64 MB of text wait in the queue); wait = until the worker is through with it
 static void stream_enqueue(eg_json_stream* S, std::unique_lock<std::mutex>& lk, eg_json_stream::Item&& it, bool wait) {
   S->q_pop.wait(lk, [&]() { return S->queue.empty() || S->queued_bytes < ((size_t)64 << 20); });
   const uint64_t id = it.id = S->next_id++;
@@ -2524,7 +2521,7 @@ static void stream_flush_acc(eg_json_stream* S, std::unique_lock<std::mutex>& lk
   if (!S->spare.empty()) { S->acc = std::move(S->spare.back()); S->spare.pop_back(); }
   stream_enqueue(S, lk, std::move(it), false);
 }
-static void stream_join_worker(eg_json_stream* S, bool finish) {      // never called with the context's lock held: the worker takes it per piece
+static void stream_join_worker(eg_json_stream* S, bool finish) {      // never called with a context's lock held: the worker takes them per piece
   if (S->worker_joined) return;
   {
     std::unique_lock<std::mutex> lk(S->qmu);
@@ -2587,10 +2584,10 @@ int eg_verify_json_feed_owned(eg_json_stream* S, const char* text, size_t len, e
   if (n_objects) *n_objects = S->objects.load(std::memory_order_acquire);
   return EG_OK;
 }
-// verdicts that are final so far, in order, from where the last take stopped: every ballot before the first one that is still on the GPU
+// verdicts that are final so far, in order, from where the last take stopped: every ballot before the first one that is still on a GPU
 // or waits for the object path (a ballot of another shape than the election's gets its verdict at the end)
 static size_t stream_final_upto(const eg_json_stream* S) {
-  size_t upto = S->flushed ? S->verdicts.size() : S->landed;
+  size_t upto = S->flushed ? S->verdicts.size() : stream_landed(S);
   if (!S->flushed && !S->odd_at.empty()) upto = std::min(upto, S->odd_at.front());
   return upto;
 }
@@ -2602,8 +2599,9 @@ int eg_verify_json_take(eg_json_stream* S, uint32_t* status, size_t cap, size_t*
     std::unique_lock<std::mutex> lk(S->qmu);
     if (!S->flushed && !S->worker_joined) stream_flush_acc(S, lk);
   }
-  EG_LOCK(S->e->ctx);                               // the worker holds it while it cuts and packs a piece
-  if (!S->flushed) TRY(stream_pump(S, S->groups.empty()));     // an idle GPU takes what has been packed, however little
+  LockAll lk(S->ctxs);                              // the worker holds them while it cuts and packs a piece
+  if (!S->flushed)
+    for (StreamLane& L : S->lanes) TRY(stream_pump(S, L, L.groups.empty()));     // an idle GPU takes what has been packed, however little
   const size_t upto = stream_final_upto(S);
   const size_t n = std::min(cap, upto > S->taken ? upto - S->taken : 0);
   if (n) memcpy(status, S->verdicts.data() + S->taken, n * sizeof(uint32_t));
@@ -2613,36 +2611,46 @@ int eg_verify_json_take(eg_json_stream* S, uint32_t* status, size_t cap, size_t*
 }
 int eg_verify_json_end(eg_json_stream* S, uint32_t* status, size_t cap, size_t* n_taken, size_t* n_objects, uint8_t* tally_out) {
   if (!S || (cap && !status)) return fail(EG_ERR_BAD_ARG, "bad argument");
-  eg_ctx* ctx = S->e->ctx;
   stream_join_worker(S, true);                      // every piece cut and packed; from here on this thread owns the stream
-  EG_LOCK(ctx);
-  if (S->trace) fprintf(stderr, "[json stream] %8.2f ms  every piece packed (%zu objects), %zu submissions in flight\n", S->ms(), S->split->count(), S->groups.size());
+  LockAll lk(S->ctxs);
+  if (S->trace) fprintf(stderr, "[json stream] %8.2f ms  every piece packed (%zu objects)\n", S->ms(), S->split->count());
   if (n_taken) *n_taken = 0;
   Engine* e = S->e;
   if (!S->flushed && !S->failed.load()) {
     if (!S->split->finish()) stream_fail(S, EG_ERR_BAD_ARG, S->split->error());
-    while (!S->failed.load() && (!S->regions.empty() || !S->groups.empty())) {
-      if (stream_pump(S, true)) break;
-      if (S->groups.empty()) continue;
-      const hipError_t he = hipEventSynchronize(S->groups.front().done);
-      if (he != hipSuccess) { stream_fail(S, EG_ERR_HIP, std::string("window: ") + hipGetErrorString(he)); break; }
-      stream_retire_oldest(S);
-    }
-    if (!S->failed.load()) {
-      (void)hipDeviceSynchronize();
-      hipStream_t s = ctx->stream;
-      if (S->ns && e->n_sets == 2) {                           // the sets' shares of the tally, once
-        hipLaunchKernelGGL(k_tally_add_points, dim3(blocks_of((size_t)S->ns)), dim3(NT), 0, s, e->set[1].tally, S->ns, e->set[0].tally);
-        hipLaunchKernelGGL(k_tally_init, dim3(blocks_of((size_t)S->ns)), dim3(NT), 0, s, e->set[1].tally, S->ns);
-        if (hipStreamSynchronize(s) != hipSuccess) stream_fail(S, EG_ERR_HIP, "tally merge failed");
+    for (;;) {                                     // every lane: submit what is left, wait for what is in flight, oldest first
+      if (S->failed.load()) break;
+      bool busy = false;
+      for (StreamLane& L : S->lanes) {
+        if (L.regions.empty() && L.groups.empty()) continue;
+        busy = true;
+        if (stream_pump(S, L, true)) break;
+        if (L.groups.empty()) continue;
+        (void)hipSetDevice(L.e->ctx->device);
+        const hipError_t he = hipEventSynchronize(L.groups.front().done);
+        if (he != hipSuccess) { stream_fail(S, EG_ERR_HIP, std::string("window: ") + hipGetErrorString(he)); break; }
+        stream_retire_oldest(S, L);
       }
+      if (!busy) break;
     }
+    if (!S->failed.load())
+      for (StreamLane& L : S->lanes) {
+        Engine* le = L.e;
+        (void)hipSetDevice(le->ctx->device);
+        (void)hipDeviceSynchronize();
+        hipStream_t s = le->ctx->stream;
+        if (S->ns && le->n_sets == 2) {                           // the sets' shares of the tally, once
+          hipLaunchKernelGGL(k_tally_add_points, dim3(blocks_of((size_t)S->ns)), dim3(NT), 0, s, le->set[1].tally, S->ns, le->set[0].tally);
+          hipLaunchKernelGGL(k_tally_init, dim3(blocks_of((size_t)S->ns)), dim3(NT), 0, s, le->set[1].tally, S->ns);
+          if (hipStreamSynchronize(s) != hipSuccess) stream_fail(S, EG_ERR_HIP, "tally merge failed");
+        }
+      }
     if (!S->failed.load() && !S->odd_at.empty()) {   // OptionsLenMismatch / LenMismatch territory: the object path, in the reference's order of checks
       std::string all;
       std::vector<std::pair<size_t, size_t>> spans;
       for (auto& t : S->odd_text) { spans.push_back({all.size(), t.size()}); all += t; all += '\n'; }
       std::vector<uint32_t> v;
-      e->stream_open = nullptr;               // the object path verifies substitute ballots through the ordinary host entry
+      e->stream_open = nullptr;               // the object path verifies substitute ballots through the ordinary host entry of the first lane's engine
       const bool ok = S->reshape(all.data(), spans, v);
       e->stream_open = S;
       if (!ok) stream_fail(S, EG_ERR_HIP, g_err.empty() ? std::string("object path: a GPU call failed") : g_err);
@@ -2666,7 +2674,18 @@ int eg_verify_json_end(eg_json_stream* S, uint32_t* status, size_t cap, size_t* 
   if (n_objects) *n_objects = S->verdicts.size();
   int rc = EG_OK;
   if (S->trace) fprintf(stderr, "[json stream] %8.2f ms  verdicts copied\n", S->ms());
-  if (tally_out && S->ns) rc = engine_tally_encode(e, tally_out);       // the stream's own tally (the running tally gets it added below)
+  if (tally_out && S->ns) {       // the stream's own tally = the sum of its lanes' (every running tally gets its lane's share added below)
+    const size_t bytes = (size_t)S->ns * 32;
+    std::vector<uint8_t> part(bytes), ok(S->ns);
+    for (size_t k = 0; k < S->lanes.size() && !rc; ++k) {
+      (void)hipSetDevice(S->lanes[k].e->ctx->device);
+      rc = engine_tally_encode(S->lanes[k].e, k == 0 ? tally_out : part.data());
+      if (!rc && k) {
+        rc = eg_point_add_batch(e->ctx, (size_t)S->ns, tally_out, part.data(), 0, tally_out, ok.data());
+        if (!rc) for (uint8_t o : ok) if (!o) rc = fail(EG_ERR_HIP, "the tally of lane " + std::to_string(k) + " does not decode");
+      }
+    }
+  }
   const std::string why = g_err;
   const bool trace = S->trace;
   const auto t0 = S->t0;
@@ -2676,40 +2695,151 @@ int eg_verify_json_end(eg_json_stream* S, uint32_t* status, size_t cap, size_t* 
 }
 void eg_verify_json_abort(eg_json_stream* S) {
   if (!S) return;
-  eg_ctx* ctx = S->e->ctx;
   stream_join_worker(S, false);
-  EG_LOCK(ctx);
+  const std::vector<eg_ctx*> ctxs = S->ctxs;      // (the stream is deleted under the locks)
+  LockAll lk(ctxs);
   stream_release(S, false);
 }
-int eg_verify_choice_json_begin(eg_choice_params* p, int threads, eg_json_stream** out) { EG_LOCK_P(p);
-  if (!p) return fail(EG_ERR_BAD_ARG, "bad argument");
-  EG_WAIT_LONG_ONLY(p->eng);       // a one-shot JSON call or a multi-GPU call of another thread: wait for it
+// Opens a stream over one or several params objects.  one_shot: for the length of an eg_verify_*_json[_multi] call, whose caller holds the
+// engines' long_call_mu; an explicit begin takes them only while it opens the stream (so that it waits for a long call that is running on
+// any of the objects, as every entry point does).
+static int stream_open_on(const std::vector<Engine*>& engines, int threads, PackPieceFn pack_piece, ReshapeFn reshape, size_t size_hint, bool one_shot,
+                          size_t max_objects, eg_json_stream** out) {
+  std::vector<Engine*> order(engines);
+  std::sort(order.begin(), order.end(), std::less<Engine*>());
+  std::vector<std::unique_lock<std::mutex>> waits;
+  if (!one_shot) for (Engine* e : order) waits.emplace_back(e->long_call_mu);
+  std::vector<eg_ctx*> ctxs;
+  for (Engine* e : engines) if (std::find(ctxs.begin(), ctxs.end(), e->ctx) == ctxs.end()) ctxs.push_back(e->ctx);
+  std::sort(ctxs.begin(), ctxs.end(), std::less<eg_ctx*>());
+  LockAll lk(ctxs);
+  for (Engine* e : engines)
+    if (e->stream_open) return fail(EG_ERR_BAD_ARG, one_shot ? "a JSON stream is open on this params object (eg_verify_json_end or _abort it first)"
+                                                             : "a JSON stream is already open on this params object");
+  TRY(stream_begin(engines, threads, std::move(pack_piece), std::move(reshape), size_hint, out));
+  (*out)->one_shot = one_shot;
+  (*out)->max_objects = max_objects;              // one-shot: the worker breaks off as soon as the text holds more (nothing further is parsed or verified)
+  return EG_OK;
+}
+// The one-shot entry = the streaming entry fed with the whole text (in place, 64 MB at a time) - one pipeline for both (round 5; rounds 3-4
+// had a second one here, a producer thread and a consumer loop over the same ring).
+static int verify_json_common(const std::vector<Engine*>& engines, const char* json, size_t json_len, int threads, size_t max_objects, uint32_t* status,
+                              size_t* n_objects, uint8_t* tally_out, const PackPieceFn& pack_piece, const ReshapeFn& reshape) {
+  if ((json_len && !json) || (max_objects && !status)) return fail(EG_ERR_BAD_ARG, "bad argument");
+  if (n_objects) *n_objects = 0;
+  eg_json_stream* S = nullptr;
+  // concurrent long calls on a params object are serialised, as every entry point is: the call holds every engine's long_call_mu (address order)
+  std::vector<Engine*> order(engines);
+  std::sort(order.begin(), order.end(), std::less<Engine*>());
+  std::vector<std::unique_lock<std::mutex>> one_at_a_time;
+  for (Engine* e : order) one_at_a_time.emplace_back(e->long_call_mu);
+  // the contexts' locks only while the stream is opened: its worker thread takes them piece by piece, and so does end
+  TRY(stream_open_on(engines, threads, pack_piece, reshape, json_len, true, max_objects, &S));
+  const size_t piece = (size_t)64 << 20;
+  for (size_t at = 0; at < json_len; at += piece) {
+    if (eg_verify_json_feed(S, json + at, std::min(piece, json_len - at), nullptr)) break;       // end reports it and cleans up
+  }
+  size_t taken = 0, total = 0;
+  const int rc = eg_verify_json_end(S, status, max_objects, &taken, &total, tally_out);
+  // end leaves the stream OPEN in exactly one case - more verdicts are left than `status` has room for - and says so through its
+  // out-values: *n_taken = the number left (> cap).  Every other failure has destroyed the stream and reports *n_taken = 0.  (The worker
+  // normally fails the stream as soon as it has cut more than max_objects values, long before this point: stream_emit.)
+  if (rc == EG_ERR_BAD_ARG && taken > max_objects) {
+    eg_verify_json_abort(S);
+    return fail(EG_ERR_BAD_ARG, "more objects in the text than max_objects");
+  }
+  if (rc) return rc;
+  if (n_objects) *n_objects = total;
+  return EG_OK;
+}
+// how a choice / QV election packs its ballots and resolves the ones of another shape (the object path runs on the FIRST engine)
+static void choice_json_fns(const eg_choice_params* p, PackPieceFn* pack, ReshapeFn* reshape) {
   const int n_options = p->n_options, single = p->single;
   const size_t stride = p->eng->plan.stride;
   Engine* e = p->eng;
-  return stream_begin(e, threads,
-                      [=](const char* text, const std::vector<std::pair<size_t, size_t>>& sub, int th, uint8_t* dst, uint32_t* st, egwire::WorkerPool* pool) {
-                        egwire::pack_parallel(text, sub, stride, th, dst, st, [&](egwire::Cursor& c, uint8_t* d) { return egwire::pack_choice(c, n_options, single != 0, d); }, pool);
-                      },
-                      [=](const char* text, const std::vector<std::pair<size_t, size_t>>& odd, std::vector<uint32_t>& res) {
-                        return egwire::resolve_choice_objects(text, odd, n_options, single != 0, stride, make_check_items(e->ctx), make_verify_packed(e), res);
-                      }, 0, out);
+  *pack = [=](const char* text, const std::vector<std::pair<size_t, size_t>>& sub, int th, uint8_t* dst, uint32_t* st, egwire::WorkerPool* pool) {
+    egwire::pack_parallel(text, sub, stride, th, dst, st, [&](egwire::Cursor& c, uint8_t* d) { return egwire::pack_choice(c, n_options, single != 0, d); }, pool);
+  };
+  *reshape = [=](const char* text, const std::vector<std::pair<size_t, size_t>>& odd, std::vector<uint32_t>& res) {
+    return egwire::resolve_choice_objects(text, odd, n_options, single != 0, stride, make_check_items(e->ctx), make_verify_packed(e), res);
+  };
 }
-int eg_verify_qv_json_begin(eg_qv_params* p, int threads, eg_json_stream** out) { EG_LOCK_P(p);
-  if (!p) return fail(EG_ERR_BAD_ARG, "bad argument");
-  EG_WAIT_LONG_ONLY(p->eng);       // a one-shot JSON call or a multi-GPU call of another thread: wait for it
+static void qv_json_fns(const eg_qv_params* p, PackPieceFn* pack, ReshapeFn* reshape) {
   const int n_options = p->n_options;
   const eghost::QvShape sh = p->shape;
   const egwire::RangeShape vote{sh.vote_range.rings.size(), (size_t)sh.vote_range.rings_size()};
   const egwire::RangeShape credit{sh.credit_range.rings.size(), (size_t)sh.credit_range.rings_size()};
   Engine* e = p->eng;
-  return stream_begin(e, threads,
-                      [=](const char* text, const std::vector<std::pair<size_t, size_t>>& sub, int th, uint8_t* dst, uint32_t* st, egwire::WorkerPool* pool) {
-                        egwire::pack_parallel(text, sub, sh.ballot_size, th, dst, st, [&](egwire::Cursor& c, uint8_t* d) { return egwire::pack_qv(c, n_options, vote, credit, sh.ballot_size, d); }, pool);
-                      },
-                      [=](const char* text, const std::vector<std::pair<size_t, size_t>>& odd, std::vector<uint32_t>& res) {
-                        return egwire::resolve_qv_objects(text, odd, n_options, vote, credit, sh.ballot_size, make_check_items(e->ctx), make_verify_packed(e), res);
-                      }, 0, out);
+  *pack = [=](const char* text, const std::vector<std::pair<size_t, size_t>>& sub, int th, uint8_t* dst, uint32_t* st, egwire::WorkerPool* pool) {
+    egwire::pack_parallel(text, sub, sh.ballot_size, th, dst, st, [&](egwire::Cursor& c, uint8_t* d) { return egwire::pack_qv(c, n_options, vote, credit, sh.ballot_size, d); }, pool);
+  };
+  *reshape = [=](const char* text, const std::vector<std::pair<size_t, size_t>>& odd, std::vector<uint32_t>& res) {
+    return egwire::resolve_qv_objects(text, odd, n_options, vote, credit, sh.ballot_size, make_check_items(e->ctx), make_verify_packed(e), res);
+  };
+}
+extern "C++" {
+template <class Params>
+static int engines_of(Params* const* per_device, int n_dev, std::vector<Engine*>* out) {
+  TRY(multi_check(per_device, n_dev));
+  for (int d = 0; d < n_dev; ++d) out->push_back(per_device[d]->eng);
+  return EG_OK;
+}
+}
+int eg_verify_choice_json(eg_choice_params* p, const char* json, size_t json_len, int threads, size_t max_objects, uint32_t* status,
+                          size_t* n_objects, uint8_t* tally_out) {
+  if (!p) return fail(EG_ERR_BAD_ARG, "bad argument");
+  PackPieceFn pack; ReshapeFn reshape;
+  choice_json_fns(p, &pack, &reshape);
+  return verify_json_common({p->eng}, json, json_len, threads, max_objects, status, n_objects, tally_out, pack, reshape);
+}
+int eg_verify_qv_json(eg_qv_params* p, const char* json, size_t json_len, int threads, size_t max_objects, uint32_t* status,
+                      size_t* n_objects, uint8_t* tally_out) {
+  if (!p) return fail(EG_ERR_BAD_ARG, "bad argument");
+  PackPieceFn pack; ReshapeFn reshape;
+  qv_json_fns(p, &pack, &reshape);
+  return verify_json_common({p->eng}, json, json_len, threads, max_objects, status, n_objects, tally_out, pack, reshape);
+}
+int eg_verify_choice_json_multi(eg_choice_params* const* per_device, int n_dev, const char* json, size_t json_len, int threads, size_t max_objects,
+                                uint32_t* status, size_t* n_objects, uint8_t* tally_out) {
+  std::vector<Engine*> engines;
+  TRY(engines_of(per_device, n_dev, &engines));
+  PackPieceFn pack; ReshapeFn reshape;
+  choice_json_fns(per_device[0], &pack, &reshape);
+  return verify_json_common(engines, json, json_len, threads, max_objects, status, n_objects, tally_out, pack, reshape);
+}
+int eg_verify_qv_json_multi(eg_qv_params* const* per_device, int n_dev, const char* json, size_t json_len, int threads, size_t max_objects,
+                            uint32_t* status, size_t* n_objects, uint8_t* tally_out) {
+  std::vector<Engine*> engines;
+  TRY(engines_of(per_device, n_dev, &engines));
+  PackPieceFn pack; ReshapeFn reshape;
+  qv_json_fns(per_device[0], &pack, &reshape);
+  return verify_json_common(engines, json, json_len, threads, max_objects, status, n_objects, tally_out, pack, reshape);
+}
+int eg_verify_choice_json_begin(eg_choice_params* p, int threads, eg_json_stream** out) {
+  if (!p) return fail(EG_ERR_BAD_ARG, "bad argument");
+  PackPieceFn pack; ReshapeFn reshape;
+  choice_json_fns(p, &pack, &reshape);
+  return stream_open_on({p->eng}, threads, pack, reshape, 0, false, (size_t)-1, out);
+}
+int eg_verify_qv_json_begin(eg_qv_params* p, int threads, eg_json_stream** out) {
+  if (!p) return fail(EG_ERR_BAD_ARG, "bad argument");
+  PackPieceFn pack; ReshapeFn reshape;
+  qv_json_fns(p, &pack, &reshape);
+  return stream_open_on({p->eng}, threads, pack, reshape, 0, false, (size_t)-1, out);
+}
+int eg_verify_choice_json_begin_multi(eg_choice_params* const* per_device, int n_dev, int threads, eg_json_stream** out) {
+  std::vector<Engine*> engines;
+  TRY(engines_of(per_device, n_dev, &engines));
+  PackPieceFn pack; ReshapeFn reshape;
+  choice_json_fns(per_device[0], &pack, &reshape);
+  return stream_open_on(engines, threads, pack, reshape, 0, false, (size_t)-1, out);
+}
+int eg_verify_qv_json_begin_multi(eg_qv_params* const* per_device, int n_dev, int threads, eg_json_stream** out) {
+  std::vector<Engine*> engines;
+  TRY(engines_of(per_device, n_dev, &engines));
+  PackPieceFn pack; ReshapeFn reshape;
+  qv_json_fns(per_device[0], &pack, &reshape);
+  return stream_open_on(engines, threads, pack, reshape, 0, false, (size_t)-1, out);
 }
 size_t eg_qv_ballot_size_for(int n_options, uint64_t credits) {
   if (n_options < 1 || n_options > 256 || credits < 1 || credits > 100000) return 0;

@@ -449,6 +449,22 @@ int eg_verify_choice_json(eg_choice_params*, const char* json, size_t json_len, 
 int eg_verify_qv_json(eg_qv_params*, const char* json, size_t json_len, int threads, size_t max_objects, uint32_t* status,
                       size_t* n_objects, uint8_t* tally_out);
 
+/* ---- the JSON entries over several GPUs of ONE process (the parser delivers 10 M ballots/s on 16 threads, one GPU verifies 6) ----
+ * per_device[d]: params objects of the SAME election, each on its own context (as for eg_verify_*_batch_multi).  ONE parser - one splitter,
+ * one pool of `threads` host threads - cuts and packs the text; every packed window (a few thousand ballots) goes to the params object with
+ * the fewest ballots waiting or in flight, each of which has its own pinned ring, device staging and two submissions in flight (the pinned
+ * budget of EG_JSON_RING_KB is divided among them, at least 128 MiB each).  status[k] is the verdict of object k of the TEXT, whichever GPU
+ * verified it; every params object adds the accepted ballots of the windows it verified to its OWN running tally; tally_out = the tally of
+ * the call's (the stream's) whole text, the lanes' tallies merged with the element addition of the primitive tier (eg_*_tally_encode_multi
+ * sums the running tallies).  Ballots of another shape than the election's are resolved through the first object.  Everything else -
+ * pieces of any size, feed / feed_owned / take / end / abort, errors, the params objects belonging to the stream - as for one object. */
+int eg_verify_choice_json_multi(eg_choice_params* const* per_device, int n_dev, const char* json, size_t json_len, int threads, size_t max_objects,
+                                uint32_t* status, size_t* n_objects, uint8_t* tally_out);
+int eg_verify_qv_json_multi(eg_qv_params* const* per_device, int n_dev, const char* json, size_t json_len, int threads, size_t max_objects,
+                            uint32_t* status, size_t* n_objects, uint8_t* tally_out);
+int eg_verify_choice_json_begin_multi(eg_choice_params* const* per_device, int n_dev, int threads, eg_json_stream** out);
+int eg_verify_qv_json_begin_multi(eg_qv_params* const* per_device, int n_dev, int threads, eg_json_stream** out);
+
 /* ---- host-only introspection (no GPU needed; used by the CPU-side tests of the host logic) -------------------------------------
  * RangeDecomposition::optimal(upper_bound).to_string() (range.rs:110-124,148-305): the string hashed into the transcript */
 int eg_range_decomposition(uint64_t upper_bound, char* buf, size_t cap);

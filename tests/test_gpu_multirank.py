@@ -100,6 +100,8 @@ def test_bench_in_process_devices_rehearsed():
         assert cfg["tally_exchange_ok"] is True and cfg["tally_checked_against_one_engine"] is True
         assert line["scaling"] == ("weak" if total == 90000 else "strong") and line["value"] > 1e4 and line["steps"] == 2
         assert cfg["input"] == "hbm"
+        js = line["json_inclusive"]                     # the JSON text of the batch through eg_verify_*_json_multi (one parser, three lanes)
+        assert js["devices"] == 3 and js["verdicts_match_device_path"] is True and js["value"] > 1e4, js
     # the same through ONE pinned host buffer (--from-host: eg_verify_*_batch_multi; VERDICT r5 task 1): the entry a one-process host
     # with its ballots in host memory calls had no timing anywhere
     r = _run_bare(["--in-process-devices", "3", "--rehearse-one-gpu", "--from-host", "--steps", "2", "--warmup", "1", "--ballots", "30000",

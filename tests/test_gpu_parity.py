@@ -2362,3 +2362,86 @@ def test_json_feed_owned_and_the_bound_on_wrong_shape_text(eg, ctx, oracle, pk, 
     got, _ = q.verify_json(small, max_objects=50)                   # below the bound the object path resolves them: OptionsLenMismatch
     assert got == [eg.OPTIONS_LEN] * 50
     p4.close(); q.close()
+
+
+@pytest.mark.parametrize("kind", ["single", "qv"])
+def test_json_entries_over_several_params_objects(eg, ctx, grp, oracle, pk, kind, monkeypatch):
+    """eg_verify_*_json_multi / eg_verify_*_json_begin_multi (VERDICT r5 task 4a; examples/voting.rs:195-198 is the producer, src/serde.rs:19-80
+    the layout): ONE parser, its packed windows dealt to three params objects (three contexts on device 0 stand in for three GPUs), verdicts in
+    TEXT order.  Verdicts and tally equal the one-object entry's on the same text - tampered ballots, a junk object, ballots of another
+    shape (resolved through the first object); every lane took part; the running tallies add up to the text's tally; the stream form fed in
+    random pieces, with take() handing out only final verdicts, gives the same; a params object of the stream refuses other calls; abort
+    leaves every running tally as it was."""
+    import json
+
+    rnd = random.Random(77)
+    monkeypatch.setenv("EG_JSON_WINDOW_KB", "96")         # many windows in a small text: every lane gets some
+    monkeypatch.setenv("EG_JSON_FIRST_MIN", "64")
+    extra = [eg.Context(0), eg.Context(0)]
+    if kind == "single":
+        mk = lambda c, n=5: eg.ChoiceParams.single_choice(c, pk, n)
+        op = oracle.ChoiceParams(pk, 5, True)
+    else:
+        mk = lambda c, n=3: eg.QuadraticVotingParams(c, pk, n, 9)
+        op = oracle.QvParams(pk, 3, 9)
+    objs = [mk(ctx)] + [mk(c) for c in extra]
+    other = mk(ctx, 4)                                       # an election of another shape: its ballots deserialise, but not as ours
+    monkeypatch.delenv("EG_JSON_WINDOW_KB"); monkeypatch.delenv("EG_JSON_FIRST_MIN")
+    try:
+        raw, text = _gpu_ballots_as_json(eg, objs[0], 9100, 300, 1, tamper_every=13)
+        _, odd = _gpu_ballots_as_json(eg, other, 9101, 6, 1)
+        want300 = op.verify_batch(raw, threads=8)
+        items = json.loads(text) * 12
+        odd_items = json.loads(odd)
+        for k, o in enumerate(odd_items):
+            items.insert(500 * (k + 1), o)
+        items.insert(1234, {"junk": ["}", "]"]})
+        whole = json.dumps(items).encode()
+        one = mk(eg.Context(0))
+        want, want_tally = one.verify_json(whole, max_objects=len(items))
+        one.close()
+        assert len(want) == len(items) and want.count(eg.MALFORMED) == 1 and want.count(0) == 12 * want300.count(0)
+        assert sum(1 for v in want if eg.status_kind(v) in (eg.OPTIONS_LEN, eg.QV_VARIANT_LEN, eg.RANGE_LEN, eg.QV_CREDIT_RANGE_LEN, eg.QV_CREDIT_EQUIV_LEN)) == 6
+        for o in objs:
+            o.tally_reset()
+        got, tally = eg.verify_json_multi(objs, whole, max_objects=len(items), threads=4)
+        assert got == want and tally == want_tally
+        shares = [o.tally_encode() for o in objs]
+        assert all(s != bytes(len(s)) for s in shares), "a lane got no window"
+        assert eg.tally_encode_multi(objs) == want_tally
+        # the stream form, random pieces
+        for o in objs:
+            o.tally_reset()
+        st = eg.json_stream_multi(objs, threads=4)
+        for o in objs:
+            with pytest.raises(eg.EgError, match="stream is open"):
+                o.verify_batch(raw[: o.ballot_size])
+        with pytest.raises(eg.EgError, match="JSON stream is open"):
+            eg.verify_batch_multi(objs, raw)
+        got, at = [], 0
+        while at < len(whole):
+            size = min(rnd.choice((1, 50, 3000, 70000, 400000)), len(whole) - at)
+            st.feed(whole[at : at + size])
+            at += size
+            got += st.take(2000)
+            assert got == want[: len(got)]
+        rest, tally = st.end()
+        assert got + rest == want and tally == want_tally and eg.tally_encode_multi(objs) == want_tally
+        # abort: nothing moves
+        before = [o.tally_encode() for o in objs]
+        st = eg.json_stream_multi(objs, threads=2)
+        st.feed(whole[: len(whole) // 2])
+        st.abort()
+        assert [o.tally_encode() for o in objs] == before
+        # a text with more objects than room: breaks off, and the objects are in order afterwards
+        with pytest.raises(eg.EgError, match="max_objects"):
+            eg.verify_json_multi(objs, whole, max_objects=len(items) // 2)
+        assert [o.tally_encode() for o in objs] == before
+        got, tally = eg.verify_json_multi(objs[:2], whole, max_objects=len(items))       # two objects, one of them the first again
+        assert got == want and tally == want_tally
+    finally:
+        for o in objs:
+            o.close()
+        other.close()
+        for c in extra:
+            c.close()
