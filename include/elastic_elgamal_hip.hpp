@@ -13,6 +13,7 @@
 #pragma once
 #include <array>
 #include <cstdint>
+#include <memory>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -316,12 +317,34 @@ class JsonStream {
  public:
   JsonStream(const ChoiceParams& p, int threads = 1) : options_(p.options_count()) { check(eg_verify_choice_json_begin(p.raw(), threads, &s_)); }
   JsonStream(const QuadraticVotingParams& p, int threads = 1) : options_(p.options_count()) { check(eg_verify_qv_json_begin(p.raw(), threads, &s_)); }
+  // several params objects of ONE election, one per GPU (eg_verify_*_json_begin_multi): one parser, its packed windows dealt to the GPUs by
+  // load, verdicts in text order; every params object tallies the windows it verified, finish() reports the text's tally
+  JsonStream(const std::vector<const ChoiceParams*>& per_device, int threads = 1) : options_(per_device.at(0)->options_count()) {
+    std::vector<eg_choice_params*> raw;
+    for (auto* p : per_device) raw.push_back(p->raw());
+    check(eg_verify_choice_json_begin_multi(raw.data(), (int)raw.size(), threads, &s_));
+  }
+  JsonStream(const std::vector<const QuadraticVotingParams*>& per_device, int threads = 1) : options_(per_device.at(0)->options_count()) {
+    std::vector<eg_qv_params*> raw;
+    for (auto* p : per_device) raw.push_back(p->raw());
+    check(eg_verify_qv_json_begin_multi(raw.data(), (int)raw.size(), threads, &s_));
+  }
   JsonStream(const JsonStream&) = delete;
   JsonStream& operator=(const JsonStream&) = delete;
   ~JsonStream() { if (s_) eg_verify_json_abort(s_); }
   // the next piece; returns the number of complete objects seen so far
   size_t feed(const char* text, size_t len) { size_t n = 0; check(eg_verify_json_feed(s_, text, len, &n)); objects_ = n; return n; }
   size_t feed(const std::string& piece) { return feed(piece.data(), piece.size()); }
+  // a block handed over WITHOUT a copy (eg_verify_json_feed_owned): the stream keeps the shared buffer alive until the library gives it back
+  size_t feed_owned(std::shared_ptr<const std::string> block) {
+    auto* keep = new std::shared_ptr<const std::string>(std::move(block));
+    size_t n = 0;
+    const int rc = eg_verify_json_feed_owned(s_, (*keep)->data(), (*keep)->size(),
+                                             [](void* user, const char*, size_t) { delete static_cast<std::shared_ptr<const std::string>*>(user); }, keep, &n);
+    if (rc != EG_OK) { delete keep; check(rc); }          // a failed call leaves the block with the caller
+    objects_ = n;
+    return n;
+  }
   // status words that are final so far, in order (never blocks)
   std::vector<uint32_t> take(size_t cap = 1 << 20) {
     std::vector<uint32_t> st(cap);

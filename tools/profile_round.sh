@@ -52,5 +52,12 @@ timeout -k 10 300 python3 tools/json_stream_probe.py > gpurun_out/json_stream_pr
 timeout -k 10 200 python3 tools/json_trace_probe.py > gpurun_out/json_trace.txt 2>&1 || exit 1
 timeout -k 10 300 python3 tools/msm_probe.py > gpurun_out/msm_by_size.txt 2>&1 || exit 1
 timeout -k 10 300 python3 bench.py --in-process-devices 2 --rehearse-one-gpu --steps 3 --warmup 1 --ballots 500000 > gpurun_out/bench_in_process2.json 2> gpurun_out/bench_in_process2.err || exit 1
-timeout -k 10 300 python3 bench.py --gpus 2 --rehearse-one-gpu --steps 3 --warmup 1 --ballots 500000 --no-isolated > gpurun_out/bench_bare2.json 2> gpurun_out/bench_bare2.err || exit 1
+timeout -k 10 400 python3 bench.py --gpus 2 --rehearse-one-gpu --steps 3 --warmup 1 --ballots 500000 --no-isolated > gpurun_out/bench_bare2.json 2> gpurun_out/bench_bare2.err || exit 1
+# round 6: the in-process leg from ONE pinned host buffer (eg_verify_*_batch_multi), the non-rehearsed bare launch at N = 1 over RCCL
+# (--spawn --force-dist: count the GPUs from sysfs -> child torch.distributed.run -> RCCL init -> preflight -> line), the driver's own
+# command, and the FP64-limb multiplier micro-benchmark with the package power beside it
+timeout -k 10 300 python3 bench.py --in-process-devices 2 --rehearse-one-gpu --from-host --steps 3 --warmup 1 --ballots 500000 > gpurun_out/bench_in_process2_host.json 2> gpurun_out/bench_in_process2_host.err || exit 1
+timeout -k 10 300 python3 bench.py --gpus 1 --force-dist --spawn --steps 5 --warmup 1 --no-extra-configs > gpurun_out/bench_spawn1.json 2> gpurun_out/bench_spawn1.err || exit 1
+timeout -k 10 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_driver_cmd.json 2> gpurun_out/bench_driver_cmd.err || exit 1
+timeout -k 10 300 tools/fp64_probe.sh gpurun_out/ubench_fp64.txt 4 || exit 1
 echo "profile round done"

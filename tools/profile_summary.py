@@ -43,7 +43,8 @@ def kname(name):
 for src, dst in () if TRAFFIC_ONLY else (("bench_single.json", "bench_line.json"), ("bench_multi.json", "bench_line_multi16.json"), ("bench_qv.json", "bench_line_qv.json"),
                  ("bench_10M.json", "bench_line_10M.json"), ("bench_tampered1pct.json", "bench_line_tampered1pct.json"),
                  ("bench_msm.json", "bench_line_msm.json"), ("bench_in_process2.json", "bench_line_in_process2_one_gpu.json"),
-                 ("bench_bare2.json", "bench_line_bare_gpus2_one_gpu.json")):
+                 ("bench_bare2.json", "bench_line_bare_gpus2_one_gpu.json"), ("bench_in_process2_host.json", "bench_line_in_process2_from_host_one_gpu.json"),
+                 ("bench_spawn1.json", "bench_line_spawn_gpus1_rccl.json"), ("bench_driver_cmd.json", "bench_line_driver_cmd.json")):
     f = OUT / src
     if f.exists() and f.read_text().strip():
         line = f.read_text().strip().splitlines()[-1]
@@ -55,6 +56,7 @@ for src, dst, head in () if TRAFFIC_ONLY else (
         ("hbm_power_probe.txt", "hbm_power_probe.txt", "# python3 tools/hbm_power_probe.py   (MI355X; package power from hwmon while device-to-device copies stream)"),
         ("json_stream_probe.txt", "json_stream_probe.txt", "# python3 tools/json_stream_probe.py   (MI355X, 16 host threads; 1 M single-choice ballots as 1.39 GB of JSON)"),
         ("json_trace.txt", "json_stream_trace.txt", "# EG_JSON_TRACE=1 python3 tools/json_trace_probe.py   (MI355X; timeline of eg_verify_choice_json on 1 M ballots, three calls)"),
+        ("ubench_fp64.txt", "ubench_fp64.txt", "# tools/fp64_probe.sh   (MI355X; FP64-limb field multiplication against the shipped integer one: bursts with the correctness check, then sustained with the package power)"),
         ("msm_by_size.txt", "msm_by_size.txt", "# python3 tools/msm_probe.py   (MI355X; one vartime_multi_mul, operands in HBM, Straus and bucket paths forced; encodings vs prepared points)")):
     f = OUT / src
     if f.exists() and f.read_text().strip():
