@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs on the GPU box (through gpurun): bench lines and rocprofv3 passes of one round, written under gpurun_out/.
-#   usage: tools/profile_round.sh [pmc]      (without "pmc": bench lines + kernel-trace stats only)
+#   usage: tools/profile_round.sh [pmc [only]]      (without "pmc": bench lines + kernel-trace stats only; "pmc only": the counter passes alone)
 # Counters are collected in their own passes (--pmc never combined with tracing), the program after `--` is python3 itself.
 # tools/profile_summary.py <round> then turns the outputs into profiles/<round>_*.txt and profiles/traffic.json.
 cd /tmp && export TMPDIR=/tmp
@@ -27,6 +27,9 @@ timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_AN
 ) || exit 1
 python3 tools/profile_summary.py --traffic-only > gpurun_out/traffic_summary.log 2>&1 || exit 1
 fi
+# "pmc-only": the counter passes alone (one gpurun call has 20 minutes); run `python3 tools/profile_summary.py --traffic-only rNN` at home
+# afterwards - the CSVs come back under gpurun_out/ - and the next call's bench lines find the traffic of their own build in profiles/traffic.json
+if [ "$2" = "only" ]; then echo "counter passes done"; exit 0; fi
 for w in single multi qv; do
   timeout -k 10 300 python3 bench.py --steps 5 --warmup 1 --workload $w > gpurun_out/bench_$w.json 2> gpurun_out/bench_$w.err || exit 1
   tail -c 300 gpurun_out/bench_$w.json; echo
