@@ -938,8 +938,8 @@ def main():
         rows = egd.gather_rows([rank, dev_index, own_elapsed / args.steps * 1e3, clock["sclk_mhz"] if clock else 0.0,
                                 clock["power_w"] if clock else 0.0, accepted, exchange_ms * 1e3,
                                 (box or {}).get("fmul_sustained_g") or 0.0, (box or {}).get("sclk_mhz") or 0.0,
-                                hi_all["value"] if hi_all else 0.0, 1.0 if hi_all and hi_all["verdicts_match_device_path"] else 0.0,
-                                js_all["value"] if js_all else 0.0, 1.0 if js_all and js_all["verdicts_match_device_path"] else 0.0], dev)
+                                hi_all["value"] if hi_all else -1.0, 1.0 if hi_all and hi_all["verdicts_match_device_path"] else 0.0,
+                                js_all["value"] if js_all else -1.0, 1.0 if js_all and js_all["verdicts_match_device_path"] else 0.0], dev)
     else:
         rows = None
 
@@ -1091,6 +1091,10 @@ def main():
                 "host_inclusive_value", "host_inclusive_ok", "json_inclusive_value", "json_inclusive_ok")
         out["per_rank"] = [{k: (int(v) if k in ("rank", "device", "accepted") else (bool(v) if k.endswith("_ok") else v))
                             for k, v in zip(keys, r)} for r in rows]
+        for pr in out["per_rank"]:          # a leg that did not run on every rank at once (one rank: it runs below, on its own) is null, not zero
+            for leg in ("host_inclusive", "json_inclusive"):
+                if pr[leg + "_value"] < 0:
+                    pr[leg + "_value"] = pr[leg + "_ok"] = None
         out["exchange"] = {"us_per_step": max(r[6] for r in rows), "us_per_step_rank0": exchange_ms * 1e3,
                            "bytes_per_rank": 64 * n_opt, "bytes_gathered_per_rank": 64 * n_opt * world,
                            "share_of_step": max(r[6] for r in rows) / 1e3 / ms_per_step,

@@ -85,14 +85,13 @@ def build(verbose: bool = False) -> Path:
 
 _lib = None
 _RELEASE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t)      # eg_json_release_fn
-_released_blocks = [0]
+# blocks given back by the library to feed_owned_ptr callers: counted by the library's own eg_json_release_count (a C function: a Python
+# callback would take the interpreter lock on the stream's worker thread once per block, in competition with the feeding thread)
+_released_blocks = C.c_size_t(0)
 
 
-def _count_release(user, text, length):        # the release function of feed_owned_ptr: the Python caller keeps its buffer alive itself
-    _released_blocks[0] += 1
-
-
-_COUNT_RELEASE = _RELEASE_FN(_count_release)
+def released_blocks() -> int:
+    return int(_released_blocks.value)
 
 
 def _load() -> C.CDLL:
@@ -199,7 +198,8 @@ def _load() -> C.CDLL:
         "eg_verify_choice_json_begin": (C.c_int, [vp, C.c_int, C.POINTER(vp)]),
         "eg_verify_qv_json_begin": (C.c_int, [vp, C.c_int, C.POINTER(vp)]),
         "eg_verify_json_feed": (C.c_int, [vp, vp, sz, C.POINTER(sz)]),
-        "eg_verify_json_feed_owned": (C.c_int, [vp, vp, sz, _RELEASE_FN, vp, C.POINTER(sz)]),
+        "eg_verify_json_feed_owned": (C.c_int, [vp, vp, sz, vp, vp, C.POINTER(sz)]),
+        "eg_json_release_count": (None, [vp, vp, sz]),
         "eg_verify_json_take": (C.c_int, [vp, vp, sz, C.POINTER(sz)]),
         "eg_verify_json_end": (C.c_int, [vp, vp, sz, C.POINTER(sz), C.POINTER(sz), vp]),
         "eg_verify_json_abort": (None, [vp]),
@@ -644,9 +644,12 @@ class JsonStream:
 
     def feed_owned_ptr(self, ptr: int, length: int) -> int:
         """``eg_verify_json_feed_owned``: the library reads the block at `ptr` in place - no copy on this thread, no wait for the worker -
-        until the stream has been ended or aborted; the CALLER keeps the memory alive until then (the release callback only counts)."""
+        until the stream has been ended or aborted; the CALLER keeps the memory alive until then (the release function is the library's own
+        eg_json_release_count: released_blocks() says how many blocks have come back)."""
         n = C.c_size_t(0)
-        _check(_load().eg_verify_json_feed_owned(self._h, C.c_void_p(ptr), length, _COUNT_RELEASE, None, C.byref(n)))
+        lib = _load()
+        _check(lib.eg_verify_json_feed_owned(self._h, C.c_void_p(ptr), length, C.cast(lib.eg_json_release_count, C.c_void_p), C.byref(_released_blocks),
+                                             C.byref(n)))
         self.objects = n.value
         return n.value
 

@@ -2189,6 +2189,9 @@ struct eg_json_stream {
   bool stop = false, worker_joined = false;
   std::atomic<size_t> objects{0};          // complete objects cut so far (by the worker)
   size_t block_bytes = (size_t)16 << 20, direct_min = (size_t)8 << 20;
+  // handed-over blocks joined per piece, and the text that may wait in the queue (8 / 32 / 64 MB pieces measured the same within the
+  // +-4 % run-to-run noise of the stream: gpurun_out/json_owned_join_ab.txt, round 6)
+  size_t join_bytes = (size_t)16 << 20, queue_bytes = (size_t)64 << 20;
   std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();      // EG_JSON_TRACE: the timeline on stderr, ms since begin
   double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
 };
@@ -2461,11 +2464,11 @@ static void stream_worker(eg_json_stream* S) {
       // a hand-over, a window of the splitter, two dispatches on the pool (a ballot straddles almost every boundary) and a look at the
       // GPU - 1 MB pieces at the rate of the verifier are 1 400 of those in 160 ms (measured: 0.48 of the resident rate).  Blocks that are
       // WAITING TOGETHER are therefore joined into one piece of up to 16 MB, copied by the pool's threads (not by the caller's, and not one
-      // after the other), and given back at once: 0.91.
+      // after the other), and given back at once: 0.85-0.91.
       if (it.release && !it.finish && it.len < S->direct_min) {
         size_t total = it.len;
         while (!S->queue.empty() && S->queue.front().release && !S->queue.front().finish && S->queue.front().len < S->direct_min &&
-               total + S->queue.front().len <= S->block_bytes) {
+               total + S->queue.front().len <= S->join_bytes) {
           total += S->queue.front().len;
           more.push_back(std::move(S->queue.front()));
           S->queue.pop_front();
@@ -2505,7 +2508,7 @@ static void stream_worker(eg_json_stream* S) {
 }
 // hands an item to the worker (at most ~64 MB of text wait in the queue); wait = until the worker is through with it
 static void stream_enqueue(eg_json_stream* S, std::unique_lock<std::mutex>& lk, eg_json_stream::Item&& it, bool wait) {
-  S->q_pop.wait(lk, [&]() { return S->queue.empty() || S->queued_bytes < ((size_t)64 << 20); });
+  S->q_pop.wait(lk, [&]() { return S->queue.empty() || S->queued_bytes < S->queue_bytes; });
   const uint64_t id = it.id = S->next_id++;
   S->queued_bytes += it.len;
   S->queue.push_back(std::move(it));
@@ -2583,6 +2586,12 @@ int eg_verify_json_feed_owned(eg_json_stream* S, const char* text, size_t len, e
   }
   if (n_objects) *n_objects = S->objects.load(std::memory_order_acquire);
   return EG_OK;
+}
+// A ready-made release function for eg_verify_json_feed_owned: counts the blocks that came back in the size_t that `user` points to.  For
+// bindings whose own callbacks are expensive - a Python (ctypes) callback takes the interpreter lock on the stream's worker thread, once per
+// block, in competition with the thread that is feeding - and for tests that only want to know that every block was given back.
+void eg_json_release_count(void* user, const char*, size_t) {
+  if (user) __atomic_fetch_add(static_cast<size_t*>(user), (size_t)1, __ATOMIC_RELAXED);
 }
 // verdicts that are final so far, in order, from where the last take stopped: every ballot before the first one that is still on a GPU
 // or waits for the object path (a ballot of another shape than the election's gets its verdict at the end)

@@ -432,6 +432,10 @@ int eg_verify_json_feed(eg_json_stream*, const char* text, size_t len, size_t* n
  * Returns at once unless ~64 MB of text are already waiting.  If the call FAILS, release is not called: the block is still the caller's. */
 typedef void (*eg_json_release_fn)(void* user, const char* text, size_t len);
 int eg_verify_json_feed_owned(eg_json_stream*, const char* text, size_t len, eg_json_release_fn release, void* user, size_t* n_objects);
+/* a ready-made eg_json_release_fn: adds one to the size_t that `user` points to (atomically; NULL: does nothing).  For a caller that keeps its
+ * blocks alive itself until the stream has ended and only wants to know that every block came back - and for bindings whose own callbacks
+ * are expensive on a foreign thread (a Python callback takes the interpreter lock on the stream's worker thread, once per block). */
+void eg_json_release_count(void* user, const char* text, size_t len);
 int eg_verify_json_take(eg_json_stream*, uint32_t* status, size_t cap, size_t* n_taken);
 int eg_verify_json_end(eg_json_stream*, uint32_t* status, size_t cap, size_t* n_taken, size_t* n_objects, uint8_t* tally_out);
 void eg_verify_json_abort(eg_json_stream*);

@@ -2330,7 +2330,7 @@ def test_json_feed_owned_and_the_bound_on_wrong_shape_text(eg, ctx, oracle, pk, 
     assert one_shot == want
     base = C.cast(C.c_char_p(text), C.c_void_p).value
     for piece in (1 << 20, 12_345, 1 << 26):
-        before = egmod._released_blocks[0]
+        before = egmod.released_blocks()
         st = p.json_stream(threads=4)
         n_blocks = 0
         for at in range(0, len(text), piece):
@@ -2338,13 +2338,13 @@ def test_json_feed_owned_and_the_bound_on_wrong_shape_text(eg, ctx, oracle, pk, 
             n_blocks += 1
         got, tally = st.end()
         assert got == want and tally == one_tally
-        assert egmod._released_blocks[0] - before == n_blocks
-    before = egmod._released_blocks[0]
+        assert egmod.released_blocks() - before == n_blocks
+    before = egmod.released_blocks()
     st = p.json_stream(threads=2)
     for at in range(0, len(text), 1 << 16):
         st.feed_owned_ptr(base + at, min(1 << 16, len(text) - at))
     st.abort()
-    assert egmod._released_blocks[0] - before == -(-len(text) // (1 << 16))
+    assert egmod.released_blocks() - before == -(-len(text) // (1 << 16))
     assert p.verify_json(text, max_objects=len(want)) == (one_shot, one_tally)
     with pytest.raises(eg.EgError, match="max_objects"):
         p.verify_json(text, max_objects=len(want) // 3)
