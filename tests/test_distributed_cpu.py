@@ -40,6 +40,8 @@ def _worker(rank, world, port, total, q):
     merged = b"".join(merged)
     accepted = egd.sum_over_ranks(st.count(0), "cpu")
     slow = egd.max_over_ranks(float(rank + 1), "cpu")
+    rows = egd.gather_rows([rank, 100.0 + rank, st.count(0)], "cpu")       # bench.py's `per_rank` block: one row of numbers per rank
+    assert rows == [[float(r), 100.0 + r, float(c)] for r, c in zip(range(world), [egd.shard_range(total, r, world)[1] - egd.shard_range(total, r, world)[0] for r in range(world)])]
     q.put((rank, merged, accepted, slow, (lo, hi)))
     dist.destroy_process_group()
 
