@@ -52,6 +52,13 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
   } while (0)
 
 #define TRY_(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+// An entry point that works on SEVERAL devices (the multi-GPU calls, a JSON stream with one lane per GPU) leaves the calling thread's current
+// device as it found it: a host that drives its own HIP work (or torch) on that thread must not find another device selected afterwards.
+struct KeepDevice {
+  int dev = -1;
+  KeepDevice() { if (hipGetDevice(&dev) != hipSuccess) { dev = -1; (void)hipGetLastError(); } }
+  ~KeepDevice() { if (dev >= 0) (void)hipSetDevice(dev); }
+};
 // runs at scope exit, on every path (early returns of HIPCHK included)
 struct ScopeExit {
   std::function<void()> fn;
@@ -1839,6 +1846,7 @@ static int held_verify_device(Params* p, size_t n, const void* d_ballots, void* 
 template <class Params>
 static int verify_batch_multi(Params* const* per_device, int n_dev, size_t n, const uint8_t* ballots, uint32_t* status, uint8_t* tally_out) {
   TRY(multi_check(per_device, n_dev));
+  KeepDevice keep;
   if (n && (!ballots || !status)) return fail(EG_ERR_BAD_ARG, "bad argument");
   MultiHold<Params> hold;
   TRY(hold.acquire(per_device, n_dev));
@@ -1868,6 +1876,7 @@ template <class Params>
 static int verify_batch_multi_device(Params* const* per_device, int n_dev, const size_t* n_per_dev, const void* const* d_ballots,
                                      void* const* d_status, void* const* streams, uint8_t* tally_out) {
   TRY(multi_check(per_device, n_dev));
+  KeepDevice keep;
   if (!n_per_dev || !d_ballots || !d_status) return fail(EG_ERR_BAD_ARG, "bad argument");
   for (int d = 0; d < n_dev; ++d)
     if (n_per_dev[d] && (!d_ballots[d] || !d_status[d])) return fail(EG_ERR_BAD_ARG, "null device pointer for a non-empty slab");
@@ -1911,6 +1920,7 @@ static int verify_batch_multi_device(Params* const* per_device, int n_dev, const
 template <class Params>
 static int tally_encode_multi(Params* const* per_device, int n_dev, uint8_t* out) {
   TRY(multi_check(per_device, n_dev));
+  KeepDevice keep;
   if (!out) return fail(EG_ERR_BAD_ARG, "bad argument");
   MultiHold<Params> hold;
   TRY(hold.acquire(per_device, n_dev));
@@ -2195,8 +2205,10 @@ struct eg_json_stream {
   std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();      // EG_JSON_TRACE: the timeline on stderr, ms since begin
   double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
 };
-// every context of a stream's lanes, locked together in address order (one context: exactly the lock every entry point takes)
+// every context of a stream's lanes, locked together in address order (one context: exactly the lock every entry point takes); the calling
+// thread's current device, which the work on the lanes changes, is put back when the locks go
 struct LockAll {
+  KeepDevice keep;
   std::vector<std::unique_lock<std::recursive_mutex>> held;
   explicit LockAll(const std::vector<eg_ctx*>& ctxs) { for (eg_ctx* c : ctxs) held.emplace_back(c->mu); }
 };
@@ -2483,7 +2495,7 @@ static void stream_worker(eg_json_stream* S) {
       if (joined.size() < len) joined.resize(len);
       std::vector<size_t> at(parts.size(), 0);
       for (size_t k = 1; k < parts.size(); ++k) at[k] = at[k - 1] + parts[k - 1]->len;
-      S->pool->run(parts.size(), 1, [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; ++k) memcpy(joined.data() + at[k], parts[k]->ptr, parts[k]->len); });
+      S->pool->run(parts.size(), 1, [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; ++k) if (parts[k]->len) memcpy(joined.data() + at[k], parts[k]->ptr, parts[k]->len); });
       text = joined.data();
       if (it.release) { it.release(it.user, it.ptr, it.len); it.release = nullptr; }       // copied: the blocks go back before they are parsed
       for (auto& m : more) m.release(m.user, m.ptr, m.len);

@@ -292,7 +292,8 @@ int eg_qv_tally_encode_device(eg_qv_params*, void* d_out, void* stream);
  * A multi call HOLDS its params objects from its first check to its merge: it waits for a one-shot eg_verify_*_json that is running on
  * one of them, fails with EG_ERR_BAD_ARG - before it has touched anything - when an explicitly opened JSON stream owns one, and calls of
  * other threads on a held object wait until it is over.  Nothing in it drains a device: the running tallies are set aside behind an event
- * of the object's last asynchronous call, and slab d starts behind that copy on streams[d].
+ * of the object's last asynchronous call, and slab d starts behind that copy on streams[d].  The calling thread's current HIP device is
+ * put back to what it was when the call returns (the multi-GPU JSON entries do the same).
  *
  * AFTER A FAILURE.  An error in any slab fails the whole call; eg_last_error names the slab.  Verdicts of other slabs may have been
  * written, but NO running tally has advanced: every multi verify call sets the running tallies aside before it starts (a
