@@ -16,14 +16,14 @@ for w in single multi qv; do
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf gpurun_out/pmc_${c}_$w
     timeout -k 10 300 rocprofv3 --pmc $c -d gpurun_out/pmc_${c}_$w -o pmc --output-format csv -- \
-      python3 bench.py --steps 1 --warmup 0 --workload $w --no-cpu-baseline --no-host-inclusive --no-wire-ingest --no-isolated --no-extra-configs --ballots $PMC_BALLOTS > gpurun_out/pmc_${c}_$w.log 2>&1 || exit 1
+      python3 bench.py --steps 1 --warmup 0 --workload $w --no-cpu-baseline --no-host-inclusive --no-wire-ingest --no-isolated --no-extra-configs --selfbench-seconds 0 --ballots $PMC_BALLOTS > gpurun_out/pmc_${c}_$w.log 2>&1 || exit 1
   done
 done
 rm -rf gpurun_out/pmc_SQ1_single gpurun_out/pmc_SQ2_single
 timeout -k 10 300 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES -d gpurun_out/pmc_SQ1_single -o pmc --output-format csv -- \
-  python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-host-inclusive --no-wire-ingest --no-isolated --no-extra-configs --ballots $PMC_BALLOTS > gpurun_out/pmc_SQ1.log 2>&1 || exit 1
+  python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-host-inclusive --no-wire-ingest --no-isolated --no-extra-configs --selfbench-seconds 0 --ballots $PMC_BALLOTS > gpurun_out/pmc_SQ1.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_WAVES -d gpurun_out/pmc_SQ2_single -o pmc --output-format csv -- \
-  python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-host-inclusive --no-wire-ingest --no-isolated --no-extra-configs --ballots $PMC_BALLOTS > gpurun_out/pmc_SQ2.log 2>&1 || exit 1
+  python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-host-inclusive --no-wire-ingest --no-isolated --no-extra-configs --selfbench-seconds 0 --ballots $PMC_BALLOTS > gpurun_out/pmc_SQ2.log 2>&1 || exit 1
 ) || exit 1
 python3 tools/profile_summary.py --traffic-only > gpurun_out/traffic_summary.log 2>&1 || exit 1
 fi
@@ -40,13 +40,13 @@ timeout -k 10 300 python3 bench.py --steps 3 --warmup 1 --workload msm > gpurun_
 for w in single multi qv; do
   rm -rf gpurun_out/prof_stats_$w
   timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_stats_$w -o stats --output-format csv -- \
-    python3 bench.py --steps 3 --warmup 1 --workload $w --no-cpu-baseline --no-host-inclusive --no-wire-ingest --no-isolated --no-extra-configs > gpurun_out/prof_stats_$w.log 2>&1 || exit 1
+    python3 bench.py --steps 3 --warmup 1 --workload $w --no-cpu-baseline --no-host-inclusive --no-wire-ingest --no-isolated --no-extra-configs --selfbench-seconds 0 > gpurun_out/prof_stats_$w.log 2>&1 || exit 1
 done
 # the same with ONE work set (EG_STREAMS=1): chunks one after the other on one stream, so that a kernel's duration is its cost
 for w in single multi qv; do
   rm -rf gpurun_out/prof_serial_$w
   EG_STREAMS=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_serial_$w -o stats --output-format csv -- \
-    python3 bench.py --steps 3 --warmup 1 --workload $w --no-cpu-baseline --no-host-inclusive --no-wire-ingest --no-isolated --no-extra-configs > gpurun_out/prof_serial_$w.log 2>&1 || exit 1
+    python3 bench.py --steps 3 --warmup 1 --workload $w --no-cpu-baseline --no-host-inclusive --no-wire-ingest --no-isolated --no-extra-configs --selfbench-seconds 0 > gpurun_out/prof_serial_$w.log 2>&1 || exit 1
 done
 # round 5: the probes behind DESIGN's paragraphs on memory-side watts, the JSON stream, the multi-scalar multiplication by size, and the
 # in-process multi-GPU leg rehearsed with two contexts on this one GPU (its value means nothing: two engines time-share the chip)

@@ -68,9 +68,12 @@ for w in () if TRAFFIC_ONLY else WORKLOADS:
     f = OUT / f"prof_stats_{w}" / "stats_kernel_stats.csv"
     if not f.exists():
         continue
-    rows = list(csv.DictReader(open(f)))
+    rows = [r for r in csv.DictReader(open(f)) if "k_selfbench_fmul" not in r["Name"]]      # the box calibration (valu_roofline.box) is not part of a step
+    all_ns = sum(int(r["TotalDurationNs"]) for r in rows) or 1
+    for r in rows:
+        r["Percentage"] = 100.0 * int(r["TotalDurationNs"]) / all_ns
     lines = [f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --workload {w} --no-cpu-baseline --no-host-inclusive --no-wire-ingest --no-isolated   (MI355X)",
-             f"# 1 warm-up + 3 timed steps of {DESCR[w]}, plus the untimed generator launch",
+             f"# 1 warm-up + 3 timed steps of {DESCR[w]}, plus the untimed generator launch (the launches of the box calibration, k_selfbench_fmul, left out)",
              f"{'kernel':64s} {'calls':>6s} {'total_ms':>12s} {'avg_ms':>11s} {'min_ms':>9s} {'max_ms':>9s} {'pct':>8s}"]
     for r in rows:
         lines.append(f"{kname(r['Name'])[:64]:64s} {int(r['Calls']):6d} {int(r['TotalDurationNs'])/1e6:12.3f} {float(r['AverageNs'])/1e6:11.4f} "
@@ -80,7 +83,7 @@ for w in () if TRAFFIC_ONLY else WORKLOADS:
     f = OUT / f"prof_serial_{w}" / "stats_kernel_stats.csv"
     if f.exists():
         rows = list(csv.DictReader(open(f)))
-        skip = ("encrypt", "k_build_fixed_table", "k_comb_window_bases", "k_setup_points", "k_const_points", "at::")
+        skip = ("encrypt", "k_build_fixed_table", "k_comb_window_bases", "k_setup_points", "k_const_points", "at::", "k_selfbench_fmul")
         step = sum(int(r["TotalDurationNs"]) for r in rows if not any(x in r["Name"] for x in skip))
         lines = [f"# EG_STREAMS=1 rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --workload {w} --no-cpu-baseline --no-host-inclusive --no-wire-ingest --no-isolated --no-extra-configs   (MI355X)",
                  f"# ONE work set on one stream: kernels run one after the other, so total_ms / 4 steps is a kernel's cost per step of {DESCR[w]}",
