@@ -529,7 +529,11 @@ def count_gpus_without_hip(topology: str = "/sys/class/kfd/kfd/topology/nodes", 
         for tok in rocr.split(","):
             tok = tok.strip()
             if tok.upper().startswith("GPU-"):
-                ok = any(u and int(u) == int(tok[4:], 16) for u in gpus if u.isdigit())
+                try:
+                    want = int(tok[4:], 16)
+                except ValueError:
+                    want = None
+                ok = want is not None and any(int(u) == want for u in gpus if u.isdigit())
             else:
                 ok = tok.isdigit() and int(tok) < n
             if not ok:

@@ -118,13 +118,20 @@ int main(int argc, char** argv) {
     BatchVerdict<ChoiceVerificationError> verdict;
     if (json) {
       // println!("{}", serde_json::to_string_pretty(&encrypted)) per voter (examples/voting.rs:195-198): every ballot is fed as it is made
-      JsonStream stream(*params[0], 4);
+      // --devices N: ONE parser for all GPUs (eg_verify_choice_json_begin_multi: the packed windows are dealt to the params objects by load),
+      // and every ballot's text is handed over without a copy (eg_verify_json_feed_owned: the stream gives the block back when it is through)
+      std::unique_ptr<JsonStream> sp(devices > 1 ? new JsonStream(per, 4) : new JsonStream(*params[0], 4));
+      JsonStream& stream = *sp;
       const size_t bs = params[0]->ballot_size();
-      for (size_t i = 0; i < votes; ++i) stream.feed(choice_to_json(ballots.data() + i * bs, options) + "\n");
+      for (size_t i = 0; i < votes; ++i) {
+        std::string text = choice_to_json(ballots.data() + i * bs, options) + "\n";
+        if (devices > 1) stream.feed_owned(std::make_shared<const std::string>(std::move(text)));
+        else stream.feed(text);
+      }
       std::vector<Ciphertext> totals;
       for (uint32_t st : stream.finish(&totals)) verdict.results.push_back(choice_error_from_status(st));
       verdict.totals = totals;
-      printf("(%zu ballots went through the JSON stream one at a time)\n", stream.objects());
+      printf("(%zu ballots went through the JSON stream one at a time%s)\n", stream.objects(), devices > 1 ? ", one parser for all devices, blocks handed over" : "");
     } else
       verdict = devices > 1 ? verify_batch_multi(per, ballots) : params[0]->verify_batch(ballots);   // encrypted.verify(&params)
     printf("%zu of %zu ballots verified\n", verdict.accepted(), votes);

@@ -238,5 +238,6 @@ def test_gpus_are_counted_without_hip(tmp_path):
     assert count(HIP_VISIBLE_DEVICES="1,7,2") == 1                # the list ends at the first entry that is not a visible device
     assert count(ROCR_VISIBLE_DEVICES="0,1,2") == 3 and count(ROCR_VISIBLE_DEVICES="0,1,2", HIP_VISIBLE_DEVICES="0,2,3") == 2
     assert count(ROCR_VISIBLE_DEVICES="GPU-%x" % 1003) == 1 and count(ROCR_VISIBLE_DEVICES="GPU-deadbeef") == 0
+    assert count(ROCR_VISIBLE_DEVICES="GPU-not-hex,0") == 0
     assert count(HIP_VISIBLE_DEVICES="") == 0 and count(HIP_VISIBLE_DEVICES="-1") == 0
     assert bench.count_gpus_without_hip(str(tmp_path / "absent"), {}) is None

@@ -589,6 +589,12 @@ def test_cpp_voting_example(tmp_path):
     assert "(700 ballots went through the JSON stream one at a time)" in out.stdout
     assert "699 of 700 ballots verified" in out.stdout and "voter #4 rejected" in out.stdout
     assert "OK: the decrypted totals equal the expected ones" in out.stdout
+    # ... and with ONE parser for two devices, every ballot's text handed over without a copy (JsonStream over several params objects,
+    # feed_owned: eg_verify_choice_json_begin_multi / eg_verify_json_feed_owned through the C++ mirror)
+    out = subprocess.run([str(exe), "--json", "--devices", "2", "900", "5", "13"], capture_output=True, text=True, timeout=180)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "(900 ballots went through the JSON stream one at a time, one parser for all devices, blocks handed over)" in out.stdout
+    assert "899 of 900 ballots verified" in out.stdout and "OK: the decrypted totals equal the expected ones" in out.stdout
     # the same elections through the in-process multi-GPU entry (two contexts; both on GPU 0 when the box has one GPU)
     for args in (["--devices", "2", "300", "5", "3"], ["--qv", "--devices", "2", "120", "3", "10", "5"]):
         out = subprocess.run([str(exe)] + args, capture_output=True, text=True, timeout=240)
