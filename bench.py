@@ -405,18 +405,31 @@ def extra_configs(args, ctx, eg, torch, dev, pk, stream, steps: int = 10):
 def host_inclusive_leg(torch, params, ballots, status, B, resident_value, before_each=None, iters=3):
     """PCIe-inclusive rate (first H2D byte to last status byte D2H): the rank's own batch from a pinned host buffer through the
     host-pointer entry point (pipelined uploads, eg_verify_*_batch).  Reported beside `value`, never as it.  before_each: a barrier, so that
-    with several ranks every iteration starts on all of them at the same time (they share one host's memory and PCIe root)."""
-    host = torch.empty(ballots.shape, dtype=torch.uint8, pin_memory=True)
-    host.copy_(ballots)
-    host_status = torch.empty(B, dtype=torch.int32, pin_memory=True)
-    torch.cuda.synchronize()
+    with several ranks every iteration starts on all of them at the same time (they share one host's memory and PCIe root).  A rank on which
+    the leg fails (no pinned memory left, say) still takes part in every barrier - the other ranks must not be left waiting in one - and
+    reports {"error": ...}."""
+    err, host, host_status = None, None, None
+    try:
+        host = torch.empty(ballots.shape, dtype=torch.uint8, pin_memory=True)
+        host.copy_(ballots)
+        host_status = torch.empty(B, dtype=torch.int32, pin_memory=True)
+        torch.cuda.synchronize()
+    except Exception as e:
+        err = repr(e)
     times = []
     for it in range(iters + 1):                      # the first call sizes the staging buffers
         if before_each:
             before_each()
-        t0 = time.perf_counter()
-        params.verify_batch_host_ptr(B, host.data_ptr(), host_status.data_ptr())
-        times.append(time.perf_counter() - t0)
+        if err:
+            continue
+        try:
+            t0 = time.perf_counter()
+            params.verify_batch_host_ptr(B, host.data_ptr(), host_status.data_ptr())
+            times.append(time.perf_counter() - t0)
+        except Exception as e:
+            err = repr(e)
+    if err:
+        return {"error": err, "value": 0.0, "verdicts_match_device_path": False}
     hs = sum(times[1:]) / iters
     return {"value": B / hs, "unit": "ballots/s", "ms": hs * 1e3, "iterations": iters, "pinned": True,
             "bytes_h2d": B * params.ballot_size, "bytes_d2h": 4 * B,
@@ -442,24 +455,36 @@ def ballots_as_json(args, eg, torch, params, ballots, B, n_opt, reps_for):
 
 def json_inclusive_leg(args, eg, torch, params, ballots, status, B, n_opt, resident_value, threads, before_each=None, text=None, distinct=None):
     """The whole wire path inside the library (eg_verify_*_json): JSON text in host memory -> status words, on as many objects as the
-    step has ballots (the first 1000 ballots repeated); host threads pack piece k+1 while the GPU verifies piece k."""
+    step has ballots (the first 1000 ballots repeated); host threads pack piece k+1 while the GPU verifies piece k.  Like
+    host_inclusive_leg, a rank on which the leg fails still takes part in every barrier."""
     import ctypes
     import numpy as np
 
-    if text is None:
-        distinct, _, _, build = ballots_as_json(args, eg, torch, params, ballots, B, n_opt, None)
-        text = build(max(1, B // distinct))
-    jreps = max(1, B // distinct)
-    jn = distinct * jreps
-    jstatus = (ctypes.c_uint32 * jn)()
+    err, jn, jstatus, jreps = None, 0, None, 1
+    try:
+        if text is None:
+            distinct, _, _, build = ballots_as_json(args, eg, torch, params, ballots, B, n_opt, None)
+            text = build(max(1, B // distinct))
+        jreps = max(1, B // distinct)
+        jn = distinct * jreps
+        jstatus = (ctypes.c_uint32 * jn)()
+    except Exception as e:
+        err = repr(e)
     json_s, jgot = None, 0
     for _ in range(3):
         if before_each:
             before_each()
-        t0 = time.perf_counter()
-        jgot = params.verify_json_into(text, jstatus, threads)
-        dt = time.perf_counter() - t0
-        json_s = dt if json_s is None else min(json_s, dt)
+        if err:
+            continue
+        try:
+            t0 = time.perf_counter()
+            jgot = params.verify_json_into(text, jstatus, threads)
+            dt = time.perf_counter() - t0
+            json_s = dt if json_s is None else min(json_s, dt)
+        except Exception as e:
+            err = repr(e)
+    if err:
+        return {"error": err, "value": 0.0, "verdicts_match_device_path": False, "threads": threads}, None
     jarr = np.frombuffer(jstatus, dtype=np.uint32)
     first_status = status[:distinct].cpu().numpy().astype(np.uint32)
     return {"value": jn / json_s, "unit": "ballots/s", "objects": jn, "json_bytes": len(text), "ms": json_s * 1e3,
@@ -1134,7 +1159,9 @@ def main():
                                                       "time, the host's cores divided among the ranks"}
 
     # ---- wire ingest: the same ballots as JSON text in serde's layout through the native packer -------------
-    if not args.no_wire_ingest and world == 1:
+    def wire_legs():
+        """wire_ingest, json_inclusive and json_stream of a one-GPU line; a closure over the batch, so that a failure in an extra leg costs
+        only that leg (the line is printed with {"error": ...} in its place)."""
         from elastic_elgamal_amd import serde as egserde
         import ctypes
         import numpy as np
@@ -1170,6 +1197,8 @@ def main():
                                                          distinct=distinct)
         # the same text through the STREAMING entry (eg_verify_json_begin / _feed / _end): pieces of 64 MB (read in place), of 1 MB copied
         # by feed on the caller's thread, and of 1 MB handed over without a copy (eg_verify_json_feed_owned)
+        if jarr is None:
+            raise RuntimeError("json_inclusive failed: " + str(out["json_inclusive"].get("error")))
         piece_rates = {}
         jbase = ctypes.cast(ctypes.c_char_p(jtext), ctypes.c_void_p).value
         for label, piece, owned in (("64MB", 64 << 20, False), ("1MB", 1 << 20, False), ("1MB_owned", 1 << 20, True)):
@@ -1197,6 +1226,13 @@ def main():
                               "python_mirror_value": distinct / py_s,
                               "note": "JSON text (serde layout, base64url) -> packed bytes on the host, before the PCIe-inclusive path above; "
                                       "by_threads: the same call with fewer parser threads (up to the hardware threads this process may use)"}
+
+
+    if not args.no_wire_ingest and world == 1:
+        try:
+            wire_legs()
+        except Exception as e:            # an extra leg must never cost the line
+            out.setdefault("wire_ingest", {"error": repr(e)})
 
     # ---- CPU baseline: the oracle ("port": CPU restatement, not curve25519-dalek) on a bounded sample --------------
     if not args.no_cpu_baseline:          # at every N, on rank 0 (the other ranks have nothing left to do: the host's cores are rank 0's)
