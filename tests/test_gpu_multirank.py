@@ -40,7 +40,8 @@ def test_bench_started_bare_launches_its_own_ranks():
     """`python3 bench.py --gpus 2 ...` with no launcher and no WORLD_SIZE: bench.py starts the two ranks itself as a child
     torch.distributed.run (before it has touched the GPU), the child's one JSON line is the last line of stdout, exit code 0
     (VERDICT r4 task 1; the loop over voters of examples/voting.rs:199-203 cut into N slabs)."""
-    r = _run_bare(["--gpus", "2", "--rehearse-one-gpu", "--steps", "1", "--warmup", "0", "--ballots", "20000"])
+    r = _run_bare(["--gpus", "2", "--rehearse-one-gpu", "--steps", "1", "--warmup", "0", "--ballots", "20000", "--cpu-seconds", "1",
+                   "--selfbench-seconds", "0.5"])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     out = r.stdout.strip().splitlines()
     lines = [l for l in out if l.startswith("{")]
@@ -50,6 +51,13 @@ def test_bench_started_bare_launches_its_own_ranks():
     assert line["config"]["tally_exchange_ok"] is True and line["config"]["parallelism"] == "shard2"
     assert line["config"]["accepted"] == 40000 and line["value"] > 1e4
     assert "starting the ranks as a child" in r.stderr
+    # the line explains itself (VERDICT r5 task 1): one entry per rank, the exchange timed on its own, the CPU path in the same run, and the
+    # host-staging legs run on both ranks at the same time
+    assert [p["rank"] for p in line["per_rank"]] == [0, 1] and all(p["accepted"] == 20000 and p["ms_per_step"] > 0 for p in line["per_rank"])
+    assert line["exchange"]["us_per_step"] > 0 and line["exchange"]["bytes_per_rank"] == 320 and line["slowest_rank"] in (0, 1)
+    assert line["cpu_baseline"]["verdicts_match_gpu"] is True
+    assert line["host_inclusive"]["all_ranks"]["ranks"] == 2 and line["host_inclusive"]["all_ranks"]["verdicts_match_device_path"] is True
+    assert line["json_inclusive"]["all_ranks"]["ranks"] == 2 and line["json_inclusive"]["all_ranks"]["verdicts_match_device_path"] is True
 
 
 def test_bench_started_bare_refuses_more_gpus_than_the_node_has():
