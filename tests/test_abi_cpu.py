@@ -241,3 +241,23 @@ def test_gpus_are_counted_without_hip(tmp_path):
     assert count(ROCR_VISIBLE_DEVICES="GPU-not-hex,0") == 0
     assert count(HIP_VISIBLE_DEVICES="") == 0 and count(HIP_VISIBLE_DEVICES="-1") == 0
     assert bench.count_gpus_without_hip(str(tmp_path / "absent"), {}) is None
+
+
+def test_abi_version_and_release_counter_without_a_gpu(lib_path):
+    """Two entry points that need no GPU: eg_abi_version is the header's EG_ABI_VERSION (and the Python binding's), and the ready-made
+    release function of eg_verify_json_feed_owned counts into the size_t it is given (NULL: does nothing)."""
+    import ctypes as C
+    import re
+
+    import elastic_elgamal_amd as eg
+
+    lib = C.CDLL(str(lib_path))
+    lib.eg_abi_version.restype = C.c_int
+    hdr = (ROOT / "include" / "eg_hip.h").read_text()
+    assert lib.eg_abi_version() == int(re.search(r"#define EG_ABI_VERSION (\d+)", hdr).group(1)) == eg.ABI_VERSION
+    lib.eg_json_release_count.restype = None
+    lib.eg_json_release_count.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    n = C.c_size_t(41)
+    lib.eg_json_release_count(C.byref(n), None, 0)
+    lib.eg_json_release_count(None, None, 0)
+    assert n.value == 42
