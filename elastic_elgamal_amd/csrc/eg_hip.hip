@@ -2489,24 +2489,33 @@ static void stream_worker(eg_json_stream* S) {
     }
     const char* text = it.ptr ? it.ptr : it.own.data();
     size_t len = it.len;
-    if (!more.empty()) {
-      std::vector<const eg_json_stream::Item*> parts{&it};
-      for (auto& m : more) { parts.push_back(&m); len += m.len; }
-      if (joined.size() < len) joined.resize(len);
-      std::vector<size_t> at(parts.size(), 0);
-      for (size_t k = 1; k < parts.size(); ++k) at[k] = at[k - 1] + parts[k - 1]->len;
-      S->pool->run(parts.size(), 1, [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; ++k) if (parts[k]->len) memcpy(joined.data() + at[k], parts[k]->ptr, parts[k]->len); });
-      text = joined.data();
-      if (it.release) { it.release(it.user, it.ptr, it.len); it.release = nullptr; }       // copied: the blocks go back before they are parsed
-      for (auto& m : more) m.release(m.user, m.ptr, m.len);
-    }
-    if (!it.finish && !S->failed.load(std::memory_order_acquire)) {
-      LockAll lk(S->ctxs);
-      if (!S->split->feed(text, len)) {
-        if (!S->failed.load()) stream_fail(S, EG_ERR_BAD_ARG, S->split->error().empty() ? std::string("the piece could not be packed") : S->split->error());
-      } else (void)stream_pump_all(S, false);
-      S->objects.store(S->split->count(), std::memory_order_release);
-    }
+    for (auto& m : more) len += m.len;
+    // nothing thrown on this thread may escape it (std::terminate): out of host memory while joining blocks, growing the verdict vector or
+    // keeping the text of odd ballots becomes the stream's error, reported by the next feed / take / end like every other
+    try {
+      if (!more.empty()) {
+        std::vector<const eg_json_stream::Item*> parts{&it};
+        for (auto& m : more) parts.push_back(&m);
+        if (joined.size() < len) joined.resize(len);
+        std::vector<size_t> at(parts.size(), 0);
+        for (size_t k = 1; k < parts.size(); ++k) at[k] = at[k - 1] + parts[k - 1]->len;
+        S->pool->run(parts.size(), 1, [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; ++k) if (parts[k]->len) memcpy(joined.data() + at[k], parts[k]->ptr, parts[k]->len); });
+        text = joined.data();
+        if (it.release) { it.release(it.user, it.ptr, it.len); it.release = nullptr; }     // copied: the blocks go back before they are parsed
+        for (auto& m : more) { m.release(m.user, m.ptr, m.len); m.release = nullptr; }
+      }
+      if (!it.finish && !S->failed.load(std::memory_order_acquire)) {
+        LockAll lk(S->ctxs);
+        if (!S->split->feed(text, len)) {
+          if (!S->failed.load()) stream_fail(S, EG_ERR_BAD_ARG, S->split->error().empty() ? std::string("the piece could not be packed") : S->split->error());
+        } else (void)stream_pump_all(S, false);
+        S->objects.store(S->split->count(), std::memory_order_release);
+      }
+    } catch (const std::bad_alloc&) { stream_fail(S, EG_ERR_NOMEM, "out of host memory in the stream's worker");
+    } catch (const std::exception& ex) { stream_fail(S, EG_ERR_HIP, std::string("exception in the stream's worker: ") + ex.what());
+    } catch (...) { stream_fail(S, EG_ERR_HIP, "unknown exception in the stream's worker"); }
+    for (auto& m : more)                           // (only after an exception above: blocks that were not given back yet)
+      if (m.release) { m.release(m.user, m.ptr, m.len); m.release = nullptr; }
     {
       std::lock_guard<std::mutex> lk(S->qmu);
       S->consumed_id = more.empty() ? it.id : more.back().id;

@@ -491,8 +491,9 @@ int eg_profile_read_tables(eg_ctx*, double* tables_ms_total, uint64_t* tables_la
  * equation kernels inline) in a bare dependent chain on changing operands, three waves per SIMD, launched back to back for `seconds`
  * (0 < seconds <= 30); *fmul_g_per_s = 10^9 multiplications per second chip-wide and *sclk_mhz (may be NULL) = the shader clock the chip
  * held (s_memtime / s_memrealtime), both over the second half of the run.  bench.py divides its achieved field-multiplication rate by this
- * figure (`valu_roofline.box`) instead of by a constant measured on another box of the pool.  No reference analogue (the reference's own
- * helper-multiplication benches: benches/basics.rs:284-319). */
+ * figure (`valu_roofline.box`) instead of by a constant measured on another box of the pool.  The call holds the context for its length
+ * (other threads' calls on the context wait) and keeps the whole chip busy: a measurement hook, not something to call beside production
+ * work.  No reference analogue (the reference's own helper-multiplication benches: benches/basics.rs:284-319). */
 int eg_selfbench_fmul(eg_ctx*, double seconds, double* fmul_g_per_s, double* sclk_mhz);
 
 /* ---- self-check of the fixed-base comb tables (election setup; no reference analogue: dalek's basepoint table is a compile-time
